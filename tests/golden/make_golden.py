@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py            # everything except long chains
+    python tests/golden/make_golden.py --chains   # + long reference chains (posterior summaries)
+
+The reference is executed unmodified: LiteRateForward.py / DDRate.py through
+runpy with ``-n 0`` (module body runs, the MCMC loop does not), which yields the
+CLI-local functions bound to the populated globals; literate_library is
+imported directly.  Only inputs and outputs are stored (npz/json) - no
+reference source text.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import runpy
+import shutil
+import subprocess
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+DATASETS = {
+    # name: (path relative to REF, extra CLI flags)
+    "example_TBP": ("example_data/example_dataTBP.txt", ["-TBP"]),
+    "example_TAD": ("example_data/example_dataTAD.txt", []),
+    "metal_bands": ("example_data/metal_bands/single_run/metal_bands_1.tsv", []),
+    "simulated": ("simulated_results.tsv", []),
+}
+
+
+def run_cli(script, data_rel, flags, workdir):
+    """runpy the reference script on a writable copy of the data; return its globals."""
+    dst = os.path.join(workdir, os.path.basename(data_rel))
+    if not os.path.exists(dst):
+        shutil.copy(os.path.join(REF, data_rel), dst)
+    argv = [script, "-d", dst] + flags
+    old_argv, old_path = sys.argv, list(sys.path)
+    sys.argv = argv
+    sys.path.insert(0, REF)
+    try:
+        with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+            warnings.simplefilter("ignore")
+            g = runpy.run_path(os.path.join(REF, script))
+    finally:
+        sys.argv, sys.path[:] = old_argv, old_path
+    return g
+
+
+def random_state(rng, start, end, kmax=12):
+    """A random valid (rates, times) pair: K in 1..kmax, interior shifts >1 apart."""
+    K = int(rng.integers(1, kmax + 1))
+    span = end - start
+    while True:
+        shifts = np.sort(rng.uniform(start, end, K - 1))
+        t = np.concatenate([[start], shifts, [end]])
+        if K == 1 or (np.min(np.diff(t)) > 1.0 and span > K):
+            break
+        K = max(1, K - 1)
+    rates = np.exp(rng.uniform(np.log(0.02), np.log(1.5), K))
+    return rates, t
+
+
+def make_binning_and_lik(work):
+    out = {}
+    for name, (rel, flags) in DATASETS.items():
+        rng = np.random.default_rng(abs(hash(name)) % 2**31 if False else sum(map(ord, name)))
+        per_model = {}
+        for model in (0, 1, 2, 3):
+            g = run_cli("LiteRateForward.py", rel, flags + ["-n", "0", "-seed", "1", "-model_BDI", str(model)], work)
+            if model == 0:
+                out[name + "/ts"] = np.asarray(g["ts"], dtype=float)
+                out[name + "/te"] = np.asarray(g["te"], dtype=float)
+                out[name + "/sp"] = np.asarray(g["sp_events_bin"], dtype=np.int64)
+                out[name + "/ex"] = np.asarray(g["ex_events_bin"], dtype=np.int64)
+                out[name + "/br"] = np.asarray(g["br_length_bin"], dtype=float)
+                out[name + "/start_end"] = np.array([g["start_time"], g["end_time"]], dtype=float)
+                out[name + "/B_EMP"] = np.asarray(g["B_EMP"], dtype=float)
+                out[name + "/D_EMP"] = np.asarray(g["D_EMP"], dtype=float)
+                # states shared by all four models
+                states = [random_state(rng, g["start_time"], g["end_time"]) + random_state(rng, g["start_time"], g["end_time"])
+                          for _ in range(24)]
+                # the state quoted in SURVEY.md section 8c (example TBP only makes sense there)
+                if name == "example_TBP":
+                    states.insert(0, (np.array([.6, .2]), np.array([0, 4.55, 24.5]),
+                                      np.array([.15, .19]), np.array([0, 16.682, 24.5])))
+                kmax = max(max(len(s[0]), len(s[2])) for s in states)
+                S = len(states)
+                KL = np.array([len(s[0]) for s in states])
+                KM = np.array([len(s[2]) for s in states])
+                Lr = np.zeros((S, kmax)); Lt = np.zeros((S, kmax + 1))
+                Mr = np.zeros((S, kmax)); Mt = np.zeros((S, kmax + 1))
+                for i, (l, tl, m, tm) in enumerate(states):
+                    Lr[i, :len(l)] = l; Lt[i, :len(tl)] = tl
+                    Mr[i, :len(m)] = m; Mt[i, :len(tm)] = tm
+                out[name + "/state_KL"], out[name + "/state_KM"] = KL, KM
+                out[name + "/state_L"], out[name + "/state_tL"] = Lr, Lt
+                out[name + "/state_M"], out[name + "/state_tM"] = Mr, Mt
+                n_bins = g["n_bins"]
+                indL = np.zeros((S, n_bins), dtype=np.int64)
+                indM = np.zeros((S, n_bins), dtype=np.int64)
+                for i, (l, tl, m, tm) in enumerate(states):
+                    indL[i] = g["get_rate_index"](np.floor(tl))
+                    indM[i] = g["get_rate_index"](np.floor(tm))
+                out[name + "/state_indL"], out[name + "/state_indM"] = indL, indM
+            if model == 3:
+                out[name + "/ex_dead"] = np.asarray(g["ex_events_bin_dead"], dtype=np.int64)
+                out[name + "/br_dead"] = np.asarray(g["br_length_bin_dead"], dtype=float)
+            liks = []
+            with np.errstate(all="ignore"):
+                for (l, tl, m, tm) in states:
+                    iL = g["get_rate_index"](np.floor(tl))
+                    iM = g["get_rate_index"](np.floor(tm))
+                    liks.append(float(g["calc_likelihood"](l[iL], m[iM])))
+            per_model[model] = np.array(liks)
+        for model, v in per_model.items():
+            out["%s/lik_model%d" % (name, model)] = v
+
+        # library path (DDRate / create_bins): parse_ts_te + create_bins
+        sys.path.insert(0, REF)
+        import literate_library as lib
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            TS, TE, PRESENT, ORIGIN = lib.parse_ts_te(os.path.join(REF, rel), "-TBP" in flags, -1, -1, .5)
+        # what the library's own parser produced (it differs from the CLI's on files with
+        # trailing tab columns, e.g. example_dataTAD.txt: pandas sees 6 columns there)
+        out[name + "/lib_ts"] = np.asarray(TS, dtype=float)
+        out[name + "/lib_te"] = np.asarray(TE, dtype=float)
+        for rm in (0, 1):
+            o, p, nsp, nex, dt, nb, tr = lib.create_bins(ORIGIN, PRESENT, TS, TE, rm)
+            out["%s/lib_bins_rm%d_sp" % (name, rm)] = np.asarray(nsp, dtype=np.int64)
+            out["%s/lib_bins_rm%d_ex" % (name, rm)] = np.asarray(nex, dtype=np.int64)
+            out["%s/lib_bins_rm%d_dt" % (name, rm)] = np.asarray(dt, dtype=float)
+            out["%s/lib_bins_rm%d_meta" % (name, rm)] = np.array([o, p, nb], dtype=float)
+        # single arbitrary windows through lib.precompute_events (non-integer edges)
+        wins = []
+        for _ in range(8):
+            a = rng.uniform(ORIGIN - 2, PRESENT)
+            b = a + rng.uniform(0.1, 9.0)
+            s_, e_, br_ = lib.precompute_events(np.asarray(TS, float), np.asarray(TE, float), a, b)
+            wins.append([a, b, s_, e_, br_])
+        out[name + "/lib_windows"] = np.array(wins, dtype=float)
+        sys.path.pop(0)
+    np.savez_compressed(os.path.join(HERE, "binning_lik.npz"), **out)
+    print("binning_lik.npz:", len(out), "arrays")
+
+
+def make_proposals(work):
+    """Proposal scorers with the draws they consumed (replayed from the same seed)."""
+    g = run_cli("LiteRateForward.py", DATASETS["example_TBP"][0], ["-TBP", "-n", "0", "-seed", "1"], work)
+    sys.path.insert(0, REF)
+    import literate_library as lib
+    rng = np.random.default_rng(7)
+    recs = {"add": [], "remove": [], "mult": [], "mult_scalar": [], "rjmcmc": []}
+    start, end = g["start_time"], g["end_time"]
+    for case in range(40):
+        rates, times = random_state(rng, start, end, kmax=8)
+        if case == 0:
+            rates, times = np.array([.6, .2]), np.array([0, 4.55, 24.5])
+        seed = 5 if case == 0 else int(rng.integers(0, 2**31 - 1))
+        # add
+        np.random.seed(seed)
+        r_, t_, s_ = g["add_shift_RJ_weighted_mean"](rates, times)
+        np.random.seed(seed)
+        ind = np.random.choice(range(len(times) - 1))
+        delta = np.random.uniform(0, np.diff(times)[ind])
+        u = np.random.beta(10., 10.)
+        recs["add"].append(dict(rates=rates.tolist(), times=times.tolist(), ind=int(ind), delta=float(delta),
+                                u=float(u), out_rates=r_.tolist(), out_times=t_.tolist(), score=float(s_)))
+        # remove (needs K>1)
+        if len(rates) > 1:
+            np.random.seed(seed)
+            r_, t_, s_ = g["remove_shift_RJ_weighted_mean"](rates, times)
+            np.random.seed(seed)
+            idx = np.random.choice(range(1, len(times) - 1))
+            recs["remove"].append(dict(rates=rates.tolist(), times=times.tolist(), idx=int(idx),
+                                       out_rates=r_.tolist(), out_times=t_.tolist(), score=float(s_)))
+        # vector multiplier (CLI-local and library versions are the same function)
+        for f in (0.75, 1.0, 0.3):
+            np.random.seed(seed)
+            q_, h_ = g["update_multiplier_freq"](rates, f=f)
+            np.random.seed(seed)
+            q2_, h2_ = lib.update_multiplier_proposal_vec(rates, 1.1, f)
+            assert np.array_equal(q_, q2_) and h_ == h2_
+            np.random.seed(seed)
+            ff = np.random.binomial(1, f, np.shape(rates))
+            uu = np.random.uniform(0, 1, np.shape(rates))
+            recs["mult"].append(dict(q=rates.tolist(), f=f, ff=ff.tolist(), u=uu.tolist(),
+                                     out=q_.tolist(), hastings=float(h_)))
+        np.random.seed(seed)
+        q_, h_ = lib.update_multiplier_proposal(rates[0], 1.1)
+        np.random.seed(seed)
+        u1 = np.random.random()
+        recs["mult_scalar"].append(dict(q=float(rates[0]), u=float(u1), out=float(q_), hastings=float(h_)))
+        # full RJ dispatcher
+        ratesM, timesM = random_state(rng, start, end, kmax=8)
+        np.random.seed(seed)
+        nL, ntL, nM, ntM, hq, upd = g["RJMCMC"]([rates, ratesM, times, timesM], 0.5)
+        np.random.seed(seed)
+        r = np.random.random(2)
+        recs["rjmcmc"].append(dict(L=rates.tolist(), M=ratesM.tolist(), tL=times.tolist(), tM=timesM.tolist(),
+                                   seed=seed, r=r.tolist(), out_L=np.asarray(nL).tolist(), out_tL=np.asarray(ntL).tolist(),
+                                   out_M=np.asarray(nM).tolist(), out_tM=np.asarray(ntM).tolist(),
+                                   score=float(hq), update_L=int(upd)))
+    # priors on grids
+    pri = {"gamma": [], "poisson": [], "sym_beta": []}
+    for case in range(30):
+        x = np.exp(rng.uniform(np.log(1e-3), np.log(20), int(rng.integers(1, 9))))
+        b = float(np.exp(rng.uniform(np.log(0.05), np.log(30))))
+        pri["gamma"].append(dict(x=x.tolist(), a=2.0, b=b, out=float(g["prior_gamma"](x, 2.0, b))))
+    pri["gamma"].append(dict(x=[0.7], a=2.0, b=2.0, out=float(g["prior_gamma"](np.array([0.7])))))
+    for k in range(1, 33):
+        for rate in (1, 0.37, 5.96):
+            pri["poisson"].append(dict(k=k, rate=rate, out=float(g["Poisson_prior"](k, rate))))
+    for x in np.linspace(0.02, 0.98, 25):
+        pri["sym_beta"].append(dict(x=float(x), a=10.0, out=float(g["prior_sym_beta"](x, 10.))))
+    # adequacy statistic and HPD
+    adq = []
+    for case in range(6):
+        eb, ed = rng.uniform(0.05, 1, 24), rng.uniform(0.05, 1, 24)
+        sb, sd = rng.uniform(0.05, 1, 24), rng.uniform(0.05, 1, 24)
+        adq.append(dict(eb=eb.tolist(), ed=ed.tolist(), sb=sb.tolist(), sd=sd.tolist(),
+                        out=[float(v) for v in lib.calculate_r_squared(eb, ed, sb, sd)]))
+    hpd = []
+    for case in range(6):
+        d = rng.gamma(2, 1, int(rng.integers(20, 400)))
+        hpd.append(dict(d=d.tolist(), out=lib.calcHPD(d, 0.95).tolist()))
+    sys.path.pop(0)
+    with open(os.path.join(HERE, "proposals_priors.json"), "w") as f:
+        json.dump(dict(proposals=recs, priors=pri, adequacy=adq, hpd=hpd), f)
+    print("proposals_priors.json written")
+
+
+def make_ddrate(work):
+    out = {}
+    rng = np.random.default_rng(11)
+    for mb, md in ((2, 2), (1, 1), (0, 0), (2, 0), (1, 2)):
+        g = run_cli("DDRate.py", DATASETS["metal_bands"][0],
+                    ["-n", "0", "-seed", "3", "-m_birth", str(mb), "-m_death", str(md)], work)
+        key = "mb%d_md%d" % (mb, md)
+        if "N_SPEC" not in out:
+            out["N_SPEC"] = np.asarray(g["N_SPEC"], dtype=np.int64)
+            out["N_EXTI"] = np.asarray(g["N_EXTI"], dtype=np.int64)
+            out["DT"] = np.asarray(g["DT"], dtype=float)
+            out["TIME_RANGE"] = np.asarray(g["TIME_RANGE"], dtype=float)
+            out["meta"] = np.array([g["ORIGIN"], g["PRESENT"], g["PRIOR_K0_L"]], dtype=float)
+        A, LK, BR, DR, NI, NF, PR = [], [], [], [], [], [], []
+        for case in range(20):
+            args = np.array([np.exp(rng.uniform(np.log(.05), np.log(1.5))), rng.normal(0, 1.5),
+                             rng.uniform(0, 40), rng.uniform(1, 200), rng.uniform(500, 40000),
+                             np.exp(rng.uniform(np.log(.02), np.log(.6))), abs(rng.normal(1, .5)) + .05,
+                             abs(rng.normal(1, .5)) + .05])
+            if case == 0:
+                args = np.array([0.5, 1.5, 16.25, 10, 20000, 0.1, 1., 1.])
+            with np.errstate(all="ignore"):
+                lik, br, dr, ni, nf = g["likelihood_function"](args)
+                pr = g["calc_prior"](args)
+            A.append(args); LK.append(lik); BR.append(br); DR.append(dr); NI.append(ni); NF.append(nf); PR.append(pr)
+        out[key + "/args"] = np.array(A); out[key + "/lik"] = np.array(LK)
+        out[key + "/birth"] = np.array(BR); out[key + "/death"] = np.array(DR)
+        out[key + "/niche"] = np.array(NI); out[key + "/niche_frac"] = np.array(NF)
+        out[key + "/prior"] = np.array(PR, dtype=float)
+    np.savez_compressed(os.path.join(HERE, "ddrate.npz"), **out)
+    print("ddrate.npz:", len(out), "arrays")
+
+
+def parse_logs(logdir, stem):
+    mc = np.loadtxt(os.path.join(logdir, stem + "_mcmc.log"), skiprows=1, ndmin=2)
+    rows = {}
+    for kind in ("sp", "ex"):
+        with open(os.path.join(logdir, "%s_%s_rates.log" % (stem, kind))) as f:
+            rows[kind] = [np.array(l.split(), dtype=float) for l in f if l.strip()]
+    return mc, rows["sp"], rows["ex"]
+
+
+def pack_rows(rows):
+    width = max(len(r) for r in rows)
+    m = np.full((len(rows), width), np.nan)
+    for i, r in enumerate(rows):
+        m[i, :len(r)] = r
+    return m
+
+
+def make_trajectories(work):
+    """Short full CLI runs (reference process, fixed seed): every sampled row is kept so
+    the oracle loop fed the same MT19937 stream must reproduce them."""
+    out = {}
+    runs = [("example_TBP", 0, 42, 20000, 10, []), ("example_TBP", 2, 7, 20000, 10, []),
+            ("example_TBP", 1, 3, 10000, 10, []), ("example_TBP", 3, 9, 10000, 10, []),
+            ("example_TBP", 0, 11, 10000, 10, ["-const_rates", "1"]),
+            ("example_TBP", 0, 12, 10000, 10, ["-const_death_rate", "1"]),
+            ("example_TBP", 0, 13, 10000, 10, ["-use_rate_HP", "0", "-Poisson_prior", "2.5"]),
+            ("metal_bands", 2, 5, 6000, 10, [])]
+    suffix = {0: "_BD", 1: "_ID", 2: "_BDk", 3: "_BDd"}
+    for name, model, seed, n, s, extra in runs:
+        rel, flags = DATASETS[name]
+        d = tempfile.mkdtemp(dir=work)
+        dst = os.path.join(d, os.path.basename(rel))
+        shutil.copy(os.path.join(REF, rel), dst)
+        cmd = [sys.executable, "-B", os.path.join(REF, "LiteRateForward.py"), "-d", dst, "-n", str(n), "-s", str(s),
+               "-p", str(10**9), "-seed", str(seed), "-model_BDI", str(model)] + flags + extra
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+        stem = os.path.splitext(os.path.basename(rel))[0] + suffix[model]
+        mc, sp, ex = parse_logs(os.path.join(d, "literate_mcmc_logs"), stem)
+        key = "%s_m%d_s%d%s" % (name, model, seed, "".join(extra).replace("-", "_"))
+        out[key + "/mcmc"] = mc
+        out[key + "/sp"] = pack_rows(sp)
+        out[key + "/ex"] = pack_rows(ex)
+        out[key + "/meta"] = np.array([model, seed, n, s], dtype=float)
+        print(key, mc.shape)
+    np.savez_compressed(os.path.join(HERE, "trajectories.npz"), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    work = tempfile.mkdtemp(prefix="lr_golden_")
+    steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate,
+                 traj=make_trajectories)
+    for name, fn in steps.items():
+        if args.only and name not in args.only.split(","):
+            continue
+        fn(work)
+    shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py - RJMCMC birth-death likelihood loop on MI355X: lineage-log-lik evals/s.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one RJMCMC iteration of every chain on this GPU: one scan of the lineage arrays
+scoring all pending proposals (lr_scan_kernel) + the per-chain accept / trace / next-proposal
+kernel.  Workload (config.workload) = BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages,
+128 unit bins, 20 true shifts per process, 1024 chains per GPU; chains shard across ranks with no
+data-path collective (weak scaling), lineage arrays are replicated; the sampled trace rows are
+gathered over RCCL once at the end of the timed region.  Inputs are resident in HBM before timing.
+
+value = iterations x lineages x chains / time (one unit = one lineage's contribution to one
+chain's proposed-state log-likelihood: "iters/sec x lineages" of BASELINE.json, summed over chains).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (lineages, n_bins, true shifts, chains per GPU, model)
+    "cfg4": (100_000, 128, 20, 1024, 0),
+    "cfg3": (10_000, 128, 20, 256, 0),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(ts, te, t0, n_bins, br, budget_s=12.0):
+    """numpy port (oracle.per_lineage_loglik: O(N) gather form of get_BDlik) on ONE host core:
+    a bounded sample of the same workload - the same lineages, as many chain states as fit the budget."""
+    from oracle import literate_oracle as lo
+    rng = np.random.default_rng(0)
+    pre = lo.lineage_bins(ts, te, t0, n_bins)          # index/fraction pass is data-only: not re-timed
+    n_eval, t_start = 0, time.perf_counter()
+    while True:
+        lam = np.exp(rng.uniform(np.log(.05), np.log(.6), n_bins))
+        mu = np.exp(rng.uniform(np.log(.02), np.log(.3), n_bins))
+        lo.per_lineage_loglik(ts, te, t0, lam, mu, 0, br, pre=pre)
+        n_eval += 1
+        el = time.perf_counter() - t_start
+        if el > budget_s:
+            break
+    return dict(value=n_eval * len(ts) / el, unit="lineage-log-lik evals/s", cores=1, kind="port",
+                sample="%d chain states x %d lineages (same synthetic lineages, model 0), %.1f s of numpy on 1 core"
+                       % (n_eval, len(ts), el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--sample-every", type=int, default=100, help="trace sampling frequency (-s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from literate_amd import synth
+    from literate_amd.engine import ChainEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_lin, n_bins, n_shifts, chains, model = WORKLOADS[args.workload]
+    if args.chains:
+        chains = args.chains
+    ts, te, _ = synth.make_lineages(n_lin, n_bins=n_bins, n_shifts=n_shifts, seed=0)   # same on every rank
+    n_slots = (args.steps + args.warmup) // args.sample_every + 2
+    eng = ChainEngine(ts, te, chains, model=model, seed=2026, s_freq=args.sample_every, n_trace_slots=n_slots,
+                      chain_offset=rank * chains)
+    eng.init()
+    eng.steps(args.warmup)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t_begin = time.perf_counter()
+    eng.steps(args.steps)
+    heads = eng.trace[:, :, :13].contiguous()       # log-posterior trace rows sampled so far
+    if world > 1:
+        gathered = [torch.empty_like(heads) for _ in range(world)] if rank == 0 else None
+        dist.gather(heads, gathered, dst=0)          # RCCL over xGMI
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the chains ran and hold finite posteriors
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == args.steps + args.warmup) and np.all(np.isfinite(snap["likA"]))
+
+    if rank == 0:
+        total_chains = chains * world
+        value = args.steps * n_lin * total_chains / elapsed
+        # roofline of the dominant kernel (lr_scan_kernel), timed live with HIP events on its stream
+        scan_ms = eng.time_scan(reps=50)
+        cb = eng.layout.chains_per_block
+        groups = -(-chains // cb)
+        alg_bytes = 16.0 * n_lin * groups                   # 16 B x N x ceil(C/Cb) per launch
+        achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("workload") == args.workload and tj.get("chains") == chains:
+                traffic = tj.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "RJMCMC iters/sec x lineages (lineage-log-lik evals/s, summed over chains)",
+            "value": value, "unit": "lineage-log-lik evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: synthetic %d lineages, %d unit bins, %d true shifts, %d chains per GPU, "
+                                   "model_BDI %d, RJ prior on shifts" % (args.workload, n_lin, n_bins, n_shifts, chains, model),
+                       "lineages": n_lin, "chains_per_gpu": chains, "chains_total": total_chains,
+                       "n_bins": eng.n_bins, "sample_every": args.sample_every,
+                       "iters_per_s_per_chain": args.steps / elapsed},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "lr_scan_kernel<%d>" % cb, "kernel_ms": scan_ms, "chains_per_pass_Cb": cb,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "effective_GBs_unamortised": 16.0 * n_lin * chains / (scan_ms * 1e-3) / 1e9,
+                         "scan_evals_per_s": n_lin * chains / (scan_ms * 1e-3),
+                         "scan_share_of_step": scan_ms / (elapsed / args.steps * 1e3)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(ts, te, eng.t0, eng.n_bins, eng.br_length.cpu().numpy())
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,226 @@
+/*
+ * literate_hip.h - C ABI of libliterate_hip.so: the MI355X (gfx950) kernels behind the
+ * LiteRate RJMCMC birth-death likelihood path.
+ *
+ * The reference (dsilvestro/LiteRate) is pure Python/numpy and has no FFI layer; the seams
+ * this library plugs into are the Python call signatures listed per entry point below
+ * (LRF = LiteRateForward.py, lib = literate_library.py, DD = DDRate.py, BDIx =
+ * other/LiteRateBDI_ext.py).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch tensor.data_ptr()) unless it is
+ *     marked "host"; the caller owns every buffer, nothing is allocated behind its back;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is
+ *     asynchronous on it and returns after enqueueing;
+ *   - return value: 0 = ok, <0 = invalid argument (LR_ERR_*), >0 = a hipError_t;
+ *   - arithmetic is IEEE fp64, counts are int64 (as numpy in the reference);
+ *   - results are bitwise reproducible: all reductions run in a fixed order, no float atomics.
+ */
+#ifndef LITERATE_HIP_H
+#define LITERATE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LR_OK 0
+#define LR_ERR_NULL (-1)      /* a required pointer is NULL                              */
+#define LR_ERR_SIZE (-2)      /* a size / count is out of range                          */
+#define LR_ERR_MODEL (-3)     /* unknown model id or missing model input                 */
+#define LR_ERR_WORKSPACE (-4) /* workspace too small                                     */
+#define LR_ERR_T0 (-5)        /* bin origin must be integer valued                       */
+#define LR_ERR_STATE (-6)     /* engine used before lr_mcmc_init / after destroy         */
+
+#define LR_KMAX 32     /* max number of rates per process held on the device (reference: unbounded) */
+#define LR_ROW 64      /* padded row length of per-chain state arrays                                 */
+#define LR_MAX_BINS 4094
+
+/* model ids = the reference's -model_BDI (LRF:388, 421-431) */
+#define LR_MODEL_BD 0       /* BDI_partial_lik, birth-death      (LRF:150-162) */
+#define LR_MODEL_ID 1       /* BDI_partial_lik, immigration-death               */
+#define LR_MODEL_KEIDING 2  /* BD_lik_Keiding                     (LRF:137-148) */
+#define LR_MODEL_KEIDING_DEAD 3 /* Keiding, death half on te<end_time (LRF:141-142, 529-546) */
+
+int lr_version(void);
+
+/* ---- A1/A2: sufficient statistics ---------------------------------------------------------
+ * Replaces precompute_events + get_br (lib:74-85; LRF:111-123) evaluated for n_windows windows
+ * at once (the loop LRF:519-523 / lib create_bins:231-245).  Window w is [win_lo[w], win_hi[w]]:
+ *   sp_events[w] = #{ts >= lo && ts <  hi}
+ *   ex_events[w] = #{te >  lo && te <= hi}
+ *   br_length[w] = sum_i max(0, min(te_i,hi) - max(ts_i,lo))
+ * Counts are exact; br_length is summed in a fixed order.                                    */
+int64_t lr_bin_events_workspace_bytes(int64_t n, int32_t n_windows);
+int lr_bin_events(const double* ts, const double* te, int64_t n,
+                  const double* win_lo, const double* win_hi, int32_t n_windows,
+                  int64_t* sp_events, int64_t* ex_events, double* br_length,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- A3: rate index -----------------------------------------------------------------------
+ * Replaces get_rate_index + fancy indexing L[indL] (LRF:125-135, 262, 306): expands K segment
+ * rates to one rate per unit bin.  rates [C,kmax], times [C,kmax+1] ascending, K [C].
+ * mode 0: floor(times) (LRF:262,272,277-278); mode 1: round-half-even (LRF:129, initial call
+ * LRF:224-225).  Bin b of chain c gets segment j with e_j <= b < e_{j+1},
+ * e_j = int(mode(times[j])) - int(mode(times[0])).                                            */
+int lr_expand_rates(const double* rates, const double* times, const int32_t* K, int32_t kmax,
+                    int32_t n_chains, int32_t n_bins, int32_t mode,
+                    double* rate_bins /* [C,n_bins] */, void* stream);
+
+/* ---- A4/A5/A6: batched per-lineage log-likelihood -----------------------------------------
+ * Replaces calc_likelihood(L[indL], M[indM]) (LRF:226, 306, 430-431) for n_chains states at
+ * once, in the per-lineage form of BD_partial_lik/get_BDlik (BDIx:124-146): one pass over
+ * ts/te per group of chains, unit bins [t0+b, t0+b+1), b < n_bins, t0 integer valued
+ * (= int(min ts), LRF:519).  lam_bins/mu_bins [C,n_bins] are the per-bin rates (the
+ * L_acc_vec/M_acc_vec arguments).  br_length [n_bins] is required for models 0/1 (it is the
+ * k = br_length_bin of LRF:154), end_time for model 3.  out_loglik [C].                     */
+int64_t lr_bd_loglik_workspace_bytes(int64_t n, int32_t n_bins, int32_t n_chains, int32_t model);
+int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n, double t0, int32_t n_bins,
+                       const double* lam_bins, const double* mu_bins, int32_t n_chains,
+                       int32_t model, const double* br_length, double end_time,
+                       double* out_loglik, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- A7/A8: proposal scoring with explicit draws ------------------------------------------
+ * Replaces update_multiplier_freq (LRF:165-176 == lib update_multiplier_proposal_vec:156-165),
+ * add_shift_RJ_weighted_mean (LRF:29-47) and remove_shift_RJ_weighted_mean (LRF:49-69), one
+ * move per chain, randomness supplied by the caller:
+ *   move[c] = 0 multiplier: draws[c, 0:K) = binomial mask (0/1), draws[c, kmax:kmax+K) = uniforms
+ *   move[c] = 1 add shift : index[c] = interval (0..K-1), draws[c,0] = offset in it, draws[c,1] = Beta(10,10) variate
+ *   move[c] = 2 remove    : index[c] = shift (1..K-1)
+ * out_score = Hastings term (multiplier) or log q + log Jacobian (RJ).                        */
+int lr_rj_propose_score(const double* rates /* [C,kmax] */, const double* times /* [C,kmax+1] */,
+                        const int32_t* K, int32_t kmax, int32_t n_chains,
+                        const int32_t* move, const int32_t* index,
+                        const double* draws /* [C,2*kmax] */, double mult_d,
+                        double* out_rates, double* out_times, int32_t* out_K, double* out_score,
+                        void* stream);
+
+/* ---- A10: priors --------------------------------------------------------------------------
+ * out[c] = prior_gamma(rates[c,:K], a=shape, b=gamma_rate[c]) (LRF:201-202)
+ *        + Poisson_prior(K[c], poi_rate[c]) if poi_rate != NULL (LRF:198-199).               */
+int lr_log_priors(const double* rates, const int32_t* K, int32_t kmax, int32_t n_chains,
+                  double shape, const double* gamma_rate, const double* poi_rate,
+                  double* out, void* stream);
+
+/* ---- A12: DDRate rates --------------------------------------------------------------------
+ * Replaces the rate half of likelihood_function (DD:71-100): args [C,8] =
+ * [l_max,k,x0,div_0,L,m_max,nuB,nuD] -> per-bin birth/death rates, niche, niche fraction
+ * (each [C,n_bins]); the likelihood half is lr_bd_loglik_batch(model 2) on those rates.      */
+int lr_dd_rates(const double* args, const double* DT, int32_t n_bins, int32_t n_chains,
+                int32_t m_birth, int32_t m_death,
+                double* birth_rates, double* death_rates, double* niche, double* niche_frac,
+                void* stream);
+
+/* ---- A11: fused multi-chain RJMCMC --------------------------------------------------------
+ * Replaces runMCMC (LRF:216-373) for n_chains independent chains.  Per iteration: one scan of
+ * the lineage arrays scoring every chain's proposal, then one chain-step kernel (reduce,
+ * Metropolis-Hastings accept, trace write, next proposal, next tables).  Randomness: Philox4x32-10
+ * addressed by (iteration, purpose, index), keyed by (seed, chain_offset + chain).            */
+typedef struct lr_mcmc_config {
+    int64_t n_lineages;
+    int32_t n_bins;
+    int32_t n_chains;
+    int32_t model;            /* LR_MODEL_*                                         */
+    int32_t const_rates;      /* -const_rates       (LRF:386, 274)                  */
+    int32_t const_death_rate; /* -const_death_rate  (LRF:387, 243-252)              */
+    int32_t use_rate_HP;      /* -use_rate_HP       (LRF:395, 285)                  */
+    int32_t s_freq;           /* -s sampling frequency (LRF:382, 321)               */
+    int32_t n_trace_slots;    /* capacity of the trace buffer in samples            */
+    double poisson_HP;        /* -Poisson_prior     (LRF:396, 220-221)              */
+    double update_fraction;   /* -update_fraction   (LRF:399)                       */
+    double t0;                /* first bin edge = int(min ts)                       */
+    double start_time;        /* min(ts)  (LRF:473)                                 */
+    double end_time;          /* max(te)  (LRF:474)                                 */
+    uint64_t seed;
+    int64_t chain_offset;     /* global index of local chain 0 (multi-GPU sharding) */
+} lr_mcmc_config;
+
+/* where things live inside the engine workspace (byte offsets), for zero-copy host views */
+typedef struct lr_mcmc_layout {
+    int64_t state_f64;    /* [C, LR_STATE_ROWS, LR_ROW] doubles  (rows: see LR_ROW_* below)  */
+    int64_t state_i32;    /* [C, LR_ISTATE_ROWS, LR_ROW] int32                                */
+    int64_t rate_bins;    /* [C, 4, n_bins] doubles: accepted lam, accepted mu, proposed lam, proposed mu */
+    int64_t tables;       /* [C, table_stride] double2                                        */
+    int64_t partials;     /* [tiles, C] doubles                                               */
+    int64_t trace;        /* [n_trace_slots, C, LR_TRACE_W] doubles                           */
+    int64_t total_bytes;
+    int32_t table_stride; /* double2 entries per chain                                         */
+    int32_t tiles;
+    int32_t chains_per_block;
+    int32_t trace_width;
+} lr_mcmc_layout;
+
+/* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */
+#define LR_ROW_L 0      /* accepted birth rates       [K_l]   */
+#define LR_ROW_M 1      /* accepted death rates       [K_m]   */
+#define LR_ROW_TL 2     /* accepted birth shift times [K_l+1] */
+#define LR_ROW_TM 3
+#define LR_ROW_PL 4     /* proposed ... */
+#define LR_ROW_PM 5
+#define LR_ROW_PTL 6
+#define LR_ROW_PTM 7
+#define LR_ROW_SCALARS 8 /* see LR_S_* */
+#define LR_STATE_ROWS 9
+/* scalar slots inside LR_ROW_SCALARS */
+#define LR_S_LIKA 0
+#define LR_S_PRIORA 1
+#define LR_S_PRIORPOIA 2
+#define LR_S_GRATE_L 3   /* Gamma_rate[0] (LRF:222, 286) */
+#define LR_S_GRATE_M 4
+#define LR_S_POI 5       /* Poi_lambda_rjHP (LRF:220-221, 284) */
+#define LR_S_HASTING 6   /* of the pending proposal */
+#define LR_S_PRIOR_P 7
+#define LR_S_PRIORPOI_P 8
+#define LR_S_CONST_P 9   /* model constant of the pending proposal (model 1)   */
+#define LR_S_CONST_A 10
+#define LR_S_LIK_P 11    /* last evaluated proposal log-likelihood (diagnostic) */
+/* rows of the int32 state block */
+#define LR_IROW_EL 0     /* accepted birth bin edges (ints, relative to bin 0) [K_l+1] */
+#define LR_IROW_EM 1
+#define LR_IROW_PEL 2
+#define LR_IROW_PEM 3
+#define LR_IROW_SCALARS 4 /* see LR_I_* */
+#define LR_ISTATE_ROWS 5
+#define LR_I_KL 0
+#define LR_I_KM 1
+#define LR_I_PKL 2
+#define LR_I_PKM 3
+#define LR_I_GIBBS 4     /* pending proposal is a Gibbs step (LRF:283-287)     */
+#define LR_I_INVALID 5   /* pending proposal fails the LRF:290 guard or K cap  */
+#define LR_I_IT_LO 6     /* next iteration number (64 bit)                      */
+#define LR_I_IT_HI 7
+#define LR_I_ACCEPTED 8  /* number of accepted proposals so far                 */
+#define LR_I_MOVE 9      /* kind of the pending proposal: 0 L-mult 1 L-times 2 M-mult 3 M-times 4 RJ 5 Gibbs */
+
+/* trace row (one per chain per sample; columns 0..12 are the _mcmc.log columns LRF:496-502
+ * without the adequacy triple, then the _sp_rates / _ex_rates rows LRF:354-359):
+ *   [it, posterior, likelihood, prior, lambda_avg, mu_avg, K_l, K_m, root_age, death_age,
+ *    gamma_rate_hp_BI, gamma_rate_hp_D, poisson_rate_hp,
+ *    L[0..KMAX), tL interior [0..KMAX-1), M[0..KMAX), tM interior [0..KMAX-1)]               */
+#define LR_TRACE_HEAD 13
+#define LR_TRACE_W (LR_TRACE_HEAD + 2 * (2 * LR_KMAX - 1))
+
+typedef struct lr_engine lr_engine;
+
+int lr_mcmc_query_layout(const lr_mcmc_config* cfg /* host */, lr_mcmc_layout* out /* host */);
+int lr_mcmc_create(const lr_mcmc_config* cfg /* host */, const double* ts, const double* te,
+                   const double* br_length /* [n_bins], models 0/1, else NULL */,
+                   void* workspace, int64_t workspace_bytes, lr_engine** out /* host */);
+/* init_state: NULL = the CLI's initial state (K=1, Gamma(2,2) rates, LRF:580-583) drawn from the
+ * chain's Philox stream; else device arrays L[C,kmax], M[C,kmax], tL[C,kmax+1], tM[C,kmax+1],
+ * KL[C], KM[C] (the runMCMC argument, LRF:218).  Evaluates likA/priorA (LRF:224-230) and
+ * prepares the proposal of iteration 0.                                                       */
+int lr_mcmc_init(lr_engine* e, const double* L, const double* M, const double* tL,
+                 const double* tM, const int32_t* KL, const int32_t* KM, int32_t kmax, void* stream);
+int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream);
+/* measurement hook (bench.py roofline): average duration in ms of `reps` back-to-back launches of
+ * the engine's lineage-scan kernel on `stream`, timed with HIP events recorded on that stream.
+ * Blocks until the launches finish; re-scores the pending proposal, so chain state is unchanged. */
+int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms /* host */, void* stream);
+int lr_mcmc_destroy(lr_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LITERATE_HIP_H */

@@ -1,0 +1,195 @@
+// lr_device.h - device-side building blocks shared by the LiteRate HIP kernels (gfx950, wave64).
+//
+//  * wave-level reductions / scans with a fixed association order (bitwise reproducible);
+//  * Philox4x32-10 addressed draws, Box-Muller normals, Marsaglia-Tsang gamma variates
+//    (restated on the CPU in oracle/philox.py, purposes must match);
+//  * the per-chain table builder that turns per-bin rates into the two lookup tables the
+//    lineage scan gathers from.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/literate_hip.h"
+
+#define LR_WAVE 64
+
+// ---------------------------------------------------------------------------------------
+// wave helpers.  The xor butterfly adds commutatively at every level, so every lane ends
+// with the same bits.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double lr_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, LR_WAVE);
+    return v;
+}
+__device__ __forceinline__ double lr_wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, LR_WAVE));
+    return v;
+}
+__device__ __forceinline__ long long lr_wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, LR_WAVE);
+    return v;
+}
+// exclusive prefix sum over lanes (Hillis-Steele, fixed order); *total = sum over all lanes
+__device__ __forceinline__ double lr_wave_exclusive_scan(double v, int lane, double* total) {
+    double incl = v;
+#pragma unroll
+    for (int o = 1; o < LR_WAVE; o <<= 1) {
+        double up = __shfl_up(incl, o, LR_WAVE);
+        if (lane >= o) incl += up;
+    }
+    *total = __shfl(incl, LR_WAVE - 1, LR_WAVE);
+    return incl - v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) and the draws built on it
+// ---------------------------------------------------------------------------------------
+#define LR_P_MOVE 0
+#define LR_P_MULT 1
+#define LR_P_TIMES 2
+#define LR_P_RJ 3
+#define LR_P_BETA_A 4
+#define LR_P_BETA_B 5
+#define LR_P_GIBBS_POI 6
+#define LR_P_GIBBS_L 7
+#define LR_P_GIBBS_M 8
+#define LR_P_ACCEPT 9
+#define LR_P_INIT 10
+#define LR_GAMMA_MAX_ATTEMPTS 32
+
+struct lr_u2 {
+    double a, b;
+};
+
+__device__ __forceinline__ void lr_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                          uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0, c1 = lo1, c2 = n2, c3 = lo0;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+struct lr_stream {
+    uint32_t k0, k1;
+};
+
+__device__ __forceinline__ lr_u2 lr_pair(const lr_stream& s, uint64_t it, uint32_t purpose, uint32_t idx) {
+    uint32_t w[4];
+    lr_philox((uint32_t)it, (uint32_t)(it >> 32), purpose, idx, s.k0, s.k1, w);
+    lr_u2 r;
+    r.a = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) / 9007199254740992.0;
+    r.b = ((double)(w[2] >> 5) * 67108864.0 + (double)(w[3] >> 6)) / 9007199254740992.0;
+    return r;
+}
+
+__device__ __forceinline__ double lr_normal(const lr_stream& s, uint64_t it, uint32_t purpose, uint32_t idx) {
+    const lr_u2 u = lr_pair(s, it, purpose, idx);
+    return sqrt(-2.0 * log(1.0 - u.a)) * cos(2.0 * 3.141592653589793 * u.b);
+}
+
+// standard Gamma(shape >= 1): attempt a uses idx base+2a (normal) and base+2a+1 (uniform)
+__device__ inline double lr_gamma(const lr_stream& s, uint64_t it, uint32_t purpose, uint32_t base, double shape) {
+    const double d = shape - 1.0 / 3.0;
+    const double c = 1.0 / sqrt(9.0 * d);
+    for (int a = 0; a < LR_GAMMA_MAX_ATTEMPTS; ++a) {
+        const double x = lr_normal(s, it, purpose, base + 2 * a);
+        const double t = 1.0 + c * x;
+        const double v = t * t * t;
+        if (v <= 0.0) continue;
+        const double u = lr_pair(s, it, purpose, base + 2 * a + 1).a;
+        if (u <= 0.0) return d * v;
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v;
+    }
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------
+// lookup tables of one chain
+//
+// Unit bins b = 0..n_bins-1 cover [t0+b, t0+b+1).  Entry j = b+1; j = 0 is "before the
+// window", j = n_bins+1 "after it".  With cum_b = sum_{b'<b} R_b' the scan evaluates
+//     contribution_i = S[js].x + fs*S[js].y + E[je].x + fe*E[je].y
+// where  S[b+1] = (logB_b + cum_b,  R_b)      birth event + exposure integral up to ts
+//        E[b+1] = (logD_b - cum_b, -R_b)      death event - exposure integral up to te
+//        S[0] = E[0] = (0,0),  S[n_bins+1] = (cum_total, 0),  E[n_bins+1] = (-cum_total, 0).
+// Layout per chain: [n_cls][2 (S,E)][n_bins+2] double2; class 1 (model 3 only) carries the
+// birth process alone and is used by extant lineages (LRF:141-142: death half on te<end_time).
+// Model conventions (LRF:137-162):
+//   2/3: logB = log lam, logD = log mu, R = lam+mu
+//   0  : k>0: logB = log(k*lam), logD = log(mu*k), R = lam+mu ; k==0: all 0
+//   1  : k>0: logB = log(lam),   logD = log(mu*k), R = mu, const -= lam ; k==0: all 0
+// One wave builds one chain's tables; lane l owns the contiguous bins [l*P, (l+1)*P).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void lr_bin_terms(int model, double lam, double mu, double k, double* logB, double* logD,
+                                             double* R, double* Rl, double* cterm) {
+    *cterm = 0.0;
+    if (model >= 2) {
+        *logB = log(lam), *logD = log(mu), *R = lam + mu, *Rl = lam;
+        return;
+    }
+    if (!(k > 0.0)) {
+        *logB = 0.0, *logD = 0.0, *R = 0.0, *Rl = 0.0;
+        return;
+    }
+    if (model == 0) {
+        *logB = log(k * lam + 0.0), *R = lam + mu;
+    } else {
+        *logB = log(k * 0.0 + lam), *R = mu, *cterm = -lam;
+    }
+    *logD = log(mu * k);
+    *Rl = 0.0;
+}
+
+__device__ inline double lr_build_tables_wave(const double* __restrict__ lam_bins, const double* __restrict__ mu_bins,
+                                              const double* __restrict__ br_length, int model, int n_bins, int n_cls,
+                                              double2* __restrict__ tab, int lane) {
+    const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
+    const int b0 = lane * P;
+    const int b1 = min(b0 + P, n_bins);
+    const int nb2 = n_bins + 2;
+    double sumR = 0.0, sumRl = 0.0, csum = 0.0;
+    for (int b = b0; b < b1; ++b) {
+        double logB, logD, R, Rl, ct;
+        lr_bin_terms(model, lam_bins[b], mu_bins[b], model < 2 ? br_length[b] : 1.0, &logB, &logD, &R, &Rl, &ct);
+        sumR += R, sumRl += Rl, csum += ct;
+    }
+    double totR, totRl;
+    double cum = lr_wave_exclusive_scan(sumR, lane, &totR);
+    double cuml = 0.0;
+    if (n_cls == 2) cuml = lr_wave_exclusive_scan(sumRl, lane, &totRl);
+    for (int b = b0; b < b1; ++b) {
+        double logB, logD, R, Rl, ct;
+        lr_bin_terms(model, lam_bins[b], mu_bins[b], model < 2 ? br_length[b] : 1.0, &logB, &logD, &R, &Rl, &ct);
+        tab[b + 1] = make_double2(logB + cum, R);
+        tab[nb2 + b + 1] = make_double2(logD - cum, -R);
+        cum += R;
+        if (n_cls == 2) {
+            tab[2 * nb2 + b + 1] = make_double2(logB + cuml, Rl);
+            tab[3 * nb2 + b + 1] = make_double2(-cuml, -Rl);
+            cuml += Rl;
+        }
+    }
+    if (lane == 0) {
+        tab[0] = make_double2(0.0, 0.0);
+        tab[nb2] = make_double2(0.0, 0.0);
+        tab[nb2 - 1] = make_double2(totR, 0.0);
+        tab[2 * nb2 - 1] = make_double2(-totR, 0.0);
+        if (n_cls == 2) {
+            tab[2 * nb2] = make_double2(0.0, 0.0);
+            tab[3 * nb2] = make_double2(0.0, 0.0);
+            tab[3 * nb2 - 1] = make_double2(totRl, 0.0);
+            tab[4 * nb2 - 1] = make_double2(-totRl, 0.0);
+        }
+    }
+    return lr_wave_sum(csum);
+}
+
+static inline int lr_table_stride(int n_bins, int n_cls) { return n_cls * 2 * (n_bins + 2); }

@@ -1,0 +1,30 @@
+// lr_internal.h - host-side declarations shared between the translation units of libliterate_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/literate_hip.h"
+
+#define LR_SCAN_THREADS 256
+#define LR_SCAN_LDS_BUDGET (48 * 1024) /* table bytes per block we aim for (3 blocks / CU) */
+#define LR_SCAN_LDS_MAX (150 * 1024)
+
+struct lr_scan_plan {
+    int cb;            // chains per block
+    int groups;        // ceil(n_chains / cb)
+    int tiles;         // lineage tiles
+    long long chunk;   // lineages per tile (multiple of 2*LR_SCAN_THREADS)
+    int tab_stride;    // double2 entries per chain
+    int n_cls;
+    size_t lds_bytes;
+};
+
+// choose the launch shape of the lineage scan for (n lineages, n_chains, n_bins, model)
+int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan* plan);
+
+// enqueue the scan: partials[tile * n_chains + chain] = sum over the tile's lineages
+int lr_launch_scan(const lr_scan_plan& plan, const double* ts, const double* te, long long n, double t0, int n_bins,
+                   double end_time, const double2* tables, int n_chains, double* partials, hipStream_t stream);
+
+static inline int lr_align_up(long long x, long long a) { return (int)((x + a - 1) / a * a); }
+static inline long long lr_align_up64(long long x, long long a) { return (x + a - 1) / a * a; }

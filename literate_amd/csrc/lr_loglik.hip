@@ -1,0 +1,242 @@
+// lr_loglik.hip - batched per-lineage birth-death log-likelihood.
+//
+// Hot kernel: lr_scan_kernel<CB>.  One 256-thread block owns a tile of lineages and CB chains.
+// The chains' lookup tables (lr_device.h) are staged in LDS once; every lineage (ts, te) is then
+// loaded from HBM/L2 once with 16-byte coalesced loads, turned into two table indices and two
+// in-bin fractions, and scored against all CB chains with two 16-byte LDS gathers + 4 fp64 ops
+// per (lineage, chain).  Per-chain sums are reduced lane -> wave (shuffle butterfly) -> block
+// (LDS, fixed order) -> one partial per (tile, chain); partials are summed in tile order by the
+// consumer, so results are bitwise reproducible.  No MFMA: this is a gather/scan/reduce.
+#include "lr_device.h"
+#include "lr_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// tables from per-bin rates: one wave per chain
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LR_WAVE) void lr_build_tables_kernel(const double* __restrict__ lam_bins,
+                                                                  const double* __restrict__ mu_bins,
+                                                                  const double* __restrict__ br_length, int model,
+                                                                  int n_bins, int n_cls, int tab_stride,
+                                                                  double2* __restrict__ tables,
+                                                                  double* __restrict__ consts) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double cst = lr_build_tables_wave(lam_bins + (size_t)c * n_bins, mu_bins + (size_t)c * n_bins, br_length,
+                                            model, n_bins, n_cls, tables + (size_t)c * tab_stride, lane);
+    if (lane == 0) consts[c] = cst;
+}
+
+// ------------------------------------------------------------------------------------------
+// the lineage scan
+// ------------------------------------------------------------------------------------------
+template <int CB>
+__device__ __forceinline__ void lr_score_lineage(double s, double e, double t0, double nb1, int nb2, int n_cls,
+                                                 double end_time, const double2* __restrict__ lds, int tab_stride,
+                                                 double (&acc)[CB]) {
+    const double fl = floor(s);
+    const double ce = ceil(e);
+    // table index: births [lo,hi) -> floor, deaths (lo,hi] -> ceil-1; 0 / n_bins+1 = outside
+    const int js = (int)fmin(fmax(fl - t0 + 1.0, 0.0), nb1);
+    const int je = (int)fmin(fmax(ce - t0, 0.0), nb1);
+    const double fs = s - fl;
+    const double fe = e - (ce - 1.0);
+    int base = 0;
+    if (n_cls == 2 && e >= end_time) base = 2 * nb2;
+    const int offS = base + js;
+    const int offE = base + nb2 + je;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const double2 S = lds[c * tab_stride + offS];
+        const double2 E = lds[c * tab_stride + offE];
+        double t = S.x + E.x;
+        t = fma(fs, S.y, t);
+        t = fma(fe, E.y, t);
+        acc[c] += t;
+    }
+}
+
+template <int CB>
+__global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_kernel(const double* __restrict__ ts,
+                                                                  const double* __restrict__ te, long long n,
+                                                                  double t0, int n_bins, int n_cls, double end_time,
+                                                                  const double2* __restrict__ tables, int tab_stride,
+                                                                  int n_chains, long long chunk,
+                                                                  double* __restrict__ partials) {
+    extern __shared__ double2 lds[];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int chain0 = blockIdx.y * CB;
+    const int nvalid = min(CB, n_chains - chain0);
+
+    // stage the CB tables (16-byte loads, contiguous in global memory)
+    {
+        const double2* src = tables + (size_t)chain0 * tab_stride;
+        const int n_valid_entries = nvalid * tab_stride;
+        for (int i = tid; i < CB * tab_stride; i += LR_SCAN_THREADS)
+            lds[i] = (i < n_valid_entries) ? src[i] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+
+    double acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = 0.0;
+
+    const long long start = (long long)tile * chunk;
+    const long long end = min(start + chunk, n);
+    const double nb1 = (double)(n_bins + 1);
+    const int nb2 = n_bins + 2;
+    const bool aligned = ((((uintptr_t)ts) | ((uintptr_t)te)) & 15) == 0;  // chunk is even, so start is
+    if (aligned) {
+        for (long long i = start + 2 * tid; i < end; i += 2 * LR_SCAN_THREADS) {
+            if (i + 1 < end) {
+                const double2 s2 = *reinterpret_cast<const double2*>(ts + i);
+                const double2 e2 = *reinterpret_cast<const double2*>(te + i);
+                lr_score_lineage<CB>(s2.x, e2.x, t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
+                lr_score_lineage<CB>(s2.y, e2.y, t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
+            } else {
+                lr_score_lineage<CB>(ts[i], te[i], t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
+            }
+        }
+    } else {
+        // same lineage -> thread assignment as the aligned path (identical summation order)
+        for (long long i = start + 2 * tid; i < end; i += 2 * LR_SCAN_THREADS) {
+            lr_score_lineage<CB>(ts[i], te[i], t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
+            if (i + 1 < end)
+                lr_score_lineage<CB>(ts[i + 1], te[i + 1], t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
+        }
+    }
+
+    // lane -> wave -> block, fixed order
+    __syncthreads();  // everyone is done reading the tables: reuse the start of LDS as scratch
+    double* red = reinterpret_cast<double*>(lds);
+    const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const double w = lr_wave_sum(acc[c]);
+        if (lane == 0) red[wave * CB + c] = w;
+    }
+    __syncthreads();
+    if (tid < nvalid) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < LR_SCAN_THREADS / LR_WAVE; ++w) t += red[w * CB + tid];
+        partials[(size_t)tile * n_chains + chain0 + tid] = t;
+    }
+}
+
+__global__ void lr_reduce_partials_kernel(const double* __restrict__ partials, const double* __restrict__ consts,
+                                          int tiles, int n_chains, double* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    double t = 0.0;
+    for (int k = 0; k < tiles; ++k) t += partials[(size_t)k * n_chains + c];
+    out[c] = t + consts[c];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan* p) {
+    if (n < 1 || n_chains < 1) return LR_ERR_SIZE;
+    if (n_bins < 1 || n_bins > LR_MAX_BINS) return LR_ERR_SIZE;
+    if (model < 0 || model > 3) return LR_ERR_MODEL;
+    p->n_cls = (model == LR_MODEL_KEIDING_DEAD) ? 2 : 1;
+    p->tab_stride = lr_table_stride(n_bins, p->n_cls);
+    const size_t per_chain = (size_t)p->tab_stride * sizeof(double2);
+    int cb = 8;
+    while (cb > 1 && per_chain * cb > LR_SCAN_LDS_BUDGET) cb >>= 1;
+    if (per_chain * cb > LR_SCAN_LDS_MAX) return LR_ERR_SIZE;
+    while (cb > 1 && cb / 2 >= n_chains) cb >>= 1;  // do not carry empty chain slots
+    p->cb = cb;
+    p->groups = (n_chains + cb - 1) / cb;
+    if (p->groups > 65535) return LR_ERR_SIZE;
+    const long long unit = 2 * LR_SCAN_THREADS;
+    long long tiles = (2048 + p->groups - 1) / p->groups;
+    const long long max_tiles = (n + 4 * unit - 1) / (4 * unit);  // >= 8 lineages per thread
+    if (tiles > max_tiles) tiles = max_tiles;
+    if (tiles < 1) tiles = 1;
+    long long chunk = lr_align_up64((n + tiles - 1) / tiles, unit);
+    tiles = (n + chunk - 1) / chunk;
+    p->tiles = (int)tiles;
+    p->chunk = chunk;
+    size_t lds = per_chain * cb;
+    const size_t red = sizeof(double) * (LR_SCAN_THREADS / LR_WAVE) * cb;
+    if (lds < red) lds = red;
+    p->lds_bytes = lds;
+    return LR_OK;
+}
+
+template <int CB>
+static int lr_launch_scan_cb(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0,
+                             int n_bins, double end_time, const double2* tables, int n_chains, double* partials,
+                             hipStream_t stream) {
+    static size_t configured = 64 * 1024;
+    if (p.lds_bytes > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_scan_kernel<CB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        configured = p.lds_bytes;
+    }
+    dim3 grid(p.tiles, p.groups);
+    hipLaunchKernelGGL(lr_scan_kernel<CB>, grid, dim3(LR_SCAN_THREADS), p.lds_bytes, stream, ts, te, n, t0, n_bins,
+                       p.n_cls, end_time, tables, p.tab_stride, n_chains, p.chunk, partials);
+    return (int)hipGetLastError();
+}
+
+int lr_launch_scan(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0, int n_bins,
+                   double end_time, const double2* tables, int n_chains, double* partials, hipStream_t stream) {
+    switch (p.cb) {
+        case 8: return lr_launch_scan_cb<8>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
+        case 4: return lr_launch_scan_cb<4>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
+        case 2: return lr_launch_scan_cb<2>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
+        default: return lr_launch_scan_cb<1>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
+    }
+}
+
+// workspace layout of lr_bd_loglik_batch: [tables | consts | partials], each 256-byte aligned
+static void lr_loglik_ws(const lr_scan_plan& p, int n_chains, size_t* off_tables, size_t* off_consts,
+                         size_t* off_partials, size_t* total) {
+    size_t o = 0;
+    *off_tables = o, o += lr_align_up64((long long)n_chains * p.tab_stride * sizeof(double2), 256);
+    *off_consts = o, o += lr_align_up64((long long)n_chains * sizeof(double), 256);
+    *off_partials = o, o += lr_align_up64((long long)p.tiles * n_chains * sizeof(double), 256);
+    *total = o;
+}
+
+extern "C" int64_t lr_bd_loglik_workspace_bytes(int64_t n, int32_t n_bins, int32_t n_chains, int32_t model) {
+    lr_scan_plan p;
+    const int rc = lr_plan_scan(n, n_chains, n_bins, model, &p);
+    if (rc != LR_OK) return rc;
+    size_t a, b, c, total;
+    lr_loglik_ws(p, n_chains, &a, &b, &c, &total);
+    return (int64_t)total;
+}
+
+extern "C" int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n, double t0, int32_t n_bins,
+                                  const double* lam_bins, const double* mu_bins, int32_t n_chains, int32_t model,
+                                  const double* br_length, double end_time, double* out_loglik, void* workspace,
+                                  int64_t workspace_bytes, void* stream_) {
+    if (!ts || !te || !lam_bins || !mu_bins || !out_loglik || !workspace) return LR_ERR_NULL;
+    if ((model == LR_MODEL_BD || model == LR_MODEL_ID) && !br_length) return LR_ERR_MODEL;
+    if (t0 != floor(t0)) return LR_ERR_T0;
+    lr_scan_plan p;
+    int rc = lr_plan_scan(n, n_chains, n_bins, model, &p);
+    if (rc != LR_OK) return rc;
+    size_t o_tab, o_cst, o_par, total;
+    lr_loglik_ws(p, n_chains, &o_tab, &o_cst, &o_par, &total);
+    if ((int64_t)total > workspace_bytes) return LR_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    double2* tables = (double2*)(ws + o_tab);
+    double* consts = (double*)(ws + o_cst);
+    double* partials = (double*)(ws + o_par);
+    hipLaunchKernelGGL(lr_build_tables_kernel, dim3(n_chains), dim3(LR_WAVE), 0, stream, lam_bins, mu_bins, br_length,
+                       model, n_bins, p.n_cls, p.tab_stride, tables, consts);
+    rc = (int)hipGetLastError();
+    if (rc) return rc;
+    rc = lr_launch_scan(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lr_reduce_partials_kernel, dim3((n_chains + 255) / 256), dim3(256), 0, stream, partials, consts,
+                       p.tiles, n_chains, out_loglik);
+    return (int)hipGetLastError();
+}

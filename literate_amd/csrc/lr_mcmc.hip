@@ -1,0 +1,607 @@
+// lr_mcmc.hip - proposal scorers with explicit draws (A7/A8/A10) and the fused multi-chain
+// RJMCMC engine (A11: runMCMC, LiteRateForward.py:216-373).
+//
+// Engine iteration = [lr_scan_kernel over all lineages x all chains] -> [lr_chain_step_kernel:
+// one wave per chain: reduce the tile partials in order, Metropolis-Hastings accept, write the
+// trace row, draw the next proposal from the chain's Philox stream, build its lookup tables].
+// Iterations are captured in a hipGraph so the host only replays it.
+#include <new>
+
+#include "lr_chain.h"
+#include "lr_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// explicit-draw scorers (parity with reference-generated vectors)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LR_WAVE) void lr_rj_propose_score_kernel(
+    const double* __restrict__ rates, const double* __restrict__ times, const int* __restrict__ K, int kmax,
+    const int* __restrict__ move, const int* __restrict__ index, const double* __restrict__ draws, double mult_d,
+    double* __restrict__ out_rates, double* __restrict__ out_times, int* __restrict__ out_K,
+    double* __restrict__ out_score) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    int k = K[c];
+    double R = (lane < k) ? rates[(size_t)c * kmax + lane] : 0.0;
+    double T = (lane <= k) ? times[(size_t)c * (kmax + 1) + lane] : 0.0;
+    const double* dr = draws + (size_t)c * 2 * kmax;
+    const int mv = move[c];
+    double score = 0.0;
+    if (mv == 0) {
+        const bool ff = (lane < k) ? (dr[lane] != 0.0) : false;
+        const double u = (lane < k) ? dr[kmax + lane] : 0.5;
+        score = lr_wave_multiplier(R, k, ff, u, mult_d, lane);
+    } else if (mv == 1) {
+        score = lr_wave_add_shift(R, T, k, index[c], dr[0], dr[1], lane);
+    } else if (mv == 2) {
+        score = lr_wave_remove_shift(R, T, k, index[c], lane);
+    }
+    if (lane < kmax) out_rates[(size_t)c * kmax + lane] = (lane < k) ? R : 0.0;
+    if (lane <= kmax) out_times[(size_t)c * (kmax + 1) + lane] = (lane <= k) ? T : 0.0;
+    if (lane == 0) out_K[c] = k, out_score[c] = score;
+}
+
+extern "C" int lr_rj_propose_score(const double* rates, const double* times, const int32_t* K, int32_t kmax,
+                                   int32_t n_chains, const int32_t* move, const int32_t* index, const double* draws,
+                                   double mult_d, double* out_rates, double* out_times, int32_t* out_K,
+                                   double* out_score, void* stream_) {
+    if (!rates || !times || !K || !move || !index || !draws || !out_rates || !out_times || !out_K || !out_score)
+        return LR_ERR_NULL;
+    // an add needs room for K+1 rates: kmax must leave it (caller pads), and a wave holds 64 lanes
+    if (kmax < 2 || kmax > LR_WAVE - 1 || n_chains < 1) return LR_ERR_SIZE;
+    hipLaunchKernelGGL(lr_rj_propose_score_kernel, dim3(n_chains), dim3(LR_WAVE), 0, (hipStream_t)stream_, rates, times,
+                       K, kmax, move, index, draws, mult_d, out_rates, out_times, out_K, out_score);
+    return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(LR_WAVE) void lr_log_priors_kernel(const double* __restrict__ rates,
+                                                                const int* __restrict__ K, int kmax, double shape,
+                                                                const double* __restrict__ gamma_rate,
+                                                                const double* __restrict__ poi_rate,
+                                                                double* __restrict__ out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int k = K[c];
+    const double R = (lane < k) ? rates[(size_t)c * kmax + lane] : 1.0;
+    double p = lr_wave_prior_gamma(R, k, shape, gamma_rate[c], lane);
+    if (poi_rate) p += lr_wave_poisson_prior(k, poi_rate[c], lane);
+    if (lane == 0) out[c] = p;
+}
+
+extern "C" int lr_log_priors(const double* rates, const int32_t* K, int32_t kmax, int32_t n_chains, double shape,
+                             const double* gamma_rate, const double* poi_rate, double* out, void* stream_) {
+    if (!rates || !K || !gamma_rate || !out) return LR_ERR_NULL;
+    if (kmax < 1 || kmax > LR_WAVE - 1 || n_chains < 1) return LR_ERR_SIZE;
+    hipLaunchKernelGGL(lr_log_priors_kernel, dim3(n_chains), dim3(LR_WAVE), 0, (hipStream_t)stream_, rates, K, kmax,
+                       shape, gamma_rate, poi_rate, out);
+    return (int)hipGetLastError();
+}
+
+// debug/parity hook for the RNG: out[i] = draw kind[i] at (it[i], purpose[i], idx[i]) of chain stream
+//   kind 0: u_a   1: u_b   2: normal   3: gamma(shape[i])
+__global__ void lr_debug_draws_kernel(uint32_t seed, uint32_t chain, const long long* it, const int* purpose,
+                                      const int* idx, const int* kind, const double* shape, int n, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    lr_stream s{seed, chain};
+    const uint64_t t = (uint64_t)it[i];
+    double v;
+    switch (kind[i]) {
+        case 0: v = lr_pair(s, t, purpose[i], idx[i]).a; break;
+        case 1: v = lr_pair(s, t, purpose[i], idx[i]).b; break;
+        case 2: v = lr_normal(s, t, purpose[i], idx[i]); break;
+        default: v = lr_gamma(s, t, purpose[i], idx[i], shape[i]); break;
+    }
+    out[i] = v;
+}
+
+extern "C" int lr_debug_draws(uint64_t seed, int64_t chain, const int64_t* it, const int32_t* purpose,
+                              const int32_t* idx, const int32_t* kind, const double* shape, int32_t n, double* out,
+                              void* stream_) {
+    if (!it || !purpose || !idx || !kind || !shape || !out) return LR_ERR_NULL;
+    hipLaunchKernelGGL(lr_debug_draws_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream_, (uint32_t)seed,
+                       (uint32_t)chain, (const long long*)it, purpose, idx, kind, shape, n, out);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// the engine
+// ------------------------------------------------------------------------------------------
+struct lr_engine {
+    lr_mcmc_config cfg;
+    lr_mcmc_layout lay;
+    lr_scan_plan plan;
+    const double* ts;
+    const double* te;
+    const double* br_length;
+    char* ws;
+    bool initialised;
+    hipGraphExec_t graph_exec;
+    int graph_iters;
+    hipStream_t graph_stream;
+};
+
+struct lr_step_args {
+    lr_mcmc_config cfg;
+    double* state_f64;
+    int* state_i32;
+    double* rate_bins;
+    double2* tables;
+    const double* partials;
+    double* trace;
+    const double* br_length;
+    int tab_stride, n_cls, tiles;
+};
+
+__device__ __forceinline__ double lr_bcast(double v, int src) { return __shfl(v, src, LR_WAVE); }
+__device__ __forceinline__ int lr_bcast_i(int v, int src) { return __shfl(v, src, LR_WAVE); }
+
+// expand K segment rates to unit bins through LDS-staged edges (get_rate_index + L[indL], LRF:125-135, 306)
+__device__ inline void lr_wave_expand(double R, int E, int K, int n_bins, double* __restrict__ out, double* s_rate,
+                                      int* s_edge, int lane) {
+    if (lane < LR_KMAX) s_rate[lane] = R;
+    if (lane <= LR_KMAX) s_edge[lane] = E;
+    __syncthreads();
+    const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
+    const int b0 = lane * P, b1 = min(b0 + P, n_bins);
+    int seg = 0;
+    for (int b = b0; b < b1; ++b) {
+        while (seg + 1 < K && s_edge[seg + 1] <= b) ++seg;
+        out[b] = s_rate[seg];
+    }
+    __syncthreads();
+}
+
+// mode: 0 = regular step (accept pending proposal, then propose), 1 = finish init (adopt the
+// evaluated initial state as accepted, then propose iteration 0)
+__global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, int mode) {
+    __shared__ double s_rate[LR_KMAX];
+    __shared__ int s_edge[LR_KMAX + 1];
+    const lr_mcmc_config& cfg = a.cfg;
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int C = cfg.n_chains, n_bins = cfg.n_bins;
+    double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
+    int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+    double* rb = a.rate_bins + (size_t)c * 4 * n_bins;
+    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
+
+    // ---- load state: lane j holds element j ----
+    double L = S[LR_ROW_L * LR_ROW + lane], M = S[LR_ROW_M * LR_ROW + lane];
+    double tL = S[LR_ROW_TL * LR_ROW + lane], tM = S[LR_ROW_TM * LR_ROW + lane];
+    const double pL0 = S[LR_ROW_PL * LR_ROW + lane], pM0 = S[LR_ROW_PM * LR_ROW + lane];
+    const double ptL0 = S[LR_ROW_PTL * LR_ROW + lane], ptM0 = S[LR_ROW_PTM * LR_ROW + lane];
+    const double sc = S[LR_ROW_SCALARS * LR_ROW + lane];
+    int eL = I[LR_IROW_EL * LR_ROW + lane], eM = I[LR_IROW_EM * LR_ROW + lane];
+    const int peL0 = I[LR_IROW_PEL * LR_ROW + lane], peM0 = I[LR_IROW_PEM * LR_ROW + lane];
+    const int isc = I[LR_IROW_SCALARS * LR_ROW + lane];
+    double likA = lr_bcast(sc, LR_S_LIKA), priorA = lr_bcast(sc, LR_S_PRIORA);
+    double priorPoiA = lr_bcast(sc, LR_S_PRIORPOIA);
+    double g0 = lr_bcast(sc, LR_S_GRATE_L), g1 = lr_bcast(sc, LR_S_GRATE_M), poi = lr_bcast(sc, LR_S_POI);
+    double constA = lr_bcast(sc, LR_S_CONST_A);
+    int KL = lr_bcast_i(isc, LR_I_KL), KM = lr_bcast_i(isc, LR_I_KM);
+    uint64_t it = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_HI) << 32);
+    int n_acc = lr_bcast_i(isc, LR_I_ACCEPTED);
+
+    // ---- log-likelihood of the pending proposal: tile partials in tile order ----
+    double part = 0.0;
+    for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * C + c];
+    const double lik_sum = lr_wave_sum(part);
+
+    const double T_span = cfg.end_time - cfg.start_time;
+    if (mode == 1) {
+        // LRF:224-230.  The initial prior uses prior_gamma's default rate b=2 (LRF:201, 227).
+        likA = lik_sum + constA;
+        priorA = lr_wave_prior_gamma(L, KL, LR_GAMMA_SHAPE, 2.0, lane) + lr_wave_prior_gamma(M, KM, LR_GAMMA_SHAPE, 2.0, lane);
+        priorA += -log(T_span) * (KL - 1 + KM - 1);
+        priorPoiA = lr_wave_poisson_prior(KL, poi, lane) + lr_wave_poisson_prior(KM, poi, lane);
+        priorA += priorPoiA;
+    } else {
+        // ---- Metropolis-Hastings accept of iteration `it` (LRF:305-319) ----
+        const int gibbs = lr_bcast_i(isc, LR_I_GIBBS), invalid = lr_bcast_i(isc, LR_I_INVALID);
+        const double hasting = lr_bcast(sc, LR_S_HASTING), priorP = lr_bcast(sc, LR_S_PRIOR_P);
+        const double priorPoiP = lr_bcast(sc, LR_S_PRIORPOI_P), constP = lr_bcast(sc, LR_S_CONST_P);
+        const double lik = gibbs ? likA : lik_sum + constP;
+        const double u = lr_pair(rng, it, LR_P_ACCEPT, 0).a;
+        const bool ok = gibbs || (!invalid && (lik - likA + priorP - priorA + hasting >= log(u)));
+        if (lane == LR_S_LIK_P) S[LR_ROW_SCALARS * LR_ROW + lane] = invalid ? -INFINITY : lik;
+        if (ok) {
+            L = pL0, M = pM0, tL = ptL0, tM = ptM0, eL = peL0, eM = peM0;
+            KL = lr_bcast_i(isc, LR_I_PKL), KM = lr_bcast_i(isc, LR_I_PKM);
+            likA = lik, priorA = priorP, priorPoiA = priorPoiP, constA = constP;
+            n_acc += 1;
+            for (int b = lane; b < n_bins; b += LR_WAVE) rb[b] = rb[2 * n_bins + b], rb[n_bins + b] = rb[3 * n_bins + b];
+        }
+        // ---- trace row (LRF:321-359) ----
+        if (it % (uint64_t)cfg.s_freq == 0) {
+            const uint64_t slot = it / (uint64_t)cfg.s_freq;
+            if (slot < (uint64_t)cfg.n_trace_slots) {
+                double* row = a.trace + ((size_t)slot * C + c) * LR_TRACE_W;
+                const double meanL = lr_wave_sum(lane < KL ? L : 0.0) / KL;
+                const double meanM = lr_wave_sum(lane < KM ? M : 0.0) / KM;
+                double h = 0.0;
+                switch (lane) {
+                    case 0: h = (double)it; break;
+                    case 1: h = likA + priorA; break;
+                    case 2: h = likA; break;
+                    case 3: h = priorA; break;
+                    case 4: h = meanL; break;
+                    case 5: h = meanM; break;
+                    case 6: h = KL; break;
+                    case 7: h = KM; break;
+                    case 8: h = cfg.start_time; break;
+                    case 9: h = cfg.end_time; break;
+                    case 10: h = g0; break;
+                    case 11: h = g1; break;
+                    case 12: h = poi; break;
+                }
+                if (lane < LR_TRACE_HEAD) row[lane] = h;
+                const double nan = __longlong_as_double(0x7ff8000000000000LL);
+                double* rl = row + LR_TRACE_HEAD;
+                double* rm = rl + (2 * LR_KMAX - 1);
+                if (lane < LR_KMAX) rl[lane] = lane < KL ? L : nan, rm[lane] = lane < KM ? M : nan;
+                if (lane >= 1 && lane < LR_KMAX) {
+                    rl[LR_KMAX + lane - 1] = lane < KL ? tL : nan;
+                    rm[LR_KMAX + lane - 1] = lane < KM ? tM : nan;
+                }
+            }
+        }
+        it += 1;
+    }
+
+    // ---- propose iteration `it` (LRF:234-287) ----
+    double pL = L, pM = M, ptL = tL, ptM = tM;
+    int peL = eL, peM = eM, PKL = KL, PKM = KM;
+    double hasting = 0.0, priorPoi = 0.0;
+    int gibbs = 0, invalid = 0, move_kind;
+    const double sample_shift_mu = cfg.const_death_rate ? 0.0 : 0.5;
+    const double b_freq = cfg.const_death_rate ? 0.7 : 0.4, d_freq = 0.8;
+    const double fL = cfg.update_fraction, fM = cfg.const_death_rate ? 1.0 : cfg.update_fraction;
+    const lr_u2 r = lr_pair(rng, it, LR_P_MOVE, 0);
+    if (r.a < b_freq) {
+        if (r.b < .5 || KL == 1) {
+            const lr_u2 d = lr_pair(rng, it, LR_P_MULT, lane);
+            hasting = lr_wave_multiplier(pL, KL, d.a < fL, d.b, LR_MULT_D, lane);
+            move_kind = 0;
+        } else {
+            peL = lr_wave_edges(tL, 0);  // update_times leaves the times unchanged (LRF:178-195)
+            move_kind = 1;
+        }
+    } else if (r.a < d_freq) {
+        if (r.b < .5 || KM == 1) {
+            const lr_u2 d = lr_pair(rng, it, LR_P_MULT, lane);
+            hasting = lr_wave_multiplier(pM, KM, d.a < fM, d.b, LR_MULT_D, lane);
+            move_kind = 2;
+        } else {
+            peM = lr_wave_edges(tM, 0);
+            move_kind = 3;
+        }
+    } else if (r.a < 0.999 && cfg.const_rates == 0) {
+        // RJMCMC (LRF:71-97)
+        move_kind = 4;
+        const lr_u2 q = lr_pair(rng, it, LR_P_RJ, 0);
+        const bool sideL = q.a > sample_shift_mu;
+        double R = sideL ? L : M, T = sideL ? tL : tM;
+        int K = sideL ? KL : KM;
+        double score = 0.0;
+        const lr_u2 q2 = lr_pair(rng, it, LR_P_RJ, 1);
+        if (q.b > 0.5) {
+            if (K >= LR_KMAX) {
+                invalid = 1;  // device cap on the number of rates; the reference has none
+            } else {
+                const int ind = min((int)(q2.a * K), K - 1);
+                const double delta = q2.b * (lr_bcast(T, ind + 1) - lr_bcast(T, ind));
+                const double ga = lr_gamma(rng, it, LR_P_BETA_A, 0, LR_SHAPE_BETA_RJ);
+                const double gb = lr_gamma(rng, it, LR_P_BETA_B, 0, LR_SHAPE_BETA_RJ);
+                score = lr_wave_add_shift(R, T, K, ind, delta, ga / (ga + gb), lane);
+            }
+        } else if (K > 1) {
+            const int idx = 1 + min((int)(q2.a * (K - 1)), K - 2);
+            score = lr_wave_remove_shift(R, T, K, idx, lane);
+        }
+        hasting = score;
+        const int E = lr_wave_edges(T, 0);
+        if (sideL) pL = R, ptL = T, PKL = K, peL = E;
+        else pM = R, ptM = T, PKM = K, peM = E;
+        priorPoi = lr_wave_poisson_prior(PKL, poi, lane) + lr_wave_poisson_prior(PKM, poi, lane);
+    } else {
+        // Gibbs draws of the hyper-parameters (LRF:283-287, 99-108, 210-213)
+        move_kind = 5;
+        if (cfg.poisson_HP == 0.0)
+            poi = lr_gamma(rng, it, LR_P_GIBBS_POI, 0, LR_RJHP_SHAPE + KL + KM) * (1. / (LR_RJHP_RATE + 2));
+        if (cfg.use_rate_HP) {
+            const double sL = lr_wave_sum(lane < KL ? L : 0.0), sM = lr_wave_sum(lane < KM ? M : 0.0);
+            g0 = lr_gamma(rng, it, LR_P_GIBBS_L, 0, LR_HP_GAMMA_SHAPE + LR_GAMMA_SHAPE * KL) * (1. / (LR_HP_GAMMA_RATE + sL));
+            g1 = lr_gamma(rng, it, LR_P_GIBBS_M, 0, LR_HP_GAMMA_SHAPE + LR_GAMMA_SHAPE * KM) * (1. / (LR_HP_GAMMA_RATE + sM));
+        }
+        gibbs = 1;
+    }
+
+    // guard against tiny time frames (LRF:290-292) and the prior of the proposal (LRF:296-304)
+    double priorP = -INFINITY;
+    if (lr_wave_min_segment(ptL, PKL, lane) <= LR_MIN_ALLOWED_T || lr_wave_min_segment(ptM, PKM, lane) <= LR_MIN_ALLOWED_T)
+        invalid = 1;
+    if (!invalid) {
+        priorP = lr_wave_prior_gamma(pL, PKL, LR_GAMMA_SHAPE, g0, lane) + lr_wave_prior_gamma(pM, PKM, LR_GAMMA_SHAPE, g1, lane);
+        priorP += -log(T_span) * (PKL - 1 + PKM - 1);
+        if (priorPoi != 0.0) priorP += priorPoi;
+        else priorP += priorPoiA, priorPoi = priorPoiA;
+    }
+
+    // ---- per-bin rates and lookup tables of the proposal ----
+    if (mode == 1) {
+        // accepted per-bin rates of the initial state were written by lr_chain_init_kernel
+    }
+    lr_wave_expand(pL, peL, PKL, n_bins, rb + 2 * n_bins, s_rate, s_edge, lane);
+    lr_wave_expand(pM, peM, PKM, n_bins, rb + 3 * n_bins, s_rate, s_edge, lane);
+    __threadfence_block();
+    const double constP = lr_build_tables_wave(rb + 2 * n_bins, rb + 3 * n_bins, a.br_length, cfg.model, n_bins, a.n_cls,
+                                               a.tables + (size_t)c * a.tab_stride, lane);
+
+    // ---- store ----
+    S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
+    S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
+    S[LR_ROW_PL * LR_ROW + lane] = pL, S[LR_ROW_PM * LR_ROW + lane] = pM;
+    S[LR_ROW_PTL * LR_ROW + lane] = ptL, S[LR_ROW_PTM * LR_ROW + lane] = ptM;
+    I[LR_IROW_EL * LR_ROW + lane] = eL, I[LR_IROW_EM * LR_ROW + lane] = eM;
+    I[LR_IROW_PEL * LR_ROW + lane] = peL, I[LR_IROW_PEM * LR_ROW + lane] = peM;
+    double so;
+    bool wr = true;
+    switch (lane) {
+        case LR_S_LIKA: so = likA; break;
+        case LR_S_PRIORA: so = priorA; break;
+        case LR_S_PRIORPOIA: so = priorPoiA; break;
+        case LR_S_GRATE_L: so = g0; break;
+        case LR_S_GRATE_M: so = g1; break;
+        case LR_S_POI: so = poi; break;
+        case LR_S_HASTING: so = hasting; break;
+        case LR_S_PRIOR_P: so = priorP; break;
+        case LR_S_PRIORPOI_P: so = priorPoi; break;
+        case LR_S_CONST_P: so = constP; break;
+        case LR_S_CONST_A: so = constA; break;
+        default: so = 0.0, wr = false; break;
+    }
+    if (wr) S[LR_ROW_SCALARS * LR_ROW + lane] = so;
+    int io;
+    wr = true;
+    switch (lane) {
+        case LR_I_KL: io = KL; break;
+        case LR_I_KM: io = KM; break;
+        case LR_I_PKL: io = PKL; break;
+        case LR_I_PKM: io = PKM; break;
+        case LR_I_GIBBS: io = gibbs; break;
+        case LR_I_INVALID: io = invalid; break;
+        case LR_I_IT_LO: io = (int)(uint32_t)it; break;
+        case LR_I_IT_HI: io = (int)(uint32_t)(it >> 32); break;
+        case LR_I_ACCEPTED: io = n_acc; break;
+        case LR_I_MOVE: io = move_kind; break;
+        default: io = 0, wr = false; break;
+    }
+    if (wr) I[LR_IROW_SCALARS * LR_ROW + lane] = io;
+}
+
+// initial state (LRF:580-583 or the caller's runMCMC argument) -> state rows, per-bin rates,
+// tables of the initial state (so that the first scan evaluates likA, LRF:224-226)
+__global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, const double* L0, const double* M0,
+                                                                const double* tL0, const double* tM0,
+                                                                const int* KL0, const int* KM0, int kmax) {
+    __shared__ double s_rate[LR_KMAX];
+    __shared__ int s_edge[LR_KMAX + 1];
+    const lr_mcmc_config& cfg = a.cfg;
+    const int c = blockIdx.x, lane = threadIdx.x, n_bins = cfg.n_bins;
+    double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
+    int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+    double* rb = a.rate_bins + (size_t)c * 4 * n_bins;
+    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
+    double L = 0.0, M = 0.0, tL = 0.0, tM = 0.0;
+    int KL = 1, KM = 1;
+    if (L0) {
+        KL = KL0[c], KM = KM0[c];
+        if (lane < KL) L = L0[(size_t)c * kmax + lane];
+        if (lane < KM) M = M0[(size_t)c * kmax + lane];
+        if (lane <= KL) tL = tL0[(size_t)c * (kmax + 1) + lane];
+        if (lane <= KM) tM = tM0[(size_t)c * (kmax + 1) + lane];
+    } else {
+        const double l0 = lr_gamma(rng, 0, LR_P_INIT, 0, 2.0) * 2.0;   // np.random.gamma(2,2,1), LRF:580
+        const double m0 = lr_gamma(rng, 0, LR_P_INIT, 64, 2.0) * 2.0;  // LRF:581
+        if (lane == 0) L = l0, M = m0, tL = tM = cfg.start_time;
+        if (lane == 1) tL = tM = cfg.end_time;
+    }
+    // the initial index comes from get_rate_index on the RAW times: round, not floor (LRF:224-225, 129)
+    const int eL = lr_wave_edges(tL, 1), eM = lr_wave_edges(tM, 1);
+    lr_wave_expand(L, eL, KL, n_bins, rb, s_rate, s_edge, lane);
+    lr_wave_expand(M, eM, KM, n_bins, rb + n_bins, s_rate, s_edge, lane);
+    __threadfence_block();
+    const double constA = lr_build_tables_wave(rb, rb + n_bins, a.br_length, cfg.model, n_bins, a.n_cls,
+                                               a.tables + (size_t)c * a.tab_stride, lane);
+    S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
+    S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
+    S[LR_ROW_PL * LR_ROW + lane] = L, S[LR_ROW_PM * LR_ROW + lane] = M;
+    S[LR_ROW_PTL * LR_ROW + lane] = tL, S[LR_ROW_PTM * LR_ROW + lane] = tM;
+    I[LR_IROW_EL * LR_ROW + lane] = eL, I[LR_IROW_EM * LR_ROW + lane] = eM;
+    I[LR_IROW_PEL * LR_ROW + lane] = eL, I[LR_IROW_PEM * LR_ROW + lane] = eM;
+    double so = 0.0;
+    if (lane == LR_S_GRATE_L || lane == LR_S_GRATE_M) so = 1.0;                       // LRF:222
+    if (lane == LR_S_POI) so = (cfg.poisson_HP == 0.0) ? 1.0 : cfg.poisson_HP;         // LRF:220-221
+    if (lane == LR_S_CONST_A || lane == LR_S_CONST_P) so = constA;
+    S[LR_ROW_SCALARS * LR_ROW + lane] = so;
+    int io = 0;
+    if (lane == LR_I_KL || lane == LR_I_PKL) io = KL;
+    if (lane == LR_I_KM || lane == LR_I_PKM) io = KM;
+    I[LR_IROW_SCALARS * LR_ROW + lane] = io;
+}
+
+// ---- host -------------------------------------------------------------------------------
+static int lr_check_cfg(const lr_mcmc_config* cfg) {
+    if (!cfg) return LR_ERR_NULL;
+    if (cfg->n_lineages < 1 || cfg->n_chains < 1 || cfg->s_freq < 1 || cfg->n_trace_slots < 0) return LR_ERR_SIZE;
+    if (cfg->n_bins < 1 || cfg->n_bins > LR_MAX_BINS) return LR_ERR_SIZE;
+    if (cfg->model < 0 || cfg->model > 3) return LR_ERR_MODEL;
+    if (cfg->t0 != floor(cfg->t0)) return LR_ERR_T0;
+    if (!(cfg->end_time > cfg->start_time)) return LR_ERR_SIZE;
+    return LR_OK;
+}
+
+extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* out) {
+    int rc = lr_check_cfg(cfg);
+    if (rc) return rc;
+    if (!out) return LR_ERR_NULL;
+    lr_scan_plan p;
+    rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, &p);
+    if (rc) return rc;
+    const long long C = cfg->n_chains;
+    long long o = 0;
+    out->state_f64 = o, o += lr_align_up64(C * LR_STATE_ROWS * LR_ROW * 8, 256);
+    out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
+    out->rate_bins = o, o += lr_align_up64(C * 4 * cfg->n_bins * 8, 256);
+    out->tables = o, o += lr_align_up64(C * p.tab_stride * 16, 256);
+    out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
+    out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
+    out->total_bytes = o;
+    out->table_stride = p.tab_stride;
+    out->tiles = p.tiles;
+    out->chains_per_block = p.cb;
+    out->trace_width = LR_TRACE_W;
+    return LR_OK;
+}
+
+extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const double* te, const double* br_length,
+                              void* workspace, int64_t workspace_bytes, lr_engine** out) {
+    if (!ts || !te || !workspace || !out) return LR_ERR_NULL;
+    lr_mcmc_layout lay;
+    int rc = lr_mcmc_query_layout(cfg, &lay);
+    if (rc) return rc;
+    if ((cfg->model == LR_MODEL_BD || cfg->model == LR_MODEL_ID) && !br_length) return LR_ERR_MODEL;
+    if (lay.total_bytes > workspace_bytes) return LR_ERR_WORKSPACE;
+    lr_engine* e = new (std::nothrow) lr_engine();
+    if (!e) return (int)hipErrorOutOfMemory;
+    e->cfg = *cfg;
+    e->lay = lay;
+    lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, &e->plan);
+    e->ts = ts, e->te = te, e->br_length = br_length;
+    e->ws = (char*)workspace;
+    e->initialised = false;
+    e->graph_exec = nullptr;
+    e->graph_iters = 0;
+    e->graph_stream = nullptr;
+    *out = e;
+    return LR_OK;
+}
+
+static lr_step_args lr_make_args(const lr_engine* e) {
+    lr_step_args a;
+    a.cfg = e->cfg;
+    a.state_f64 = (double*)(e->ws + e->lay.state_f64);
+    a.state_i32 = (int*)(e->ws + e->lay.state_i32);
+    a.rate_bins = (double*)(e->ws + e->lay.rate_bins);
+    a.tables = (double2*)(e->ws + e->lay.tables);
+    a.partials = (const double*)(e->ws + e->lay.partials);
+    a.trace = (double*)(e->ws + e->lay.trace);
+    a.br_length = e->br_length;
+    a.tab_stride = e->plan.tab_stride;
+    a.n_cls = e->plan.n_cls;
+    a.tiles = e->plan.tiles;
+    return a;
+}
+
+static int lr_enqueue_scan(const lr_engine* e, hipStream_t stream) {
+    return lr_launch_scan(e->plan, e->ts, e->te, e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins, e->cfg.end_time,
+                          (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains,
+                          (double*)(e->ws + e->lay.partials), stream);
+}
+
+extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, const double* tL, const double* tM,
+                            const int32_t* KL, const int32_t* KM, int32_t kmax, void* stream_) {
+    if (!e) return LR_ERR_NULL;
+    if (L && (!M || !tL || !tM || !KL || !KM)) return LR_ERR_NULL;
+    if (L && (kmax < 1 || kmax > LR_KMAX)) return LR_ERR_SIZE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const lr_step_args a = lr_make_args(e);
+    hipLaunchKernelGGL(lr_chain_init_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, L, M, tL, tM, KL, KM,
+                       kmax);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    rc = lr_enqueue_scan(e, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lr_chain_step_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, 1);
+    rc = (int)hipGetLastError();
+    if (rc) return rc;
+    e->initialised = true;
+    return LR_OK;
+}
+
+#define LR_GRAPH_ITERS 32
+
+static int lr_enqueue_iteration(const lr_engine* e, const lr_step_args& a, hipStream_t stream) {
+    int rc = lr_enqueue_scan(e, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lr_chain_step_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
+    if (!e) return LR_ERR_NULL;
+    if (!e->initialised) return LR_ERR_STATE;
+    if (n_iters < 0) return LR_ERR_SIZE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const lr_step_args a = lr_make_args(e);
+    int64_t done = 0;
+    if (n_iters >= LR_GRAPH_ITERS) {
+        if (!e->graph_exec) {
+            // capture LR_GRAPH_ITERS iterations once; the kernels read the iteration number from
+            // device memory, so the same graph is valid for every replay
+            hipStream_t cs;
+            hipError_t he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+            if (he != hipSuccess) return (int)he;
+            hipGraph_t graph;
+            he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+            if (he != hipSuccess) return (int)he;
+            int rc = LR_OK;
+            for (int i = 0; i < LR_GRAPH_ITERS && rc == LR_OK; ++i) rc = lr_enqueue_iteration(e, a, cs);
+            he = hipStreamEndCapture(cs, &graph);
+            if (rc) return rc;
+            if (he != hipSuccess) return (int)he;
+            he = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            (void)hipStreamDestroy(cs);
+            if (he != hipSuccess) return (int)he;
+            e->graph_iters = LR_GRAPH_ITERS;
+        }
+        while (n_iters - done >= e->graph_iters) {
+            hipError_t he = hipGraphLaunch(e->graph_exec, stream);
+            if (he != hipSuccess) return (int)he;
+            done += e->graph_iters;
+        }
+    }
+    for (; done < n_iters; ++done) {
+        const int rc = lr_enqueue_iteration(e, a, stream);
+        if (rc) return rc;
+    }
+    return LR_OK;
+}
+
+extern "C" int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms, void* stream_) {
+    if (!e || !avg_ms) return LR_ERR_NULL;
+    if (!e->initialised) return LR_ERR_STATE;
+    if (reps < 1) return LR_ERR_SIZE;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipEvent_t t0, t1;
+    hipError_t he = hipEventCreate(&t0);
+    if (he != hipSuccess) return (int)he;
+    he = hipEventCreate(&t1);
+    if (he != hipSuccess) return (int)he;
+    int rc = lr_enqueue_scan(e, stream);  // warm
+    if (rc == LR_OK) rc = (int)hipEventRecord(t0, stream);
+    for (int i = 0; i < reps && rc == LR_OK; ++i) rc = lr_enqueue_scan(e, stream);
+    if (rc == LR_OK) rc = (int)hipEventRecord(t1, stream);
+    if (rc == LR_OK) rc = (int)hipEventSynchronize(t1);
+    float ms = 0.f;
+    if (rc == LR_OK) rc = (int)hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    *avg_ms = ms / reps;
+    return rc;
+}
+
+extern "C" int lr_mcmc_destroy(lr_engine* e) {
+    if (!e) return LR_ERR_NULL;
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    delete e;
+    return LR_OK;
+}

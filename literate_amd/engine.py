@@ -1,0 +1,166 @@
+"""Multi-chain RJMCMC engine on one GPU: the host mirror of runMCMC (LiteRateForward.py:216-373).
+
+All chain state lives in one torch uint8 workspace in HBM whose layout the C ABI reports
+(lr_mcmc_query_layout); this class only creates views on it and calls lr_mcmc_*.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _hip, ops
+
+
+class ChainEngine:
+    def __init__(self, ts, te, n_chains, model=0, seed=1, const_rates=0, const_death_rate=0, use_rate_HP=1,
+                 poisson_HP=0.0, update_fraction=0.75, s_freq=1000, n_trace_slots=0, chain_offset=0,
+                 device=None, stats=None):
+        """ts/te: lineage birth/death times (death_jitter already added, LRF:471).
+
+        stats: optional (t0, n_bins, br_length) if the caller already binned the data; otherwise the
+        binning kernel runs here (LRF:515-523)."""
+        torch = _hip.require_gpu()
+        self.lib = _hip.load()
+        self.device = torch.device(device or "cuda")
+        self.ts = ops._dev(ts, torch.float64, self.device)
+        self.te = ops._dev(te, torch.float64, self.device)
+        self.start_time = float(self.ts.min().item())
+        self.end_time = float(self.te.max().item())
+        if stats is None:
+            t0, n_bins = int(self.start_time), int(self.end_time) - int(self.start_time)
+            lo = torch.arange(t0, t0 + n_bins, dtype=torch.float64, device=self.device)
+            self.sp_events, self.ex_events, self.br_length = ops.bin_events(self.ts, self.te, lo, lo + 1.0)
+        else:
+            t0, n_bins, br = stats
+            self.br_length = ops._dev(br, torch.float64, self.device)
+            self.sp_events = self.ex_events = None
+        self.t0, self.n_bins, self.model = float(t0), int(n_bins), int(model)
+        self.cfg = _hip.McmcConfig(
+            n_lineages=self.ts.numel(), n_bins=self.n_bins, n_chains=int(n_chains), model=int(model),
+            const_rates=int(const_rates), const_death_rate=int(const_death_rate), use_rate_HP=int(use_rate_HP),
+            s_freq=int(s_freq), n_trace_slots=int(n_trace_slots), poisson_HP=float(poisson_HP),
+            update_fraction=float(update_fraction), t0=self.t0, start_time=self.start_time, end_time=self.end_time,
+            seed=int(seed), chain_offset=int(chain_offset))
+        self.layout = _hip.McmcLayout()
+        _hip.check(self.lib.lr_mcmc_query_layout(C.byref(self.cfg), C.byref(self.layout)), "lr_mcmc_query_layout")
+        self.workspace = torch.zeros(self.layout.total_bytes, dtype=torch.uint8, device=self.device)
+        handle = C.c_void_p()
+        br_ptr = _hip.ptr(self.br_length) if model in (0, 1) else None
+        _hip.check(self.lib.lr_mcmc_create(C.byref(self.cfg), _hip.ptr(self.ts), _hip.ptr(self.te), br_ptr,
+                                           _hip.ptr(self.workspace), self.workspace.numel(), C.byref(handle)),
+                   "lr_mcmc_create")
+        self.handle = handle
+        self.n_chains = int(n_chains)
+        self.iterations = 0
+
+    # ---- views on the workspace ----
+    def _view(self, off, dtype, shape):
+        torch = _hip.require_gpu()
+        n = int(np.prod(shape))
+        item = torch.empty((), dtype=dtype).element_size()
+        return self.workspace[off:off + n * item].view(dtype).view(*shape)
+
+    @property
+    def state_f64(self):
+        import torch
+        return self._view(self.layout.state_f64, torch.float64, (self.n_chains, _hip.LR_STATE_ROWS, _hip.LR_ROW))
+
+    @property
+    def state_i32(self):
+        import torch
+        return self._view(self.layout.state_i32, torch.int32, (self.n_chains, _hip.LR_ISTATE_ROWS, _hip.LR_ROW))
+
+    @property
+    def rate_bins(self):
+        import torch
+        return self._view(self.layout.rate_bins, torch.float64, (self.n_chains, 4, self.n_bins))
+
+    @property
+    def trace(self):
+        import torch
+        return self._view(self.layout.trace, torch.float64,
+                          (self.cfg.n_trace_slots, self.n_chains, _hip.LR_TRACE_W))
+
+    # ---- control ----
+    def init(self, L=None, M=None, tL=None, tM=None):
+        """Initial state: None = CLI init (K=1, Gamma(2,2) rates; LRF:580-583); else lists/arrays per
+        chain (ragged allowed: pass 2-D arrays padded with anything plus K inferred from times)."""
+        import torch
+        if L is None:
+            rc = self.lib.lr_mcmc_init(self.handle, None, None, None, None, None, None, 0, _hip.stream_ptr())
+        else:
+            kmax = _hip.LR_KMAX
+            Ls = np.zeros((self.n_chains, kmax)); Ms = np.zeros((self.n_chains, kmax))
+            tLs = np.zeros((self.n_chains, kmax + 1)); tMs = np.zeros((self.n_chains, kmax + 1))
+            KL = np.zeros(self.n_chains, dtype=np.int32); KM = np.zeros(self.n_chains, dtype=np.int32)
+            for c in range(self.n_chains):
+                l, m = np.atleast_1d(L[c]), np.atleast_1d(M[c])
+                KL[c], KM[c] = len(l), len(m)
+                Ls[c, :len(l)], Ms[c, :len(m)] = l, m
+                tLs[c, :len(l) + 1], tMs[c, :len(m) + 1] = tL[c], tM[c]
+            dev = [ops._dev(x, torch.float64, self.device) for x in (Ls, Ms, tLs, tMs)]
+            dk = [ops._dev(x, torch.int32, self.device) for x in (KL, KM)]
+            self._init_keep = dev + dk
+            rc = self.lib.lr_mcmc_init(self.handle, *[_hip.ptr(x) for x in dev + dk], kmax, _hip.stream_ptr())
+        _hip.check(rc, "lr_mcmc_init")
+        self.iterations = 0
+
+    def steps(self, n):
+        _hip.check(self.lib.lr_mcmc_steps(self.handle, int(n), _hip.stream_ptr()), "lr_mcmc_steps")
+        self.iterations += int(n)
+
+    def time_scan(self, reps=20):
+        """Average duration (ms) of the lineage-scan kernel, HIP events on the launch stream."""
+        ms = C.c_float(0.0)
+        _hip.check(self.lib.lr_mcmc_time_scan(self.handle, int(reps), C.byref(ms), _hip.stream_ptr()),
+                   "lr_mcmc_time_scan")
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            self.lib.lr_mcmc_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-side snapshots ----
+    def snapshot(self):
+        """Accepted state of every chain as numpy: dict(L, M, tL, tM (lists), likA, priorA, K_l, K_m, ...)."""
+        S = self.state_f64.cpu().numpy()
+        I = self.state_i32.cpu().numpy()
+        KL, KM = I[:, _hip.IROW_SCALARS, _hip.I_KL], I[:, _hip.IROW_SCALARS, _hip.I_KM]
+        sc = S[:, _hip.ROW_SCALARS]
+        return dict(
+            K_l=KL.copy(), K_m=KM.copy(),
+            L=[S[c, _hip.ROW_L, :KL[c]].copy() for c in range(self.n_chains)],
+            M=[S[c, _hip.ROW_M, :KM[c]].copy() for c in range(self.n_chains)],
+            tL=[S[c, _hip.ROW_TL, :KL[c] + 1].copy() for c in range(self.n_chains)],
+            tM=[S[c, _hip.ROW_TM, :KM[c] + 1].copy() for c in range(self.n_chains)],
+            likA=sc[:, _hip.S_LIKA].copy(), priorA=sc[:, _hip.S_PRIORA].copy(),
+            gamma_rate=sc[:, [_hip.S_GRATE_L, _hip.S_GRATE_M]].copy(), poi=sc[:, _hip.S_POI].copy(),
+            accepted=I[:, _hip.IROW_SCALARS, _hip.I_ACCEPTED].copy(),
+            it=(I[:, _hip.IROW_SCALARS, _hip.I_IT_LO].astype(np.int64) & 0xFFFFFFFF)
+               | (I[:, _hip.IROW_SCALARS, _hip.I_IT_HI].astype(np.int64) << 32),
+        )
+
+    def trace_rows(self, n_samples=None):
+        """Trace buffer as numpy [samples, chains, LR_TRACE_W] (see include/literate_hip.h)."""
+        n_avail = min(self.cfg.n_trace_slots, (self.iterations + self.cfg.s_freq - 1) // self.cfg.s_freq)
+        n = n_avail if n_samples is None else min(n_samples, n_avail)
+        return self.trace[:n].cpu().numpy()
+
+
+def split_trace_row(row):
+    """One trace row -> (mcmc head[13], sp_rates row, ex_rates row) in the reference's log layout
+    (LRF:343-359): rates then interior shift times."""
+    K = _hip.LR_KMAX
+    head = row[:_hip.LR_TRACE_HEAD]
+    kl, km = int(head[6]), int(head[7])
+    rl = row[_hip.LR_TRACE_HEAD:_hip.LR_TRACE_HEAD + 2 * K - 1]
+    rm = row[_hip.LR_TRACE_HEAD + 2 * K - 1:]
+    sp = np.concatenate([rl[:kl], rl[K:K + kl - 1]])
+    ex = np.concatenate([rm[:km], rm[K:K + km - 1]])
+    return head, sp, ex

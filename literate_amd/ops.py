@@ -1,0 +1,165 @@
+"""Tensor-level wrappers of the C ABI: torch tensors in HBM in, torch tensors out.
+
+Every function enqueues on torch's current HIP stream and raises if the HIP library or a GPU is
+missing (no CPU path).  Shapes follow include/literate_hip.h.
+"""
+import numpy as np
+
+from . import _hip
+
+_ws_cache = {}
+
+
+def _torch():
+    return _hip.require_gpu()
+
+
+def _dev(x, dtype, device=None):
+    torch = _torch()
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=device or "cuda", dtype=dtype)
+    else:
+        t = torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(device or "cuda")
+    return t.contiguous()
+
+
+def _workspace(nbytes, device):
+    """A reusable byte workspace per device (grown on demand)."""
+    torch = _torch()
+    key = str(device)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def bin_events(ts, te, win_lo, win_hi):
+    """(sp_events int64[W], ex_events int64[W], br_length f64[W]) for windows [lo_w, hi_w]
+    (precompute_events / get_br, lib:74-85, for all windows in one launch)."""
+    torch = _torch()
+    lib = _hip.load()
+    ts, te = _dev(ts, torch.float64), _dev(te, torch.float64)
+    lo, hi = _dev(win_lo, torch.float64), _dev(win_hi, torch.float64)
+    n, w = ts.numel(), lo.numel()
+    if te.numel() != n or hi.numel() != w:
+        raise ValueError("ts/te or window arrays differ in length")
+    sp = torch.empty(w, dtype=torch.int64, device=ts.device)
+    ex = torch.empty(w, dtype=torch.int64, device=ts.device)
+    br = torch.empty(w, dtype=torch.float64, device=ts.device)
+    nbytes = lib.lr_bin_events_workspace_bytes(n, w)
+    if nbytes < 0:
+        _hip.check(int(nbytes), "lr_bin_events_workspace_bytes")
+    ws = _workspace(nbytes, ts.device)
+    rc = lib.lr_bin_events(_hip.ptr(ts), _hip.ptr(te), n, _hip.ptr(lo), _hip.ptr(hi), w, _hip.ptr(sp), _hip.ptr(ex),
+                           _hip.ptr(br), _hip.ptr(ws), ws.numel(), _hip.stream_ptr())
+    _hip.check(rc, "lr_bin_events")
+    return sp, ex, br
+
+
+def expand_rates(rates, times, K, n_bins, mode=0):
+    """[C,n_bins] per-bin rates from K segment rates (get_rate_index + L[ind], LRF:125-135)."""
+    torch = _torch()
+    lib = _hip.load()
+    rates, times = _dev(rates, torch.float64), _dev(times, torch.float64)
+    K = _dev(K, torch.int32)
+    C, kmax = rates.shape
+    if times.shape != (C, kmax + 1) or K.shape != (C,):
+        raise ValueError("shape mismatch: rates [C,kmax], times [C,kmax+1], K [C]")
+    out = torch.empty((C, n_bins), dtype=torch.float64, device=rates.device)
+    rc = lib.lr_expand_rates(_hip.ptr(rates), _hip.ptr(times), _hip.ptr(K), kmax, C, n_bins, mode, _hip.ptr(out),
+                             _hip.stream_ptr())
+    _hip.check(rc, "lr_expand_rates")
+    return out
+
+
+def bd_loglik_batch(ts, te, t0, lam_bins, mu_bins, model=2, br_length=None, end_time=0.0):
+    """out[C]: per-lineage birth-death log-likelihood of C per-bin rate vectors (LRF:137-162,
+    BDIx:124-146).  ts/te are scanned once per group of chains."""
+    torch = _torch()
+    lib = _hip.load()
+    ts, te = _dev(ts, torch.float64), _dev(te, torch.float64)
+    lam, mu = _dev(lam_bins, torch.float64), _dev(mu_bins, torch.float64)
+    if lam.dim() == 1:
+        lam, mu = lam[None, :], mu[None, :]
+    C, n_bins = lam.shape
+    if mu.shape != lam.shape or te.numel() != ts.numel():
+        raise ValueError("shape mismatch")
+    br = None if br_length is None else _dev(br_length, torch.float64)
+    if br is not None and br.numel() != n_bins:
+        raise ValueError("br_length must have n_bins entries")
+    out = torch.empty(C, dtype=torch.float64, device=ts.device)
+    nbytes = lib.lr_bd_loglik_workspace_bytes(ts.numel(), n_bins, C, model)
+    if nbytes < 0:
+        _hip.check(int(nbytes), "lr_bd_loglik_workspace_bytes")
+    ws = _workspace(nbytes, ts.device)
+    rc = lib.lr_bd_loglik_batch(_hip.ptr(ts), _hip.ptr(te), ts.numel(), float(t0), n_bins, _hip.ptr(lam), _hip.ptr(mu),
+                                C, model, _hip.ptr(br), float(end_time), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                                _hip.stream_ptr())
+    _hip.check(rc, "lr_bd_loglik_batch")
+    return out
+
+
+def rj_propose_score(rates, times, K, move, index, draws, mult_d=1.1):
+    """Batched explicit-draw proposal scorer (LRF:29-69, 165-176).  Returns
+    (rates'[C,kmax], times'[C,kmax+1], K'[C], score[C])."""
+    torch = _torch()
+    lib = _hip.load()
+    rates, times = _dev(rates, torch.float64), _dev(times, torch.float64)
+    K, move, index = _dev(K, torch.int32), _dev(move, torch.int32), _dev(index, torch.int32)
+    draws = _dev(draws, torch.float64)
+    C, kmax = rates.shape
+    if times.shape != (C, kmax + 1) or draws.shape != (C, 2 * kmax):
+        raise ValueError("shape mismatch: times [C,kmax+1], draws [C,2*kmax]")
+    o_r, o_t = torch.empty_like(rates), torch.empty_like(times)
+    o_k = torch.empty_like(K)
+    o_s = torch.empty(C, dtype=torch.float64, device=rates.device)
+    rc = lib.lr_rj_propose_score(_hip.ptr(rates), _hip.ptr(times), _hip.ptr(K), kmax, C, _hip.ptr(move), _hip.ptr(index),
+                                 _hip.ptr(draws), float(mult_d), _hip.ptr(o_r), _hip.ptr(o_t), _hip.ptr(o_k),
+                                 _hip.ptr(o_s), _hip.stream_ptr())
+    _hip.check(rc, "lr_rj_propose_score")
+    return o_r, o_t, o_k, o_s
+
+
+def log_priors(rates, K, shape, gamma_rate, poi_rate=None):
+    """out[C] = prior_gamma(rates[:K], shape, gamma_rate) (+ Poisson_prior(K, poi_rate)) (LRF:198-202)."""
+    torch = _torch()
+    lib = _hip.load()
+    rates, K = _dev(rates, torch.float64), _dev(K, torch.int32)
+    C, kmax = rates.shape
+    g = _dev(gamma_rate, torch.float64)
+    p = None if poi_rate is None else _dev(poi_rate, torch.float64)
+    out = torch.empty(C, dtype=torch.float64, device=rates.device)
+    rc = lib.lr_log_priors(_hip.ptr(rates), _hip.ptr(K), kmax, C, float(shape), _hip.ptr(g), _hip.ptr(p), _hip.ptr(out),
+                           _hip.stream_ptr())
+    _hip.check(rc, "lr_log_priors")
+    return out
+
+
+def dd_rates(args, DT, m_birth=2, m_death=2):
+    """DDRate per-bin (birth, death, niche, niche_frac), each [C,n_bins] (DD:71-100)."""
+    torch = _torch()
+    lib = _hip.load()
+    args, DT = _dev(args, torch.float64), _dev(DT, torch.float64)
+    if args.dim() == 1:
+        args = args[None, :]
+    C, n_bins = args.shape[0], DT.numel()
+    outs = [torch.empty((C, n_bins), dtype=torch.float64, device=args.device) for _ in range(4)]
+    rc = lib.lr_dd_rates(_hip.ptr(args), _hip.ptr(DT), n_bins, C, m_birth, m_death, *[_hip.ptr(o) for o in outs],
+                         _hip.stream_ptr())
+    _hip.check(rc, "lr_dd_rates")
+    return tuple(outs)
+
+
+def debug_draws(seed, chain, it, purpose, idx, kind, shape):
+    """Device RNG probe: kind 0 u_a, 1 u_b, 2 normal, 3 gamma(shape) at (it, purpose, idx)."""
+    torch = _torch()
+    lib = _hip.load()
+    it = _dev(it, torch.int64)
+    purpose, idx, kind = _dev(purpose, torch.int32), _dev(idx, torch.int32), _dev(kind, torch.int32)
+    shape = _dev(shape, torch.float64)
+    out = torch.empty(it.numel(), dtype=torch.float64, device=it.device)
+    rc = lib.lr_debug_draws(int(seed), int(chain), _hip.ptr(it), _hip.ptr(purpose), _hip.ptr(idx), _hip.ptr(kind),
+                            _hip.ptr(shape), it.numel(), _hip.ptr(out), _hip.stream_ptr())
+    _hip.check(rc, "lr_debug_draws")
+    return out

@@ -1,0 +1,143 @@
+"""GPU parity of the fused RJMCMC engine (lr_mcmc_*): device chains against the oracle's
+restatement of runMCMC (pinned to the reference's own trajectories in test_oracle_golden.py)
+fed the SAME Philox draws, step by step."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X: no ROCm device visible")
+    return np.load(os.path.join(golden_dir, "binning_lik.npz"))
+
+
+def _oracle_run(G, name, model, seed, chain, n_it, **kw):
+    from oracle import mcmc_oracle as mo
+    stats = dict(sp=G[name + "/sp"], ex=G[name + "/ex"], br=G[name + "/br"],
+                 ex_dead=G[name + "/ex_dead"], br_dead=G[name + "/br_dead"])
+    start, end = G[name + "/start_end"]
+    st = mo.Settings(model_BDI=model, **kw)
+    with np.errstate(all="ignore"):
+        return mo.run_mcmc(stats, start, end, st, mo.PhiloxDraws(seed, chain), n_it, 1, k_max=32)
+
+
+@pytest.mark.parametrize("model,kw", [(0, {}), (2, {}), (1, {}), (3, {}),
+                                       (0, dict(const_rates=1)), (0, dict(const_death_rate=1)),
+                                       (2, dict(use_rate_HP=0, Poisson_HP=2.5))])
+def test_engine_follows_oracle_trajectory(G, model, kw):
+    from literate_amd.engine import ChainEngine, split_trace_row
+    name, seed, n_it, C, off = "example_TBP", 2024, 1500, 6, 40
+    ekw = dict(const_rates=kw.get("const_rates", 0), const_death_rate=kw.get("const_death_rate", 0),
+               use_rate_HP=kw.get("use_rate_HP", 1), poisson_HP=kw.get("Poisson_HP", 0.0))
+    eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=model, seed=seed, s_freq=1,
+                      n_trace_slots=n_it, chain_offset=off, **ekw)
+    # binning done by the engine's own kernel must equal the reference's
+    assert np.array_equal(eng.sp_events.cpu().numpy(), G[name + "/sp"])
+    assert np.array_equal(eng.br_length.cpu().numpy(), G[name + "/br"])
+    eng.init()
+    eng.steps(n_it)
+    tr = eng.trace_rows()
+    assert tr.shape[0] == n_it
+    n_moves = 0
+    for c in range(C):
+        ref = _oracle_run(G, name, model, seed, off + c, n_it, **kw)
+        for i in range(n_it):
+            head, sp, ex = split_trace_row(tr[i, c])
+            r = ref["mcmc"][i]
+            assert head[0] == r[0] and head[6] == r[6] and head[7] == r[7], (c, i, head[:8], r[:8])
+            assert np.allclose(head[1:13], r[1:13], rtol=1e-9, atol=1e-9), (c, i, head, r)
+            assert np.allclose(sp, ref["sp"][i], rtol=1e-10) and np.allclose(ex, ref["ex"][i], rtol=1e-10)
+        n_moves += len(set(np.round(np.array(ref["mcmc"])[:, 2], 6)))
+    assert n_moves > C * 50          # the chains actually moved
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it)
+    eng.close()
+
+
+def test_engine_given_initial_state_and_graph_replay(G):
+    """runMCMC called with a multi-rate initial state (SURVEY 'config-1 note'); > 32 iterations so the
+    captured hipGraph path runs, compared with single-launch stepping bit for bit."""
+    from literate_amd.engine import ChainEngine
+    name = "example_TBP"
+    C = 3
+    L = [np.array([.6, .2, .3])] * C
+    M = [np.array([.15, .19])] * C
+    tL = [np.array([0, 4.55, 12.2, 24.5])] * C
+    tM = [np.array([0, 16.682, 24.5])] * C
+    outs = []
+    for chunks in ([100], [1] * 100, [33, 67]):
+        eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=2, seed=5, s_freq=10, n_trace_slots=10)
+        eng.init(L, M, tL, tM)
+        for n in chunks:
+            eng.steps(n)
+        outs.append((eng.trace_rows().copy(), eng.state_f64.cpu().numpy().copy()))
+        eng.close()
+    for tr, st in outs[1:]:
+        assert np.array_equal(tr, outs[0][0], equal_nan=True)
+        assert np.array_equal(st, outs[0][1], equal_nan=True)
+    # oracle with the same init
+    from oracle import mcmc_oracle as mo
+    stats = dict(sp=G[name + "/sp"], ex=G[name + "/ex"], br=G[name + "/br"])
+    start, end = G[name + "/start_end"]
+    with np.errstate(all="ignore"):
+        ref = mo.run_mcmc(stats, start, end, mo.Settings(model_BDI=2), mo.PhiloxDraws(5, 1), 100, 10,
+                          init=(L[0], M[0], tL[0], tM[0]), k_max=32)
+    got = outs[0][0][:, 1, :13]
+    assert np.allclose(got, np.array(ref["mcmc"])[:, :13], rtol=1e-9)
+
+
+def test_engine_chain_streams_do_not_depend_on_sharding(G):
+    """Chain g gives the same trajectory whether it is local chain g of one engine or local chain 0
+    of an engine with chain_offset=g (how ranks shard chains)."""
+    from literate_amd.engine import ChainEngine
+    name = "example_TBP"
+    a = ChainEngine(G[name + "/ts"], G[name + "/te"], 8, model=0, seed=9, s_freq=5, n_trace_slots=40)
+    a.init(); a.steps(200)
+    b = ChainEngine(G[name + "/ts"], G[name + "/te"], 3, model=0, seed=9, s_freq=5, n_trace_slots=40, chain_offset=4)
+    b.init(); b.steps(200)
+    ta, tb = a.trace_rows(), b.trace_rows()
+    assert np.allclose(ta[:, 4:7], tb, rtol=1e-12, equal_nan=True)
+    a.close(); b.close()
+
+
+def test_engine_posterior_matches_reference_chains(G, golden_dir):
+    """Posterior rate marginals within Monte-Carlo error of long runs of the reference CLI
+    (tests/golden/make_chains.py): per-bin marginal means, K distribution."""
+    path = os.path.join(golden_dir, "posterior_example_TBP_m0.npz")
+    if not os.path.exists(path):
+        pytest.skip("reference posterior summary not generated")
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import literate_oracle as lo
+    R = np.load(path)
+    n_ref = int(R["meta"][3])
+    name = "example_TBP"
+    C, n_it, s = 256, 100_000, 100
+    eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=0, seed=77, s_freq=s, n_trace_slots=n_it // s)
+    eng.init(); eng.steps(n_it)
+    tr = eng.trace_rows()
+    eng.close()
+    start, end = G[name + "/start_end"]
+    burn = tr.shape[0] // 5
+    per_chain_sp, per_chain_ex, kl = [], [], []
+    for c in range(C):
+        rows = [split_trace_row(tr[i, c]) for i in range(tr.shape[0])]
+        per_chain_sp.append(lo.marginal_rates_from_rows([r[1] for r in rows], end, start)[0])
+        per_chain_ex.append(lo.marginal_rates_from_rows([r[2] for r in rows], end, start)[0])
+        kl.append(np.mean([r[0][6] for r in rows[burn:]]))
+    sp = np.array(per_chain_sp); ex = np.array(per_chain_ex)
+    ref_sp = np.array([R["c%d/sp_mean" % c] for c in range(n_ref)])
+    ref_ex = np.array([R["c%d/ex_mean" % c] for c in range(n_ref)])
+    # z-score of the difference of grand means, using between-chain spread on both sides
+    for mine, ref in ((sp, ref_sp), (ex, ref_ex)):
+        se = np.sqrt(mine.var(0, ddof=1) / len(mine) + ref.var(0, ddof=1) / len(ref))
+        z = (mine.mean(0) - ref.mean(0)) / se
+        assert np.max(np.abs(z)) < 5.0, z
+        assert np.allclose(mine.mean(0), ref.mean(0), rtol=0.15)
+    ref_kl = [np.dot(R["c%d/K_l_hist" % c], np.arange(40)) / R["c%d/K_l_hist" % c].sum() for c in range(n_ref)]
+    assert abs(np.mean(kl) - np.mean(ref_kl)) < 0.25

@@ -526,7 +526,18 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
     return LR_OK;
 }
 
-#define LR_GRAPH_ITERS 32
+#include <cstdlib>
+// iterations captured per hipGraph; LR_GRAPH_ITERS=0 in the environment disables graph replay
+static int lr_graph_iters() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LR_GRAPH_ITERS");
+        v = e ? atoi(e) : 32;
+        if (v < 0) v = 0;
+        if (v > 4096) v = 4096;
+    }
+    return v;
+}
 
 static int lr_enqueue_iteration(const lr_engine* e, const lr_step_args& a, hipStream_t stream) {
     int rc = lr_enqueue_scan(e, stream);
@@ -542,7 +553,8 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const lr_step_args a = lr_make_args(e);
     int64_t done = 0;
-    if (n_iters >= LR_GRAPH_ITERS) {
+    const int G = lr_graph_iters();
+    if (G > 0 && n_iters >= G) {
         if (!e->graph_exec) {
             // capture LR_GRAPH_ITERS iterations once; the kernels read the iteration number from
             // device memory, so the same graph is valid for every replay
@@ -553,7 +565,7 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
             he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
             if (he != hipSuccess) return (int)he;
             int rc = LR_OK;
-            for (int i = 0; i < LR_GRAPH_ITERS && rc == LR_OK; ++i) rc = lr_enqueue_iteration(e, a, cs);
+            for (int i = 0; i < G && rc == LR_OK; ++i) rc = lr_enqueue_iteration(e, a, cs);
             he = hipStreamEndCapture(cs, &graph);
             if (rc) return rc;
             if (he != hipSuccess) return (int)he;
@@ -561,7 +573,7 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
             (void)hipGraphDestroy(graph);
             (void)hipStreamDestroy(cs);
             if (he != hipSuccess) return (int)he;
-            e->graph_iters = LR_GRAPH_ITERS;
+            e->graph_iters = G;
         }
         while (n_iters - done >= e->graph_iters) {
             hipError_t he = hipGraphLaunch(e->graph_exec, stream);

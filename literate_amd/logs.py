@@ -1,0 +1,120 @@
+"""Reference-format log writers and the posterior marginal-rate summary (host side).
+
+File names, headers and column order follow LiteRateForward.py:485-512, 321-359, 558-564 so
+that plotRJforward.v3.py-style consumers read them unchanged; `marginal_rates` restates
+plotRJforward.v3.py:92-139, the definition of "posterior rate marginals"."""
+import csv
+import os
+
+import numpy as np
+
+from ._hip import LR_KMAX, LR_TRACE_HEAD
+
+MCMC_HEAD = ["it", "posterior", "likelihood", "prior", "lambda_avg", "mu_avg", "K_l", "K_m", "root_age", "death_age",
+             "gamma_rate_hp_BI", "gamma_rate_hp_D", "poisson_rate_hp"]
+ADEQUACY_HEAD = ["corr_coeff", "rsquared", "gelman_r2"]
+SUFFIX = {0: "_BD", 1: "_ID", 2: "_BDk", 3: "_BDd"}       # LRF:422-428
+
+
+def split_row(row):
+    """trace row -> (head[13], sp_rates row, ex_rates row): rates then interior shift times."""
+    head = row[:LR_TRACE_HEAD]
+    kl, km = int(head[6]), int(head[7])
+    rl = row[LR_TRACE_HEAD:LR_TRACE_HEAD + 2 * LR_KMAX - 1]
+    rm = row[LR_TRACE_HEAD + 2 * LR_KMAX - 1:]
+    return head, np.concatenate([rl[:kl], rl[LR_KMAX:LR_KMAX + kl - 1]]), np.concatenate([rm[:km], rm[LR_KMAX:LR_KMAX + km - 1]])
+
+
+def rates_per_bin(rates, shifts, start_time, n_bins):
+    """L_acc[indLA] from a logged row: floor-to-bin index of get_rate_index (LRF:125-135, 262)."""
+    edges = np.floor(np.asarray(shifts, dtype=float)) - np.floor(start_time)
+    seg = np.searchsorted(edges, np.arange(n_bins), side="right")
+    return np.asarray(rates, dtype=float)[seg]
+
+
+def adequacy(emp_birth, emp_death, est_birth, est_death):
+    """calculate_r_squared (lib:268-279)."""
+    x = np.concatenate([emp_birth, emp_death])
+    y = np.concatenate([est_birth, est_death])
+    coeff = np.sum(x * y) / np.sum(x * x)
+    fitted = coeff * x
+    resid = y - fitted
+    r2 = 1 - np.sum(resid ** 2) / np.sum(y ** 2)
+    vf = np.var(fitted, ddof=1)
+    return coeff, r2, vf / (vf + np.var(resid, ddof=1))
+
+
+def log_paths(data_file, model, out="", chain=None):
+    out_dir = os.path.dirname(data_file) or os.getcwd()
+    out_dir = "%s/literate_mcmc_logs" % out_dir
+    stem = os.path.splitext(os.path.basename(data_file))[0] + SUFFIX[model] + out
+    if chain is not None:
+        stem += "_c%d" % chain
+    return out_dir, {k: "%s/%s_%s.log" % (out_dir, stem, k) for k in ("mcmc", "sp_rates", "ex_rates", "div")}
+
+
+def write_div_log(path, sp_events, ex_events, br_length):
+    with open(path, "w") as f:
+        f.write('sp_events\tex_events\tbr_length\n')
+        w = csv.writer(f, delimiter='\t')
+        for row in zip(sp_events.tolist(), ex_events.tolist(), br_length.tolist()):
+            w.writerow(row)
+
+
+def write_chain_logs(paths, rows, emp=None, n_bins=None, pyrate_output=False, true_root_age=0.0):
+    """rows: [samples, LR_TRACE_W] of ONE chain.  emp=(B_EMP, D_EMP) adds the adequacy columns
+    (-calc_adequacy 1, LRF:327-329); pyrate_output flips times to root_age - t (LRF:324-341)."""
+    with open(paths["mcmc"], "w") as fm, open(paths["sp_rates"], "w") as fs, open(paths["ex_rates"], "w") as fe:
+        fm.write('\t'.join(MCMC_HEAD + (ADEQUACY_HEAD if emp is not None else [])) + '\n')
+        for row in rows:
+            head, sp, ex = split_row(row)
+            kl, km = int(head[6]), int(head[7])
+            start, end = head[8], head[9]
+            vals = [str(int(head[0]))] + [str(float(v)) for v in head[1:6]] + [str(kl), str(km)]
+            if pyrate_output:
+                vals += [str(float(true_root_age)), str(float(true_root_age - end))]
+            else:
+                vals += [str(float(start)), str(float(end))]
+            vals += [str(float(v)) for v in head[10:13]]
+            if emp is not None:
+                lam = rates_per_bin(sp[:kl], sp[kl:], start, n_bins)
+                mu = rates_per_bin(ex[:km], ex[km:], start, n_bins)
+                with np.errstate(all="ignore"):
+                    vals += [str(float(v)) for v in adequacy(emp[0], emp[1], lam, mu)]
+            fm.write('\t'.join(vals) + '\n')
+            if pyrate_output:
+                sp = np.concatenate([sp[:kl], true_root_age - sp[kl:]])
+                ex = np.concatenate([ex[:km], true_root_age - ex[km:]])
+            fs.write('\t'.join(str(float(v)) for v in sp) + '\n')
+            fe.write('\t'.join(str(float(v)) for v in ex) + '\n')
+
+
+def calcHPD(data, level=0.95):
+    d = np.sort(np.asarray(data, dtype=float))
+    n_in = int(round(level * len(d)))
+    if n_in < 2:
+        raise RuntimeError("not enough data")
+    i = int(np.argmin(d[n_in - 1:] - d[:len(d) - n_in + 1]))
+    return np.array([d[i], d[i + n_in - 1]])
+
+
+def marginal_rates(rows, start_age, end_age, burnin=0.2):
+    """plotRJforward.v3.py:92-139.  rows: sp_rates / ex_rates rows (rates then shift times).
+    Returns (time_frames, mean, hpd_lo, hpd_hi, matrix[samples, nbins]); bins most recent first."""
+    nbins = abs(int(end_age - start_age))
+    edges = np.arange(end_age, start_age)
+    if burnin < 1:
+        burnin = min(int(burnin * len(rows)), int(0.9 * len(rows)))
+    mat = []
+    for row in rows[burnin:]:
+        row = np.asarray(row, dtype=float)
+        if len(row) == 1:
+            mat.append(np.zeros(nbins) + row[0])
+            continue
+        nr = int(np.ceil(len(row) / 2.))
+        h = np.histogram(row[nr:], bins=edges)[0]
+        mat.append(row[:nr][np.cumsum(h)][::-1])
+    mat = np.array(mat)
+    hpd = np.array([calcHPD(mat[:, i], 0.95) for i in range(mat.shape[1])])
+    frames = (edges - abs(edges[1] - edges[0]) / 2.)[1:]
+    return frames, mat.mean(axis=0), hpd[:, 0], hpd[:, 1], mat

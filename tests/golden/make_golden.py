@@ -175,7 +175,7 @@ def make_proposals(work):
         ind = np.random.choice(range(len(times) - 1))
         delta = np.random.uniform(0, np.diff(times)[ind])
         u = np.random.beta(10., 10.)
-        recs["add"].append(dict(rates=rates.tolist(), times=times.tolist(), ind=int(ind), delta=float(delta),
+        recs["add"].append(dict(seed=seed, rates=rates.tolist(), times=times.tolist(), ind=int(ind), delta=float(delta),
                                 u=float(u), out_rates=r_.tolist(), out_times=t_.tolist(), score=float(s_)))
         # remove (needs K>1)
         if len(rates) > 1:
@@ -183,7 +183,7 @@ def make_proposals(work):
             r_, t_, s_ = g["remove_shift_RJ_weighted_mean"](rates, times)
             np.random.seed(seed)
             idx = np.random.choice(range(1, len(times) - 1))
-            recs["remove"].append(dict(rates=rates.tolist(), times=times.tolist(), idx=int(idx),
+            recs["remove"].append(dict(seed=seed, rates=rates.tolist(), times=times.tolist(), idx=int(idx),
                                        out_rates=r_.tolist(), out_times=t_.tolist(), score=float(s_)))
         # vector multiplier (CLI-local and library versions are the same function)
         for f in (0.75, 1.0, 0.3):
@@ -195,13 +195,13 @@ def make_proposals(work):
             np.random.seed(seed)
             ff = np.random.binomial(1, f, np.shape(rates))
             uu = np.random.uniform(0, 1, np.shape(rates))
-            recs["mult"].append(dict(q=rates.tolist(), f=f, ff=ff.tolist(), u=uu.tolist(),
+            recs["mult"].append(dict(seed=seed, q=rates.tolist(), f=f, ff=ff.tolist(), u=uu.tolist(),
                                      out=q_.tolist(), hastings=float(h_)))
         np.random.seed(seed)
         q_, h_ = lib.update_multiplier_proposal(rates[0], 1.1)
         np.random.seed(seed)
         u1 = np.random.random()
-        recs["mult_scalar"].append(dict(q=float(rates[0]), u=float(u1), out=float(q_), hastings=float(h_)))
+        recs["mult_scalar"].append(dict(seed=seed, q=float(rates[0]), u=float(u1), out=float(q_), hastings=float(h_)))
         # full RJ dispatcher
         ratesM, timesM = random_state(rng, start, end, kmax=8)
         np.random.seed(seed)

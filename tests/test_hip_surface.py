@@ -1,0 +1,124 @@
+"""GPU: the drop-in literate_library surface and the CLI end to end, against reference-generated vectors."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    return np.load(os.path.join(golden_dir, "binning_lik.npz"))
+
+
+def test_library_binning_functions(G):
+    import literate_library as ll
+    for name in ("example_TBP", "metal_bands"):
+        ts, te = G[name + "/lib_ts"], G[name + "/lib_te"]
+        for a, b, s_, e_, br_ in G[name + "/lib_windows"]:
+            assert ll.precompute_events(ts, te, a, b) == (int(s_), int(e_), pytest.approx(br_, rel=1e-12))
+            assert ll.get_br(ts, te, a, b) == pytest.approx(br_, rel=1e-12)
+        for rm in (0, 1):
+            o, p, nb = G["%s/lib_bins_rm%d_meta" % (name, rm)]
+            o2, p2, sp, ex, dt, nb2, tr = ll.create_bins(o - rm, p, ts, te, rm)
+            assert (o2, p2, nb2) == (o, p, nb) and np.array_equal(tr, np.arange(nb))
+            assert np.array_equal(sp, G["%s/lib_bins_rm%d_sp" % (name, rm)])
+            assert np.array_equal(ex, G["%s/lib_bins_rm%d_ex" % (name, rm)])
+            assert np.array_equal(dt, G["%s/lib_bins_rm%d_dt" % (name, rm)])
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
+def test_library_likelihood_operators(G, model):
+    import literate_library as ll
+    name = "example_TBP"
+    sp, ex, br = ll.bind_lineages(G[name + "/ts"], G[name + "/te"], model)
+    assert np.array_equal(sp, G[name + "/sp"]) and np.array_equal(br, G[name + "/br"])
+    assert ll.n_bins == 24 and ll.start_time == 0.0 and ll.end_time == 24.5
+    calc = ll.BDI_partial_lik if model <= 1 else ll.BD_lik_Keiding            # LRF:430-431
+    KL, KM = G[name + "/state_KL"], G[name + "/state_KM"]
+    for i in range(len(KL)):
+        L, M = G[name + "/state_L"][i, :KL[i]], G[name + "/state_M"][i, :KM[i]]
+        tL, tM = G[name + "/state_tL"][i, :KL[i] + 1], G[name + "/state_tM"][i, :KM[i] + 1]
+        iL, iM = ll.get_rate_index(np.floor(tL)), ll.get_rate_index(np.floor(tM))
+        assert np.array_equal(iL, G[name + "/state_indL"][i])
+        v = calc(L[iL], M[iM])
+        assert isinstance(v, np.float64)
+        assert v == pytest.approx(G["%s/lik_model%d" % (name, model)][i], rel=1e-9, abs=1e-9)
+        if model == 2:
+            fl, fm = np.floor(tL), np.floor(tM)
+            fl[-1] = fm[-1] = ll.n_bins
+            assert ll.get_BDlik(fl, L, "l") + ll.get_BDlik(fm, M, "m") == pytest.approx(v, rel=1e-9)
+    with pytest.raises(SystemExit):
+        ll.BD_lik_Keiding(np.ones(5), np.ones(5))           # wrong length: the reference prints and exits
+
+
+def test_library_proposals_consume_numpy_stream_like_reference(G, golden_dir):
+    import literate_library as ll
+    with open(os.path.join(golden_dir, "proposals_priors.json")) as f:
+        P = json.load(f)
+    pr = P["proposals"]
+    for r in pr["add"][:12]:
+        np.random.seed(r["seed"])
+        ra, ti, sc = ll.add_shift_RJ_weighted_mean(np.array(r["rates"]), np.array(r["times"]))
+        assert np.allclose(ra, r["out_rates"], rtol=1e-13) and np.allclose(ti, r["out_times"], rtol=1e-15)
+        assert sc == pytest.approx(r["score"], rel=1e-11, abs=1e-11)
+    for r in pr["remove"][:12]:
+        np.random.seed(r["seed"])
+        ra, ti, sc = ll.remove_shift_RJ_weighted_mean(np.array(r["rates"]), np.array(r["times"]))
+        assert np.allclose(ra, r["out_rates"], rtol=1e-13) and np.array_equal(ti, r["out_times"])
+        assert sc == pytest.approx(r["score"], rel=1e-11, abs=1e-11)
+    for r in pr["mult"][:12]:
+        np.random.seed(r["seed"])
+        q, h = ll.update_multiplier_proposal_vec(np.array(r["q"]), 1.1, r["f"])
+        assert np.allclose(q, r["out"], rtol=1e-14) and h == pytest.approx(r["hastings"], rel=1e-12, abs=1e-14)
+    for r in pr["mult_scalar"][:12]:
+        np.random.seed(r["seed"])
+        q, h = ll.update_multiplier_proposal(r["q"], 1.1)
+        assert q == pytest.approx(r["out"], rel=1e-14) and h == pytest.approx(r["hastings"], rel=1e-12, abs=1e-15)
+    for r in P["priors"]["gamma"][:8]:
+        assert ll.prior_gamma(np.array(r["x"]), r["a"], r["b"]) == pytest.approx(r["out"], rel=1e-12, abs=1e-12)
+    for r in P["priors"]["poisson"][:20]:
+        assert ll.Poisson_prior(r["k"], r["rate"]) == pytest.approx(r["out"], rel=1e-11, abs=1e-11)
+
+
+def test_cli_end_to_end(G, tmp_path):
+    """python LiteRateForward.py -d <file> -TBP ... writes the reference's four logs; the div log is
+    byte-identical to the reference's, the chain rows equal the engine/oracle trajectory."""
+    from oracle import mcmc_oracle as mo
+    # rebuild the example file from the golden arrays (TBP: ts = max - ts_years), 3 columns
+    ts, te = G["example_TBP/ts"], G["example_TBP/te"] - 0.5
+    root = ts.max() if False else 24.0
+    data = tmp_path / "example.tsv"
+    with open(data, "w") as f:
+        f.write("id\tts\tte\n")
+        for i, (a, b) in enumerate(zip(ts, te)):
+            f.write("%d\t%g\t%g\n" % (i, root - a, root - b))
+    cmd = [sys.executable, os.path.join(ROOT, "LiteRateForward.py"), "-d", str(data), "-TBP", "-n", "400", "-s", "20",
+           "-p", "200", "-seed", "31", "-model_BDI", "2", "--chains", "3"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, timeout=300)
+    logdir = tmp_path / "literate_mcmc_logs"
+    div = open(logdir / "example_BDk_div.log").read().splitlines()
+    assert div[0] == "sp_events\tex_events\tbr_length"
+    for line, a, b, c in zip(div[1:], G["example_TBP/sp"], G["example_TBP/ex"], G["example_TBP/br"]):
+        assert line == "%d\t%d\t%s" % (a, b, c)
+    stats = dict(sp=G["example_TBP/sp"], ex=G["example_TBP/ex"], br=G["example_TBP/br"])
+    emp = (G["example_TBP/B_EMP"], G["example_TBP/D_EMP"])
+    for c in range(3):
+        mc = np.loadtxt(logdir / ("example_BDk_c%d_mcmc.log" % c), skiprows=1)
+        assert mc.shape == (20, 16)
+        with np.errstate(all="ignore"):
+            ref = mo.run_mcmc(stats, 0.0, 24.5, mo.Settings(model_BDI=2), mo.PhiloxDraws(31, c), 400, 20, emp=emp, k_max=32)
+        assert np.allclose(mc[:, :13], np.array(ref["mcmc"])[:, :13], rtol=1e-9)
+        assert np.allclose(mc[:, 13:], np.array(ref["mcmc"])[:, 13:], rtol=1e-8, equal_nan=True)
+        sp_rows = [np.array(l.split(), float) for l in open(logdir / ("example_BDk_c%d_sp_rates.log" % c))]
+        assert all(np.allclose(a, b, rtol=1e-10) for a, b in zip(sp_rows, ref["sp"]))
+    shutil.rmtree(logdir)

@@ -1,0 +1,185 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, the product has no
+CPU compute path, host logic (sharding, log writers, marginal rates), world_size-2 gloo gather."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from literate_amd import _hip
+    from literate_amd.build import build_hip
+    lib_path = build_hip()
+    lib = ctypes.CDLL(lib_path)
+    header = open(os.path.join(ROOT, "include", "literate_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(lr_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), name
+        assert name in _hip.SIGNATURES, "ctypes binding missing for " + name
+    assert _hip.load().lr_version() >= 100
+    # layout query is pure host code: check it without a GPU
+    cfg = _hip.McmcConfig(n_lineages=100000, n_bins=128, n_chains=1024, model=0, s_freq=100, n_trace_slots=10,
+                          t0=0.0, start_time=0.0, end_time=128.5, seed=1)
+    lay = _hip.McmcLayout()
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
+    assert lay.chains_per_block == 8 and lay.table_stride == 2 * 130 and lay.trace_width == _hip.LR_TRACE_W
+    assert lay.total_bytes > lay.trace > lay.partials > lay.tables > lay.rate_bins > lay.state_i32 > 0
+    cfg.t0 = 0.5
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == -5        # LR_ERR_T0
+    assert _hip.load().lr_bd_loglik_workspace_bytes(1000, 5000, 4, 2) == -2   # LR_ERR_SIZE
+
+
+def test_header_constants_match_python_binding():
+    from literate_amd import _hip
+    header = open(os.path.join(ROOT, "include", "literate_hip.h")).read()
+    defs = dict(re.findall(r"#define\s+(LR_\w+)\s+(-?\d+)\b", header))
+    assert int(defs["LR_KMAX"]) == _hip.LR_KMAX and int(defs["LR_ROW"]) == _hip.LR_ROW
+    assert int(defs["LR_STATE_ROWS"]) == _hip.LR_STATE_ROWS and int(defs["LR_ISTATE_ROWS"]) == _hip.LR_ISTATE_ROWS
+    for name in ("S_LIKA", "S_PRIORA", "S_POI", "S_LIK_P", "I_KL", "I_PKM", "I_IT_HI", "I_MOVE"):
+        assert int(defs["LR_" + name]) == getattr(_hip, name)
+    for name in ("ROW_L", "ROW_PTM", "ROW_SCALARS", "IROW_EL", "IROW_SCALARS"):
+        assert int(defs["LR_" + name]) == getattr(_hip, name)
+
+
+def test_no_cpu_compute_path():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from literate_amd import _hip, ops
+    import literate_library as ll
+    with pytest.raises(_hip.HipLibraryError):
+        ops.bin_events(np.zeros(3), np.ones(3), [0.0], [1.0])
+    with pytest.raises(_hip.HipLibraryError):
+        ll.precompute_events(np.zeros(3), np.ones(3), 0, 1)
+    with pytest.raises(_hip.HipLibraryError):
+        ll.bind_lineages(np.zeros(3), np.ones(3))
+    with pytest.raises(NameError):
+        ll.BDI_partial_lik(np.ones(3), np.ones(3))     # data not bound (the reference raises NameError too)
+    # the product never imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "literate_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src, f
+
+
+def test_drop_in_surface_names():
+    import literate_library as ll
+    for name in ["BD_partial_lik", "BDI_partial_lik", "BD_lik_Keiding", "precompute_events", "get_br", "create_bins",
+                 "get_rate_index", "update_multiplier_proposal", "update_multiplier_proposal_vec", "parse_ts_te",
+                 "core_arguments", "set_seed", "calculate_r_squared", "calcHPD"]:
+        assert callable(getattr(ll, name)), name
+    a = ll.core_arguments().parse_args(["-d", "x.tsv"])
+    assert (a.n, a.p, a.s, a.seed, a.death_jitter, a.rm_first_bin, a.TBP) == (10000000, 1000, 1000, -1, .5, 0, False)
+    import LiteRateForward as cli
+    b = cli.build_parser().parse_args(["-d", "x.tsv"])
+    assert (b.n, b.s, b.model_BDI, b.use_rate_HP, b.Poisson_prior, b.update_fraction, b.calc_adequacy,
+            b.const_rates, b.const_death_rate, b.death_jitter, b.chains) == (10000000, 1000, 0, 1, 0, 0.75, 1, 0, 0, .5, 1)
+
+
+def test_shard_chains():
+    from literate_amd.dist import shard_chains
+    for total, world in ((1024, 8), (10, 3), (1, 4), (7, 7)):
+        spans = [shard_chains(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(n for _, n in spans) == total
+        for (o1, n1), (o2, _) in zip(spans, spans[1:]):
+            assert o1 + n1 == o2
+
+
+def _trace_row(it, L, tL, M, tM, start, end):
+    from literate_amd import _hip
+    K = _hip.LR_KMAX
+    row = np.full(_hip.LR_TRACE_W, np.nan)
+    row[:13] = [it, -10.5, -8.25, -2.25, np.mean(L), np.mean(M), len(L), len(M), start, end, 1.0, 1.5, 2.0]
+    rl = row[13:13 + 2 * K - 1]; rm = row[13 + 2 * K - 1:]
+    rl[:len(L)] = L; rl[K:K + len(L) - 1] = tL[1:-1]
+    rm[:len(M)] = M; rm[K:K + len(M) - 1] = tM[1:-1]
+    return row
+
+
+def test_log_writers_and_marginal_rates(tmp_path):
+    from literate_amd import logs
+    from oracle import literate_oracle as lo
+    rng = np.random.default_rng(0)
+    start, end, n_bins = 0.0, 24.5, 24
+    rows, sp_rows = [], []
+    for i in range(60):
+        k = int(rng.integers(1, 6))
+        tL = np.concatenate([[start], np.sort(rng.uniform(1, 23, k - 1)), [end]])
+        L = rng.uniform(.05, .6, k)
+        rows.append(_trace_row(i * 10, L, tL, np.array([.2]), np.array([start, end]), start, end))
+        sp_rows.append(np.concatenate([L, tL[1:-1]]))
+    rows = np.array(rows)
+    head, sp, ex = logs.split_row(rows[3])
+    assert np.array_equal(sp, sp_rows[3]) and np.array_equal(ex, [.2])
+    data = tmp_path / "toy.tsv"
+    data.write_text("id\tts\tte\n")
+    out_dir, paths = logs.log_paths(str(data), 0, "")
+    assert paths["mcmc"].endswith("literate_mcmc_logs/toy_BD_mcmc.log")
+    assert logs.log_paths(str(data), 2, "_x", 3)[1]["sp_rates"].endswith("toy_BDk_x_c3_sp_rates.log")
+    os.mkdir(out_dir)
+    emp = (rng.uniform(.1, 1, n_bins), rng.uniform(.1, 1, n_bins))
+    logs.write_chain_logs(paths, rows, emp, n_bins)
+    lines = open(paths["mcmc"]).read().splitlines()
+    assert lines[0].split("\t") == logs.MCMC_HEAD + logs.ADEQUACY_HEAD and len(lines) == 61
+    assert lines[1].split("\t")[0] == "0" and lines[1].split("\t")[6] in "12345"
+    back = [np.array(l.split(), float) for l in open(paths["sp_rates"])]
+    assert all(np.array_equal(a, b) for a, b in zip(back, sp_rows))
+    # adequacy columns = oracle's statistic on the reconstructed per-bin rates
+    cols = np.array(lines[4].split("\t"), float)
+    k = int(cols[6])
+    lam = sp_rows[3][:k][lo.get_rate_index(np.concatenate([[start], np.floor(sp_rows[3][k:]), [np.floor(end)]]), n_bins)] \
+        if k > 1 else np.full(n_bins, sp_rows[3][0])
+    ref = lo.calculate_r_squared(emp[0], emp[1], lam, np.full(n_bins, .2))
+    assert np.allclose(cols[13:], ref, rtol=1e-12)
+    # marginal rates: product restatement == oracle restatement of plotRJforward.v3.py:92-139
+    a = logs.marginal_rates(sp_rows, end, start)
+    b = lo.marginal_rates_from_rows(sp_rows, end, start)
+    assert np.array_equal(a[1], b[0]) and np.array_equal(a[2], b[1]) and np.array_equal(a[4], b[3])
+    logs.write_div_log(paths["div"], np.arange(3), np.arange(3), np.array([1.5, 2.0, 3.0]))
+    assert open(paths["div"]).read().splitlines()[1] == "0\t0\t1.5"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, total, ret):
+    import torch
+    import torch.distributed as dist
+    from literate_amd.dist import gather_traces, shard_chains
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    off, n = shard_chains(total, world, rank)
+    local = torch.zeros(4, n, 5, dtype=torch.float64)
+    for c in range(n):
+        local[:, c, :] = float(off + c) + torch.arange(4, dtype=torch.float64)[:, None] * 100
+    out = gather_traces(local, total)
+    if rank == 0:
+        ok = out.shape == (4, total, 5) and all(float(out[s, c, 0]) == c + 100 * s for s in range(4) for c in range(total))
+        ret.put(bool(ok))
+    else:
+        assert out is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [6, 5])
+def test_trace_gather_world2_gloo(total):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, total, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert ret.get(timeout=5) is True

@@ -140,7 +140,7 @@ typedef struct lr_mcmc_config {
 typedef struct lr_mcmc_layout {
     int64_t state_f64;    /* [C, LR_STATE_ROWS, LR_ROW] doubles  (rows: see LR_ROW_* below)  */
     int64_t state_i32;    /* [C, LR_ISTATE_ROWS, LR_ROW] int32                                */
-    int64_t rate_bins;    /* [C, 4, n_bins] doubles: accepted lam, accepted mu, proposed lam, proposed mu */
+    int64_t bin_consts;   /* [n_bins] doubles: log(br_length) (models 0/1)                    */
     int64_t tables;       /* [C, table_stride] double2                                        */
     int64_t partials;     /* [tiles, C] doubles                                               */
     int64_t trace;        /* [n_trace_slots, C, LR_TRACE_W] doubles                           */
@@ -175,6 +175,9 @@ typedef struct lr_mcmc_layout {
 #define LR_S_CONST_P 9   /* model constant of the pending proposal (model 1)   */
 #define LR_S_CONST_A 10
 #define LR_S_LIK_P 11    /* last evaluated proposal log-likelihood (diagnostic) */
+#define LR_S_LOG_G0 12   /* cached log(Gamma_rate[0]), log(Gamma_rate[1]), log(Poi_lambda_rjHP) */
+#define LR_S_LOG_G1 13
+#define LR_S_LOG_POI 14
 /* rows of the int32 state block */
 #define LR_IROW_EL 0     /* accepted birth bin edges (ints, relative to bin 0) [K_l+1] */
 #define LR_IROW_EM 1

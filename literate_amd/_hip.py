@@ -16,7 +16,7 @@ LR_TRACE_W = LR_TRACE_HEAD + 2 * (2 * LR_KMAX - 1)
 # rows / scalar slots (include/literate_hip.h)
 ROW_L, ROW_M, ROW_TL, ROW_TM, ROW_PL, ROW_PM, ROW_PTL, ROW_PTM, ROW_SCALARS = range(9)
 (S_LIKA, S_PRIORA, S_PRIORPOIA, S_GRATE_L, S_GRATE_M, S_POI, S_HASTING, S_PRIOR_P, S_PRIORPOI_P, S_CONST_P,
- S_CONST_A, S_LIK_P) = range(12)
+ S_CONST_A, S_LIK_P, S_LOG_G0, S_LOG_G1, S_LOG_POI) = range(15)
 IROW_EL, IROW_EM, IROW_PEL, IROW_PEM, IROW_SCALARS = range(5)
 (I_KL, I_KM, I_PKL, I_PKM, I_GIBBS, I_INVALID, I_IT_LO, I_IT_HI, I_ACCEPTED, I_MOVE) = range(10)
 
@@ -29,7 +29,7 @@ class McmcConfig(C.Structure):
 
 
 class McmcLayout(C.Structure):
-    _fields_ = [("state_f64", c_i64), ("state_i32", c_i64), ("rate_bins", c_i64), ("tables", c_i64),
+    _fields_ = [("state_f64", c_i64), ("state_i32", c_i64), ("bin_consts", c_i64), ("tables", c_i64),
                 ("partials", c_i64), ("trace", c_i64), ("total_bytes", c_i64), ("table_stride", c_i32),
                 ("tiles", c_i32), ("chains_per_block", c_i32), ("trace_width", c_i32)]
 

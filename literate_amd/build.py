@@ -21,7 +21,8 @@ def build_hip(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + SOURCES
+    extra = os.environ.get("LR_EXTRA_FLAGS", "").split()
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, cwd=CSRC, check=True)

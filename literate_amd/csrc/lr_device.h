@@ -120,7 +120,8 @@ __device__ inline double lr_gamma(const lr_stream& s, uint64_t it, uint32_t purp
 // where  S[b+1] = (logB_b + cum_b,  R_b)      birth event + exposure integral up to ts
 //        E[b+1] = (logD_b - cum_b, -R_b)      death event - exposure integral up to te
 //        S[0] = E[0] = (0,0),  S[n_bins+1] = (cum_total, 0),  E[n_bins+1] = (-cum_total, 0).
-// Layout per chain: [n_cls][2 (S,E)][n_bins+2] double2; class 1 (model 3 only) carries the
+// Layout per chain: [n_cls][2 (S,E)][H] double2, H >= n_bins+2 (padded so that the fast scan kernel
+// can use immediate LDS offsets); class 1 (model 3 only) carries the
 // birth process alone and is used by extant lineages (LRF:141-142: death half on te<end_time).
 // Model conventions (LRF:137-162):
 //   2/3: logB = log lam, logD = log mu, R = lam+mu
@@ -150,11 +151,10 @@ __device__ __forceinline__ void lr_bin_terms(int model, double lam, double mu, d
 
 __device__ inline double lr_build_tables_wave(const double* __restrict__ lam_bins, const double* __restrict__ mu_bins,
                                               const double* __restrict__ br_length, int model, int n_bins, int n_cls,
-                                              double2* __restrict__ tab, int lane) {
+                                              int H, double2* __restrict__ tab, int lane) {
     const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
     const int b0 = lane * P;
     const int b1 = min(b0 + P, n_bins);
-    const int nb2 = n_bins + 2;
     double sumR = 0.0, sumRl = 0.0, csum = 0.0;
     for (int b = b0; b < b1; ++b) {
         double logB, logD, R, Rl, ct;
@@ -169,27 +169,27 @@ __device__ inline double lr_build_tables_wave(const double* __restrict__ lam_bin
         double logB, logD, R, Rl, ct;
         lr_bin_terms(model, lam_bins[b], mu_bins[b], model < 2 ? br_length[b] : 1.0, &logB, &logD, &R, &Rl, &ct);
         tab[b + 1] = make_double2(logB + cum, R);
-        tab[nb2 + b + 1] = make_double2(logD - cum, -R);
+        tab[H + b + 1] = make_double2(logD - cum, -R);
         cum += R;
         if (n_cls == 2) {
-            tab[2 * nb2 + b + 1] = make_double2(logB + cuml, Rl);
-            tab[3 * nb2 + b + 1] = make_double2(-cuml, -Rl);
+            tab[2 * H + b + 1] = make_double2(logB + cuml, Rl);
+            tab[3 * H + b + 1] = make_double2(-cuml, -Rl);
             cuml += Rl;
         }
     }
     if (lane == 0) {
         tab[0] = make_double2(0.0, 0.0);
-        tab[nb2] = make_double2(0.0, 0.0);
-        tab[nb2 - 1] = make_double2(totR, 0.0);
-        tab[2 * nb2 - 1] = make_double2(-totR, 0.0);
+        tab[H] = make_double2(0.0, 0.0);
+        tab[n_bins + 1] = make_double2(totR, 0.0);
+        tab[H + n_bins + 1] = make_double2(-totR, 0.0);
         if (n_cls == 2) {
-            tab[2 * nb2] = make_double2(0.0, 0.0);
-            tab[3 * nb2] = make_double2(0.0, 0.0);
-            tab[3 * nb2 - 1] = make_double2(totRl, 0.0);
-            tab[4 * nb2 - 1] = make_double2(-totRl, 0.0);
+            tab[2 * H] = make_double2(0.0, 0.0);
+            tab[3 * H] = make_double2(0.0, 0.0);
+            tab[2 * H + n_bins + 1] = make_double2(totRl, 0.0);
+            tab[3 * H + n_bins + 1] = make_double2(-totRl, 0.0);
         }
     }
     return lr_wave_sum(csum);
 }
 
-static inline int lr_table_stride(int n_bins, int n_cls) { return n_cls * 2 * (n_bins + 2); }
+

@@ -5,7 +5,9 @@
 
 #include "../../include/literate_hip.h"
 
+#ifndef LR_SCAN_THREADS
 #define LR_SCAN_THREADS 256
+#endif
 #define LR_SCAN_LDS_BUDGET (48 * 1024) /* table bytes per block we aim for (3 blocks / CU) */
 #define LR_SCAN_LDS_MAX (150 * 1024)
 
@@ -14,7 +16,9 @@ struct lr_scan_plan {
     int groups;        // ceil(n_chains / cb)
     int tiles;         // lineage tiles
     long long chunk;   // lineages per tile (multiple of 2*LR_SCAN_THREADS)
-    int tab_stride;    // double2 entries per chain
+    int tab_stride;    // double2 entries per chain = n_cls * 2 * H
+    int H;             // entries reserved for each of the S and E tables (>= n_bins + 2)
+    int fast;          // 1: templated immediate-offset kernel (n_cls == 1, H in {40,72,136,264})
     int n_cls;
     size_t lds_bytes;
 };

@@ -7,6 +7,8 @@
 // per (lineage, chain).  Per-chain sums are reduced lane -> wave (shuffle butterfly) -> block
 // (LDS, fixed order) -> one partial per (tile, chain); partials are summed in tile order by the
 // consumer, so results are bitwise reproducible.  No MFMA: this is a gather/scan/reduce.
+#include <cstdlib>
+
 #include "lr_device.h"
 #include "lr_internal.h"
 
@@ -16,13 +18,13 @@
 __global__ __launch_bounds__(LR_WAVE) void lr_build_tables_kernel(const double* __restrict__ lam_bins,
                                                                   const double* __restrict__ mu_bins,
                                                                   const double* __restrict__ br_length, int model,
-                                                                  int n_bins, int n_cls, int tab_stride,
+                                                                  int n_bins, int n_cls, int H, int tab_stride,
                                                                   double2* __restrict__ tables,
                                                                   double* __restrict__ consts) {
     const int c = blockIdx.x;
     const int lane = threadIdx.x;
     const double cst = lr_build_tables_wave(lam_bins + (size_t)c * n_bins, mu_bins + (size_t)c * n_bins, br_length,
-                                            model, n_bins, n_cls, tables + (size_t)c * tab_stride, lane);
+                                            model, n_bins, n_cls, H, tables + (size_t)c * tab_stride, lane);
     if (lane == 0) consts[c] = cst;
 }
 
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(LR_WAVE) void lr_build_tables_kernel(const double* 
 // the lineage scan
 // ------------------------------------------------------------------------------------------
 template <int CB>
-__device__ __forceinline__ void lr_score_lineage(double s, double e, double t0, double nb1, int nb2, int n_cls,
+__device__ __forceinline__ void lr_score_lineage(double s, double e, double t0, double nb1, int H, int n_cls,
                                                  double end_time, const double2* __restrict__ lds, int tab_stride,
                                                  double (&acc)[CB]) {
     const double fl = floor(s);
@@ -41,9 +43,9 @@ __device__ __forceinline__ void lr_score_lineage(double s, double e, double t0, 
     const double fs = s - fl;
     const double fe = e - (ce - 1.0);
     int base = 0;
-    if (n_cls == 2 && e >= end_time) base = 2 * nb2;
+    if (n_cls == 2 && e >= end_time) base = 2 * H;
     const int offS = base + js;
-    const int offE = base + nb2 + je;
+    const int offE = base + H + je;
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
         const double2 S = lds[c * tab_stride + offS];
@@ -58,7 +60,8 @@ __device__ __forceinline__ void lr_score_lineage(double s, double e, double t0, 
 template <int CB>
 __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_kernel(const double* __restrict__ ts,
                                                                   const double* __restrict__ te, long long n,
-                                                                  double t0, int n_bins, int n_cls, double end_time,
+                                                                  double t0, int n_bins, int n_cls, int H,
+                                                                  double end_time,
                                                                   const double2* __restrict__ tables, int tab_stride,
                                                                   int n_chains, long long chunk,
                                                                   double* __restrict__ partials) {
@@ -84,30 +87,129 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_kernel(const double* 
     const long long start = (long long)tile * chunk;
     const long long end = min(start + chunk, n);
     const double nb1 = (double)(n_bins + 1);
-    const int nb2 = n_bins + 2;
     const bool aligned = ((((uintptr_t)ts) | ((uintptr_t)te)) & 15) == 0;  // chunk is even, so start is
     if (aligned) {
         for (long long i = start + 2 * tid; i < end; i += 2 * LR_SCAN_THREADS) {
             if (i + 1 < end) {
                 const double2 s2 = *reinterpret_cast<const double2*>(ts + i);
                 const double2 e2 = *reinterpret_cast<const double2*>(te + i);
-                lr_score_lineage<CB>(s2.x, e2.x, t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
-                lr_score_lineage<CB>(s2.y, e2.y, t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
+                lr_score_lineage<CB>(s2.x, e2.x, t0, nb1, H, n_cls, end_time, lds, tab_stride, acc);
+                lr_score_lineage<CB>(s2.y, e2.y, t0, nb1, H, n_cls, end_time, lds, tab_stride, acc);
             } else {
-                lr_score_lineage<CB>(ts[i], te[i], t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
+                lr_score_lineage<CB>(ts[i], te[i], t0, nb1, H, n_cls, end_time, lds, tab_stride, acc);
             }
         }
     } else {
         // same lineage -> thread assignment as the aligned path (identical summation order)
         for (long long i = start + 2 * tid; i < end; i += 2 * LR_SCAN_THREADS) {
-            lr_score_lineage<CB>(ts[i], te[i], t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
+            lr_score_lineage<CB>(ts[i], te[i], t0, nb1, H, n_cls, end_time, lds, tab_stride, acc);
             if (i + 1 < end)
-                lr_score_lineage<CB>(ts[i + 1], te[i + 1], t0, nb1, nb2, n_cls, end_time, lds, tab_stride, acc);
+                lr_score_lineage<CB>(ts[i + 1], te[i + 1], t0, nb1, H, n_cls, end_time, lds, tab_stride, acc);
         }
     }
 
     // lane -> wave -> block, fixed order
     __syncthreads();  // everyone is done reading the tables: reuse the start of LDS as scratch
+    double* red = reinterpret_cast<double*>(lds);
+    const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const double w = lr_wave_sum(acc[c]);
+        if (lane == 0) red[wave * CB + c] = w;
+    }
+    __syncthreads();
+    if (tid < nvalid) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < LR_SCAN_THREADS / LR_WAVE; ++w) t += red[w * CB + tid];
+        partials[(size_t)tile * n_chains + chain0 + tid] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fast path (one table class, H a template constant): every LDS gather address is
+// lane_offset + immediate, the index math is integer (cvt + med3), the next pair of lineages
+// is prefetched while the current one is scored.
+// ------------------------------------------------------------------------------------------
+template <int CB, int H>
+__device__ __forceinline__ void lr_score_lineage_fast(double s, double e, double t0, int n_bins,
+                                                      const char* __restrict__ lds, double (&acc)[CB]) {
+    const double fl = floor(s);
+    const double ce = ceil(e);
+    // v_cvt_i32_f64 saturates, so far-away times clamp correctly before the med3
+    const int a = min(max(__double2int_rz(fl - t0), -1), n_bins);          // birth bin, -1 / n_bins = outside
+    const int b = min(max(__double2int_rz(ce - t0), 0), n_bins + 1);       // death entry index
+    const double fs = s - fl;
+    const double fe = (e - ce) + 1.0;
+    const char* pS = lds + ((a + 1) << 4);
+    const char* pE = lds + (b << 4) + H * 16;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const double2 S = *reinterpret_cast<const double2*>(pS + c * (2 * H * 16));
+        const double2 E = *reinterpret_cast<const double2*>(pE + c * (2 * H * 16));
+        double t = S.x + E.x;
+        t = fma(fs, S.y, t);
+        t = fma(fe, E.y, t);
+        acc[c] += t;
+    }
+}
+
+template <int CB, int H>
+__global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_fast_kernel(const double* __restrict__ ts,
+                                                                       const double* __restrict__ te, long long n,
+                                                                       double t0, int n_bins,
+                                                                       const double2* __restrict__ tables,
+                                                                       int n_chains, long long chunk,
+                                                                       double* __restrict__ partials) {
+    extern __shared__ double2 lds[];
+    constexpr int STRIDE = 2 * H;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int chain0 = blockIdx.y * CB;
+    const int nvalid = min(CB, n_chains - chain0);
+    {
+        const double2* src = tables + (size_t)chain0 * STRIDE;
+        const int n_valid_entries = nvalid * STRIDE;
+#pragma unroll 4
+        for (int i = tid; i < CB * STRIDE; i += LR_SCAN_THREADS)
+            lds[i] = (i < n_valid_entries) ? src[i] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+
+    double acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = 0.0;
+    const char* lbase = reinterpret_cast<const char*>(lds);
+    const long long start = (long long)tile * chunk;
+    const long long end = min(start + chunk, n);
+    const bool aligned = ((((uintptr_t)ts) | ((uintptr_t)te)) & 15) == 0;
+    long long i = start + 2 * tid;
+    if (aligned) {
+        double2 s2 = make_double2(0.0, 0.0), e2 = make_double2(0.0, 0.0);
+        if (i + 1 < end) {
+            s2 = *reinterpret_cast<const double2*>(ts + i);
+            e2 = *reinterpret_cast<const double2*>(te + i);
+        }
+        while (i + 1 < end) {
+            const double2 sc = s2, ec = e2;
+            const long long nx = i + 2 * LR_SCAN_THREADS;
+            if (nx + 1 < end) {  // prefetch the next pair
+                s2 = *reinterpret_cast<const double2*>(ts + nx);
+                e2 = *reinterpret_cast<const double2*>(te + nx);
+            }
+            lr_score_lineage_fast<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
+            lr_score_lineage_fast<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
+            i = nx;
+        }
+        if (i < end) lr_score_lineage_fast<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
+    } else {
+        for (; i < end; i += 2 * LR_SCAN_THREADS) {
+            lr_score_lineage_fast<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
+            if (i + 1 < end) lr_score_lineage_fast<CB, H>(ts[i + 1], te[i + 1], t0, n_bins, lbase, acc);
+        }
+    }
+
+    __syncthreads();
     double* red = reinterpret_cast<double*>(lds);
     const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
 #pragma unroll
@@ -141,7 +243,18 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan*
     if (n_bins < 1 || n_bins > LR_MAX_BINS) return LR_ERR_SIZE;
     if (model < 0 || model > 3) return LR_ERR_MODEL;
     p->n_cls = (model == LR_MODEL_KEIDING_DEAD) ? 2 : 1;
-    p->tab_stride = lr_table_stride(n_bins, p->n_cls);
+    // fast path: one table class and a padded half-stride the kernel is instantiated for
+    static const int fast_H[] = {40, 72, 136, 264};
+    p->fast = 0;
+    p->H = n_bins + 2;
+    if (p->n_cls == 1) {
+        for (int h : fast_H)
+            if (n_bins + 2 <= h) {
+                p->H = h, p->fast = 1;
+                break;
+            }
+    }
+    p->tab_stride = p->n_cls * 2 * p->H;
     const size_t per_chain = (size_t)p->tab_stride * sizeof(double2);
     int cb = 8;
     while (cb > 1 && per_chain * cb > LR_SCAN_LDS_BUDGET) cb >>= 1;
@@ -151,7 +264,8 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan*
     p->groups = (n_chains + cb - 1) / cb;
     if (p->groups > 65535) return LR_ERR_SIZE;
     const long long unit = 2 * LR_SCAN_THREADS;
-    long long tiles = (2048 + p->groups - 1) / p->groups;
+    static const long long target_blocks = getenv("LR_SCAN_BLOCKS") ? atoll(getenv("LR_SCAN_BLOCKS")) : 2048;
+    long long tiles = (target_blocks + p->groups - 1) / p->groups;
     const long long max_tiles = (n + 4 * unit - 1) / (4 * unit);  // >= 8 lineages per thread
     if (tiles > max_tiles) tiles = max_tiles;
     if (tiles < 1) tiles = 1;
@@ -164,6 +278,35 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan*
     if (lds < red) lds = red;
     p->lds_bytes = lds;
     return LR_OK;
+}
+
+template <int CB, int H>
+static int lr_launch_scan_fast(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0,
+                               int n_bins, const double2* tables, int n_chains, double* partials,
+                               hipStream_t stream) {
+    static bool configured = false;
+    if (p.lds_bytes > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_scan_fast_kernel<CB, H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    dim3 grid(p.tiles, p.groups);
+    hipLaunchKernelGGL((lr_scan_fast_kernel<CB, H>), grid, dim3(LR_SCAN_THREADS), p.lds_bytes, stream, ts, te, n, t0,
+                       n_bins, tables, n_chains, p.chunk, partials);
+    return (int)hipGetLastError();
+}
+
+template <int H>
+static int lr_launch_scan_fast_h(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0,
+                                 int n_bins, const double2* tables, int n_chains, double* partials,
+                                 hipStream_t stream) {
+    switch (p.cb) {
+        case 8: return lr_launch_scan_fast<8, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+        case 4: return lr_launch_scan_fast<4, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+        case 2: return lr_launch_scan_fast<2, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+        default: return lr_launch_scan_fast<1, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+    }
 }
 
 template <int CB>
@@ -179,12 +322,21 @@ static int lr_launch_scan_cb(const lr_scan_plan& p, const double* ts, const doub
     }
     dim3 grid(p.tiles, p.groups);
     hipLaunchKernelGGL(lr_scan_kernel<CB>, grid, dim3(LR_SCAN_THREADS), p.lds_bytes, stream, ts, te, n, t0, n_bins,
-                       p.n_cls, end_time, tables, p.tab_stride, n_chains, p.chunk, partials);
+                       p.n_cls, p.H, end_time, tables, p.tab_stride, n_chains, p.chunk, partials);
     return (int)hipGetLastError();
 }
 
 int lr_launch_scan(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0, int n_bins,
                    double end_time, const double2* tables, int n_chains, double* partials, hipStream_t stream) {
+    if (p.fast) {
+        switch (p.H) {
+            case 40: return lr_launch_scan_fast_h<40>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+            case 72: return lr_launch_scan_fast_h<72>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+            case 136: return lr_launch_scan_fast_h<136>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+            case 264: return lr_launch_scan_fast_h<264>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+            default: return LR_ERR_SIZE;
+        }
+    }
     switch (p.cb) {
         case 8: return lr_launch_scan_cb<8>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
         case 4: return lr_launch_scan_cb<4>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
@@ -231,7 +383,7 @@ extern "C" int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n,
     double* consts = (double*)(ws + o_cst);
     double* partials = (double*)(ws + o_par);
     hipLaunchKernelGGL(lr_build_tables_kernel, dim3(n_chains), dim3(LR_WAVE), 0, stream, lam_bins, mu_bins, br_length,
-                       model, n_bins, p.n_cls, p.tab_stride, tables, consts);
+                       model, n_bins, p.n_cls, p.H, p.tab_stride, tables, consts);
     rc = (int)hipGetLastError();
     if (rc) return rc;
     rc = lr_launch_scan(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(LR_WAVE) void lr_rj_propose_score_kernel(
     if (mv == 0) {
         const bool ff = (lane < k) ? (dr[lane] != 0.0) : false;
         const double u = (lane < k) ? dr[kmax + lane] : 0.5;
-        score = lr_wave_multiplier(R, k, ff, u, mult_d, lane);
+        score = lr_wave_multiplier(R, k, ff, u, 2.0 * log(mult_d), lane);
     } else if (mv == 1) {
         score = lr_wave_add_shift(R, T, k, index[c], dr[0], dr[1], lane);
     } else if (mv == 2) {
@@ -115,54 +115,130 @@ struct lr_engine {
     bool initialised;
     hipGraphExec_t graph_exec;
     int graph_iters;
-    hipStream_t graph_stream;
 };
 
 struct lr_step_args {
     lr_mcmc_config cfg;
     double* state_f64;
     int* state_i32;
-    double* rate_bins;
+    const double* log_br;   // [n_bins] log(br_length) (models 0/1)
     double2* tables;
     const double* partials;
     double* trace;
     const double* br_length;
-    int tab_stride, n_cls, tiles;
+    double log_T;           // log(end_time - start_time)
+    double mult_l;          // 2 log d of the multiplier proposal (LRF:169)
+    int tab_stride, n_cls, tiles, H;
 };
 
-__device__ __forceinline__ double lr_bcast(double v, int src) { return __shfl(v, src, LR_WAVE); }
-__device__ __forceinline__ int lr_bcast_i(int v, int src) { return __shfl(v, src, LR_WAVE); }
+// per-wave LDS scratch: segment rates, their logs and integer edges of both processes
+struct lr_seg_scratch {
+    double rate[2][LR_KMAX];
+    double lograte[2][LR_KMAX];
+    int edge[2][LR_KMAX + 1];
+};
 
-// expand K segment rates to unit bins through LDS-staged edges (get_rate_index + L[indL], LRF:125-135, 306)
-__device__ inline void lr_wave_expand(double R, int E, int K, int n_bins, double* __restrict__ out, double* s_rate,
-                                      int* s_edge, int lane) {
-    if (lane < LR_KMAX) s_rate[lane] = R;
-    if (lane <= LR_KMAX) s_edge[lane] = E;
-    __syncthreads();
+// Lookup tables of one chain straight from its segments (get_rate_index + L[indL] + the table
+// builder of lr_device.h in one go, no per-bin transcendental): bin b of process p takes segment
+// j with edge[p][j] <= b < edge[p][j+1].  Model conventions as lr_bin_terms, with
+// log(k*lam) taken as log k + log lam (log_br = log k is a data constant).
+__device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc, int KL, int KM,
+                                                       const double* __restrict__ br_length,
+                                                       const double* __restrict__ log_br, int model, int n_bins,
+                                                       int n_cls, int H, double2* __restrict__ tab, int lane) {
     const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
-    const int b0 = lane * P, b1 = min(b0 + P, n_bins);
-    int seg = 0;
+    const int b0 = min(lane * P, n_bins), b1 = min(b0 + P, n_bins);
+    int sl0 = 0, sm0 = 0;
+    while (sl0 + 1 < KL && sc->edge[0][sl0 + 1] <= b0) ++sl0;
+    while (sm0 + 1 < KM && sc->edge[1][sm0 + 1] <= b0) ++sm0;
+    double sumR = 0.0, sumRl = 0.0, csum = 0.0;
+    int sl = sl0, sm = sm0;
     for (int b = b0; b < b1; ++b) {
-        while (seg + 1 < K && s_edge[seg + 1] <= b) ++seg;
-        out[b] = s_rate[seg];
+        while (sl + 1 < KL && sc->edge[0][sl + 1] <= b) ++sl;
+        while (sm + 1 < KM && sc->edge[1][sm + 1] <= b) ++sm;
+        const double lam = sc->rate[0][sl], mu = sc->rate[1][sm];
+        const bool live = (model >= 2) || (br_length[b] > 0.0);
+        double R = 0.0;
+        if (live) R = (model == 1) ? mu : lam + mu;
+        sumR += R;
+        if (model >= 2) sumRl += lam;
+        if (model == 1 && live) csum -= lam;
     }
-    __syncthreads();
+    double totR, totRl = 0.0;
+    double cum = lr_wave_exclusive_scan(sumR, lane, &totR);
+    double cuml = 0.0;
+    if (n_cls == 2) cuml = lr_wave_exclusive_scan(sumRl, lane, &totRl);
+    sl = sl0, sm = sm0;
+    for (int b = b0; b < b1; ++b) {
+        while (sl + 1 < KL && sc->edge[0][sl + 1] <= b) ++sl;
+        while (sm + 1 < KM && sc->edge[1][sm + 1] <= b) ++sm;
+        const double lam = sc->rate[0][sl], mu = sc->rate[1][sm];
+        const double llam = sc->lograte[0][sl], lmu = sc->lograte[1][sm];
+        double logB = 0.0, logD = 0.0, R = 0.0;
+        if (model >= 2) {
+            logB = llam, logD = lmu, R = lam + mu;
+        } else if (br_length[b] > 0.0) {
+            const double lk = log_br[b];
+            logB = (model == 0) ? lk + llam : llam;
+            logD = lmu + lk;
+            R = (model == 0) ? lam + mu : mu;
+        }
+        tab[b + 1] = make_double2(logB + cum, R);
+        tab[H + b + 1] = make_double2(logD - cum, -R);
+        cum += R;
+        if (n_cls == 2) {
+            tab[2 * H + b + 1] = make_double2(logB + cuml, lam);
+            tab[3 * H + b + 1] = make_double2(-cuml, -lam);
+            cuml += lam;
+        }
+    }
+    if (lane == 0) {
+        tab[0] = make_double2(0.0, 0.0);
+        tab[H] = make_double2(0.0, 0.0);
+        tab[n_bins + 1] = make_double2(totR, 0.0);
+        tab[H + n_bins + 1] = make_double2(-totR, 0.0);
+        if (n_cls == 2) {
+            tab[2 * H] = make_double2(0.0, 0.0);
+            tab[3 * H] = make_double2(0.0, 0.0);
+            tab[2 * H + n_bins + 1] = make_double2(totRl, 0.0);
+            tab[3 * H + n_bins + 1] = make_double2(-totRl, 0.0);
+        }
+    }
+    return lr_wave_sum(csum);
+}
+
+// stage one chain's segments in the wave's LDS scratch; log of all rates in ONE call
+// (lanes 0..31 carry the birth rates, lanes 32..63 the death rates)
+__device__ __forceinline__ void lr_stage_segments(lr_seg_scratch* sc, double L, double M, int eL, int eM, int KL,
+                                                  int KM, int lane, double* logL, double* logM) {
+    const double Mhi = __shfl(M, lane & 31, LR_WAVE);
+    const bool hi = lane >= 32;
+    const int j = lane & 31;
+    const bool valid = hi ? (j < KM) : (j < KL);
+    const double x = valid ? (hi ? Mhi : L) : 1.0;
+    const double lx = log(x);
+    sc->rate[hi][j] = x;
+    sc->lograte[hi][j] = lx;
+    if (lane <= LR_KMAX) sc->edge[0][lane] = eL, sc->edge[1][lane] = eM;
+    *logL = lx;                                        // valid on lanes < 32
+    *logM = __shfl(lx, 32 + (lane & 31), LR_WAVE);     // lane j gets log M[j]
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // mode: 0 = regular step (accept pending proposal, then propose), 1 = finish init (adopt the
 // evaluated initial state as accepted, then propose iteration 0)
 __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, int mode) {
-    __shared__ double s_rate[LR_KMAX];
-    __shared__ int s_edge[LR_KMAX + 1];
+    __shared__ lr_seg_scratch scratch;
     const lr_mcmc_config& cfg = a.cfg;
     const int c = blockIdx.x, lane = threadIdx.x;
     const int C = cfg.n_chains, n_bins = cfg.n_bins;
     double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
     int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
-    double* rb = a.rate_bins + (size_t)c * 4 * n_bins;
     const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
 
-    // ---- load state: lane j holds element j ----
+    // ---- load state: lane j holds element j; tile partials in flight at the same time ----
     double L = S[LR_ROW_L * LR_ROW + lane], M = S[LR_ROW_M * LR_ROW + lane];
     double tL = S[LR_ROW_TL * LR_ROW + lane], tM = S[LR_ROW_TM * LR_ROW + lane];
     const double pL0 = S[LR_ROW_PL * LR_ROW + lane], pM0 = S[LR_ROW_PM * LR_ROW + lane];
@@ -171,26 +247,26 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, 
     int eL = I[LR_IROW_EL * LR_ROW + lane], eM = I[LR_IROW_EM * LR_ROW + lane];
     const int peL0 = I[LR_IROW_PEL * LR_ROW + lane], peM0 = I[LR_IROW_PEM * LR_ROW + lane];
     const int isc = I[LR_IROW_SCALARS * LR_ROW + lane];
+    double part = 0.0;
+    for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * C + c];
+
     double likA = lr_bcast(sc, LR_S_LIKA), priorA = lr_bcast(sc, LR_S_PRIORA);
     double priorPoiA = lr_bcast(sc, LR_S_PRIORPOIA);
     double g0 = lr_bcast(sc, LR_S_GRATE_L), g1 = lr_bcast(sc, LR_S_GRATE_M), poi = lr_bcast(sc, LR_S_POI);
+    double lg0 = lr_bcast(sc, LR_S_LOG_G0), lg1 = lr_bcast(sc, LR_S_LOG_G1), lpoi = lr_bcast(sc, LR_S_LOG_POI);
     double constA = lr_bcast(sc, LR_S_CONST_A);
     int KL = lr_bcast_i(isc, LR_I_KL), KM = lr_bcast_i(isc, LR_I_KM);
     uint64_t it = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_HI) << 32);
     int n_acc = lr_bcast_i(isc, LR_I_ACCEPTED);
-
-    // ---- log-likelihood of the pending proposal: tile partials in tile order ----
-    double part = 0.0;
-    for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * C + c];
+    // log-likelihood of the pending proposal: tile partials summed in tile order
     const double lik_sum = lr_wave_sum(part);
 
-    const double T_span = cfg.end_time - cfg.start_time;
     if (mode == 1) {
         // LRF:224-230.  The initial prior uses prior_gamma's default rate b=2 (LRF:201, 227).
         likA = lik_sum + constA;
         priorA = lr_wave_prior_gamma(L, KL, LR_GAMMA_SHAPE, 2.0, lane) + lr_wave_prior_gamma(M, KM, LR_GAMMA_SHAPE, 2.0, lane);
-        priorA += -log(T_span) * (KL - 1 + KM - 1);
-        priorPoiA = lr_wave_poisson_prior(KL, poi, lane) + lr_wave_poisson_prior(KM, poi, lane);
+        priorA += -a.log_T * (KL - 1 + KM - 1);
+        priorPoiA = lr_poisson_prior(KL, poi, lpoi) + lr_poisson_prior(KM, poi, lpoi);
         priorA += priorPoiA;
     } else {
         // ---- Metropolis-Hastings accept of iteration `it` (LRF:305-319) ----
@@ -206,7 +282,6 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, 
             KL = lr_bcast_i(isc, LR_I_PKL), KM = lr_bcast_i(isc, LR_I_PKM);
             likA = lik, priorA = priorP, priorPoiA = priorPoiP, constA = constP;
             n_acc += 1;
-            for (int b = lane; b < n_bins; b += LR_WAVE) rb[b] = rb[2 * n_bins + b], rb[n_bins + b] = rb[3 * n_bins + b];
         }
         // ---- trace row (LRF:321-359) ----
         if (it % (uint64_t)cfg.s_freq == 0) {
@@ -257,7 +332,7 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, 
     if (r.a < b_freq) {
         if (r.b < .5 || KL == 1) {
             const lr_u2 d = lr_pair(rng, it, LR_P_MULT, lane);
-            hasting = lr_wave_multiplier(pL, KL, d.a < fL, d.b, LR_MULT_D, lane);
+            hasting = lr_wave_multiplier(pL, KL, d.a < fL, d.b, a.mult_l, lane);
             move_kind = 0;
         } else {
             peL = lr_wave_edges(tL, 0);  // update_times leaves the times unchanged (LRF:178-195)
@@ -266,7 +341,7 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, 
     } else if (r.a < d_freq) {
         if (r.b < .5 || KM == 1) {
             const lr_u2 d = lr_pair(rng, it, LR_P_MULT, lane);
-            hasting = lr_wave_multiplier(pM, KM, d.a < fM, d.b, LR_MULT_D, lane);
+            hasting = lr_wave_multiplier(pM, KM, d.a < fM, d.b, a.mult_l, lane);
             move_kind = 2;
         } else {
             peM = lr_wave_edges(tM, 0);
@@ -287,8 +362,8 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, 
             } else {
                 const int ind = min((int)(q2.a * K), K - 1);
                 const double delta = q2.b * (lr_bcast(T, ind + 1) - lr_bcast(T, ind));
-                const double ga = lr_gamma(rng, it, LR_P_BETA_A, 0, LR_SHAPE_BETA_RJ);
-                const double gb = lr_gamma(rng, it, LR_P_BETA_B, 0, LR_SHAPE_BETA_RJ);
+                double ga, gb;
+                lr_wave_gamma2(rng, it, LR_P_BETA_A, LR_SHAPE_BETA_RJ, LR_P_BETA_B, LR_SHAPE_BETA_RJ, lane, &ga, &gb);
                 score = lr_wave_add_shift(R, T, K, ind, delta, ga / (ga + gb), lane);
             }
         } else if (K > 1) {
@@ -299,40 +374,47 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, 
         const int E = lr_wave_edges(T, 0);
         if (sideL) pL = R, ptL = T, PKL = K, peL = E;
         else pM = R, ptM = T, PKM = K, peM = E;
-        priorPoi = lr_wave_poisson_prior(PKL, poi, lane) + lr_wave_poisson_prior(PKM, poi, lane);
+        priorPoi = lr_poisson_prior(PKL, poi, lpoi) + lr_poisson_prior(PKM, poi, lpoi);
     } else {
         // Gibbs draws of the hyper-parameters (LRF:283-287, 99-108, 210-213)
         move_kind = 5;
+        double gl = 0.0, gm = 0.0, gp = 0.0, dummy;
+        if (cfg.use_rate_HP)
+            lr_wave_gamma2(rng, it, LR_P_GIBBS_L, LR_HP_GAMMA_SHAPE + LR_GAMMA_SHAPE * KL, LR_P_GIBBS_M,
+                           LR_HP_GAMMA_SHAPE + LR_GAMMA_SHAPE * KM, lane, &gl, &gm);
         if (cfg.poisson_HP == 0.0)
-            poi = lr_gamma(rng, it, LR_P_GIBBS_POI, 0, LR_RJHP_SHAPE + KL + KM) * (1. / (LR_RJHP_RATE + 2));
+            lr_wave_gamma2(rng, it, LR_P_GIBBS_POI, LR_RJHP_SHAPE + KL + KM, LR_P_GIBBS_POI, LR_RJHP_SHAPE + KL + KM, lane,
+                           &gp, &dummy);
+        if (cfg.poisson_HP == 0.0) poi = gp * (1. / (LR_RJHP_RATE + 2));
         if (cfg.use_rate_HP) {
             const double sL = lr_wave_sum(lane < KL ? L : 0.0), sM = lr_wave_sum(lane < KM ? M : 0.0);
-            g0 = lr_gamma(rng, it, LR_P_GIBBS_L, 0, LR_HP_GAMMA_SHAPE + LR_GAMMA_SHAPE * KL) * (1. / (LR_HP_GAMMA_RATE + sL));
-            g1 = lr_gamma(rng, it, LR_P_GIBBS_M, 0, LR_HP_GAMMA_SHAPE + LR_GAMMA_SHAPE * KM) * (1. / (LR_HP_GAMMA_RATE + sM));
+            g0 = gl * (1. / (LR_HP_GAMMA_RATE + sL));
+            g1 = gm * (1. / (LR_HP_GAMMA_RATE + sM));
         }
+        // one packed log for the three cached logarithms
+        const double lx = log(lane == 0 ? g0 : (lane == 1 ? g1 : (lane == 2 ? poi : 1.0)));
+        lg0 = lr_bcast(lx, 0), lg1 = lr_bcast(lx, 1), lpoi = lr_bcast(lx, 2);
         gibbs = 1;
     }
+
+    // segments of the proposal -> LDS scratch (+ log of every rate in one call)
+    double logpL, logpM;
+    lr_stage_segments(&scratch, pL, pM, peL, peM, PKL, PKM, lane, &logpL, &logpM);
 
     // guard against tiny time frames (LRF:290-292) and the prior of the proposal (LRF:296-304)
     double priorP = -INFINITY;
     if (lr_wave_min_segment(ptL, PKL, lane) <= LR_MIN_ALLOWED_T || lr_wave_min_segment(ptM, PKM, lane) <= LR_MIN_ALLOWED_T)
         invalid = 1;
     if (!invalid) {
-        priorP = lr_wave_prior_gamma(pL, PKL, LR_GAMMA_SHAPE, g0, lane) + lr_wave_prior_gamma(pM, PKM, LR_GAMMA_SHAPE, g1, lane);
-        priorP += -log(T_span) * (PKL - 1 + PKM - 1);
+        priorP = lr_wave_prior_gamma2(pL, logpL, PKL, g0, lg0, lane) + lr_wave_prior_gamma2(pM, logpM, PKM, g1, lg1, lane);
+        priorP += -a.log_T * (PKL - 1 + PKM - 1);
         if (priorPoi != 0.0) priorP += priorPoi;
         else priorP += priorPoiA, priorPoi = priorPoiA;
     }
 
-    // ---- per-bin rates and lookup tables of the proposal ----
-    if (mode == 1) {
-        // accepted per-bin rates of the initial state were written by lr_chain_init_kernel
-    }
-    lr_wave_expand(pL, peL, PKL, n_bins, rb + 2 * n_bins, s_rate, s_edge, lane);
-    lr_wave_expand(pM, peM, PKM, n_bins, rb + 3 * n_bins, s_rate, s_edge, lane);
-    __threadfence_block();
-    const double constP = lr_build_tables_wave(rb + 2 * n_bins, rb + 3 * n_bins, a.br_length, cfg.model, n_bins, a.n_cls,
-                                               a.tables + (size_t)c * a.tab_stride, lane);
+    // ---- lookup tables of the proposal ----
+    const double constP = lr_build_tables_segments_wave(&scratch, PKL, PKM, a.br_length, a.log_br, cfg.model, n_bins,
+                                                        a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane);
 
     // ---- store ----
     S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
@@ -355,6 +437,9 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, 
         case LR_S_PRIORPOI_P: so = priorPoi; break;
         case LR_S_CONST_P: so = constP; break;
         case LR_S_CONST_A: so = constA; break;
+        case LR_S_LOG_G0: so = lg0; break;
+        case LR_S_LOG_G1: so = lg1; break;
+        case LR_S_LOG_POI: so = lpoi; break;
         default: so = 0.0, wr = false; break;
     }
     if (wr) S[LR_ROW_SCALARS * LR_ROW + lane] = so;
@@ -376,18 +461,22 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, 
     if (wr) I[LR_IROW_SCALARS * LR_ROW + lane] = io;
 }
 
-// initial state (LRF:580-583 or the caller's runMCMC argument) -> state rows, per-bin rates,
-// tables of the initial state (so that the first scan evaluates likA, LRF:224-226)
+// log(br_length) once per engine (data constant used by models 0/1)
+__global__ void lr_log_br_kernel(const double* __restrict__ br, int n_bins, double* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_bins) out[b] = (br && br[b] > 0.0) ? log(br[b]) : 0.0;
+}
+
+// initial state (LRF:580-583 or the caller's runMCMC argument) -> state rows and the tables of
+// the initial state (so that the first scan evaluates likA, LRF:224-226)
 __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, const double* L0, const double* M0,
                                                                 const double* tL0, const double* tM0,
                                                                 const int* KL0, const int* KM0, int kmax) {
-    __shared__ double s_rate[LR_KMAX];
-    __shared__ int s_edge[LR_KMAX + 1];
+    __shared__ lr_seg_scratch scratch;
     const lr_mcmc_config& cfg = a.cfg;
     const int c = blockIdx.x, lane = threadIdx.x, n_bins = cfg.n_bins;
     double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
     int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
-    double* rb = a.rate_bins + (size_t)c * 4 * n_bins;
     const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
     double L = 0.0, M = 0.0, tL = 0.0, tM = 0.0;
     int KL = 1, KM = 1;
@@ -405,20 +494,21 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
     }
     // the initial index comes from get_rate_index on the RAW times: round, not floor (LRF:224-225, 129)
     const int eL = lr_wave_edges(tL, 1), eM = lr_wave_edges(tM, 1);
-    lr_wave_expand(L, eL, KL, n_bins, rb, s_rate, s_edge, lane);
-    lr_wave_expand(M, eM, KM, n_bins, rb + n_bins, s_rate, s_edge, lane);
-    __threadfence_block();
-    const double constA = lr_build_tables_wave(rb, rb + n_bins, a.br_length, cfg.model, n_bins, a.n_cls,
-                                               a.tables + (size_t)c * a.tab_stride, lane);
+    double logL, logM;
+    lr_stage_segments(&scratch, L, M, eL, eM, KL, KM, lane, &logL, &logM);
+    const double constA = lr_build_tables_segments_wave(&scratch, KL, KM, a.br_length, a.log_br, cfg.model, n_bins,
+                                                        a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane);
     S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
     S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
     S[LR_ROW_PL * LR_ROW + lane] = L, S[LR_ROW_PM * LR_ROW + lane] = M;
     S[LR_ROW_PTL * LR_ROW + lane] = tL, S[LR_ROW_PTM * LR_ROW + lane] = tM;
     I[LR_IROW_EL * LR_ROW + lane] = eL, I[LR_IROW_EM * LR_ROW + lane] = eM;
     I[LR_IROW_PEL * LR_ROW + lane] = eL, I[LR_IROW_PEM * LR_ROW + lane] = eM;
+    const double poi0 = (cfg.poisson_HP == 0.0) ? 1.0 : cfg.poisson_HP;             // LRF:220-221
     double so = 0.0;
-    if (lane == LR_S_GRATE_L || lane == LR_S_GRATE_M) so = 1.0;                       // LRF:222
-    if (lane == LR_S_POI) so = (cfg.poisson_HP == 0.0) ? 1.0 : cfg.poisson_HP;         // LRF:220-221
+    if (lane == LR_S_GRATE_L || lane == LR_S_GRATE_M) so = 1.0;                       // LRF:222 (log = 0)
+    if (lane == LR_S_POI) so = poi0;
+    if (lane == LR_S_LOG_POI) so = log(poi0);
     if (lane == LR_S_CONST_A || lane == LR_S_CONST_P) so = constA;
     S[LR_ROW_SCALARS * LR_ROW + lane] = so;
     int io = 0;
@@ -449,7 +539,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     long long o = 0;
     out->state_f64 = o, o += lr_align_up64(C * LR_STATE_ROWS * LR_ROW * 8, 256);
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
-    out->rate_bins = o, o += lr_align_up64(C * 4 * cfg->n_bins * 8, 256);
+    out->bin_consts = o, o += lr_align_up64((long long)cfg->n_bins * 8, 256);
     out->tables = o, o += lr_align_up64(C * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
     out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
@@ -479,7 +569,6 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->initialised = false;
     e->graph_exec = nullptr;
     e->graph_iters = 0;
-    e->graph_stream = nullptr;
     *out = e;
     return LR_OK;
 }
@@ -489,7 +578,9 @@ static lr_step_args lr_make_args(const lr_engine* e) {
     a.cfg = e->cfg;
     a.state_f64 = (double*)(e->ws + e->lay.state_f64);
     a.state_i32 = (int*)(e->ws + e->lay.state_i32);
-    a.rate_bins = (double*)(e->ws + e->lay.rate_bins);
+    a.log_br = (const double*)(e->ws + e->lay.bin_consts);
+    a.log_T = log(e->cfg.end_time - e->cfg.start_time);
+    a.mult_l = 2.0 * log(LR_MULT_D);
     a.tables = (double2*)(e->ws + e->lay.tables);
     a.partials = (const double*)(e->ws + e->lay.partials);
     a.trace = (double*)(e->ws + e->lay.trace);
@@ -497,6 +588,7 @@ static lr_step_args lr_make_args(const lr_engine* e) {
     a.tab_stride = e->plan.tab_stride;
     a.n_cls = e->plan.n_cls;
     a.tiles = e->plan.tiles;
+    a.H = e->plan.H;
     return a;
 }
 
@@ -513,6 +605,8 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
     if (L && (kmax < 1 || kmax > LR_KMAX)) return LR_ERR_SIZE;
     hipStream_t stream = (hipStream_t)stream_;
     const lr_step_args a = lr_make_args(e);
+    hipLaunchKernelGGL(lr_log_br_kernel, dim3((e->cfg.n_bins + 127) / 128), dim3(128), 0, stream, e->br_length,
+                       e->cfg.n_bins, (double*)(e->ws + e->lay.bin_consts));
     hipLaunchKernelGGL(lr_chain_init_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, L, M, tL, tM, KL, KM,
                        kmax);
     int rc = (int)hipGetLastError();

@@ -1,0 +1,25 @@
+import sys, time, os
+sys.path.insert(0, '/root/repo')
+import torch, numpy as np
+from literate_amd import synth
+from literate_amd.engine import ChainEngine
+ts, te, _ = synth.make_lineages(100000, 128, 20, 0)
+o = np.lexsort((te, ts)); ts, te = ts[o], te[o]
+def run(P, total=1024, n=640):
+    engs = [ChainEngine(ts, te, total // P, model=0, seed=1, s_freq=100, n_trace_slots=100, chain_offset=p * (total // P)) for p in range(P)]
+    streams = [torch.cuda.Stream() for _ in range(P)]
+    for e, s in zip(engs, streams):
+        with torch.cuda.stream(s):
+            e.init(); e.steps(64)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for rep in range(n // 64):
+        for e, s in zip(engs, streams):
+            with torch.cuda.stream(s):
+                e.steps(64)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t
+    print('P=%d: %.1f us per iteration of all %d chains -> %.3e evals/s' % (P, el / n * 1e6, total, n * 1e5 * total / el))
+    for e in engs: e.close()
+for P in (1, 2, 4, 8):
+    run(P)

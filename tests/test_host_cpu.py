@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol():
                           t0=0.0, start_time=0.0, end_time=128.5, seed=1)
     lay = _hip.McmcLayout()
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
-    assert lay.chains_per_block == 8 and lay.table_stride == 2 * 130 and lay.trace_width == _hip.LR_TRACE_W
-    assert lay.total_bytes > lay.trace > lay.partials > lay.tables > lay.rate_bins > lay.state_i32 > 0
+    assert lay.chains_per_block == 8 and lay.table_stride == 2 * 136 and lay.trace_width == _hip.LR_TRACE_W
+    assert lay.total_bytes > lay.trace > lay.partials > lay.tables > lay.bin_consts > lay.state_i32 > 0
     cfg.t0 = 0.5
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == -5        # LR_ERR_T0
     assert _hip.load().lr_bd_loglik_workspace_bytes(1000, 5000, 4, 2) == -2   # LR_ERR_SIZE

@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one RJMCMC iteration of every chain on this GPU: one scan of the lineage arrays
-scoring all pending proposals (lr_scan_kernel) + the per-chain accept / trace / next-proposal
-kernel.  Workload (config.workload) = BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages,
+scoring all pending proposals + the per-chain accept / trace / next-proposal step (fused and software
+pipelined over two halves of the chains: lr_fused_iter_kernel).  Workload (config.workload) = BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages,
 128 unit bins, 20 true shifts per process, 1024 chains per GPU; chains shard across ranks with no
 data-path collective (weak scaling), lineage arrays are replicated; the sampled trace rows are
 gathered over RCCL once at the end of the timed region.  Inputs are resident in HBM before timing.
@@ -113,16 +113,25 @@ def main():
     # sanity: the chains ran and hold finite posteriors
     snap = eng.snapshot()
     assert np.all(snap["it"] == args.steps + args.warmup) and np.all(np.isfinite(snap["likA"]))
+    assert snap["accepted"].min() > 0
 
     if rank == 0:
         total_chains = chains * world
         value = args.steps * n_lin * total_chains / elapsed
-        # roofline of the dominant kernel (lr_scan_kernel), timed live with HIP events on its stream
-        scan_ms = eng.time_scan(reps=50)
+        # roofline of the dominant kernel, timed live with HIP events on its launch stream.
+        # Pipelined engine: one iteration = two launches of lr_fused_iter_kernel (lineage scan of one half of
+        # the chains + chain step of the other half); each launch scores N x C/2 (lineage, chain) pairs.
         cb = eng.layout.chains_per_block
-        groups = -(-chains // cb)
+        n_ev = 200
+        ev_ms = eng.timed_steps(n_ev)                       # device time of n_ev more iterations (HIP events)
+        pipelined = os.environ.get("LR_PIPELINE", "1") != "0" and chains >= 2 * cb
+        launches = 2 * n_ev if pipelined else n_ev
+        kernel_ms = ev_ms / launches
+        chains_per_launch = chains / 2 if pipelined else chains
+        groups = -(-int(chains_per_launch) // cb)
         alg_bytes = 16.0 * n_lin * groups                   # 16 B x N x ceil(C/Cb) per launch
-        achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        scan_ms = eng.time_scan(reps=50)                    # stand-alone scan of ALL chains (same block body)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
@@ -142,11 +151,14 @@ def main():
                        "iters_per_s_per_chain": args.steps / elapsed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "lr_scan_kernel<%d>" % cb, "kernel_ms": scan_ms, "chains_per_pass_Cb": cb,
+                         "kernel": ("lr_fused_iter_kernel<%d,136>" if pipelined else "lr_scan_fast_kernel<%d,136> + lr_chain_step_kernel") % cb,
+                         "kernel_ms": kernel_ms, "launches_per_step": 2 if pipelined else 1,
+                         "pairs_per_launch": n_lin * chains_per_launch, "chains_per_pass_Cb": cb,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "effective_GBs_unamortised": 16.0 * n_lin * chains / (scan_ms * 1e-3) / 1e9,
-                         "scan_evals_per_s": n_lin * chains / (scan_ms * 1e-3),
-                         "scan_share_of_step": scan_ms / (elapsed / args.steps * 1e3)},
+                         "effective_GBs_unamortised": 16.0 * n_lin * chains_per_launch / (kernel_ms * 1e-3) / 1e9,
+                         "scan_only_kernel_ms_all_chains": scan_ms,
+                         "scan_only_evals_per_s": n_lin * chains / (scan_ms * 1e-3),
+                         "scan_only_frac": 16.0 * n_lin * (-(-chains // cb)) / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ts, te, eng.t0, eng.n_bins, eng.br_length.cpu().numpy())

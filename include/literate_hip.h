@@ -221,6 +221,8 @@ int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream);
  * the engine's lineage-scan kernel on `stream`, timed with HIP events recorded on that stream.
  * Blocks until the launches finish; re-scores the pending proposal, so chain state is unchanged. */
 int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms /* host */, void* stream);
+/* lr_mcmc_steps(n_iters) bracketed by HIP events on `stream`; blocks; *total_ms = elapsed device time. */
+int lr_mcmc_time_steps(lr_engine* e, int64_t n_iters, float* total_ms /* host */, void* stream);
 int lr_mcmc_destroy(lr_engine* e);
 
 #ifdef __cplusplus

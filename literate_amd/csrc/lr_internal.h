@@ -26,9 +26,11 @@ struct lr_scan_plan {
 // choose the launch shape of the lineage scan for (n lineages, n_chains, n_bins, model)
 int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan* plan);
 
-// enqueue the scan: partials[tile * n_chains + chain] = sum over the tile's lineages
+// enqueue the scan of `n_chains` chains whose tables start at `tables`:
+// partials[tile * partial_stride + chain] = sum over the tile's lineages
 int lr_launch_scan(const lr_scan_plan& plan, const double* ts, const double* te, long long n, double t0, int n_bins,
-                   double end_time, const double2* tables, int n_chains, double* partials, hipStream_t stream);
+                   double end_time, const double2* tables, int n_chains, double* partials, int partial_stride,
+                   hipStream_t stream);
 
 static inline int lr_align_up(long long x, long long a) { return (int)((x + a - 1) / a * a); }
 static inline long long lr_align_up64(long long x, long long a) { return (x + a - 1) / a * a; }

@@ -11,6 +11,7 @@
 
 #include "lr_device.h"
 #include "lr_internal.h"
+#include "lr_scan.h"
 
 // ------------------------------------------------------------------------------------------
 // tables from per-bin rates: one wave per chain
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_kernel(const double* 
                                                                   double end_time,
                                                                   const double2* __restrict__ tables, int tab_stride,
                                                                   int n_chains, long long chunk,
-                                                                  double* __restrict__ partials) {
+                                                                  double* __restrict__ partials, int partial_stride) {
     extern __shared__ double2 lds[];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
@@ -122,107 +123,7 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_kernel(const double* 
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < LR_SCAN_THREADS / LR_WAVE; ++w) t += red[w * CB + tid];
-        partials[(size_t)tile * n_chains + chain0 + tid] = t;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// fast path (one table class, H a template constant): every LDS gather address is
-// lane_offset + immediate, the index math is integer (cvt + med3), the next pair of lineages
-// is prefetched while the current one is scored.
-// ------------------------------------------------------------------------------------------
-template <int CB, int H>
-__device__ __forceinline__ void lr_score_lineage_fast(double s, double e, double t0, int n_bins,
-                                                      const char* __restrict__ lds, double (&acc)[CB]) {
-    const double fl = floor(s);
-    const double ce = ceil(e);
-    // v_cvt_i32_f64 saturates, so far-away times clamp correctly before the med3
-    const int a = min(max(__double2int_rz(fl - t0), -1), n_bins);          // birth bin, -1 / n_bins = outside
-    const int b = min(max(__double2int_rz(ce - t0), 0), n_bins + 1);       // death entry index
-    const double fs = s - fl;
-    const double fe = (e - ce) + 1.0;
-    const char* pS = lds + ((a + 1) << 4);
-    const char* pE = lds + (b << 4) + H * 16;
-#pragma unroll
-    for (int c = 0; c < CB; ++c) {
-        const double2 S = *reinterpret_cast<const double2*>(pS + c * (2 * H * 16));
-        const double2 E = *reinterpret_cast<const double2*>(pE + c * (2 * H * 16));
-        double t = S.x + E.x;
-        t = fma(fs, S.y, t);
-        t = fma(fe, E.y, t);
-        acc[c] += t;
-    }
-}
-
-template <int CB, int H>
-__global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_fast_kernel(const double* __restrict__ ts,
-                                                                       const double* __restrict__ te, long long n,
-                                                                       double t0, int n_bins,
-                                                                       const double2* __restrict__ tables,
-                                                                       int n_chains, long long chunk,
-                                                                       double* __restrict__ partials) {
-    extern __shared__ double2 lds[];
-    constexpr int STRIDE = 2 * H;
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int chain0 = blockIdx.y * CB;
-    const int nvalid = min(CB, n_chains - chain0);
-    {
-        const double2* src = tables + (size_t)chain0 * STRIDE;
-        const int n_valid_entries = nvalid * STRIDE;
-#pragma unroll 4
-        for (int i = tid; i < CB * STRIDE; i += LR_SCAN_THREADS)
-            lds[i] = (i < n_valid_entries) ? src[i] : make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-
-    double acc[CB];
-#pragma unroll
-    for (int c = 0; c < CB; ++c) acc[c] = 0.0;
-    const char* lbase = reinterpret_cast<const char*>(lds);
-    const long long start = (long long)tile * chunk;
-    const long long end = min(start + chunk, n);
-    const bool aligned = ((((uintptr_t)ts) | ((uintptr_t)te)) & 15) == 0;
-    long long i = start + 2 * tid;
-    if (aligned) {
-        double2 s2 = make_double2(0.0, 0.0), e2 = make_double2(0.0, 0.0);
-        if (i + 1 < end) {
-            s2 = *reinterpret_cast<const double2*>(ts + i);
-            e2 = *reinterpret_cast<const double2*>(te + i);
-        }
-        while (i + 1 < end) {
-            const double2 sc = s2, ec = e2;
-            const long long nx = i + 2 * LR_SCAN_THREADS;
-            if (nx + 1 < end) {  // prefetch the next pair
-                s2 = *reinterpret_cast<const double2*>(ts + nx);
-                e2 = *reinterpret_cast<const double2*>(te + nx);
-            }
-            lr_score_lineage_fast<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
-            lr_score_lineage_fast<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
-            i = nx;
-        }
-        if (i < end) lr_score_lineage_fast<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
-    } else {
-        for (; i < end; i += 2 * LR_SCAN_THREADS) {
-            lr_score_lineage_fast<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
-            if (i + 1 < end) lr_score_lineage_fast<CB, H>(ts[i + 1], te[i + 1], t0, n_bins, lbase, acc);
-        }
-    }
-
-    __syncthreads();
-    double* red = reinterpret_cast<double*>(lds);
-    const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
-#pragma unroll
-    for (int c = 0; c < CB; ++c) {
-        const double w = lr_wave_sum(acc[c]);
-        if (lane == 0) red[wave * CB + c] = w;
-    }
-    __syncthreads();
-    if (tid < nvalid) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < LR_SCAN_THREADS / LR_WAVE; ++w) t += red[w * CB + tid];
-        partials[(size_t)tile * n_chains + chain0 + tid] = t;
+        partials[(size_t)tile * partial_stride + chain0 + tid] = t;
     }
 }
 
@@ -282,7 +183,7 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan*
 
 template <int CB, int H>
 static int lr_launch_scan_fast(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0,
-                               int n_bins, const double2* tables, int n_chains, double* partials,
+                               int n_bins, const double2* tables, int n_chains, double* partials, int partial_stride,
                                hipStream_t stream) {
     static bool configured = false;
     if (p.lds_bytes > 64 * 1024 && !configured) {
@@ -291,28 +192,28 @@ static int lr_launch_scan_fast(const lr_scan_plan& p, const double* ts, const do
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    dim3 grid(p.tiles, p.groups);
+    dim3 grid(p.tiles, (n_chains + CB - 1) / CB);
     hipLaunchKernelGGL((lr_scan_fast_kernel<CB, H>), grid, dim3(LR_SCAN_THREADS), p.lds_bytes, stream, ts, te, n, t0,
-                       n_bins, tables, n_chains, p.chunk, partials);
+                       n_bins, tables, n_chains, p.chunk, partials, partial_stride);
     return (int)hipGetLastError();
 }
 
 template <int H>
 static int lr_launch_scan_fast_h(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0,
                                  int n_bins, const double2* tables, int n_chains, double* partials,
-                                 hipStream_t stream) {
+                                 int partial_stride, hipStream_t stream) {
     switch (p.cb) {
-        case 8: return lr_launch_scan_fast<8, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
-        case 4: return lr_launch_scan_fast<4, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
-        case 2: return lr_launch_scan_fast<2, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
-        default: return lr_launch_scan_fast<1, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+        case 8: return lr_launch_scan_fast<8, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+        case 4: return lr_launch_scan_fast<4, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+        case 2: return lr_launch_scan_fast<2, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+        default: return lr_launch_scan_fast<1, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
     }
 }
 
 template <int CB>
 static int lr_launch_scan_cb(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0,
                              int n_bins, double end_time, const double2* tables, int n_chains, double* partials,
-                             hipStream_t stream) {
+                             int partial_stride, hipStream_t stream) {
     static size_t configured = 64 * 1024;
     if (p.lds_bytes > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_scan_kernel<CB>),
@@ -320,28 +221,29 @@ static int lr_launch_scan_cb(const lr_scan_plan& p, const double* ts, const doub
         if (e != hipSuccess) return (int)e;
         configured = p.lds_bytes;
     }
-    dim3 grid(p.tiles, p.groups);
+    dim3 grid(p.tiles, (n_chains + CB - 1) / CB);
     hipLaunchKernelGGL(lr_scan_kernel<CB>, grid, dim3(LR_SCAN_THREADS), p.lds_bytes, stream, ts, te, n, t0, n_bins,
-                       p.n_cls, p.H, end_time, tables, p.tab_stride, n_chains, p.chunk, partials);
+                       p.n_cls, p.H, end_time, tables, p.tab_stride, n_chains, p.chunk, partials, partial_stride);
     return (int)hipGetLastError();
 }
 
 int lr_launch_scan(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0, int n_bins,
-                   double end_time, const double2* tables, int n_chains, double* partials, hipStream_t stream) {
+                   double end_time, const double2* tables, int n_chains, double* partials, int partial_stride,
+                   hipStream_t stream) {
     if (p.fast) {
         switch (p.H) {
-            case 40: return lr_launch_scan_fast_h<40>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
-            case 72: return lr_launch_scan_fast_h<72>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
-            case 136: return lr_launch_scan_fast_h<136>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
-            case 264: return lr_launch_scan_fast_h<264>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, stream);
+            case 40: return lr_launch_scan_fast_h<40>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+            case 72: return lr_launch_scan_fast_h<72>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+            case 136: return lr_launch_scan_fast_h<136>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+            case 264: return lr_launch_scan_fast_h<264>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
             default: return LR_ERR_SIZE;
         }
     }
     switch (p.cb) {
-        case 8: return lr_launch_scan_cb<8>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
-        case 4: return lr_launch_scan_cb<4>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
-        case 2: return lr_launch_scan_cb<2>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
-        default: return lr_launch_scan_cb<1>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
+        case 8: return lr_launch_scan_cb<8>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, partial_stride, stream);
+        case 4: return lr_launch_scan_cb<4>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, partial_stride, stream);
+        case 2: return lr_launch_scan_cb<2>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, partial_stride, stream);
+        default: return lr_launch_scan_cb<1>(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, partial_stride, stream);
     }
 }
 
@@ -386,7 +288,7 @@ extern "C" int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n,
                        model, n_bins, p.n_cls, p.H, p.tab_stride, tables, consts);
     rc = (int)hipGetLastError();
     if (rc) return rc;
-    rc = lr_launch_scan(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, stream);
+    rc = lr_launch_scan(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, n_chains, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(lr_reduce_partials_kernel, dim3((n_chains + 255) / 256), dim3(256), 0, stream, partials, consts,
                        p.tiles, n_chains, out_loglik);

@@ -5,10 +5,12 @@
 // one wave per chain: reduce the tile partials in order, Metropolis-Hastings accept, write the
 // trace row, draw the next proposal from the chain's Philox stream, build its lookup tables].
 // Iterations are captured in a hipGraph so the host only replays it.
+#include <cstdlib>
 #include <new>
 
 #include "lr_chain.h"
 #include "lr_internal.h"
+#include "lr_scan.h"
 
 // ------------------------------------------------------------------------------------------
 // explicit-draw scorers (parity with reference-generated vectors)
@@ -222,17 +224,19 @@ __device__ __forceinline__ void lr_stage_segments(lr_seg_scratch* sc, double L, 
     if (lane <= LR_KMAX) sc->edge[0][lane] = eL, sc->edge[1][lane] = eM;
     *logL = lx;                                        // valid on lanes < 32
     *logM = __shfl(lx, 32 + (lane & 31), LR_WAVE);     // lane j gets log M[j]
+    // the scratch is private to this wave; LDS operations of one wave execute in order, the fence keeps
+    // the compiler from moving the reads of lr_build_tables_segments_wave above these writes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // mode: 0 = regular step (accept pending proposal, then propose), 1 = finish init (adopt the
 // evaluated initial state as accepted, then propose iteration 0)
-__global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, int mode) {
-    __shared__ lr_seg_scratch scratch;
+__device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mode, int c, int lane,
+                                                   lr_seg_scratch* scratch_p) {
+    lr_seg_scratch& scratch = *scratch_p;
     const lr_mcmc_config& cfg = a.cfg;
-    const int c = blockIdx.x, lane = threadIdx.x;
     const int C = cfg.n_chains, n_bins = cfg.n_bins;
     double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
     int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
@@ -461,6 +465,49 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_step_kernel(lr_step_args a, 
     if (wr) I[LR_IROW_SCALARS * LR_ROW + lane] = io;
 }
 
+#define LR_STEP_WAVES (LR_SCAN_THREADS / LR_WAVE)
+
+// chains [chain_base, chain_base + n_sub): one wave per chain, LR_STEP_WAVES chains per block
+__global__ __launch_bounds__(LR_SCAN_THREADS) void lr_chain_step_kernel(lr_step_args a, int mode, int chain_base,
+                                                                        int n_sub) {
+    __shared__ lr_seg_scratch scratch[LR_STEP_WAVES];
+    const int wave = threadIdx.x / LR_WAVE, lane = threadIdx.x & (LR_WAVE - 1);
+    const int j = blockIdx.x * LR_STEP_WAVES + wave;
+    if (j < n_sub) lr_chain_step_body(a, mode, chain_base + j, lane, &scratch[wave]);
+}
+
+// Fused launch of the software-pipelined engine: the first `step_blocks` blocks run the chain step of the
+// half whose scan finished in the PREVIOUS launch, all other blocks scan the lineages for the other half.
+// The step is latency bound (a serial stream per wave) and the scan is throughput bound, so they overlap.
+struct lr_fused_args {
+    const double* ts;
+    const double* te;
+    long long n, chunk;
+    double t0;
+    int n_bins, tiles;
+    int scan_base, scan_n;     // chains scanned by this launch
+    int step_base, step_n;     // chains stepped by this launch
+    int step_blocks;
+};
+
+template <int CB, int H>
+__global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_args a, lr_fused_args f) {
+    extern __shared__ double2 lds[];
+    __shared__ lr_seg_scratch scratch[LR_STEP_WAVES];
+    const int bid = blockIdx.x;
+    if (bid < f.step_blocks) {
+        const int wave = threadIdx.x / LR_WAVE, lane = threadIdx.x & (LR_WAVE - 1);
+        const int j = bid * LR_STEP_WAVES + wave;
+        if (j < f.step_n) lr_chain_step_body(a, 0, f.step_base + j, lane, &scratch[wave]);
+        return;
+    }
+    const int sb = bid - f.step_blocks;
+    const int tile = sb % f.tiles, group = sb / f.tiles;   // tiles of one chain group are adjacent
+    lr_scan_fast_body<CB, H>(lds, tile, group * CB, f.ts, f.te, f.n, f.t0, f.n_bins,
+                             a.tables + (size_t)f.scan_base * a.tab_stride, f.scan_n, f.chunk,
+                             const_cast<double*>(a.partials) + f.scan_base, a.cfg.n_chains);
+}
+
 // log(br_length) once per engine (data constant used by models 0/1)
 __global__ void lr_log_br_kernel(const double* __restrict__ br, int n_bins, double* __restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -518,6 +565,43 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
 }
 
 // ---- host -------------------------------------------------------------------------------
+static int lr_pipeline_env() {
+    static int env = -1;
+    if (env < 0) {
+        const char* v = getenv("LR_PIPELINE");
+        env = v ? atoi(v) : 1;
+    }
+    return env;
+}
+static bool lr_plan_pipelined(const lr_scan_plan& p, int n_chains) {
+    return lr_pipeline_env() && p.fast && n_chains >= 2 * p.cb;
+}
+static int lr_half_a_of(int n_chains, int cb) { return ((n_chains / 2 + cb - 1) / cb) * cb; }
+
+// launch shape of the engine: as lr_plan_scan, but when the pipelined schedule applies the lineage tiles are
+// sized so that one fused launch (step blocks of one half + scan blocks of the other) fills the resident
+// block slots of the chip (256 CUs x 4 blocks) exactly once - no second, mostly empty round of blocks.
+static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
+    int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, p);
+    if (rc) return rc;
+    if (!lr_plan_pipelined(*p, cfg->n_chains)) return LR_OK;
+    const int hA = lr_half_a_of(cfg->n_chains, p->cb);
+    const int half = hA > cfg->n_chains - hA ? hA : cfg->n_chains - hA;
+    const int groups_half = (half + p->cb - 1) / p->cb;
+    const int step_blocks = (half + (LR_SCAN_THREADS / LR_WAVE) - 1) / (LR_SCAN_THREADS / LR_WAVE);
+    static const int slots = getenv("LR_SLOTS") ? atoi(getenv("LR_SLOTS")) : 256 * 4;
+    long long tiles = (slots - step_blocks) / groups_half;
+    const long long unit = 2 * LR_SCAN_THREADS;
+    const long long max_tiles = (cfg->n_lineages + 4 * unit - 1) / (4 * unit);
+    if (tiles > max_tiles) tiles = max_tiles;
+    if (tiles < 1) tiles = 1;
+    long long chunk = lr_align_up64((cfg->n_lineages + tiles - 1) / tiles, unit);
+    tiles = (cfg->n_lineages + chunk - 1) / chunk;
+    p->tiles = (int)tiles;
+    p->chunk = chunk;
+    return LR_OK;
+}
+
 static int lr_check_cfg(const lr_mcmc_config* cfg) {
     if (!cfg) return LR_ERR_NULL;
     if (cfg->n_lineages < 1 || cfg->n_chains < 1 || cfg->s_freq < 1 || cfg->n_trace_slots < 0) return LR_ERR_SIZE;
@@ -533,7 +617,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     if (rc) return rc;
     if (!out) return LR_ERR_NULL;
     lr_scan_plan p;
-    rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, &p);
+    rc = lr_plan_engine(cfg, &p);
     if (rc) return rc;
     const long long C = cfg->n_chains;
     long long o = 0;
@@ -563,7 +647,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     if (!e) return (int)hipErrorOutOfMemory;
     e->cfg = *cfg;
     e->lay = lay;
-    lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, &e->plan);
+    lr_plan_engine(cfg, &e->plan);
     e->ts = ts, e->te = te, e->br_length = br_length;
     e->ws = (char*)workspace;
     e->initialised = false;
@@ -592,10 +676,19 @@ static lr_step_args lr_make_args(const lr_engine* e) {
     return a;
 }
 
-static int lr_enqueue_scan(const lr_engine* e, hipStream_t stream) {
+static int lr_enqueue_scan_range(const lr_engine* e, int base, int count, hipStream_t stream) {
     return lr_launch_scan(e->plan, e->ts, e->te, e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins, e->cfg.end_time,
-                          (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains,
-                          (double*)(e->ws + e->lay.partials), stream);
+                          (const double2*)(e->ws + e->lay.tables) + (size_t)base * e->plan.tab_stride, count,
+                          (double*)(e->ws + e->lay.partials) + base, e->cfg.n_chains, stream);
+}
+static int lr_enqueue_scan(const lr_engine* e, hipStream_t stream) {
+    return lr_enqueue_scan_range(e, 0, e->cfg.n_chains, stream);
+}
+static int lr_enqueue_step_range(const lr_engine* e, const lr_step_args& a, int mode, int base, int count,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL(lr_chain_step_kernel, dim3((count + LR_STEP_WAVES - 1) / LR_STEP_WAVES), dim3(LR_SCAN_THREADS),
+                       0, stream, a, mode, base, count);
+    return (int)hipGetLastError();
 }
 
 extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, const double* tL, const double* tM,
@@ -613,14 +706,12 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
     if (rc) return rc;
     rc = lr_enqueue_scan(e, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(lr_chain_step_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, 1);
-    rc = (int)hipGetLastError();
+    rc = lr_enqueue_step_range(e, a, 1, 0, e->cfg.n_chains, stream);
     if (rc) return rc;
     e->initialised = true;
     return LR_OK;
 }
 
-#include <cstdlib>
 // iterations captured per hipGraph; LR_GRAPH_ITERS=0 in the environment disables graph replay
 static int lr_graph_iters() {
     static int v = -1;
@@ -633,25 +724,71 @@ static int lr_graph_iters() {
     return v;
 }
 
-static int lr_enqueue_iteration(const lr_engine* e, const lr_step_args& a, hipStream_t stream) {
-    int rc = lr_enqueue_scan(e, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(lr_chain_step_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, 0);
+// ---- software-pipelined schedule --------------------------------------------------------------
+// Chains are split into halves A = [0, hA) and B = [hA, C).  A call of n iterations enqueues
+//     scan(A);  (n-1) x { fused(scan B | step A); fused(scan A | step B) };  fused(scan B | step A);  step(B)
+// so that every launch but the first and last overlaps the latency-bound chain step of one half with
+// the throughput-bound lineage scan of the other.  LR_PIPELINE=0 falls back to scan; step; ...
+static bool lr_pipeline_enabled(const lr_engine* e) { return lr_plan_pipelined(e->plan, e->cfg.n_chains); }
+static int lr_half_a(const lr_engine* e) { return lr_half_a_of(e->cfg.n_chains, e->plan.cb); }
+
+template <int CB, int H>
+static int lr_launch_fused(const lr_engine* e, const lr_step_args& a, const lr_fused_args& f, hipStream_t stream) {
+    const int groups = (f.scan_n + CB - 1) / CB;
+    const int blocks = f.step_blocks + groups * f.tiles;
+    hipLaunchKernelGGL((lr_fused_iter_kernel<CB, H>), dim3(blocks), dim3(LR_SCAN_THREADS), e->plan.lds_bytes, stream, a,
+                       f);
     return (int)hipGetLastError();
 }
 
-extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
-    if (!e) return LR_ERR_NULL;
-    if (!e->initialised) return LR_ERR_STATE;
-    if (n_iters < 0) return LR_ERR_SIZE;
-    hipStream_t stream = (hipStream_t)stream_;
-    const lr_step_args a = lr_make_args(e);
+template <int H>
+static int lr_launch_fused_h(const lr_engine* e, const lr_step_args& a, const lr_fused_args& f, hipStream_t stream) {
+    switch (e->plan.cb) {
+        case 8: return lr_launch_fused<8, H>(e, a, f, stream);
+        case 4: return lr_launch_fused<4, H>(e, a, f, stream);
+        case 2: return lr_launch_fused<2, H>(e, a, f, stream);
+        default: return lr_launch_fused<1, H>(e, a, f, stream);
+    }
+}
+
+// one fused launch: scan chains [scan_base, +scan_n), step chains [step_base, +step_n)
+static int lr_enqueue_fused(const lr_engine* e, const lr_step_args& a, int scan_base, int scan_n, int step_base,
+                            int step_n, hipStream_t stream) {
+    lr_fused_args f;
+    f.ts = e->ts, f.te = e->te, f.n = e->cfg.n_lineages, f.chunk = e->plan.chunk, f.t0 = e->cfg.t0;
+    f.n_bins = e->cfg.n_bins, f.tiles = e->plan.tiles;
+    f.scan_base = scan_base, f.scan_n = scan_n, f.step_base = step_base, f.step_n = step_n;
+    f.step_blocks = (step_n + LR_STEP_WAVES - 1) / LR_STEP_WAVES;
+    switch (e->plan.H) {
+        case 40: return lr_launch_fused_h<40>(e, a, f, stream);
+        case 72: return lr_launch_fused_h<72>(e, a, f, stream);
+        case 136: return lr_launch_fused_h<136>(e, a, f, stream);
+        case 264: return lr_launch_fused_h<264>(e, a, f, stream);
+        default: return LR_ERR_SIZE;
+    }
+}
+
+// the unit the graph repeats: pipelined = two fused launches, plain = scan + step
+static int lr_enqueue_unit(const lr_engine* e, const lr_step_args& a, bool pipelined, hipStream_t stream) {
+    const int C = e->cfg.n_chains;
+    if (!pipelined) {
+        int rc = lr_enqueue_scan(e, stream);
+        if (rc) return rc;
+        return lr_enqueue_step_range(e, a, 0, 0, C, stream);
+    }
+    const int hA = lr_half_a(e);
+    int rc = lr_enqueue_fused(e, a, hA, C - hA, 0, hA, stream);      // scan B | step A
+    if (rc) return rc;
+    return lr_enqueue_fused(e, a, 0, hA, hA, C - hA, stream);       // scan A | step B
+}
+
+static int lr_run_units(lr_engine* e, const lr_step_args& a, bool pipelined, int64_t units, hipStream_t stream) {
     int64_t done = 0;
     const int G = lr_graph_iters();
-    if (G > 0 && n_iters >= G) {
+    if (G > 0 && units >= G) {
         if (!e->graph_exec) {
-            // capture LR_GRAPH_ITERS iterations once; the kernels read the iteration number from
-            // device memory, so the same graph is valid for every replay
+            // capture G units once; the kernels read the iteration number from device memory, so the
+            // same graph is valid for every replay
             hipStream_t cs;
             hipError_t he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
             if (he != hipSuccess) return (int)he;
@@ -659,7 +796,7 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
             he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
             if (he != hipSuccess) return (int)he;
             int rc = LR_OK;
-            for (int i = 0; i < G && rc == LR_OK; ++i) rc = lr_enqueue_iteration(e, a, cs);
+            for (int i = 0; i < G && rc == LR_OK; ++i) rc = lr_enqueue_unit(e, a, pipelined, cs);
             he = hipStreamEndCapture(cs, &graph);
             if (rc) return rc;
             if (he != hipSuccess) return (int)he;
@@ -669,17 +806,55 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
             if (he != hipSuccess) return (int)he;
             e->graph_iters = G;
         }
-        while (n_iters - done >= e->graph_iters) {
+        while (units - done >= e->graph_iters) {
             hipError_t he = hipGraphLaunch(e->graph_exec, stream);
             if (he != hipSuccess) return (int)he;
             done += e->graph_iters;
         }
     }
-    for (; done < n_iters; ++done) {
-        const int rc = lr_enqueue_iteration(e, a, stream);
+    for (; done < units; ++done) {
+        const int rc = lr_enqueue_unit(e, a, pipelined, stream);
         if (rc) return rc;
     }
     return LR_OK;
+}
+
+extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
+    if (!e) return LR_ERR_NULL;
+    if (!e->initialised) return LR_ERR_STATE;
+    if (n_iters < 0) return LR_ERR_SIZE;
+    if (n_iters == 0) return LR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const lr_step_args a = lr_make_args(e);
+    if (!lr_pipeline_enabled(e)) return lr_run_units(e, a, false, n_iters, stream);
+    const int C = e->cfg.n_chains, hA = lr_half_a(e);
+    int rc = lr_enqueue_scan_range(e, 0, hA, stream);                          // scan A
+    if (rc) return rc;
+    rc = lr_run_units(e, a, true, n_iters - 1, stream);
+    if (rc) return rc;
+    rc = lr_enqueue_fused(e, a, hA, C - hA, 0, hA, stream);                     // scan B | step A
+    if (rc) return rc;
+    return lr_enqueue_step_range(e, a, 0, hA, C - hA, stream);                  // step B
+}
+
+extern "C" int lr_mcmc_time_steps(lr_engine* e, int64_t n_iters, float* total_ms, void* stream_) {
+    if (!e || !total_ms) return LR_ERR_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipEvent_t t0, t1;
+    hipError_t he = hipEventCreate(&t0);
+    if (he != hipSuccess) return (int)he;
+    he = hipEventCreate(&t1);
+    if (he != hipSuccess) return (int)he;
+    int rc = (int)hipEventRecord(t0, stream);
+    if (rc == LR_OK) rc = lr_mcmc_steps(e, n_iters, stream_);
+    if (rc == LR_OK) rc = (int)hipEventRecord(t1, stream);
+    if (rc == LR_OK) rc = (int)hipEventSynchronize(t1);
+    float ms = 0.f;
+    if (rc == LR_OK) rc = (int)hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    *total_ms = ms;
+    return rc;
 }
 
 extern "C" int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms, void* stream_) {

@@ -119,6 +119,14 @@ class ChainEngine:
                    "lr_mcmc_time_scan")
         return float(ms.value)
 
+    def timed_steps(self, n):
+        """steps(n) bracketed by HIP events on the launch stream; returns elapsed device ms (blocks)."""
+        ms = C.c_float(0.0)
+        _hip.check(self.lib.lr_mcmc_time_steps(self.handle, int(n), C.byref(ms), _hip.stream_ptr()),
+                   "lr_mcmc_time_steps")
+        self.iterations += int(n)
+        return float(ms.value)
+
     def close(self):
         if getattr(self, "handle", None) is not None:
             self.lib.lr_mcmc_destroy(self.handle)

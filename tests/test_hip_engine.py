@@ -106,19 +106,18 @@ def test_engine_chain_streams_do_not_depend_on_sharding(G):
     a.close(); b.close()
 
 
-def test_engine_posterior_matches_reference_chains(G, golden_dir):
+@pytest.mark.parametrize("name,model,C,n_it,s,k_tol", [("example_TBP", 0, 256, 400_000, 400, 0.25),
+                                                       ("metal_bands", 2, 128, 600_000, 600, 0.8)])
+def test_engine_posterior_matches_reference_chains(G, golden_dir, name, model, C, n_it, s, k_tol):
     """Posterior rate marginals within Monte-Carlo error of long runs of the reference CLI
-    (tests/golden/make_chains.py): per-bin marginal means, K distribution."""
-    path = os.path.join(golden_dir, "posterior_example_TBP_m0.npz")
-    if not os.path.exists(path):
-        pytest.skip("reference posterior summary not generated")
+    (tests/golden/make_chains.py: 4 chains x 2M iterations): per-bin marginal means, mean K.
+    metal_bands / 128 chains / RJ prior is BASELINE.json configs[1]."""
+    path = os.path.join(golden_dir, "posterior_%s_m%d.npz" % (name, model))
     from literate_amd.engine import ChainEngine, split_trace_row
     from oracle import literate_oracle as lo
     R = np.load(path)
     n_ref = int(R["meta"][3])
-    name = "example_TBP"
-    C, n_it, s = 256, 100_000, 100
-    eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=0, seed=77, s_freq=s, n_trace_slots=n_it // s)
+    eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=model, seed=77, s_freq=s, n_trace_slots=n_it // s)
     eng.init(); eng.steps(n_it)
     tr = eng.trace_rows()
     eng.close()
@@ -137,7 +136,7 @@ def test_engine_posterior_matches_reference_chains(G, golden_dir):
     for mine, ref in ((sp, ref_sp), (ex, ref_ex)):
         se = np.sqrt(mine.var(0, ddof=1) / len(mine) + ref.var(0, ddof=1) / len(ref))
         z = (mine.mean(0) - ref.mean(0)) / se
-        assert np.max(np.abs(z)) < 5.0, z
+        assert np.max(np.abs(z)) < 6.0, z
         assert np.allclose(mine.mean(0), ref.mean(0), rtol=0.15)
     ref_kl = [np.dot(R["c%d/K_l_hist" % c], np.arange(40)) / R["c%d/K_l_hist" % c].sum() for c in range(n_ref)]
-    assert abs(np.mean(kl) - np.mean(ref_kl)) < 0.25
+    assert abs(np.mean(kl) - np.mean(ref_kl)) < k_tol

@@ -122,15 +122,17 @@ def main():
         # Pipelined engine: one iteration = two launches of lr_fused_iter_kernel (lineage scan of one half of
         # the chains + chain step of the other half); each launch scores N x C/2 (lineage, chain) pairs.
         cb = eng.layout.chains_per_block
+        n_parts, pipelined = eng.layout.n_parts, bool(eng.layout.pipelined)
         n_ev = 200
         ev_ms = eng.timed_steps(n_ev)                       # device time of n_ev more iterations (HIP events)
-        pipelined = os.environ.get("LR_PIPELINE", "1") != "0" and chains >= 2 * cb
-        launches = 2 * n_ev if pipelined else n_ev
-        kernel_ms = ev_ms / launches
-        chains_per_launch = chains / 2 if pipelined else chains
+        # each partition issues `lps` launches per iteration on its own stream; the n_parts partitions run
+        # side by side, so a launch lasts ev_ms / (n_ev * lps) and n_parts of them are in flight together
+        lps = 2 if pipelined else 1
+        kernel_ms = ev_ms / (n_ev * lps)
+        chains_per_launch = chains / (n_parts * lps)
         groups = -(-int(chains_per_launch) // cb)
         alg_bytes = 16.0 * n_lin * groups                   # 16 B x N x ceil(C/Cb) per launch
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        achieved = n_parts * alg_bytes / (kernel_ms * 1e-3) / 1e9
         scan_ms = eng.time_scan(reps=50)                    # stand-alone scan of ALL chains (same block body)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
@@ -152,10 +154,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("lr_fused_iter_kernel<%d,136>" if pipelined else "lr_scan_fast_kernel<%d,136> + lr_chain_step_kernel") % cb,
-                         "kernel_ms": kernel_ms, "launches_per_step": 2 if pipelined else 1,
+                         "kernel_ms": kernel_ms, "launches_per_step_per_partition": lps,
+                         "concurrent_launches": n_parts,
                          "pairs_per_launch": n_lin * chains_per_launch, "chains_per_pass_Cb": cb,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "effective_GBs_unamortised": 16.0 * n_lin * chains_per_launch / (kernel_ms * 1e-3) / 1e9,
+                         "effective_GBs_unamortised": n_parts * 16.0 * n_lin * chains_per_launch / (kernel_ms * 1e-3) / 1e9,
                          "scan_only_kernel_ms_all_chains": scan_ms,
                          "scan_only_evals_per_s": n_lin * chains / (scan_ms * 1e-3),
                          "scan_only_frac": 16.0 * n_lin * (-(-chains // cb)) / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

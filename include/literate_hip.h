@@ -149,6 +149,8 @@ typedef struct lr_mcmc_layout {
     int32_t tiles;
     int32_t chains_per_block;
     int32_t trace_width;
+    int32_t n_parts;      /* independent chain partitions, each on its own stream                  */
+    int32_t pipelined;    /* 1: each partition runs the fused scan|step schedule over two halves   */
 } lr_mcmc_layout;
 
 /* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */

@@ -106,6 +106,18 @@ extern "C" int lr_debug_draws(uint64_t seed, int64_t chain, const int64_t* it, c
 // ------------------------------------------------------------------------------------------
 // the engine
 // ------------------------------------------------------------------------------------------
+#define LR_MAX_PARTS 4
+// a partition = a contiguous, independent block of chains with its own stream and captured graph; inside it
+// the chains are software-pipelined in two halves (A = [base, base+hA), B = the rest)
+struct lr_part {
+    int base, count, hA;
+    bool pipelined;
+    hipStream_t stream;
+    hipEvent_t done;
+    hipGraphExec_t graph_exec;
+    int graph_units;
+};
+
 struct lr_engine {
     lr_mcmc_config cfg;
     lr_mcmc_layout lay;
@@ -115,8 +127,9 @@ struct lr_engine {
     const double* br_length;
     char* ws;
     bool initialised;
-    hipGraphExec_t graph_exec;
-    int graph_iters;
+    int n_parts;
+    lr_part part[LR_MAX_PARTS];
+    hipEvent_t fork;
 };
 
 struct lr_step_args {
@@ -565,32 +578,55 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
 }
 
 // ---- host -------------------------------------------------------------------------------
+static int lr_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 static int lr_pipeline_env() {
-    static int env = -1;
-    if (env < 0) {
-        const char* v = getenv("LR_PIPELINE");
-        env = v ? atoi(v) : 1;
-    }
+    static int env = lr_env_int("LR_PIPELINE", 1);
     return env;
 }
-static bool lr_plan_pipelined(const lr_scan_plan& p, int n_chains) {
-    return lr_pipeline_env() && p.fast && n_chains >= 2 * p.cb;
+
+// Partition layout of the engine.  LR_PARTS (default 2) independent partitions run on their own streams so
+// that the ramp-up / drain of one partition's launches overlaps the other's; each partition with at least
+// 2*cb chains is software-pipelined in two halves.  All boundaries are multiples of cb.
+static int lr_partition(int n_chains, int cb, bool fast, int base[LR_MAX_PARTS + 1], int hA[LR_MAX_PARTS],
+                        bool pipelined[LR_MAX_PARTS]) {
+    static const int want_parts = lr_env_int("LR_PARTS", 2);
+    int parts = want_parts < 1 ? 1 : (want_parts > LR_MAX_PARTS ? LR_MAX_PARTS : want_parts);
+    const int groups = (n_chains + cb - 1) / cb;
+    const bool pipe = lr_pipeline_env() && fast;
+    while (parts > 1 && groups < parts * (pipe ? 2 : 1)) --parts;
+    base[0] = 0;
+    for (int p = 0; p < parts; ++p) {
+        const int g = groups / parts + (p < groups % parts ? 1 : 0);
+        base[p + 1] = base[p] + g * cb < n_chains ? base[p] + g * cb : n_chains;
+    }
+    base[parts] = n_chains;
+    for (int p = 0; p < parts; ++p) {
+        const int count = base[p + 1] - base[p];
+        pipelined[p] = pipe && count >= 2 * cb;
+        hA[p] = pipelined[p] ? ((count / 2 + cb - 1) / cb) * cb : count;
+    }
+    return parts;
 }
-static int lr_half_a_of(int n_chains, int cb) { return ((n_chains / 2 + cb - 1) / cb) * cb; }
 
 // launch shape of the engine: as lr_plan_scan, but when the pipelined schedule applies the lineage tiles are
-// sized so that one fused launch (step blocks of one half + scan blocks of the other) fills the resident
-// block slots of the chip (256 CUs x 4 blocks) exactly once - no second, mostly empty round of blocks.
+// sized so that the fused launches that run concurrently (one per partition: step blocks of one half + scan
+// blocks of the other) fill the resident block slots of the chip (256 CUs x 4 blocks) exactly once.
 static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, p);
     if (rc) return rc;
-    if (!lr_plan_pipelined(*p, cfg->n_chains)) return LR_OK;
-    const int hA = lr_half_a_of(cfg->n_chains, p->cb);
-    const int half = hA > cfg->n_chains - hA ? hA : cfg->n_chains - hA;
+    int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
+    bool pipelined[LR_MAX_PARTS];
+    const int parts = lr_partition(cfg->n_chains, p->cb, p->fast != 0, base, hA, pipelined);
+    if (!pipelined[0]) return LR_OK;
+    const int count = base[1] - base[0];
+    const int half = hA[0] > count - hA[0] ? hA[0] : count - hA[0];
     const int groups_half = (half + p->cb - 1) / p->cb;
     const int step_blocks = (half + (LR_SCAN_THREADS / LR_WAVE) - 1) / (LR_SCAN_THREADS / LR_WAVE);
-    static const int slots = getenv("LR_SLOTS") ? atoi(getenv("LR_SLOTS")) : 256 * 4;
-    long long tiles = (slots - step_blocks) / groups_half;
+    static const int slots = lr_env_int("LR_SLOTS", 256 * 4);
+    long long tiles = (slots / parts - step_blocks) / groups_half;
     const long long unit = 2 * LR_SCAN_THREADS;
     const long long max_tiles = (cfg->n_lineages + 4 * unit - 1) / (4 * unit);
     if (tiles > max_tiles) tiles = max_tiles;
@@ -632,6 +668,12 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->tiles = p.tiles;
     out->chains_per_block = p.cb;
     out->trace_width = LR_TRACE_W;
+    {
+        int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
+        bool pipelined[LR_MAX_PARTS];
+        out->n_parts = lr_partition(cfg->n_chains, p.cb, p.fast != 0, base, hA, pipelined);
+        out->pipelined = pipelined[0] ? 1 : 0;
+    }
     return LR_OK;
 }
 
@@ -651,8 +693,26 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->ts = ts, e->te = te, e->br_length = br_length;
     e->ws = (char*)workspace;
     e->initialised = false;
-    e->graph_exec = nullptr;
-    e->graph_iters = 0;
+    int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
+    bool pipelined[LR_MAX_PARTS];
+    e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, e->plan.fast != 0, base, hA, pipelined);
+    e->fork = nullptr;
+    for (int p = 0; p < e->n_parts; ++p) {
+        lr_part& q = e->part[p];
+        q.base = base[p], q.count = base[p + 1] - base[p], q.hA = hA[p], q.pipelined = pipelined[p];
+        q.stream = nullptr, q.done = nullptr, q.graph_exec = nullptr, q.graph_units = 0;
+    }
+    if (e->n_parts > 1) {
+        hipError_t he = hipEventCreateWithFlags(&e->fork, hipEventDisableTiming);
+        for (int p = 0; p < e->n_parts && he == hipSuccess; ++p) {
+            he = hipStreamCreateWithFlags(&e->part[p].stream, hipStreamNonBlocking);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->part[p].done, hipEventDisableTiming);
+        }
+        if (he != hipSuccess) {
+            lr_mcmc_destroy(e);
+            return (int)he;
+        }
+    }
     *out = e;
     return LR_OK;
 }
@@ -729,9 +789,6 @@ static int lr_graph_iters() {
 //     scan(A);  (n-1) x { fused(scan B | step A); fused(scan A | step B) };  fused(scan B | step A);  step(B)
 // so that every launch but the first and last overlaps the latency-bound chain step of one half with
 // the throughput-bound lineage scan of the other.  LR_PIPELINE=0 falls back to scan; step; ...
-static bool lr_pipeline_enabled(const lr_engine* e) { return lr_plan_pipelined(e->plan, e->cfg.n_chains); }
-static int lr_half_a(const lr_engine* e) { return lr_half_a_of(e->cfg.n_chains, e->plan.cb); }
-
 template <int CB, int H>
 static int lr_launch_fused(const lr_engine* e, const lr_step_args& a, const lr_fused_args& f, hipStream_t stream) {
     const int groups = (f.scan_n + CB - 1) / CB;
@@ -768,25 +825,28 @@ static int lr_enqueue_fused(const lr_engine* e, const lr_step_args& a, int scan_
     }
 }
 
-// the unit the graph repeats: pipelined = two fused launches, plain = scan + step
-static int lr_enqueue_unit(const lr_engine* e, const lr_step_args& a, bool pipelined, hipStream_t stream) {
-    const int C = e->cfg.n_chains;
-    if (!pipelined) {
-        int rc = lr_enqueue_scan(e, stream);
+// ---- schedule of one partition ------------------------------------------------------------------
+// pipelined, n iterations:
+//     scan(A);  (n-1) x { fused(scan B | step A); fused(scan A | step B) };  fused(scan B | step A);  step(B)
+// every launch but the first and last overlaps the latency-bound chain step of one half with the
+// throughput-bound lineage scan of the other.  Not pipelined: n x { scan; step }.
+// The repeating unit {...} is captured once per partition in a hipGraph of LR_GRAPH_ITERS units.
+static int lr_enqueue_unit(const lr_engine* e, const lr_step_args& a, const lr_part& q, hipStream_t stream) {
+    if (!q.pipelined) {
+        int rc = lr_enqueue_scan_range(e, q.base, q.count, stream);
         if (rc) return rc;
-        return lr_enqueue_step_range(e, a, 0, 0, C, stream);
+        return lr_enqueue_step_range(e, a, 0, q.base, q.count, stream);
     }
-    const int hA = lr_half_a(e);
-    int rc = lr_enqueue_fused(e, a, hA, C - hA, 0, hA, stream);      // scan B | step A
+    int rc = lr_enqueue_fused(e, a, q.base + q.hA, q.count - q.hA, q.base, q.hA, stream);      // scan B | step A
     if (rc) return rc;
-    return lr_enqueue_fused(e, a, 0, hA, hA, C - hA, stream);       // scan A | step B
+    return lr_enqueue_fused(e, a, q.base, q.hA, q.base + q.hA, q.count - q.hA, stream);       // scan A | step B
 }
 
-static int lr_run_units(lr_engine* e, const lr_step_args& a, bool pipelined, int64_t units, hipStream_t stream) {
+static int lr_run_units(lr_engine* e, const lr_step_args& a, lr_part& q, int64_t units, hipStream_t stream) {
     int64_t done = 0;
     const int G = lr_graph_iters();
     if (G > 0 && units >= G) {
-        if (!e->graph_exec) {
+        if (!q.graph_exec) {
             // capture G units once; the kernels read the iteration number from device memory, so the
             // same graph is valid for every replay
             hipStream_t cs;
@@ -796,27 +856,38 @@ static int lr_run_units(lr_engine* e, const lr_step_args& a, bool pipelined, int
             he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
             if (he != hipSuccess) return (int)he;
             int rc = LR_OK;
-            for (int i = 0; i < G && rc == LR_OK; ++i) rc = lr_enqueue_unit(e, a, pipelined, cs);
+            for (int i = 0; i < G && rc == LR_OK; ++i) rc = lr_enqueue_unit(e, a, q, cs);
             he = hipStreamEndCapture(cs, &graph);
             if (rc) return rc;
             if (he != hipSuccess) return (int)he;
-            he = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
+            he = hipGraphInstantiate(&q.graph_exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             (void)hipStreamDestroy(cs);
             if (he != hipSuccess) return (int)he;
-            e->graph_iters = G;
+            q.graph_units = G;
         }
-        while (units - done >= e->graph_iters) {
-            hipError_t he = hipGraphLaunch(e->graph_exec, stream);
+        while (units - done >= q.graph_units) {
+            hipError_t he = hipGraphLaunch(q.graph_exec, stream);
             if (he != hipSuccess) return (int)he;
-            done += e->graph_iters;
+            done += q.graph_units;
         }
     }
     for (; done < units; ++done) {
-        const int rc = lr_enqueue_unit(e, a, pipelined, stream);
+        const int rc = lr_enqueue_unit(e, a, q, stream);
         if (rc) return rc;
     }
     return LR_OK;
+}
+
+static int lr_run_part(lr_engine* e, const lr_step_args& a, lr_part& q, int64_t n_iters, hipStream_t stream) {
+    if (!q.pipelined) return lr_run_units(e, a, q, n_iters, stream);
+    int rc = lr_enqueue_scan_range(e, q.base, q.hA, stream);                                   // scan A
+    if (rc) return rc;
+    rc = lr_run_units(e, a, q, n_iters - 1, stream);
+    if (rc) return rc;
+    rc = lr_enqueue_fused(e, a, q.base + q.hA, q.count - q.hA, q.base, q.hA, stream);          // scan B | step A
+    if (rc) return rc;
+    return lr_enqueue_step_range(e, a, 0, q.base + q.hA, q.count - q.hA, stream);              // step B
 }
 
 extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
@@ -826,15 +897,22 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
     if (n_iters == 0) return LR_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const lr_step_args a = lr_make_args(e);
-    if (!lr_pipeline_enabled(e)) return lr_run_units(e, a, false, n_iters, stream);
-    const int C = e->cfg.n_chains, hA = lr_half_a(e);
-    int rc = lr_enqueue_scan_range(e, 0, hA, stream);                          // scan A
-    if (rc) return rc;
-    rc = lr_run_units(e, a, true, n_iters - 1, stream);
-    if (rc) return rc;
-    rc = lr_enqueue_fused(e, a, hA, C - hA, 0, hA, stream);                     // scan B | step A
-    if (rc) return rc;
-    return lr_enqueue_step_range(e, a, 0, hA, C - hA, stream);                  // step B
+    if (e->n_parts == 1) return lr_run_part(e, a, e->part[0], n_iters, stream);
+    // fork: every partition's stream waits for the caller's stream, runs its own sequence, and is joined back
+    hipError_t he = hipEventRecord(e->fork, stream);
+    if (he != hipSuccess) return (int)he;
+    for (int p = 0; p < e->n_parts; ++p) {
+        lr_part& q = e->part[p];
+        he = hipStreamWaitEvent(q.stream, e->fork, 0);
+        if (he != hipSuccess) return (int)he;
+        const int rc = lr_run_part(e, a, q, n_iters, q.stream);
+        if (rc) return rc;
+        he = hipEventRecord(q.done, q.stream);
+        if (he != hipSuccess) return (int)he;
+        he = hipStreamWaitEvent(stream, q.done, 0);
+        if (he != hipSuccess) return (int)he;
+    }
+    return LR_OK;
 }
 
 extern "C" int lr_mcmc_time_steps(lr_engine* e, int64_t n_iters, float* total_ms, void* stream_) {
@@ -882,7 +960,13 @@ extern "C" int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms, void
 
 extern "C" int lr_mcmc_destroy(lr_engine* e) {
     if (!e) return LR_ERR_NULL;
-    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    for (int p = 0; p < e->n_parts; ++p) {
+        lr_part& q = e->part[p];
+        if (q.graph_exec) (void)hipGraphExecDestroy(q.graph_exec);
+        if (q.done) (void)hipEventDestroy(q.done);
+        if (q.stream) (void)hipStreamDestroy(q.stream);
+    }
+    if (e->fork) (void)hipEventDestroy(e->fork);
     delete e;
     return LR_OK;
 }

@@ -60,6 +60,29 @@ def test_engine_follows_oracle_trajectory(G, model, kw):
     eng.close()
 
 
+def test_pipelined_partitioned_engine_follows_oracle(G):
+    """64 chains: two stream partitions, each software-pipelined in two halves (fused scan|step launches,
+    hipGraph replays).  Chains from every half of every partition are compared with the oracle loop, and the
+    engine layout is checked to really be the pipelined one."""
+    from literate_amd.engine import ChainEngine, split_trace_row
+    name, seed, n_it, C = "metal_bands", 404, 400, 64
+    eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=2, seed=seed, s_freq=1, n_trace_slots=n_it)
+    assert eng.layout.n_parts == 2 and eng.layout.pipelined == 1
+    eng.init()
+    eng.steps(150); eng.steps(1); eng.steps(249)        # graph replays + prologue/epilogue launches, three calls
+    tr = eng.trace_rows()
+    for c in (0, 15, 16, 31, 32, 47, 48, 63):
+        ref = _oracle_run(G, name, 2, seed, c, n_it)
+        for i in range(n_it):
+            head, sp, ex = split_trace_row(tr[i, c])
+            r = ref["mcmc"][i]
+            assert head[0] == r[0] and head[6] == r[6] and head[7] == r[7], (c, i, head[:8], r[:8])
+            assert np.allclose(head[1:13], r[1:13], rtol=1e-9, atol=1e-9), (c, i, head, r)
+            assert np.allclose(sp, ref["sp"][i], rtol=1e-10) and np.allclose(ex, ref["ex"][i], rtol=1e-10)
+    assert np.all(eng.snapshot()["it"] == n_it)
+    eng.close()
+
+
 def test_engine_given_initial_state_and_graph_replay(G):
     """runMCMC called with a multi-rate initial state (SURVEY 'config-1 note'); > 32 iterations so the
     captured hipGraph path runs, compared with single-launch stepping bit for bit."""

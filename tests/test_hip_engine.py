@@ -163,3 +163,58 @@ def test_engine_posterior_matches_reference_chains(G, golden_dir, name, model, C
         assert np.allclose(mine.mean(0), ref.mean(0), rtol=0.15)
     ref_kl = [np.dot(R["c%d/K_l_hist" % c], np.arange(40)) / R["c%d/K_l_hist" % c].sum() for c in range(n_ref)]
     assert abs(np.mean(kl) - np.mean(ref_kl)) < k_tol
+
+
+def test_cfg3_synthetic_10k_lineages_256_chains(G):
+    """BASELINE.json configs[2]: synthetic 10k lineages, 20 true shifts, 256 chains, RJ prior.  A few chains are
+    followed against the oracle loop (binned statistics from the oracle's own binning of the same data)."""
+    from literate_amd import synth
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import literate_oracle as lo
+    from oracle import mcmc_oracle as mo
+    ts, te, _ = synth.make_lineages(10_000, n_bins=128, n_shifts=20, seed=3)
+    n_it, seed = 300, 12
+    eng = ChainEngine(ts, te, 256, model=0, seed=seed, s_freq=1, n_trace_slots=n_it)
+    t0, sp, ex, br = lo.bin_events_cli(ts, te)
+    assert np.array_equal(eng.sp_events.cpu().numpy(), sp) and np.array_equal(eng.br_length.cpu().numpy(), br)
+    eng.init(); eng.steps(n_it)
+    tr = eng.trace_rows()
+    stats = dict(sp=sp, ex=ex, br=br)
+    for c in (0, 100, 255):
+        with np.errstate(all="ignore"):
+            ref = mo.run_mcmc(stats, ts.min(), te.max(), mo.Settings(model_BDI=0), mo.PhiloxDraws(seed, c), n_it, 1, k_max=32)
+        for i in range(n_it):
+            head, s_row, e_row = split_trace_row(tr[i, c])
+            assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9), (c, i)
+    eng.close()
+
+
+def test_cfg5_ddrate_50k_lineages_256_states():
+    """BASELINE.json configs[4]: DDRate likelihood (DD:71-107) on 50k synthetic lineages for 256 parameter
+    states: lr_dd_rates + the per-lineage Keiding scan against the oracle's binned likelihood_function on
+    create_bins statistics (lib:231-257: last bin dropped)."""
+    from literate_amd import ops, synth
+    from oracle import literate_oracle as lo
+    ts, te, _ = synth.make_lineages(50_000, n_bins=64, n_shifts=6, seed=5)
+    origin, present = float(ts.min()), float(te.max())
+    o, p, nsp, nex, dt, nb, tr = lo.create_bins(origin, present, ts, te, 0)
+    import literate_library as ll
+    o2, p2, nsp2, nex2, dt2, nb2, tr2 = ll.create_bins(origin, present, ts, te, 0)
+    assert nb2 == nb and np.array_equal(nsp2, nsp) and np.array_equal(nex2, nex) and np.array_equal(dt2, dt)
+    rng = np.random.default_rng(8)
+    C = 256
+    args = np.stack([np.exp(rng.uniform(np.log(.05), np.log(1.2), C)), rng.normal(0, 1.0, C), rng.uniform(0, nb, C),
+                     rng.uniform(1, 500, C), rng.uniform(2 * dt.max(), 20 * dt.max(), C),
+                     np.exp(rng.uniform(np.log(.02), np.log(.5), C)), rng.uniform(.3, 2, C), rng.uniform(.3, 2, C)], 1)
+    b, d, ni, nf = ops.dd_rates(args, dt, 2, 2)
+    lik = ops.bd_loglik_batch(ts, te, origin, b, d, 2).cpu().numpy()
+    n_checked = 0
+    for c in range(C):
+        with np.errstate(all="ignore"):
+            ref = lo.dd_likelihood_function(args[c], nsp, nex, dt, tr, 2, 2)
+        assert np.allclose(b[c].cpu().numpy(), ref[1], rtol=1e-12, equal_nan=True)
+        assert np.allclose(d[c].cpu().numpy(), ref[2], rtol=1e-12, equal_nan=True)
+        if np.isfinite(ref[0].sum()):
+            assert lik[c] == pytest.approx(ref[0].sum(), rel=1e-9)
+            n_checked += 1
+    assert n_checked > C // 2

@@ -134,6 +134,14 @@ typedef struct lr_mcmc_config {
     double end_time;          /* max(te)  (LRF:474)                                 */
     uint64_t seed;
     int64_t chain_offset;     /* global index of local chain 0 (multi-GPU sharding) */
+    /* unit-resolution data: 1 asserts that EVERY lineage has ts - floor(ts) == frac_birth and
+     * te - (ceil(te) - 1) == frac_death (true for year-resolution input + death_jitter, i.e. every
+     * dataset the reference ships: 0 and 0.5).  The fractions are then folded into the lookup
+     * tables (8-byte entries, half the LDS traffic per lineage).  0 = general times.            */
+    int32_t unit_resolution;
+    int32_t reserved0;
+    double frac_birth;
+    double frac_death;
 } lr_mcmc_config;
 
 /* where things live inside the engine workspace (byte offsets), for zero-copy host views */

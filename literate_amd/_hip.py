@@ -25,7 +25,8 @@ class McmcConfig(C.Structure):
     _fields_ = [("n_lineages", c_i64), ("n_bins", c_i32), ("n_chains", c_i32), ("model", c_i32),
                 ("const_rates", c_i32), ("const_death_rate", c_i32), ("use_rate_HP", c_i32), ("s_freq", c_i32),
                 ("n_trace_slots", c_i32), ("poisson_HP", c_f64), ("update_fraction", c_f64), ("t0", c_f64),
-                ("start_time", c_f64), ("end_time", c_f64), ("seed", C.c_uint64), ("chain_offset", c_i64)]
+                ("start_time", c_f64), ("end_time", c_f64), ("seed", C.c_uint64), ("chain_offset", c_i64),
+                ("unit_resolution", c_i32), ("reserved0", c_i32), ("frac_birth", c_f64), ("frac_death", c_f64)]
 
 
 class McmcLayout(C.Structure):

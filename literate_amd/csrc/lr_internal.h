@@ -19,18 +19,24 @@ struct lr_scan_plan {
     int tab_stride;    // double2 entries per chain = n_cls * 2 * H
     int H;             // entries reserved for each of the S and E tables (>= n_bins + 2)
     int fast;          // 1: templated immediate-offset kernel (n_cls == 1, H in {40,72,136,264})
+    int unit;          // 1: unit-resolution tables (8-byte entries, fractions folded in); implies fast
     int n_cls;
     size_t lds_bytes;
 };
 
 // choose the launch shape of the lineage scan for (n lineages, n_chains, n_bins, model)
-int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan* plan);
+int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit, lr_scan_plan* plan);
 
 // enqueue the scan of `n_chains` chains whose tables start at `tables`:
 // partials[tile * partial_stride + chain] = sum over the tile's lineages
 int lr_launch_scan(const lr_scan_plan& plan, const double* ts, const double* te, long long n, double t0, int n_bins,
                    double end_time, const double2* tables, int n_chains, double* partials, int partial_stride,
                    hipStream_t stream);
+// can the engine use the fused scan|step kernel for this plan?  (instantiated for a subset of shapes)
+static inline bool lr_fused_supported(const lr_scan_plan& p) {
+    if (!p.fast) return false;
+    return p.unit ? (p.cb == 16 || p.cb == 8) : (p.cb == 8 || p.cb == 4);
+}
 
 static inline int lr_align_up(long long x, long long a) { return (int)((x + a - 1) / a * a); }
 static inline long long lr_align_up64(long long x, long long a) { return (x + a - 1) / a * a; }

@@ -139,7 +139,7 @@ __global__ void lr_reduce_partials_kernel(const double* __restrict__ partials, c
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan* p) {
+int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res, lr_scan_plan* p) {
     if (n < 1 || n_chains < 1) return LR_ERR_SIZE;
     if (n_bins < 1 || n_bins > LR_MAX_BINS) return LR_ERR_SIZE;
     if (model < 0 || model > 3) return LR_ERR_MODEL;
@@ -155,9 +155,11 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan*
                 break;
             }
     }
-    p->tab_stride = p->n_cls * 2 * p->H;
+    p->unit = (unit_res && p->fast) ? 1 : 0;
+    // unit-resolution tables hold doubles: 2*H doubles = H double2 entries per chain
+    p->tab_stride = p->unit ? p->H : p->n_cls * 2 * p->H;
     const size_t per_chain = (size_t)p->tab_stride * sizeof(double2);
-    int cb = 8;
+    int cb = p->unit ? 16 : 8;
     while (cb > 1 && per_chain * cb > LR_SCAN_LDS_BUDGET) cb >>= 1;
     if (per_chain * cb > LR_SCAN_LDS_MAX) return LR_ERR_SIZE;
     while (cb > 1 && cb / 2 >= n_chains) cb >>= 1;  // do not carry empty chain slots
@@ -175,7 +177,9 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, lr_scan_plan*
     p->tiles = (int)tiles;
     p->chunk = chunk;
     size_t lds = per_chain * cb;
-    const size_t red = sizeof(double) * (LR_SCAN_THREADS / LR_WAVE) * cb;
+    // block reduction scratch: generic kernel [waves][cb], fast/unit kernels [cb][threads] + [threads]
+    const size_t red = p->fast ? sizeof(double) * ((size_t)cb * LR_SCAN_THREADS + LR_SCAN_THREADS)
+                               : sizeof(double) * (LR_SCAN_THREADS / LR_WAVE) * cb;
     if (lds < red) lds = red;
     p->lds_bytes = lds;
     return LR_OK;
@@ -227,9 +231,41 @@ static int lr_launch_scan_cb(const lr_scan_plan& p, const double* ts, const doub
     return (int)hipGetLastError();
 }
 
+template <int CB, int H>
+static int lr_launch_scan_unit(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0,
+                               int n_bins, const double2* tables, int n_chains, double* partials, int partial_stride,
+                               hipStream_t stream) {
+    dim3 grid(p.tiles, (n_chains + CB - 1) / CB);
+    hipLaunchKernelGGL((lr_scan_unit_kernel<CB, H>), grid, dim3(LR_SCAN_THREADS), p.lds_bytes, stream, ts, te, n, t0,
+                       n_bins, tables, n_chains, p.chunk, partials, partial_stride);
+    return (int)hipGetLastError();
+}
+
+template <int H>
+static int lr_launch_scan_unit_h(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0,
+                                 int n_bins, const double2* tables, int n_chains, double* partials,
+                                 int partial_stride, hipStream_t stream) {
+    switch (p.cb) {
+        case 16: return lr_launch_scan_unit<16, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+        case 8: return lr_launch_scan_unit<8, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+        case 4: return lr_launch_scan_unit<4, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+        case 2: return lr_launch_scan_unit<2, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+        default: return lr_launch_scan_unit<1, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+    }
+}
+
 int lr_launch_scan(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0, int n_bins,
                    double end_time, const double2* tables, int n_chains, double* partials, int partial_stride,
                    hipStream_t stream) {
+    if (p.unit) {
+        switch (p.H) {
+            case 40: return lr_launch_scan_unit_h<40>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+            case 72: return lr_launch_scan_unit_h<72>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+            case 136: return lr_launch_scan_unit_h<136>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+            case 264: return lr_launch_scan_unit_h<264>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
+            default: return LR_ERR_SIZE;
+        }
+    }
     if (p.fast) {
         switch (p.H) {
             case 40: return lr_launch_scan_fast_h<40>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
@@ -259,7 +295,7 @@ static void lr_loglik_ws(const lr_scan_plan& p, int n_chains, size_t* off_tables
 
 extern "C" int64_t lr_bd_loglik_workspace_bytes(int64_t n, int32_t n_bins, int32_t n_chains, int32_t model) {
     lr_scan_plan p;
-    const int rc = lr_plan_scan(n, n_chains, n_bins, model, &p);
+    const int rc = lr_plan_scan(n, n_chains, n_bins, model, 0, &p);
     if (rc != LR_OK) return rc;
     size_t a, b, c, total;
     lr_loglik_ws(p, n_chains, &a, &b, &c, &total);
@@ -274,7 +310,7 @@ extern "C" int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n,
     if ((model == LR_MODEL_BD || model == LR_MODEL_ID) && !br_length) return LR_ERR_MODEL;
     if (t0 != floor(t0)) return LR_ERR_T0;
     lr_scan_plan p;
-    int rc = lr_plan_scan(n, n_chains, n_bins, model, &p);
+    int rc = lr_plan_scan(n, n_chains, n_bins, model, 0, &p);
     if (rc != LR_OK) return rc;
     size_t o_tab, o_cst, o_par, total;
     lr_loglik_ws(p, n_chains, &o_tab, &o_cst, &o_par, &total);
@@ -294,3 +330,9 @@ extern "C" int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n,
                        p.tiles, n_chains, out_loglik);
     return (int)hipGetLastError();
 }
+
+#ifdef LR_DIAG
+extern "C" int lr_diag_dump(unsigned long long* host_out, int n_words) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lr_diag_buf), (size_t)n_words * 8);
+}
+#endif

@@ -143,7 +143,7 @@ struct lr_step_args {
     const double* br_length;
     double log_T;           // log(end_time - start_time)
     double mult_l;          // 2 log d of the multiplier proposal (LRF:169)
-    int tab_stride, n_cls, tiles, H;
+    int tab_stride, n_cls, tiles, H, unit;
 };
 
 // per-wave LDS scratch: segment rates, their logs and integer edges of both processes
@@ -160,7 +160,9 @@ struct lr_seg_scratch {
 __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc, int KL, int KM,
                                                        const double* __restrict__ br_length,
                                                        const double* __restrict__ log_br, int model, int n_bins,
-                                                       int n_cls, int H, double2* __restrict__ tab, int lane) {
+                                                       int n_cls, int H, double2* __restrict__ tab, int lane,
+                                                       bool unit = false, double fs0 = 0.0, double fe0 = 0.0) {
+    double* tabd = reinterpret_cast<double*>(tab);   // unit-resolution layout: [2][H] doubles
     const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
     const int b0 = min(lane * P, n_bins), b1 = min(b0 + P, n_bins);
     int sl0 = 0, sm0 = 0;
@@ -198,8 +200,13 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
             logD = lmu + lk;
             R = (model == 0) ? lam + mu : mu;
         }
-        tab[b + 1] = make_double2(logB + cum, R);
-        tab[H + b + 1] = make_double2(logD - cum, -R);
+        if (unit) {
+            tabd[b + 1] = (logB + cum) + fs0 * R;
+            tabd[H + b + 1] = (logD - cum) - fe0 * R;
+        } else {
+            tab[b + 1] = make_double2(logB + cum, R);
+            tab[H + b + 1] = make_double2(logD - cum, -R);
+        }
         cum += R;
         if (n_cls == 2) {
             tab[2 * H + b + 1] = make_double2(logB + cuml, lam);
@@ -208,10 +215,15 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
         }
     }
     if (lane == 0) {
-        tab[0] = make_double2(0.0, 0.0);
-        tab[H] = make_double2(0.0, 0.0);
-        tab[n_bins + 1] = make_double2(totR, 0.0);
-        tab[H + n_bins + 1] = make_double2(-totR, 0.0);
+        if (unit) {
+            tabd[0] = 0.0, tabd[H] = 0.0;
+            tabd[n_bins + 1] = totR, tabd[H + n_bins + 1] = -totR;
+        } else {
+            tab[0] = make_double2(0.0, 0.0);
+            tab[H] = make_double2(0.0, 0.0);
+            tab[n_bins + 1] = make_double2(totR, 0.0);
+            tab[H + n_bins + 1] = make_double2(-totR, 0.0);
+        }
         if (n_cls == 2) {
             tab[2 * H] = make_double2(0.0, 0.0);
             tab[3 * H] = make_double2(0.0, 0.0);
@@ -431,7 +443,8 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
 
     // ---- lookup tables of the proposal ----
     const double constP = lr_build_tables_segments_wave(&scratch, PKL, PKM, a.br_length, a.log_br, cfg.model, n_bins,
-                                                        a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane);
+                                                        a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane,
+                                                        a.unit != 0, cfg.frac_birth, cfg.frac_death);
 
     // ---- store ----
     S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
@@ -503,7 +516,7 @@ struct lr_fused_args {
     int step_blocks;
 };
 
-template <int CB, int H>
+template <int CB, int H, bool UNIT>
 __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_args a, lr_fused_args f) {
     extern __shared__ double2 lds[];
     __shared__ lr_seg_scratch scratch[LR_STEP_WAVES];
@@ -514,11 +527,21 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
         if (j < f.step_n) lr_chain_step_body(a, 0, f.step_base + j, lane, &scratch[wave]);
         return;
     }
-    const int sb = bid - f.step_blocks;
-    const int tile = sb % f.tiles, group = sb / f.tiles;   // tiles of one chain group are adjacent
-    lr_scan_fast_body<CB, H>(lds, tile, group * CB, f.ts, f.te, f.n, f.t0, f.n_bins,
-                             a.tables + (size_t)f.scan_base * a.tab_stride, f.scan_n, f.chunk,
-                             const_cast<double*>(a.partials) + f.scan_base, a.cfg.n_chains);
+    int group, tile;
+    if ((f.step_blocks & 7) == 0) {
+        lr_xcd_remap(bid - f.step_blocks, f.tiles, (f.scan_n + CB - 1) / CB, &group, &tile);
+    } else {
+        const int sb = bid - f.step_blocks;
+        tile = sb % f.tiles, group = sb / f.tiles;
+    }
+    const double2* tables = a.tables + (size_t)f.scan_base * a.tab_stride;
+    double* partials = const_cast<double*>(a.partials) + f.scan_base;
+    if (UNIT)
+        lr_scan_unit_body<CB, H>(lds, tile, group * CB, f.ts, f.te, f.n, f.t0, f.n_bins, tables, f.scan_n, f.chunk,
+                                 partials, a.cfg.n_chains);
+    else
+        lr_scan_fast_body<CB, H>(lds, tile, group * CB, f.ts, f.te, f.n, f.t0, f.n_bins, tables, f.scan_n, f.chunk,
+                                 partials, a.cfg.n_chains);
 }
 
 // log(br_length) once per engine (data constant used by models 0/1)
@@ -557,7 +580,8 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
     double logL, logM;
     lr_stage_segments(&scratch, L, M, eL, eM, KL, KM, lane, &logL, &logM);
     const double constA = lr_build_tables_segments_wave(&scratch, KL, KM, a.br_length, a.log_br, cfg.model, n_bins,
-                                                        a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane);
+                                                        a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane,
+                                                        a.unit != 0, cfg.frac_birth, cfg.frac_death);
     S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
     S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
     S[LR_ROW_PL * LR_ROW + lane] = L, S[LR_ROW_PM * LR_ROW + lane] = M;
@@ -590,12 +614,12 @@ static int lr_pipeline_env() {
 // Partition layout of the engine.  LR_PARTS (default 2) independent partitions run on their own streams so
 // that the ramp-up / drain of one partition's launches overlaps the other's; each partition with at least
 // 2*cb chains is software-pipelined in two halves.  All boundaries are multiples of cb.
-static int lr_partition(int n_chains, int cb, bool fast, int base[LR_MAX_PARTS + 1], int hA[LR_MAX_PARTS],
+static int lr_partition(int n_chains, int cb, bool fused_ok, int base[LR_MAX_PARTS + 1], int hA[LR_MAX_PARTS],
                         bool pipelined[LR_MAX_PARTS]) {
     static const int want_parts = lr_env_int("LR_PARTS", 2);
     int parts = want_parts < 1 ? 1 : (want_parts > LR_MAX_PARTS ? LR_MAX_PARTS : want_parts);
     const int groups = (n_chains + cb - 1) / cb;
-    const bool pipe = lr_pipeline_env() && fast;
+    const bool pipe = lr_pipeline_env() && fused_ok;
     while (parts > 1 && groups < parts * (pipe ? 2 : 1)) --parts;
     base[0] = 0;
     for (int p = 0; p < parts; ++p) {
@@ -615,11 +639,11 @@ static int lr_partition(int n_chains, int cb, bool fast, int base[LR_MAX_PARTS +
 // sized so that the fused launches that run concurrently (one per partition: step blocks of one half + scan
 // blocks of the other) fill the resident block slots of the chip (256 CUs x 4 blocks) exactly once.
 static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
-    int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, p);
+    int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, cfg->unit_resolution, p);
     if (rc) return rc;
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
-    const int parts = lr_partition(cfg->n_chains, p->cb, p->fast != 0, base, hA, pipelined);
+    const int parts = lr_partition(cfg->n_chains, p->cb, lr_fused_supported(*p), base, hA, pipelined);
     if (!pipelined[0]) return LR_OK;
     const int count = base[1] - base[0];
     const int half = hA[0] > count - hA[0] ? hA[0] : count - hA[0];
@@ -671,7 +695,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     {
         int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
         bool pipelined[LR_MAX_PARTS];
-        out->n_parts = lr_partition(cfg->n_chains, p.cb, p.fast != 0, base, hA, pipelined);
+        out->n_parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined);
         out->pipelined = pipelined[0] ? 1 : 0;
     }
     return LR_OK;
@@ -695,7 +719,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->initialised = false;
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
-    e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, e->plan.fast != 0, base, hA, pipelined);
+    e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, lr_fused_supported(e->plan), base, hA, pipelined);
     e->fork = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
         lr_part& q = e->part[p];
@@ -733,6 +757,7 @@ static lr_step_args lr_make_args(const lr_engine* e) {
     a.n_cls = e->plan.n_cls;
     a.tiles = e->plan.tiles;
     a.H = e->plan.H;
+    a.unit = e->plan.unit;
     return a;
 }
 
@@ -789,22 +814,29 @@ static int lr_graph_iters() {
 //     scan(A);  (n-1) x { fused(scan B | step A); fused(scan A | step B) };  fused(scan B | step A);  step(B)
 // so that every launch but the first and last overlaps the latency-bound chain step of one half with
 // the throughput-bound lineage scan of the other.  LR_PIPELINE=0 falls back to scan; step; ...
-template <int CB, int H>
+template <int CB, int H, bool UNIT>
 static int lr_launch_fused(const lr_engine* e, const lr_step_args& a, const lr_fused_args& f, hipStream_t stream) {
     const int groups = (f.scan_n + CB - 1) / CB;
     const int blocks = f.step_blocks + groups * f.tiles;
-    hipLaunchKernelGGL((lr_fused_iter_kernel<CB, H>), dim3(blocks), dim3(LR_SCAN_THREADS), e->plan.lds_bytes, stream, a,
-                       f);
+    hipLaunchKernelGGL((lr_fused_iter_kernel<CB, H, UNIT>), dim3(blocks), dim3(LR_SCAN_THREADS), e->plan.lds_bytes,
+                       stream, a, f);
     return (int)hipGetLastError();
 }
 
+// instantiated shapes: see lr_fused_supported()
 template <int H>
 static int lr_launch_fused_h(const lr_engine* e, const lr_step_args& a, const lr_fused_args& f, hipStream_t stream) {
+    if (e->plan.unit) {
+        switch (e->plan.cb) {
+            case 16: return lr_launch_fused<16, H, true>(e, a, f, stream);
+            case 8: return lr_launch_fused<8, H, true>(e, a, f, stream);
+            default: return LR_ERR_SIZE;
+        }
+    }
     switch (e->plan.cb) {
-        case 8: return lr_launch_fused<8, H>(e, a, f, stream);
-        case 4: return lr_launch_fused<4, H>(e, a, f, stream);
-        case 2: return lr_launch_fused<2, H>(e, a, f, stream);
-        default: return lr_launch_fused<1, H>(e, a, f, stream);
+        case 8: return lr_launch_fused<8, H, false>(e, a, f, stream);
+        case 4: return lr_launch_fused<4, H, false>(e, a, f, stream);
+        default: return LR_ERR_SIZE;
     }
 }
 

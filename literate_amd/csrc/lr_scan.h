@@ -4,6 +4,15 @@
 #include "lr_device.h"
 #include "lr_internal.h"
 
+// diagnostic build only (-DLR_DIAG): per-block phase stamps (100 MHz wall clock) for timeline analysis
+#ifdef LR_DIAG
+static __device__ unsigned long long lr_diag_buf[8192 * 8];
+#define LR_STAMP(blk, k)                                                                          \
+    if (threadIdx.x == 0 && (blk) < 8192) lr_diag_buf[(blk) * 8 + (k)] = wall_clock64()
+#else
+#define LR_STAMP(blk, k)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // fast path (one table class, H a template constant): every LDS gather address is
 // lane_offset + immediate, the index math is integer (cvt + med3), the next pair of lineages
@@ -29,6 +38,22 @@ __device__ __forceinline__ void lr_score_lineage_fast(double s, double e, double
         t = fma(fs, S.y, t);
         t = fma(fe, E.y, t);
         acc[c] += t;
+    }
+}
+
+// XCD-aware block -> (chain group, tile) map.  Blocks are dealt round-robin over the 8 XCDs (block b and
+// b + 8 share an XCD and its L2, MI355X_MICROARCH.md "Workgroup dispatch"), and L2 does not survive a kernel
+// boundary, so every XCD re-fetches what its blocks stage.  Keeping ALL tiles of a chain group on ONE XCD
+// means the group's 35 KB of tables leave the Infinity Cache once per launch instead of once per tile.
+// Placement only changes speed, never results.
+__device__ __forceinline__ void lr_xcd_remap(int sb, int tiles, int groups, int* group, int* tile) {
+    if ((groups & 7) == 0) {
+        const int x = sb & 7, idx = sb >> 3;
+        *group = x + 8 * (idx / tiles);
+        *tile = idx % tiles;
+    } else {
+        *tile = sb % tiles;
+        *group = sb / tiles;
     }
 }
 
@@ -59,6 +84,31 @@ __device__ __forceinline__ void lr_wave_reduce_chains(double (&acc)[CB], int lan
         o >>= 1;
     }
     if ((lane & (group - 1)) == 0) out[chain] = acc[0];
+}
+
+// Block reduction of the per-thread accumulators through LDS (no cross-lane shuffles, which run on the LDS
+// crossbar and cost ~3.5 us per block as 17 dependent steps): every thread stores its CB sums ([chain][thread],
+// conflict-free), THREADS/CB threads per chain each add CB of them in a fixed order, then one thread per chain
+// adds those.  Needs CB*THREADS + THREADS doubles of LDS (the staged tables are dead by then).
+template <int CB>
+__device__ __forceinline__ void lr_block_reduce_chains(const double (&acc)[CB], double* red, int tid, int nvalid,
+                                                       double* __restrict__ out /* partials + chain0 */) {
+    constexpr int T = LR_SCAN_THREADS;
+    constexpr int TPC = T / CB;            // threads per chain in stage 1
+#pragma unroll
+    for (int c = 0; c < CB; ++c) red[c * T + tid] = acc[c];
+    __syncthreads();
+    const int c1 = tid / TPC, j = tid % TPC;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < CB; ++k) s += red[c1 * T + j + TPC * k];
+    red[CB * T + tid] = s;                 // = [c1][j]
+    __syncthreads();
+    if (tid < nvalid) {
+        double t = 0.0;
+        for (int k = 0; k < TPC; ++k) t += red[CB * T + tid * TPC + k];
+        out[tid] = t;
+    }
 }
 
 // One block: tile `tile` of the lineages x chains [chain0, chain0+CB) of the `n_chains` whose tables start at
@@ -125,16 +175,8 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
     }
 
     __syncthreads();
-    double* red = reinterpret_cast<double*>(lds);
-    const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
-    lr_wave_reduce_chains<CB>(acc, lane, red + wave * CB);
-    __syncthreads();
-    if (tid < nvalid) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < LR_SCAN_THREADS / LR_WAVE; ++w) t += red[w * CB + tid];
-        partials[(size_t)tile * partial_stride + chain0 + tid] = t;
-    }
+    lr_block_reduce_chains<CB>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
+                               partials + (size_t)tile * partial_stride + chain0);
 }
 
 
@@ -147,6 +189,126 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_fast_kernel(const dou
                                                                        double* __restrict__ partials,
                                                                        int partial_stride) {
     extern __shared__ double2 lds[];
-    lr_scan_fast_body<CB, H>(lds, blockIdx.x, blockIdx.y * CB, ts, te, n, t0, n_bins, tables, n_chains, chunk, partials,
+    int group, tile;
+    lr_xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.y, &group, &tile);
+    lr_scan_fast_body<CB, H>(lds, tile, group * CB, ts, te, n, t0, n_bins, tables, n_chains, chunk, partials,
+                             partial_stride);
+}
+
+// ------------------------------------------------------------------------------------------
+// unit-resolution path: every lineage has the same in-bin fractions (fs0, fe0), which the table
+// builder has folded into 8-byte entries  S'[b+1] = logB_b + cum_b + fs0*R_b,
+// E'[b+1] = logD_b - cum_b - fe0*R_b.  Per (lineage, chain): two 8-byte LDS gathers + 2 fp64 adds.
+// Layout per chain: [2 (S', E')][H] doubles.
+// ------------------------------------------------------------------------------------------
+template <int CB, int H>
+__device__ __forceinline__ void lr_score_lineage_unit(double s, double e, double t0, int n_bins,
+                                                      const char* __restrict__ lds, double (&acc)[CB]) {
+    const int a = min(max(__double2int_rz(floor(s) - t0), -1), n_bins);
+    const int b = min(max(__double2int_rz(ceil(e) - t0), 0), n_bins + 1);
+    const char* pS = lds + ((a + 1) << 3);
+    const char* pE = lds + (b << 3) + H * 8;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const double S = *reinterpret_cast<const double*>(pS + c * (2 * H * 8));
+        const double E = *reinterpret_cast<const double*>(pE + c * (2 * H * 8));
+        acc[c] += S + E;
+    }
+}
+
+template <int CB, int H>
+__device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int chain0, const double* __restrict__ ts,
+                                                  const double* __restrict__ te, long long n, double t0, int n_bins,
+                                                  const double2* __restrict__ tables, int n_chains, long long chunk,
+                                                  double* __restrict__ partials, int partial_stride) {
+    constexpr int STRIDE = H;  // double2 entries per chain (= 2*H doubles)
+    const int tid = threadIdx.x;
+    const int diag_blk = blockIdx.x + blockIdx.y * gridDim.x;
+    (void)diag_blk;
+    LR_STAMP(diag_blk, 0);
+    const int nvalid = min(CB, n_chains - chain0);
+    const long long start = (long long)tile * chunk;
+    const long long end = min(start + chunk, n);
+    const bool aligned = ((((uintptr_t)ts) | ((uintptr_t)te)) & 15) == 0;
+    long long i = start + 2 * tid;
+    double2 s2 = make_double2(0.0, 0.0), e2 = make_double2(0.0, 0.0);
+    if (aligned && i + 1 < end) {
+        s2 = *reinterpret_cast<const double2*>(ts + i);
+        e2 = *reinterpret_cast<const double2*>(te + i);
+    }
+    {
+        const double2* src = tables + (size_t)chain0 * STRIDE;
+        const int n_valid_entries = nvalid * STRIDE;
+        constexpr int NI = (CB * STRIDE + LR_SCAN_THREADS - 1) / LR_SCAN_THREADS;
+        double2 buf[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int j = tid + k * LR_SCAN_THREADS;
+            buf[k] = src[min(j, n_valid_entries - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int j = tid + k * LR_SCAN_THREADS;
+            if (j < CB * STRIDE) lds[j] = (j < n_valid_entries) ? buf[k] : make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+    LR_STAMP(diag_blk, 1);
+
+    double acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = 0.0;
+    const char* lbase = reinterpret_cast<const char*>(lds);
+    if (aligned) {
+        while (i + 1 < end) {
+            const double2 sc = s2, ec = e2;
+            const long long nx = i + 2 * LR_SCAN_THREADS;
+            if (nx + 1 < end) {
+                s2 = *reinterpret_cast<const double2*>(ts + nx);
+                e2 = *reinterpret_cast<const double2*>(te + nx);
+            }
+            lr_score_lineage_unit<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
+            lr_score_lineage_unit<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
+            i = nx;
+        }
+        if (i < end) lr_score_lineage_unit<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
+    } else {
+        for (; i < end; i += 2 * LR_SCAN_THREADS) {
+            lr_score_lineage_unit<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
+            if (i + 1 < end) lr_score_lineage_unit<CB, H>(ts[i + 1], te[i + 1], t0, n_bins, lbase, acc);
+        }
+    }
+
+    LR_STAMP(diag_blk, 2);
+    __syncthreads();
+    LR_STAMP(diag_blk, 3);
+    lr_block_reduce_chains<CB>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
+                               partials + (size_t)tile * partial_stride + chain0);
+    LR_STAMP(diag_blk, 4);
+#ifdef LR_DIAG
+    if (threadIdx.x == 0 && diag_blk < 8192) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        lr_diag_buf[diag_blk * 8 + 5] = hw;
+        lr_diag_buf[diag_blk * 8 + 6] = xcc;
+        lr_diag_buf[diag_blk * 8 + 7] = ((unsigned long long)tile << 32) | (unsigned)chain0;
+    }
+#endif
+}
+
+template <int CB, int H>
+__global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_unit_kernel(const double* __restrict__ ts,
+                                                                       const double* __restrict__ te, long long n,
+                                                                       double t0, int n_bins,
+                                                                       const double2* __restrict__ tables,
+                                                                       int n_chains, long long chunk,
+                                                                       double* __restrict__ partials,
+                                                                       int partial_stride) {
+    extern __shared__ double2 lds[];
+    int group, tile;
+    lr_xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.y, &group, &tile);
+    lr_scan_unit_body<CB, H>(lds, tile, group * CB, ts, te, n, t0, n_bins, tables, n_chains, chunk, partials,
                              partial_stride);
 }

@@ -13,7 +13,7 @@ from . import _hip, ops
 class ChainEngine:
     def __init__(self, ts, te, n_chains, model=0, seed=1, const_rates=0, const_death_rate=0, use_rate_HP=1,
                  poisson_HP=0.0, update_fraction=0.75, s_freq=1000, n_trace_slots=0, chain_offset=0,
-                 device=None, stats=None, sort_lineages=True):
+                 device=None, stats=None, sort_lineages=True, unit_resolution=None):
         """ts/te: lineage birth/death times (death_jitter already added, LRF:471).
 
         stats: optional (t0, n_bins, br_length) if the caller already binned the data; otherwise the
@@ -43,12 +43,24 @@ class ChainEngine:
             self.br_length = ops._dev(br, torch.float64, self.device)
             self.sp_events = self.ex_events = None
         self.t0, self.n_bins, self.model = float(t0), int(n_bins), int(model)
+        # unit-resolution data (integer years + death_jitter: every dataset the reference ships): all lineages
+        # share the in-bin fractions, which the kernels then fold into 8-byte lookup tables
+        fs = self.ts - torch.floor(self.ts)
+        fe = self.te - (torch.ceil(self.te) - 1.0)
+        fs0, fe0 = float(fs.min().item()), float(fe.min().item())
+        is_unit = bool((fs.max().item() == fs0) and (fe.max().item() == fe0))
+        if unit_resolution is None:
+            unit_resolution = is_unit
+        if unit_resolution and not is_unit:
+            raise ValueError("unit_resolution=True but the lineages do not share their in-bin fractions")
+        self.unit_resolution = bool(unit_resolution)
         self.cfg = _hip.McmcConfig(
             n_lineages=self.ts.numel(), n_bins=self.n_bins, n_chains=int(n_chains), model=int(model),
             const_rates=int(const_rates), const_death_rate=int(const_death_rate), use_rate_HP=int(use_rate_HP),
             s_freq=int(s_freq), n_trace_slots=int(n_trace_slots), poisson_HP=float(poisson_HP),
             update_fraction=float(update_fraction), t0=self.t0, start_time=self.start_time, end_time=self.end_time,
-            seed=int(seed), chain_offset=int(chain_offset))
+            seed=int(seed), chain_offset=int(chain_offset), unit_resolution=int(self.unit_resolution),
+            frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0)
         self.layout = _hip.McmcLayout()
         _hip.check(self.lib.lr_mcmc_query_layout(C.byref(self.cfg), C.byref(self.layout)), "lr_mcmc_query_layout")
         self.workspace = torch.zeros(self.layout.total_bytes, dtype=torch.uint8, device=self.device)

@@ -29,12 +29,15 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
 
 @pytest.mark.parametrize("model,kw", [(0, {}), (2, {}), (1, {}), (3, {}),
                                        (0, dict(const_rates=1)), (0, dict(const_death_rate=1)),
-                                       (2, dict(use_rate_HP=0, Poisson_HP=2.5))])
+                                       (2, dict(use_rate_HP=0, Poisson_HP=2.5)),
+                                       (0, dict(unit_resolution=False)), (1, dict(unit_resolution=False))])
 def test_engine_follows_oracle_trajectory(G, model, kw):
     from literate_amd.engine import ChainEngine, split_trace_row
     name, seed, n_it, C, off = "example_TBP", 2024, 1500, 6, 40
+    kw = dict(kw)
     ekw = dict(const_rates=kw.get("const_rates", 0), const_death_rate=kw.get("const_death_rate", 0),
-               use_rate_HP=kw.get("use_rate_HP", 1), poisson_HP=kw.get("Poisson_HP", 0.0))
+               use_rate_HP=kw.get("use_rate_HP", 1), poisson_HP=kw.get("Poisson_HP", 0.0),
+               unit_resolution=kw.pop("unit_resolution", None))
     eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=model, seed=seed, s_freq=1,
                       n_trace_slots=n_it, chain_offset=off, **ekw)
     # binning done by the engine's own kernel must equal the reference's
@@ -60,13 +63,17 @@ def test_engine_follows_oracle_trajectory(G, model, kw):
     eng.close()
 
 
-def test_pipelined_partitioned_engine_follows_oracle(G):
+@pytest.mark.parametrize("unit", [True, False])
+def test_pipelined_partitioned_engine_follows_oracle(G, unit):
     """64 chains: two stream partitions, each software-pipelined in two halves (fused scan|step launches,
     hipGraph replays).  Chains from every half of every partition are compared with the oracle loop, and the
-    engine layout is checked to really be the pipelined one."""
+    engine layout is checked to really be the pipelined one.  unit=True: unit-resolution tables (8-byte
+    entries, 16 chains per block), False: the general-times kernels on the same data."""
     from literate_amd.engine import ChainEngine, split_trace_row
     name, seed, n_it, C = "metal_bands", 404, 400, 64
-    eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=2, seed=seed, s_freq=1, n_trace_slots=n_it)
+    eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=2, seed=seed, s_freq=1, n_trace_slots=n_it,
+                      unit_resolution=unit)
+    assert eng.unit_resolution == unit and eng.layout.chains_per_block == (16 if unit else 8)
     assert eng.layout.n_parts == 2 and eng.layout.pipelined == 1
     eng.init()
     eng.steps(150); eng.steps(1); eng.steps(249)        # graph replays + prologue/epilogue launches, three calls
@@ -80,6 +87,35 @@ def test_pipelined_partitioned_engine_follows_oracle(G):
             assert np.allclose(head[1:13], r[1:13], rtol=1e-9, atol=1e-9), (c, i, head, r)
             assert np.allclose(sp, ref["sp"][i], rtol=1e-10) and np.allclose(ex, ref["ex"][i], rtol=1e-10)
     assert np.all(eng.snapshot()["it"] == n_it)
+    eng.close()
+
+
+def test_engine_continuous_times_general_path(G):
+    """Lineage times that are NOT unit-resolution (uniform jitter added): the engine must pick the general
+    kernels by itself and still follow the oracle loop run on statistics binned from the same jittered data."""
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import literate_oracle as lo
+    from oracle import mcmc_oracle as mo
+    rng = np.random.default_rng(4)
+    ts = G["metal_bands/ts"][:6000] + rng.uniform(0, 0.999, 6000)
+    te = np.maximum(G["metal_bands/te"][:6000] + rng.uniform(0, 0.4, 6000), ts + 0.01)
+    te[G["metal_bands/te"][:6000] >= 2000.5] = 2000.5
+    n_it, seed, C = 300, 21, 40
+    eng = ChainEngine(ts, te, C, model=2, seed=seed, s_freq=1, n_trace_slots=n_it)
+    assert not eng.unit_resolution and eng.layout.chains_per_block == 8 and eng.layout.pipelined == 1
+    with pytest.raises(ValueError):
+        ChainEngine(ts, te, C, model=2, unit_resolution=True)
+    eng.init(); eng.steps(n_it)
+    tr = eng.trace_rows()
+    t0, sp, ex, br = lo.bin_events_cli(ts, te)
+    assert np.array_equal(eng.sp_events.cpu().numpy(), sp) and np.allclose(eng.br_length.cpu().numpy(), br, rtol=1e-12)
+    for c in (0, 19, 20, 39):
+        with np.errstate(all="ignore"):
+            ref = mo.run_mcmc(dict(sp=sp, ex=ex, br=br), ts.min(), te.max(), mo.Settings(model_BDI=2),
+                              mo.PhiloxDraws(seed, c), n_it, 1, k_max=32)
+        for i in range(n_it):
+            head, s_row, e_row = split_trace_row(tr[i, c])
+            assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9), (c, i, head, ref["mcmc"][i])
     eng.close()
 
 

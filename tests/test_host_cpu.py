@@ -30,6 +30,10 @@ def test_library_exports_every_declared_symbol():
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
     assert lay.chains_per_block == 8 and lay.table_stride == 2 * 136 and lay.trace_width == _hip.LR_TRACE_W
     assert lay.total_bytes > lay.trace > lay.partials > lay.tables > lay.bin_consts > lay.state_i32 > 0
+    assert lay.n_parts == 2 and lay.pipelined == 1
+    cfg.unit_resolution, cfg.frac_death = 1, 0.5                  # unit-resolution tables: 8-byte entries, 16 chains/block
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
+    assert lay.chains_per_block == 16 and lay.table_stride == 136 and lay.pipelined == 1
     cfg.t0 = 0.5
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == -5        # LR_ERR_T0
     assert _hip.load().lr_bd_loglik_workspace_bytes(1000, 5000, 4, 2) == -2   # LR_ERR_SIZE

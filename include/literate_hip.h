@@ -205,6 +205,9 @@ typedef struct lr_mcmc_layout {
 #define LR_I_IT_HI 7
 #define LR_I_ACCEPTED 8  /* number of accepted proposals so far                 */
 #define LR_I_MOVE 9      /* kind of the pending proposal: 0 L-mult 1 L-times 2 M-mult 3 M-times 4 RJ 5 Gibbs */
+#define LR_I_NEXT_LO 10  /* next iteration number that writes a trace row (64 bit) and its slot     */
+#define LR_I_NEXT_HI 11
+#define LR_I_SLOT 12
 
 /* trace row (one per chain per sample; columns 0..12 are the _mcmc.log columns LRF:496-502
  * without the adequacy triple, then the _sp_rates / _ex_rates rows LRF:354-359):

@@ -18,7 +18,8 @@ ROW_L, ROW_M, ROW_TL, ROW_TM, ROW_PL, ROW_PM, ROW_PTL, ROW_PTM, ROW_SCALARS = ra
 (S_LIKA, S_PRIORA, S_PRIORPOIA, S_GRATE_L, S_GRATE_M, S_POI, S_HASTING, S_PRIOR_P, S_PRIORPOI_P, S_CONST_P,
  S_CONST_A, S_LIK_P, S_LOG_G0, S_LOG_G1, S_LOG_POI) = range(15)
 IROW_EL, IROW_EM, IROW_PEL, IROW_PEM, IROW_SCALARS = range(5)
-(I_KL, I_KM, I_PKL, I_PKM, I_GIBBS, I_INVALID, I_IT_LO, I_IT_HI, I_ACCEPTED, I_MOVE) = range(10)
+(I_KL, I_KM, I_PKL, I_PKM, I_GIBBS, I_INVALID, I_IT_LO, I_IT_HI, I_ACCEPTED, I_MOVE, I_NEXT_LO, I_NEXT_HI,
+ I_SLOT) = range(13)
 
 
 class McmcConfig(C.Structure):

@@ -14,34 +14,85 @@
 #define LR_WAVE 64
 
 // ---------------------------------------------------------------------------------------
-// wave helpers.  The xor butterfly adds commutatively at every level, so every lane ends
-// with the same bits.
+// wave helpers on DPP (data-parallel primitives: the cross-lane move happens inside the VALU
+// instruction, no trip through the LDS crossbar as ds_bpermute / __shfl would make).  Fixed
+// association order, so results are bitwise reproducible; every lane gets the same total.
+// Scan pattern (AMD GCN cross-lane ops): row_shr 1,2,3 of the input, row_shr 4 / 8 of the
+// running value under bank masks, then row_bcast15 / row_bcast31 under row masks.
+// ALL 64 lanes must be active.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double lr_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, LR_WAVE);
+#define LR_DPP_ROW_SHR(n) (0x110 | (n))
+#define LR_DPP_ROW_BCAST15 0x142
+#define LR_DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double lr_dpp_zero(double src) {  // src moved by DPP, 0 where masked / out of range
+    int lo = __double2loint(src), hi = __double2hiint(src);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double lr_dpp_self(double src) {  // src moved by DPP, own value where masked / out of range
+    int lo = __double2loint(src), hi = __double2hiint(src);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, BANK_MASK, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ long long lr_dpp_zero_i64(long long src) {
+    int lo = (int)(src & 0xffffffffll), hi = (int)(src >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, true);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ double lr_wave_inclusive_scan(double x) {
+    double v = x;
+    v += lr_dpp_zero<LR_DPP_ROW_SHR(1), 0xf, 0xf>(x);
+    v += lr_dpp_zero<LR_DPP_ROW_SHR(2), 0xf, 0xf>(x);
+    v += lr_dpp_zero<LR_DPP_ROW_SHR(3), 0xf, 0xf>(x);
+    v += lr_dpp_zero<LR_DPP_ROW_SHR(4), 0xf, 0xe>(v);
+    v += lr_dpp_zero<LR_DPP_ROW_SHR(8), 0xf, 0xc>(v);
+    v += lr_dpp_zero<LR_DPP_ROW_BCAST15, 0xa, 0xf>(v);
+    v += lr_dpp_zero<LR_DPP_ROW_BCAST31, 0xc, 0xf>(v);
     return v;
 }
-__device__ __forceinline__ double lr_wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, LR_WAVE));
-    return v;
+__device__ __forceinline__ double lr_readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-__device__ __forceinline__ long long lr_wave_sum_i64(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, LR_WAVE);
-    return v;
+__device__ __forceinline__ double lr_wave_sum(double v) { return lr_readlane_f64(lr_wave_inclusive_scan(v), 63); }
+__device__ __forceinline__ double lr_wave_min(double x) {
+    double v = x;
+    v = fmin(v, lr_dpp_self<LR_DPP_ROW_SHR(1), 0xf, 0xf>(v));
+    v = fmin(v, lr_dpp_self<LR_DPP_ROW_SHR(2), 0xf, 0xf>(v));
+    v = fmin(v, lr_dpp_self<LR_DPP_ROW_SHR(4), 0xf, 0xf>(v));
+    v = fmin(v, lr_dpp_self<LR_DPP_ROW_SHR(8), 0xf, 0xf>(v));     // lane 15 of each row: row minimum
+    v = fmin(v, lr_dpp_self<LR_DPP_ROW_BCAST15, 0xa, 0xf>(v));    // lane 31 / 63: min of rows 0-1 / 2-3
+    v = fmin(v, lr_dpp_self<LR_DPP_ROW_BCAST31, 0xc, 0xf>(v));    // lane 63: min of all
+    return lr_readlane_f64(v, 63);
 }
-// exclusive prefix sum over lanes (Hillis-Steele, fixed order); *total = sum over all lanes
+__device__ __forceinline__ long long lr_wave_sum_i64(long long x) {
+    long long v = x;
+    v += lr_dpp_zero_i64<LR_DPP_ROW_SHR(1), 0xf, 0xf>(x);
+    v += lr_dpp_zero_i64<LR_DPP_ROW_SHR(2), 0xf, 0xf>(x);
+    v += lr_dpp_zero_i64<LR_DPP_ROW_SHR(3), 0xf, 0xf>(x);
+    v += lr_dpp_zero_i64<LR_DPP_ROW_SHR(4), 0xf, 0xe>(v);
+    v += lr_dpp_zero_i64<LR_DPP_ROW_SHR(8), 0xf, 0xc>(v);
+    v += lr_dpp_zero_i64<LR_DPP_ROW_BCAST15, 0xa, 0xf>(v);
+    v += lr_dpp_zero_i64<LR_DPP_ROW_BCAST31, 0xc, 0xf>(v);
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+// exclusive prefix sum over lanes; *total = sum over all lanes
 __device__ __forceinline__ double lr_wave_exclusive_scan(double v, int lane, double* total) {
-    double incl = v;
-#pragma unroll
-    for (int o = 1; o < LR_WAVE; o <<= 1) {
-        double up = __shfl_up(incl, o, LR_WAVE);
-        if (lane >= o) incl += up;
-    }
-    *total = __shfl(incl, LR_WAVE - 1, LR_WAVE);
-    return incl - v;
+    const double incl = lr_wave_inclusive_scan(v);
+    *total = lr_readlane_f64(incl, 63);
+    (void)lane;
+    return lr_dpp_zero<0x138 /* wave_shr:1 */, 0xf, 0xf>(incl);   // lane l <- incl[l-1], lane 0 <- 0
 }
 
 // ---------------------------------------------------------------------------------------

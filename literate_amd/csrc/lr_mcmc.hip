@@ -234,6 +234,102 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
     return lr_wave_sum(csum);
 }
 
+// Same tables for the common shape (one table class, at most 4 bins per lane, i.e. n_bins <= 256) in ONE pass
+// with everything in registers: the segment of a bin is the number of interior edges <= bin, counted by
+// broadcasting the K-1 edges with v_readlane (edges live in lanes: lane j holds edge j); rates and their logs
+// come from the LDS scratch with independent reads; one DPP scan gives the cumulative exposure.
+template <int P>
+__device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scratch* sc, int eL, int eM, int KL,
+                                                                int KM, const double* __restrict__ br_length,
+                                                                const double* __restrict__ log_br, int model,
+                                                                int n_bins, int H, double2* __restrict__ tab,
+                                                                int lane, bool unit, double fs0, double fe0) {
+    double* tabd = reinterpret_cast<double*>(tab);
+    const int b0 = lane * P;
+    int segL[P], segM[P];
+    double k_b[P], lk_b[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        segL[p] = 0, segM[p] = 0;
+        const int b = min(b0 + p, n_bins - 1);
+        k_b[p] = (model < 2) ? br_length[b] : 1.0;
+        lk_b[p] = (model < 2) ? log_br[b] : 0.0;
+    }
+    for (int j = 1; j < KL; ++j) {
+        const int e = __builtin_amdgcn_readlane(eL, j);
+#pragma unroll
+        for (int p = 0; p < P; ++p) segL[p] += (e <= b0 + p) ? 1 : 0;
+    }
+    for (int j = 1; j < KM; ++j) {
+        const int e = __builtin_amdgcn_readlane(eM, j);
+#pragma unroll
+        for (int p = 0; p < P; ++p) segM[p] += (e <= b0 + p) ? 1 : 0;
+    }
+    double logB[P], logD[P], R[P];
+    double sumR = 0.0, csum = 0.0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const double lam = sc->rate[0][segL[p]], mu = sc->rate[1][segM[p]];
+        const double llam = sc->lograte[0][segL[p]], lmu = sc->lograte[1][segM[p]];
+        logB[p] = 0.0, logD[p] = 0.0, R[p] = 0.0;
+        if (b0 + p < n_bins) {
+            if (model >= 2) {
+                logB[p] = llam, logD[p] = lmu, R[p] = lam + mu;
+            } else if (k_b[p] > 0.0) {
+                logB[p] = (model == 0) ? lk_b[p] + llam : llam;
+                logD[p] = lmu + lk_b[p];
+                R[p] = (model == 0) ? lam + mu : mu;
+                if (model == 1) csum -= lam;
+            }
+        }
+        sumR += R[p];
+    }
+    double totR;
+    double cum = lr_wave_exclusive_scan(sumR, lane, &totR);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int b = b0 + p;
+        if (b < n_bins) {
+            if (unit) {
+                tabd[b + 1] = (logB[p] + cum) + fs0 * R[p];
+                tabd[H + b + 1] = (logD[p] - cum) - fe0 * R[p];
+            } else {
+                tab[b + 1] = make_double2(logB[p] + cum, R[p]);
+                tab[H + b + 1] = make_double2(logD[p] - cum, -R[p]);
+            }
+        }
+        cum += R[p];
+    }
+    if (lane == 0) {
+        if (unit) {
+            tabd[0] = 0.0, tabd[H] = 0.0;
+            tabd[n_bins + 1] = totR, tabd[H + n_bins + 1] = -totR;
+        } else {
+            tab[0] = make_double2(0.0, 0.0);
+            tab[H] = make_double2(0.0, 0.0);
+            tab[n_bins + 1] = make_double2(totR, 0.0);
+            tab[H + n_bins + 1] = make_double2(-totR, 0.0);
+        }
+    }
+    return (model == 1) ? lr_wave_sum(csum) : 0.0;
+}
+
+// dispatcher: fast one-pass builder when the shape allows, general two-pass builder otherwise
+__device__ __forceinline__ double lr_build_tables_segments(const lr_seg_scratch* sc, int eL, int eM, int KL, int KM,
+                                                           const double* __restrict__ br_length,
+                                                           const double* __restrict__ log_br, int model, int n_bins,
+                                                           int n_cls, int H, double2* __restrict__ tab, int lane,
+                                                           bool unit, double fs0, double fe0) {
+    if (n_cls == 1 && n_bins <= 2 * LR_WAVE)
+        return lr_build_tables_segments_fast<2>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
+                                                fs0, fe0);
+    if (n_cls == 1 && n_bins <= 4 * LR_WAVE)
+        return lr_build_tables_segments_fast<4>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
+                                                fs0, fe0);
+    return lr_build_tables_segments_wave(sc, KL, KM, br_length, log_br, model, n_bins, n_cls, H, tab, lane, unit, fs0,
+                                         fe0);
+}
+
 // stage one chain's segments in the wave's LDS scratch; log of all rates in ONE call
 // (lanes 0..31 carry the birth rates, lanes 32..63 the death rates)
 __device__ __forceinline__ void lr_stage_segments(lr_seg_scratch* sc, double L, double M, int eL, int eM, int KL,
@@ -256,6 +352,13 @@ __device__ __forceinline__ void lr_stage_segments(lr_seg_scratch* sc, double L, 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+#ifdef LR_DIAG
+static __device__ unsigned long long lr_diag_step[4096 * 12];
+#define LR_SSTAMP(k) if (lane == 0 && c < 4096) lr_diag_step[c * 12 + (k)] = wall_clock64()
+#else
+#define LR_SSTAMP(k)
+#endif
+
 // mode: 0 = regular step (accept pending proposal, then propose), 1 = finish init (adopt the
 // evaluated initial state as accepted, then propose iteration 0)
 __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mode, int c, int lane,
@@ -266,6 +369,7 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
     int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
     const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
+    LR_SSTAMP(0);
 
     // ---- load state: lane j holds element j; tile partials in flight at the same time ----
     double L = S[LR_ROW_L * LR_ROW + lane], M = S[LR_ROW_M * LR_ROW + lane];
@@ -287,8 +391,11 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     int KL = lr_bcast_i(isc, LR_I_KL), KM = lr_bcast_i(isc, LR_I_KM);
     uint64_t it = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_HI) << 32);
     int n_acc = lr_bcast_i(isc, LR_I_ACCEPTED);
+    uint64_t next_sample = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_HI) << 32);
+    int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
     // log-likelihood of the pending proposal: tile partials summed in tile order
     const double lik_sum = lr_wave_sum(part);
+    LR_SSTAMP(1);
 
     if (mode == 1) {
         // LRF:224-230.  The initial prior uses prior_gamma's default rate b=2 (LRF:201, 227).
@@ -313,9 +420,12 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
             n_acc += 1;
         }
         // ---- trace row (LRF:321-359) ----
-        if (it % (uint64_t)cfg.s_freq == 0) {
-            const uint64_t slot = it / (uint64_t)cfg.s_freq;
-            if (slot < (uint64_t)cfg.n_trace_slots) {
+        // `it % s_freq == 0` kept as a running (next sample, slot) pair: no 64-bit division on the device
+        if (it == next_sample) {
+            const int slot = trace_slot;
+            trace_slot += 1;
+            next_sample += (uint64_t)cfg.s_freq;
+            if (slot < cfg.n_trace_slots) {
                 double* row = a.trace + ((size_t)slot * C + c) * LR_TRACE_W;
                 const double meanL = lr_wave_sum(lane < KL ? L : 0.0) / KL;
                 const double meanM = lr_wave_sum(lane < KM ? M : 0.0) / KM;
@@ -349,6 +459,7 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
         it += 1;
     }
 
+    LR_SSTAMP(2);
     // ---- propose iteration `it` (LRF:234-287) ----
     double pL = L, pM = M, ptL = tL, ptM = tM;
     int peL = eL, peM = eM, PKL = KL, PKM = KM;
@@ -426,26 +537,38 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
         gibbs = 1;
     }
 
+    LR_SSTAMP(3);
     // segments of the proposal -> LDS scratch (+ log of every rate in one call)
     double logpL, logpM;
     lr_stage_segments(&scratch, pL, pM, peL, peM, PKL, PKM, lane, &logpL, &logpM);
 
+    LR_SSTAMP(4);
     // guard against tiny time frames (LRF:290-292) and the prior of the proposal (LRF:296-304)
     double priorP = -INFINITY;
-    if (lr_wave_min_segment(ptL, PKL, lane) <= LR_MIN_ALLOWED_T || lr_wave_min_segment(ptM, PKM, lane) <= LR_MIN_ALLOWED_T)
-        invalid = 1;
+    {
+        // one reduction for both processes: min over all segment lengths
+        const double nL = lr_dpp_zero<0x130 /* wave_shl:1 */, 0xf, 0xf>(ptL);   // lane l <- element l+1
+        const double nM = lr_dpp_zero<0x130, 0xf, 0xf>(ptM);
+        const double dmin = fmin(lane < PKL ? fabs(nL - ptL) : 1e300, lane < PKM ? fabs(nM - ptM) : 1e300);
+        if (lr_wave_min(dmin) <= LR_MIN_ALLOWED_T) invalid = 1;
+    }
     if (!invalid) {
-        priorP = lr_wave_prior_gamma2(pL, logpL, PKL, g0, lg0, lane) + lr_wave_prior_gamma2(pM, logpM, PKM, g1, lg1, lane);
+        // Gamma(2, g) log-densities of all rates of both processes in one reduction (LRF:296)
+        const double vL = (lane < PKL) ? (logpL + lg0) - pL * g0 + lg0 : 0.0;
+        const double vM = (lane < PKM) ? (logpM + lg1) - pM * g1 + lg1 : 0.0;
+        priorP = lr_wave_sum(vL + vM);
         priorP += -a.log_T * (PKL - 1 + PKM - 1);
         if (priorPoi != 0.0) priorP += priorPoi;
         else priorP += priorPoiA, priorPoi = priorPoiA;
     }
 
+    LR_SSTAMP(5);
     // ---- lookup tables of the proposal ----
-    const double constP = lr_build_tables_segments_wave(&scratch, PKL, PKM, a.br_length, a.log_br, cfg.model, n_bins,
-                                                        a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane,
-                                                        a.unit != 0, cfg.frac_birth, cfg.frac_death);
+    const double constP = lr_build_tables_segments(&scratch, peL, peM, PKL, PKM, a.br_length, a.log_br, cfg.model,
+                                                   n_bins, a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane,
+                                                   a.unit != 0, cfg.frac_birth, cfg.frac_death);
 
+    LR_SSTAMP(6);
     // ---- store ----
     S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
     S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
@@ -486,9 +609,16 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
         case LR_I_IT_HI: io = (int)(uint32_t)(it >> 32); break;
         case LR_I_ACCEPTED: io = n_acc; break;
         case LR_I_MOVE: io = move_kind; break;
+        case LR_I_NEXT_LO: io = (int)(uint32_t)next_sample; break;
+        case LR_I_NEXT_HI: io = (int)(uint32_t)(next_sample >> 32); break;
+        case LR_I_SLOT: io = trace_slot; break;
         default: io = 0, wr = false; break;
     }
     if (wr) I[LR_IROW_SCALARS * LR_ROW + lane] = io;
+    LR_SSTAMP(7);
+#ifdef LR_DIAG
+    if (lane == 0 && c < 4096) lr_diag_step[c * 12 + 8] = move_kind;
+#endif
 }
 
 #define LR_STEP_WAVES (LR_SCAN_THREADS / LR_WAVE)
@@ -579,9 +709,9 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
     const int eL = lr_wave_edges(tL, 1), eM = lr_wave_edges(tM, 1);
     double logL, logM;
     lr_stage_segments(&scratch, L, M, eL, eM, KL, KM, lane, &logL, &logM);
-    const double constA = lr_build_tables_segments_wave(&scratch, KL, KM, a.br_length, a.log_br, cfg.model, n_bins,
-                                                        a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane,
-                                                        a.unit != 0, cfg.frac_birth, cfg.frac_death);
+    const double constA = lr_build_tables_segments(&scratch, eL, eM, KL, KM, a.br_length, a.log_br, cfg.model, n_bins,
+                                                   a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane,
+                                                   a.unit != 0, cfg.frac_birth, cfg.frac_death);
     S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
     S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
     S[LR_ROW_PL * LR_ROW + lane] = L, S[LR_ROW_PM * LR_ROW + lane] = M;
@@ -1002,3 +1132,9 @@ extern "C" int lr_mcmc_destroy(lr_engine* e) {
     delete e;
     return LR_OK;
 }
+
+#ifdef LR_DIAG
+extern "C" int lr_diag_dump_step(unsigned long long* host_out, int n_words) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lr_diag_step), (size_t)n_words * 8);
+}
+#endif

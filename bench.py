@@ -87,8 +87,25 @@ def main():
     n_slots = (args.steps + args.warmup) // args.sample_every + 2
     eng = ChainEngine(ts, te, chains, model=model, seed=2026, s_freq=args.sample_every, n_trace_slots=n_slots,
                       chain_offset=rank * chains)
+    # bring the device out of its idle power state before anything is measured (a cold MI355X runs the first
+    # tens of milliseconds at a fraction of its clock): ~0.4 s of throw-away iterations, then a fresh init so
+    # that exactly W warm-up + K timed iterations follow
+    eng.init()
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.4:
+        eng.steps(256)
+        torch.cuda.synchronize()
     eng.init()
     eng.steps(args.warmup)
+
+    def gather_traces():
+        heads = eng.trace[:, :, :13].contiguous()       # log-posterior trace rows sampled so far
+        if world > 1:
+            gathered = [torch.empty_like(heads) for _ in range(world)] if rank == 0 else None
+            dist.gather(heads, gathered, dst=0)          # RCCL over xGMI
+        return heads
+
+    gather_traces()     # untimed: loads the copy kernel and sets up the RCCL communicator (one-off costs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -99,10 +116,7 @@ def main():
     barrier()
     t_begin = time.perf_counter()
     eng.steps(args.steps)
-    heads = eng.trace[:, :, :13].contiguous()       # log-posterior trace rows sampled so far
-    if world > 1:
-        gathered = [torch.empty_like(heads) for _ in range(world)] if rank == 0 else None
-        dist.gather(heads, gathered, dst=0)          # RCCL over xGMI
+    gather_traces()
     barrier()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
@@ -118,28 +132,32 @@ def main():
     if rank == 0:
         total_chains = chains * world
         value = args.steps * n_lin * total_chains / elapsed
-        # roofline of the dominant kernel, timed live with HIP events on its launch stream.
-        # Pipelined engine: one iteration = two launches of lr_fused_iter_kernel (lineage scan of one half of
-        # the chains + chain step of the other half); each launch scores N x C/2 (lineage, chain) pairs.
+        # ---- roofline ------------------------------------------------------------------------------------
+        # Dominant kernel = the lineage scan.  Inside the engine it runs as the scan blocks of
+        # lr_fused_iter_kernel (beside the chain-step blocks of the other half, 2 partitions in flight), which
+        # HIP events cannot bracket launch by launch under graph replay; the SAME block body is therefore timed
+        # live as the stand-alone lr_scan_*_kernel over all chains: `reps` back-to-back launches bracketed by
+        # HIP events recorded on the launch stream (lr_mcmc_time_scan).
         cb = eng.layout.chains_per_block
         n_parts, pipelined = eng.layout.n_parts, bool(eng.layout.pipelined)
-        n_ev = 200
-        ev_ms = eng.timed_steps(n_ev)                       # device time of n_ev more iterations (HIP events)
-        # each partition issues `lps` launches per iteration on its own stream; the n_parts partitions run
-        # side by side, so a launch lasts ev_ms / (n_ev * lps) and n_parts of them are in flight together
-        lps = 2 if pipelined else 1
-        kernel_ms = ev_ms / (n_ev * lps)
-        chains_per_launch = chains / (n_parts * lps)
-        groups = -(-int(chains_per_launch) // cb)
+        scan_ms = eng.time_scan(reps=50)
+        groups = -(-chains // cb)
         alg_bytes = 16.0 * n_lin * groups                   # 16 B x N x ceil(C/Cb) per launch
-        achieved = n_parts * alg_bytes / (kernel_ms * 1e-3) / 1e9
-        scan_ms = eng.time_scan(reps=50)                    # stand-alone scan of ALL chains (same block body)
+        achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
+        # engine-level view: device time of n_ev more iterations (HIP events around lr_mcmc_steps)
+        n_ev = 200
+        ev_ms = eng.timed_steps(n_ev)
+        lps = 2 if pipelined else 1
+        unit = bool(eng.unit_resolution)
+        kname = ("lr_scan_unit_kernel<%d,136>" if unit else "lr_scan_fast_kernel<%d,136>") % cb
+        # physical limiter: LDS gather rate, 256 B/clk/CU; bytes gathered per (lineage, chain) pair: 16 (unit) / 32
+        lds_peak_pairs = 256 * 2.4e9 * 256 / (16 if unit else 32)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("workload") == args.workload and tj.get("chains") == chains:
+            if tj.get("workload") == args.workload and tj.get("chains") == chains and tj.get("kernel") == kname:
                 traffic = tj.get("hbm_bytes_per_launch")
         out = {
             "metric": "RJMCMC iters/sec x lineages (lineage-log-lik evals/s, summed over chains)",
@@ -153,15 +171,17 @@ def main():
                        "iters_per_s_per_chain": args.steps / elapsed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("lr_fused_iter_kernel<%d,136>" if pipelined else "lr_scan_fast_kernel<%d,136> + lr_chain_step_kernel") % cb,
-                         "kernel_ms": kernel_ms, "launches_per_step_per_partition": lps,
-                         "concurrent_launches": n_parts,
-                         "pairs_per_launch": n_lin * chains_per_launch, "chains_per_pass_Cb": cb,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "effective_GBs_unamortised": n_parts * 16.0 * n_lin * chains_per_launch / (kernel_ms * 1e-3) / 1e9,
-                         "scan_only_kernel_ms_all_chains": scan_ms,
-                         "scan_only_evals_per_s": n_lin * chains / (scan_ms * 1e-3),
-                         "scan_only_frac": 16.0 * n_lin * (-(-chains // cb)) / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "kernel": kname, "kernel_ms": scan_ms, "pairs_per_launch": n_lin * chains,
+                         "chains_per_pass_Cb": cb, "algorithmic_bytes_per_launch": alg_bytes,
+                         "effective_GBs_unamortised": 16.0 * n_lin * chains / (scan_ms * 1e-3) / 1e9,
+                         "kernel_evals_per_s": n_lin * chains / (scan_ms * 1e-3),
+                         "physical_bound": "lds", "lds_peak_evals_per_s": lds_peak_pairs,
+                         "lds_frac_kernel": n_lin * chains / (scan_ms * 1e-3) / lds_peak_pairs,
+                         "lds_frac_engine": value / world / lds_peak_pairs,
+                         "engine": {"kernel": "lr_fused_iter_kernel<%d,136,%s>" % (cb, "true" if unit else "false"),
+                                    "partitions_in_flight": n_parts, "launches_per_step_per_partition": lps,
+                                    "device_ms_per_step_hip_events": ev_ms / n_ev,
+                                    "unit_resolution_tables": unit}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ts, te, eng.t0, eng.n_bins, eng.br_length.cpu().numpy())

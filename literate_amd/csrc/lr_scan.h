@@ -57,35 +57,6 @@ __device__ __forceinline__ void lr_xcd_remap(int sb, int tiles, int groups, int*
     }
 }
 
-// Per-chain sums of one wave in log2 steps that HALVE the number of live accumulators: at offset 32
-// the lower half-wave keeps chains [0,CB/2), the upper half chains [CB/2,CB), and so on; afterwards a
-// plain butterfly over the remaining offsets.  10 exchanges instead of 48 for CB = 8, fixed order.
-template <int CB>
-__device__ __forceinline__ void lr_wave_reduce_chains(double (&acc)[CB], int lane, double* out /* [CB] */) {
-    int off = 32;
-#pragma unroll
-    for (int n = CB; n > 1; n >>= 1) {
-        const int h = n >> 1;
-        const bool hi = (lane & off) != 0;
-#pragma unroll
-        for (int k = 0; k < h; ++k) {
-            const double send = hi ? acc[k] : acc[k + h];
-            const double keep = hi ? acc[k + h] : acc[k];
-            acc[k] = keep + __shfl_xor(send, off, LR_WAVE);
-        }
-        off >>= 1;
-    }
-    const int group = 2 * off;  // lanes sharing one chain
-    for (; off > 0; off >>= 1) acc[0] += __shfl_xor(acc[0], off, LR_WAVE);
-    int chain = 0, o = 32;
-#pragma unroll
-    for (int n = CB; n > 1; n >>= 1) {
-        chain = chain * 2 + ((lane & o) ? 1 : 0);
-        o >>= 1;
-    }
-    if ((lane & (group - 1)) == 0) out[chain] = acc[0];
-}
-
 // Block reduction of the per-thread accumulators through LDS (no cross-lane shuffles, which run on the LDS
 // crossbar and cost ~3.5 us per block as 17 dependent steps): every thread stores its CB sums ([chain][thread],
 // conflict-free), THREADS/CB threads per chain each add CB of them in a fixed order, then one thread per chain

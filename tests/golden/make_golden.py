@@ -3,8 +3,8 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py            # everything except long chains
-    python tests/golden/make_golden.py --chains   # + long reference chains (posterior summaries)
+    python tests/golden/make_golden.py [--only binning,proposals,ddrate,traj]
+    python tests/golden/make_chains.py <dataset> <model> <n> <s> <chains>   # long reference chains
 
 The reference is executed unmodified: LiteRateForward.py / DDRate.py through
 runpy with ``-n 0`` (module body runs, the MCMC loop does not), which yields the

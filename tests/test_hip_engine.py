@@ -254,3 +254,54 @@ def test_cfg5_ddrate_50k_lineages_256_states():
             assert lik[c] == pytest.approx(ref[0].sum(), rel=1e-9)
             n_checked += 1
     assert n_checked > C // 2
+
+
+@pytest.mark.parametrize("n_bins,unit", [(60, None), (134, None), (135, None), (200, False), (300, None)])
+def test_engine_shapes_bins(n_bins, unit):
+    """Table half-stride classes (H = 72, 136, 264) and the generic kernel beyond them (n_bins = 300),
+    unit-resolution and general tables: a few chains against the oracle loop on synthetic data."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    from literate_amd import synth
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import literate_oracle as lo
+    from oracle import mcmc_oracle as mo
+    ts, te, _ = synth.make_lineages(4000, n_bins=n_bins, n_shifts=5, seed=n_bins)
+    ts = np.concatenate([[0.0], ts]); te = np.concatenate([[float(n_bins) + 0.5], te])   # pin the window to n_bins
+    n_it, seed, C = 120, 7, 37
+    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, unit_resolution=unit)
+    assert eng.n_bins == n_bins
+    eng.init(); eng.steps(n_it)
+    tr = eng.trace_rows()
+    t0, sp, ex, br = lo.bin_events_cli(ts, te)
+    for c in (0, 18, 36):
+        with np.errstate(all="ignore"):
+            ref = mo.run_mcmc(dict(sp=sp, ex=ex, br=br), ts.min(), te.max(), mo.Settings(model_BDI=0),
+                              mo.PhiloxDraws(seed, c), n_it, 1, k_max=32)
+        for i in range(n_it):
+            head, s_row, e_row = split_trace_row(tr[i, c])
+            assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9), (n_bins, c, i, head, ref["mcmc"][i])
+    eng.close()
+
+
+def test_engine_chain_count_shapes(G):
+    """Any number of chains: single partition / two partitions, pipelined or not, ragged last block.  The same
+    global chains must walk the same path in every engine shape (sums differ only by their tile partition)."""
+    from literate_amd.engine import ChainEngine
+    name, n_it = "metal_bands", 60
+    ref = ChainEngine(G[name + "/ts"], G[name + "/te"], 1, model=2, seed=3, s_freq=1, n_trace_slots=n_it, chain_offset=0)
+    ref.init(); ref.steps(n_it)
+    first = ref.trace_rows()[:, 0]
+    ref.close()
+    for C in (1, 2, 5, 16, 17, 31, 32, 33, 47, 100, 129):
+        eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=2, seed=3, s_freq=1, n_trace_slots=n_it)
+        eng.init(); eng.steps(25); eng.steps(n_it - 25)
+        tr = eng.trace_rows()
+        assert np.allclose(tr[:, 0], first, rtol=1e-10, atol=1e-9, equal_nan=True), C
+        last = ChainEngine(G[name + "/ts"], G[name + "/te"], 1, model=2, seed=3, s_freq=1, n_trace_slots=n_it,
+                           chain_offset=C - 1)
+        last.init(); last.steps(n_it)
+        assert np.allclose(tr[:, C - 1], last.trace_rows()[:, 0], rtol=1e-10, atol=1e-9, equal_nan=True), C
+        assert np.all(eng.snapshot()["it"] == n_it)
+        eng.close(); last.close()

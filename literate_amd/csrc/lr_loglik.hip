@@ -156,13 +156,22 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res,
             }
     }
     p->unit = (unit_res && p->fast) ? 1 : 0;
-    // unit-resolution tables hold doubles: 2*H doubles = H double2 entries per chain
-    p->tab_stride = p->unit ? p->H : p->n_cls * 2 * p->H;
+    int cb = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // unit-resolution tables hold doubles, two chains per 16-byte entry: H double2 per chain
+        p->tab_stride = p->unit ? p->H : p->n_cls * 2 * p->H;
+        const size_t per_chain_ = (size_t)p->tab_stride * sizeof(double2);
+        cb = p->unit ? 16 : 8;
+        while (cb > 1 && per_chain_ * cb > LR_SCAN_LDS_BUDGET) cb >>= 1;
+        if (per_chain_ * cb > LR_SCAN_LDS_MAX) return LR_ERR_SIZE;
+        while (cb > 1 && cb / 2 >= n_chains) cb >>= 1;  // do not carry empty chain slots
+        if (p->unit && cb < 2) {
+            p->unit = 0;  // a lone chain cannot fill a pair entry: general tables
+            continue;
+        }
+        break;
+    }
     const size_t per_chain = (size_t)p->tab_stride * sizeof(double2);
-    int cb = p->unit ? 16 : 8;
-    while (cb > 1 && per_chain * cb > LR_SCAN_LDS_BUDGET) cb >>= 1;
-    if (per_chain * cb > LR_SCAN_LDS_MAX) return LR_ERR_SIZE;
-    while (cb > 1 && cb / 2 >= n_chains) cb >>= 1;  // do not carry empty chain slots
     p->cb = cb;
     p->groups = (n_chains + cb - 1) / cb;
     if (p->groups > 65535) return LR_ERR_SIZE;

@@ -143,8 +143,18 @@ struct lr_step_args {
     const double* br_length;
     double log_T;           // log(end_time - start_time)
     double mult_l;          // 2 log d of the multiplier proposal (LRF:169)
-    int tab_stride, n_cls, tiles, H, unit;
+    int tab_stride, n_cls, tiles, H, unit, cb;
 };
+
+// where chain c's lookup table starts.  General layout: chain-major, tab_stride double2 per chain.
+// Unit-resolution layout: groups of cb chains, inside a group [pair][2H] double2 = (even chain, odd chain);
+// the returned pointer addresses this chain's component, consecutive entries are 2 doubles apart.
+__device__ __forceinline__ double2* lr_chain_table(const lr_step_args& a, int c) {
+    if (!a.unit) return a.tables + (size_t)c * a.tab_stride;
+    const int l = c % a.cb;
+    double* base = reinterpret_cast<double*>(a.tables + (size_t)(c - l) * a.tab_stride);
+    return reinterpret_cast<double2*>(base + (size_t)(l >> 1) * (4 * a.H) + (l & 1));
+}
 
 // per-wave LDS scratch: segment rates, their logs and integer edges of both processes
 struct lr_seg_scratch {
@@ -162,7 +172,8 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
                                                        const double* __restrict__ log_br, int model, int n_bins,
                                                        int n_cls, int H, double2* __restrict__ tab, int lane,
                                                        bool unit = false, double fs0 = 0.0, double fe0 = 0.0) {
-    double* tabd = reinterpret_cast<double*>(tab);   // unit-resolution layout: [2][H] doubles
+    // unit-resolution layout: tab points at this chain's component of its pair table, entries 2 doubles apart
+    double* tabd = reinterpret_cast<double*>(tab);
     const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
     const int b0 = min(lane * P, n_bins), b1 = min(b0 + P, n_bins);
     int sl0 = 0, sm0 = 0;
@@ -201,8 +212,8 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
             R = (model == 0) ? lam + mu : mu;
         }
         if (unit) {
-            tabd[b + 1] = (logB + cum) + fs0 * R;
-            tabd[H + b + 1] = (logD - cum) - fe0 * R;
+            tabd[2 * (b + 1)] = (logB + cum) + fs0 * R;
+            tabd[2 * (H + b + 1)] = (logD - cum) - fe0 * R;
         } else {
             tab[b + 1] = make_double2(logB + cum, R);
             tab[H + b + 1] = make_double2(logD - cum, -R);
@@ -216,8 +227,8 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
     }
     if (lane == 0) {
         if (unit) {
-            tabd[0] = 0.0, tabd[H] = 0.0;
-            tabd[n_bins + 1] = totR, tabd[H + n_bins + 1] = -totR;
+            tabd[0] = 0.0, tabd[2 * H] = 0.0;
+            tabd[2 * (n_bins + 1)] = totR, tabd[2 * (H + n_bins + 1)] = -totR;
         } else {
             tab[0] = make_double2(0.0, 0.0);
             tab[H] = make_double2(0.0, 0.0);
@@ -291,8 +302,8 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
         const int b = b0 + p;
         if (b < n_bins) {
             if (unit) {
-                tabd[b + 1] = (logB[p] + cum) + fs0 * R[p];
-                tabd[H + b + 1] = (logD[p] - cum) - fe0 * R[p];
+                tabd[2 * (b + 1)] = (logB[p] + cum) + fs0 * R[p];
+                tabd[2 * (H + b + 1)] = (logD[p] - cum) - fe0 * R[p];
             } else {
                 tab[b + 1] = make_double2(logB[p] + cum, R[p]);
                 tab[H + b + 1] = make_double2(logD[p] - cum, -R[p]);
@@ -302,8 +313,8 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
     }
     if (lane == 0) {
         if (unit) {
-            tabd[0] = 0.0, tabd[H] = 0.0;
-            tabd[n_bins + 1] = totR, tabd[H + n_bins + 1] = -totR;
+            tabd[0] = 0.0, tabd[2 * H] = 0.0;
+            tabd[2 * (n_bins + 1)] = totR, tabd[2 * (H + n_bins + 1)] = -totR;
         } else {
             tab[0] = make_double2(0.0, 0.0);
             tab[H] = make_double2(0.0, 0.0);
@@ -565,7 +576,7 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     LR_SSTAMP(5);
     // ---- lookup tables of the proposal ----
     const double constP = lr_build_tables_segments(&scratch, peL, peM, PKL, PKM, a.br_length, a.log_br, cfg.model,
-                                                   n_bins, a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane,
+                                                   n_bins, a.n_cls, a.H, lr_chain_table(a, c), lane,
                                                    a.unit != 0, cfg.frac_birth, cfg.frac_death);
 
     LR_SSTAMP(6);
@@ -710,7 +721,7 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
     double logL, logM;
     lr_stage_segments(&scratch, L, M, eL, eM, KL, KM, lane, &logL, &logM);
     const double constA = lr_build_tables_segments(&scratch, eL, eM, KL, KM, a.br_length, a.log_br, cfg.model, n_bins,
-                                                   a.n_cls, a.H, a.tables + (size_t)c * a.tab_stride, lane,
+                                                   a.n_cls, a.H, lr_chain_table(a, c), lane,
                                                    a.unit != 0, cfg.frac_birth, cfg.frac_death);
     S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
     S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
@@ -814,7 +825,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->state_f64 = o, o += lr_align_up64(C * LR_STATE_ROWS * LR_ROW * 8, 256);
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
     out->bin_consts = o, o += lr_align_up64((long long)cfg->n_bins * 8, 256);
-    out->tables = o, o += lr_align_up64(C * p.tab_stride * 16, 256);
+    out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
     out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
     out->total_bytes = o;
@@ -888,6 +899,7 @@ static lr_step_args lr_make_args(const lr_engine* e) {
     a.tiles = e->plan.tiles;
     a.H = e->plan.H;
     a.unit = e->plan.unit;
+    a.cb = e->plan.cb;
     return a;
 }
 

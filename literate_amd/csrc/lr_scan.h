@@ -169,21 +169,27 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_fast_kernel(const dou
 // ------------------------------------------------------------------------------------------
 // unit-resolution path: every lineage has the same in-bin fractions (fs0, fe0), which the table
 // builder has folded into 8-byte entries  S'[b+1] = logB_b + cum_b + fs0*R_b,
-// E'[b+1] = logD_b - cum_b - fe0*R_b.  Per (lineage, chain): two 8-byte LDS gathers + 2 fp64 adds.
-// Layout per chain: [2 (S', E')][H] doubles.
+// E'[b+1] = logD_b - cum_b - fe0*R_b.  Two chains share one 16-byte entry, so per lineage and PAIR of chains:
+// two ds_read_b128 gathers + 4 fp64 adds (b128 reads reach the LDS rate with few waves per SIMD, b64 do not).
+// Layout per group of CB chains: [CB/2 pairs][2 (S', E')][H] double2 = (chain 2p, chain 2p+1).
 // ------------------------------------------------------------------------------------------
 template <int CB, int H>
 __device__ __forceinline__ void lr_score_lineage_unit(double s, double e, double t0, int n_bins,
                                                       const char* __restrict__ lds, double (&acc)[CB]) {
     const int a = min(max(__double2int_rz(floor(s) - t0), -1), n_bins);
     const int b = min(max(__double2int_rz(ceil(e) - t0), 0), n_bins + 1);
-    const char* pS = lds + ((a + 1) << 3);
-    const char* pE = lds + (b << 3) + H * 8;
+    const char* pS = lds + ((a + 1) << 4);
+    const char* pE = lds + (b << 4) + H * 16;
+    if (CB == 1) {
+        acc[0] += reinterpret_cast<const double2*>(pS)->x + reinterpret_cast<const double2*>(pE)->x;
+        return;
+    }
 #pragma unroll
-    for (int c = 0; c < CB; ++c) {
-        const double S = *reinterpret_cast<const double*>(pS + c * (2 * H * 8));
-        const double E = *reinterpret_cast<const double*>(pE + c * (2 * H * 8));
-        acc[c] += S + E;
+    for (int p = 0; p < CB / 2; ++p) {
+        const double2 S = *reinterpret_cast<const double2*>(pS + p * (2 * H * 16));
+        const double2 E = *reinterpret_cast<const double2*>(pE + p * (2 * H * 16));
+        acc[2 * p] += S.x + E.x;
+        acc[2 * p + 1] += S.y + E.y;
     }
 }
 
@@ -192,7 +198,8 @@ __device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int ch
                                                   const double* __restrict__ te, long long n, double t0, int n_bins,
                                                   const double2* __restrict__ tables, int n_chains, long long chunk,
                                                   double* __restrict__ partials, int partial_stride) {
-    constexpr int STRIDE = H;  // double2 entries per chain (= 2*H doubles)
+    constexpr int STRIDE = H;  // double2 entries per chain; a group of CB chains owns max(CB,2)*H entries
+    constexpr int GROUP_ENTRIES = (CB < 2 ? 2 : CB) * STRIDE;
     const int tid = threadIdx.x;
     const int diag_blk = blockIdx.x + blockIdx.y * gridDim.x;
     (void)diag_blk;
@@ -208,19 +215,19 @@ __device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int ch
         e2 = *reinterpret_cast<const double2*>(te + i);
     }
     {
+        // the whole group region is staged: pair tables of chains past n_chains hold zeros (workspace is zeroed)
         const double2* src = tables + (size_t)chain0 * STRIDE;
-        const int n_valid_entries = nvalid * STRIDE;
-        constexpr int NI = (CB * STRIDE + LR_SCAN_THREADS - 1) / LR_SCAN_THREADS;
+        constexpr int NI = (GROUP_ENTRIES + LR_SCAN_THREADS - 1) / LR_SCAN_THREADS;
         double2 buf[NI];
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int j = tid + k * LR_SCAN_THREADS;
-            buf[k] = src[min(j, n_valid_entries - 1)];
+            buf[k] = src[min(j, GROUP_ENTRIES - 1)];
         }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int j = tid + k * LR_SCAN_THREADS;
-            if (j < CB * STRIDE) lds[j] = (j < n_valid_entries) ? buf[k] : make_double2(0.0, 0.0);
+            if (j < GROUP_ENTRIES) lds[j] = buf[k];
         }
     }
     __syncthreads();

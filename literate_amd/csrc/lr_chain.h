@@ -21,8 +21,9 @@
 #define LR_MULT_D 1.1           /* LRF:165 */
 #define LR_BETALN_10_10 (-13.736229227036555) /* scipy.special.betaln(10, 10) */
 
-__device__ __forceinline__ double lr_bcast(double v, int src) { return __shfl(v, src, LR_WAVE); }
-__device__ __forceinline__ int lr_bcast_i(int v, int src) { return __shfl(v, src, LR_WAVE); }
+// broadcast of lane `src` (wave-uniform index) through v_readlane: no trip through the LDS crossbar
+__device__ __forceinline__ double lr_bcast(double v, int src) { return lr_readlane_f64(v, src); }
+__device__ __forceinline__ int lr_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 // log(k!) summed the way the reference does, np.sum(np.log(np.arange(1, k+1))) (LRF:199)
 __device__ __forceinline__ double lr_log_factorial(int k) {
@@ -50,23 +51,25 @@ __device__ __forceinline__ double lr_wave_multiplier(double& R, int K, bool ff, 
 // add_shift_RJ_weighted_mean (LRF:29-47).  ind = interval, delta = offset inside it, u ~ Beta(10,10).
 __device__ __forceinline__ double lr_wave_add_shift(double& R, double& T, int& K, int ind, double delta, double u,
                                                     int lane) {
-    const double t_i1 = __shfl(T, ind, LR_WAVE);
-    const double t_i2 = __shfl(T, ind + 1, LR_WAVE);
-    const double rate_i = __shfl(R, ind, LR_WAVE);
-    const double Tup = __shfl_up(T, 1, LR_WAVE);
-    const double Rup = __shfl_up(R, 1, LR_WAVE);
+    const double t_i1 = lr_bcast(T, ind);
+    const double t_i2 = lr_bcast(T, ind + 1);
+    const double rate_i = lr_bcast(R, ind);
+    const double Tup = lr_dpp_zero<0x138 /* wave_shr:1 */, 0xf, 0xf>(T);
+    const double Rup = lr_dpp_zero<0x138, 0xf, 0xf>(R);
     const double r_time = t_i2 - t_i1;
     const double t_prime = t_i1 + delta;
     const double p1 = (t_i1 - t_prime) / (t_i1 - t_i2);
     const double p2 = (t_prime - t_i2) / (t_i1 - t_i2);
-    // one packed log: lane0 (1-u)/u, lane1 rate_i, lane2 |r_time|, lane3 u
+    // one packed log: lane0 (1-u)/u, lane1 rate_i, lane2 |r_time|, lane3 u, lane4 1-u
     double x = 1.0;
     if (lane == 0) x = (1 - u) / u;
     if (lane == 1) x = rate_i;
     if (lane == 2) x = fabs(r_time);
     if (lane == 3) x = u;
+    if (lane == 4) x = 1 - u;
     const double lx = log(x);
     const double logit = lr_bcast(lx, 0), log_rate = lr_bcast(lx, 1), log_rt = lr_bcast(lx, 2), log_u = lr_bcast(lx, 3);
+    const double log_1mu = lr_bcast(lx, 4);
     // one packed exp: lane0 -> r1, lane1 -> r2
     const double ex = exp(lane == 0 ? log_rate - p2 * logit : (lane == 1 ? log_rate + p1 * logit : 0.0));
     const double r1 = lr_bcast(ex, 0), r2 = lr_bcast(ex, 1);
@@ -78,7 +81,7 @@ __device__ __forceinline__ double lr_wave_add_shift(double& R, double& T, int& K
     else if (lane > ind + 1) R = Rup;
     K += 1;
     const double a = LR_SHAPE_BETA_RJ;
-    const double log_beta = (a - 1.0) * log1p(-u) + (a - 1.0) * log_u - LR_BETALN_10_10;   // LRF:22-23
+    const double log_beta = (a - 1.0) * log_1mu + (a - 1.0) * log_u - LR_BETALN_10_10;   // LRF:22-23
     const double log_q = log_rt - log_beta;
     const double jac = 2 * log(r1 + r2) - log_rate;
     return log_q + jac;
@@ -87,34 +90,35 @@ __device__ __forceinline__ double lr_wave_add_shift(double& R, double& T, int& K
 // remove_shift_RJ_weighted_mean (LRF:49-69).  idx = removed shift, 1..K-1.  The reference deletes
 // by VALUE (LRF:56, 63); that equals deletion by index unless two rates / times are bit-identical.
 __device__ __forceinline__ double lr_wave_remove_shift(double& R, double& T, int& K, int idx, int lane) {
-    const double t_prime = __shfl(T, idx, LR_WAVE);
-    const double t_i1 = __shfl(T, idx - 1, LR_WAVE);
-    const double t_i2 = __shfl(T, idx + 1, LR_WAVE);
-    const double r1 = __shfl(R, idx - 1, LR_WAVE);
-    const double r2 = __shfl(R, idx, LR_WAVE);
-    const double Tdn = __shfl_down(T, 1, LR_WAVE);
-    const double Rdn = __shfl_down(R, 1, LR_WAVE);
+    const double t_prime = lr_bcast(T, idx);
+    const double t_i1 = lr_bcast(T, idx - 1);
+    const double t_i2 = lr_bcast(T, idx + 1);
+    const double r1 = lr_bcast(R, idx - 1);
+    const double r2 = lr_bcast(R, idx);
+    const double Tdn = lr_dpp_zero<0x130 /* wave_shl:1 */, 0xf, 0xf>(T);
+    const double Rdn = lr_dpp_zero<0x130, 0xf, 0xf>(R);
     const double dT = fabs(t_i2 - t_i1);
     const double p1 = (t_i1 - t_prime) / (t_i1 - t_i2);
     const double p2 = (t_prime - t_i2) / (t_i1 - t_i2);
     const double u = 1. / (1 + r2 / r1);
-    // packed log: lane0 r1, lane1 r2, lane2 dT, lane3 r1+r2, lane4 u
+    // packed log: lane0 r1, lane1 r2, lane2 dT, lane3 r1+r2, lane4 u, lane5 1-u
     double x = 1.0;
     if (lane == 0) x = r1;
     if (lane == 1) x = r2;
     if (lane == 2) x = dT;
     if (lane == 3) x = r1 + r2;
     if (lane == 4) x = u;
+    if (lane == 5) x = 1 - u;
     const double lx = log(x);
     const double l1 = lr_bcast(lx, 0), l2 = lr_bcast(lx, 1), log_dT = lr_bcast(lx, 2), log_sum = lr_bcast(lx, 3);
-    const double log_u = lr_bcast(lx, 4);
+    const double log_u = lr_bcast(lx, 4), log_1mu = lr_bcast(lx, 5);
     const double rate_prime = exp(p1 * l1 + p2 * l2);
     if (lane >= idx) T = Tdn;
     if (lane == idx - 1) R = rate_prime;
     else if (lane >= idx) R = Rdn;
     K -= 1;
     const double a = LR_SHAPE_BETA_RJ;
-    const double log_beta = (a - 1.0) * log1p(-u) + (a - 1.0) * log_u - LR_BETALN_10_10;
+    const double log_beta = (a - 1.0) * log_1mu + (a - 1.0) * log_u - LR_BETALN_10_10;
     const double log_q = -log_dT + log_beta;
     const double jac = log(rate_prime) - (2 * log_sum);
     return log_q + jac;
@@ -147,13 +151,13 @@ __device__ __forceinline__ double lr_wave_poisson_prior(int k, double rate, int 
 // integer bin edge of shift time j relative to the first one: floor (LRF:262 etc.) or round (LRF:129)
 __device__ __forceinline__ int lr_wave_edges(double T, int mode) {
     const double e = mode ? rint(T) : floor(T);
-    const double e0 = __shfl(e, 0, LR_WAVE);
+    const double e0 = lr_bcast(e, 0);
     return (int)(e - e0);
 }
 
 // min_j |T[j+1]-T[j]| over j < K (guard of LRF:290)
 __device__ __forceinline__ double lr_wave_min_segment(double T, int K, int lane) {
-    const double Tn = __shfl_down(T, 1, LR_WAVE);
+    const double Tn = lr_dpp_zero<0x130 /* wave_shl:1 */, 0xf, 0xf>(T);
     return lr_wave_min(lane < K ? fabs(Tn - T) : 1e300);
 }
 
@@ -171,6 +175,15 @@ __device__ __forceinline__ void lr_wave_gamma2(const lr_stream& s, uint64_t it, 
     const double t = 1.0 + c * x;
     const double v = t * t * t;
     const double u = lr_pair(s, it, purpose, 2 * a + 1).a;
+    const double val0 = d * v;
+    // Marsaglia-Tsang squeeze: u < 1 - 0.0331 x^4 implies the log test below.  When attempt 0 of BOTH variates
+    // passes it (~85 % of the calls) the two logarithms are not needed at all.
+    const double x2 = x * x;
+    const unsigned long long sq = __ballot(v > 0.0 && u < 1.0 - 0.0331 * x2 * x2);
+    if ((sq & 1ull) && (sq & (1ull << 32))) {
+        *ga = lr_bcast(val0, 0), *gb = lr_bcast(val0, 32);
+        return;
+    }
     bool ok = false;
     if (v > 0.0) ok = (u <= 0.0) || (log(u) < 0.5 * x * x + d - d * v + d * log(v));
     const unsigned long long m = __ballot(ok);

@@ -143,7 +143,7 @@ __device__ __forceinline__ lr_u2 lr_pair(const lr_stream& s, uint64_t it, uint32
 
 __device__ __forceinline__ double lr_normal(const lr_stream& s, uint64_t it, uint32_t purpose, uint32_t idx) {
     const lr_u2 u = lr_pair(s, it, purpose, idx);
-    return sqrt(-2.0 * log(1.0 - u.a)) * cos(2.0 * 3.141592653589793 * u.b);
+    return sqrt(-2.0 * log(1.0 - u.a)) * cospi(2.0 * u.b);   // cos(2 pi u_b) without the range reduction
 }
 
 // standard Gamma(shape >= 1): attempt a uses idx base+2a (normal) and base+2a+1 (uniform)

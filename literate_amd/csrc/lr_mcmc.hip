@@ -587,45 +587,40 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     S[LR_ROW_PTL * LR_ROW + lane] = ptL, S[LR_ROW_PTM * LR_ROW + lane] = ptM;
     I[LR_IROW_EL * LR_ROW + lane] = eL, I[LR_IROW_EM * LR_ROW + lane] = eM;
     I[LR_IROW_PEL * LR_ROW + lane] = peL, I[LR_IROW_PEM * LR_ROW + lane] = peM;
-    double so;
-    bool wr = true;
-    switch (lane) {
-        case LR_S_LIKA: so = likA; break;
-        case LR_S_PRIORA: so = priorA; break;
-        case LR_S_PRIORPOIA: so = priorPoiA; break;
-        case LR_S_GRATE_L: so = g0; break;
-        case LR_S_GRATE_M: so = g1; break;
-        case LR_S_POI: so = poi; break;
-        case LR_S_HASTING: so = hasting; break;
-        case LR_S_PRIOR_P: so = priorP; break;
-        case LR_S_PRIORPOI_P: so = priorPoi; break;
-        case LR_S_CONST_P: so = constP; break;
-        case LR_S_CONST_A: so = constA; break;
-        case LR_S_LOG_G0: so = lg0; break;
-        case LR_S_LOG_G1: so = lg1; break;
-        case LR_S_LOG_POI: so = lpoi; break;
-        default: so = 0.0, wr = false; break;
+    {
+        // scalar slots: branch-free select chains (a switch over the lane id runs every case under its own exec mask)
+        double so = 0.0;
+        so = (lane == LR_S_LIKA) ? likA : so;
+        so = (lane == LR_S_PRIORA) ? priorA : so;
+        so = (lane == LR_S_PRIORPOIA) ? priorPoiA : so;
+        so = (lane == LR_S_GRATE_L) ? g0 : so;
+        so = (lane == LR_S_GRATE_M) ? g1 : so;
+        so = (lane == LR_S_POI) ? poi : so;
+        so = (lane == LR_S_HASTING) ? hasting : so;
+        so = (lane == LR_S_PRIOR_P) ? priorP : so;
+        so = (lane == LR_S_PRIORPOI_P) ? priorPoi : so;
+        so = (lane == LR_S_CONST_P) ? constP : so;
+        so = (lane == LR_S_CONST_A) ? constA : so;
+        so = (lane == LR_S_LOG_G0) ? lg0 : so;
+        so = (lane == LR_S_LOG_G1) ? lg1 : so;
+        so = (lane == LR_S_LOG_POI) ? lpoi : so;
+        if (lane <= LR_S_LOG_POI && lane != LR_S_LIK_P) S[LR_ROW_SCALARS * LR_ROW + lane] = so;
+        int io = 0;
+        io = (lane == LR_I_KL) ? KL : io;
+        io = (lane == LR_I_KM) ? KM : io;
+        io = (lane == LR_I_PKL) ? PKL : io;
+        io = (lane == LR_I_PKM) ? PKM : io;
+        io = (lane == LR_I_GIBBS) ? gibbs : io;
+        io = (lane == LR_I_INVALID) ? invalid : io;
+        io = (lane == LR_I_IT_LO) ? (int)(uint32_t)it : io;
+        io = (lane == LR_I_IT_HI) ? (int)(uint32_t)(it >> 32) : io;
+        io = (lane == LR_I_ACCEPTED) ? n_acc : io;
+        io = (lane == LR_I_MOVE) ? move_kind : io;
+        io = (lane == LR_I_NEXT_LO) ? (int)(uint32_t)next_sample : io;
+        io = (lane == LR_I_NEXT_HI) ? (int)(uint32_t)(next_sample >> 32) : io;
+        io = (lane == LR_I_SLOT) ? trace_slot : io;
+        if (lane <= LR_I_SLOT) I[LR_IROW_SCALARS * LR_ROW + lane] = io;
     }
-    if (wr) S[LR_ROW_SCALARS * LR_ROW + lane] = so;
-    int io;
-    wr = true;
-    switch (lane) {
-        case LR_I_KL: io = KL; break;
-        case LR_I_KM: io = KM; break;
-        case LR_I_PKL: io = PKL; break;
-        case LR_I_PKM: io = PKM; break;
-        case LR_I_GIBBS: io = gibbs; break;
-        case LR_I_INVALID: io = invalid; break;
-        case LR_I_IT_LO: io = (int)(uint32_t)it; break;
-        case LR_I_IT_HI: io = (int)(uint32_t)(it >> 32); break;
-        case LR_I_ACCEPTED: io = n_acc; break;
-        case LR_I_MOVE: io = move_kind; break;
-        case LR_I_NEXT_LO: io = (int)(uint32_t)next_sample; break;
-        case LR_I_NEXT_HI: io = (int)(uint32_t)(next_sample >> 32); break;
-        case LR_I_SLOT: io = trace_slot; break;
-        default: io = 0, wr = false; break;
-    }
-    if (wr) I[LR_IROW_SCALARS * LR_ROW + lane] = io;
     LR_SSTAMP(7);
 #ifdef LR_DIAG
     if (lane == 0 && c < 4096) lr_diag_step[c * 12 + 8] = move_kind;

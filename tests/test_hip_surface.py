@@ -122,3 +122,33 @@ def test_cli_end_to_end(G, tmp_path):
         sp_rows = [np.array(l.split(), float) for l in open(logdir / ("example_BDk_c%d_sp_rates.log" % c))]
         assert all(np.allclose(a, b, rtol=1e-10) for a, b in zip(sp_rows, ref["sp"]))
     shutil.rmtree(logdir)
+
+
+def test_cli_cfg1_fixed_two_shifts(G, tmp_path):
+    """BASELINE.json configs[0]: example_dataTBP, 1 chain, fixed 2 rate shifts (-const_rates 1 with a
+    3-rate initial state, SURVEY 8c 'config-1 note').  K stays (3, 3), shift times never move (A9), the
+    rows equal the oracle loop started from the same state."""
+    from oracle import mcmc_oracle as mo
+    ts, te = G["example_TBP/ts"], G["example_TBP/te"] - 0.5
+    data = tmp_path / "example.tsv"
+    with open(data, "w") as f:
+        f.write("id\tts\tte\n")
+        for i, (a, b) in enumerate(zip(ts, te)):
+            f.write("%d\t%g\t%g\n" % (i, 24.0 - a, 24.0 - b))
+    cmd = [sys.executable, os.path.join(ROOT, "LiteRateForward.py"), "-d", str(data), "-TBP", "-n", "3000", "-s", "50",
+           "-p", "1000", "-seed", "17", "-const_rates", "1", "--init_shifts", "2", "--chains", "1", "-calc_adequacy", "0"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, timeout=300)
+    logdir = tmp_path / "literate_mcmc_logs"
+    mc = np.loadtxt(logdir / "example_BD_mcmc.log", skiprows=1)          # reference file name for 1 chain
+    assert mc.shape == (60, 13) and np.all(mc[:, 6] == 3) and np.all(mc[:, 7] == 3)
+    sp_rows = [np.array(l.split(), float) for l in open(logdir / "example_BD_sp_rates.log")]
+    t = np.linspace(0.0, 24.5, 4)
+    assert all(np.array_equal(r[3:], t[1:3]) for r in sp_rows)           # shift times fixed
+    rng = np.random.default_rng(17)
+    L0, M0 = rng.gamma(2, 2, 3), rng.gamma(2, 2, 3)
+    stats = dict(sp=G["example_TBP/sp"], ex=G["example_TBP/ex"], br=G["example_TBP/br"])
+    with np.errstate(all="ignore"):
+        ref = mo.run_mcmc(stats, 0.0, 24.5, mo.Settings(model_BDI=0, const_rates=1), mo.PhiloxDraws(17, 0), 3000, 50,
+                          init=(L0, M0, t, t), k_max=32)
+    assert np.allclose(mc, np.array(ref["mcmc"])[:, :13], rtol=1e-9)
+    assert all(np.allclose(a, b, rtol=1e-10) for a, b in zip(sp_rows, ref["sp"]))

@@ -1050,7 +1050,9 @@ static int lr_run_units(lr_engine* e, const lr_step_args& a, lr_part& q, int64_t
 
 static int lr_run_part(lr_engine* e, const lr_step_args& a, lr_part& q, int64_t n_iters, hipStream_t stream) {
     if (!q.pipelined) return lr_run_units(e, a, q, n_iters, stream);
-    int rc = lr_enqueue_scan_range(e, q.base, q.hA, stream);                                   // scan A
+    // prologue: scan A alone (the fused kernel with no step blocks, so that the stand-alone scan kernel is
+    // launched only at full size - by lr_mcmc_init and the lr_mcmc_time_scan measurement hook)
+    int rc = lr_enqueue_fused(e, a, q.base, q.hA, q.base, 0, stream);                          // scan A
     if (rc) return rc;
     rc = lr_run_units(e, a, q, n_iters - 1, stream);
     if (rc) return rc;

@@ -372,27 +372,58 @@ static __device__ unsigned long long lr_diag_step[4096 * 12];
 
 // mode: 0 = regular step (accept pending proposal, then propose), 1 = finish init (adopt the
 // evaluated initial state as accepted, then propose iteration 0)
-__device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mode, int c, int lane,
-                                                   lr_seg_scratch* scratch_p) {
+// chain state as it lives in the registers of the chain's wave (lane j holds element j of every row)
+struct lr_chain_regs {
+    double L, M, tL, tM;        // accepted rates / shift times
+    double pL, pM, ptL, ptM;    // pending proposal
+    double sc;                  // LR_ROW_SCALARS (lane s holds scalar s)
+    int eL, eM, peL, peM;       // integer bin edges, accepted / proposed
+    int isc;                    // LR_IROW_SCALARS
+};
+
+__device__ __forceinline__ void lr_chain_load(lr_chain_regs& r, const lr_step_args& a, int c, int lane) {
+    const double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
+    const int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+    r.L = S[LR_ROW_L * LR_ROW + lane], r.M = S[LR_ROW_M * LR_ROW + lane];
+    r.tL = S[LR_ROW_TL * LR_ROW + lane], r.tM = S[LR_ROW_TM * LR_ROW + lane];
+    r.pL = S[LR_ROW_PL * LR_ROW + lane], r.pM = S[LR_ROW_PM * LR_ROW + lane];
+    r.ptL = S[LR_ROW_PTL * LR_ROW + lane], r.ptM = S[LR_ROW_PTM * LR_ROW + lane];
+    r.sc = S[LR_ROW_SCALARS * LR_ROW + lane];
+    r.eL = I[LR_IROW_EL * LR_ROW + lane], r.eM = I[LR_IROW_EM * LR_ROW + lane];
+    r.peL = I[LR_IROW_PEL * LR_ROW + lane], r.peM = I[LR_IROW_PEM * LR_ROW + lane];
+    r.isc = I[LR_IROW_SCALARS * LR_ROW + lane];
+}
+
+__device__ __forceinline__ void lr_chain_store(const lr_chain_regs& r, const lr_step_args& a, int c, int lane) {
+    double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
+    int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+    S[LR_ROW_L * LR_ROW + lane] = r.L, S[LR_ROW_M * LR_ROW + lane] = r.M;
+    S[LR_ROW_TL * LR_ROW + lane] = r.tL, S[LR_ROW_TM * LR_ROW + lane] = r.tM;
+    S[LR_ROW_PL * LR_ROW + lane] = r.pL, S[LR_ROW_PM * LR_ROW + lane] = r.pM;
+    S[LR_ROW_PTL * LR_ROW + lane] = r.ptL, S[LR_ROW_PTM * LR_ROW + lane] = r.ptM;
+    S[LR_ROW_SCALARS * LR_ROW + lane] = r.sc;
+    I[LR_IROW_EL * LR_ROW + lane] = r.eL, I[LR_IROW_EM * LR_ROW + lane] = r.eM;
+    I[LR_IROW_PEL * LR_ROW + lane] = r.peL, I[LR_IROW_PEM * LR_ROW + lane] = r.peM;
+    I[LR_IROW_SCALARS * LR_ROW + lane] = r.isc;
+}
+
+// One chain step on register-resident state: accept the pending proposal given its log-likelihood sum
+// (lik_sum, without the model constant), write the trace row, draw the next proposal and build its lookup
+// tables at `table` (global memory or LDS; see lr_chain_table for the addressing).
+// mode: 0 = regular step, 1 = finish init (adopt the evaluated initial state, then propose iteration 0)
+__device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
+                                                   lr_seg_scratch* scratch_p, double lik_sum, double2* table) {
     lr_seg_scratch& scratch = *scratch_p;
     const lr_mcmc_config& cfg = a.cfg;
     const int C = cfg.n_chains, n_bins = cfg.n_bins;
-    double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
-    int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
     const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
-    LR_SSTAMP(0);
-
-    // ---- load state: lane j holds element j; tile partials in flight at the same time ----
-    double L = S[LR_ROW_L * LR_ROW + lane], M = S[LR_ROW_M * LR_ROW + lane];
-    double tL = S[LR_ROW_TL * LR_ROW + lane], tM = S[LR_ROW_TM * LR_ROW + lane];
-    const double pL0 = S[LR_ROW_PL * LR_ROW + lane], pM0 = S[LR_ROW_PM * LR_ROW + lane];
-    const double ptL0 = S[LR_ROW_PTL * LR_ROW + lane], ptM0 = S[LR_ROW_PTM * LR_ROW + lane];
-    const double sc = S[LR_ROW_SCALARS * LR_ROW + lane];
-    int eL = I[LR_IROW_EL * LR_ROW + lane], eM = I[LR_IROW_EM * LR_ROW + lane];
-    const int peL0 = I[LR_IROW_PEL * LR_ROW + lane], peM0 = I[LR_IROW_PEM * LR_ROW + lane];
-    const int isc = I[LR_IROW_SCALARS * LR_ROW + lane];
-    double part = 0.0;
-    for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * C + c];
+    double L = st.L, M = st.M, tL = st.tL, tM = st.tM;
+    const double pL0 = st.pL, pM0 = st.pM, ptL0 = st.ptL, ptM0 = st.ptM;
+    const double sc = st.sc;
+    int eL = st.eL, eM = st.eM;
+    const int peL0 = st.peL, peM0 = st.peM;
+    const int isc = st.isc;
+    double lik_p = lr_bcast(sc, LR_S_LIK_P);
 
     double likA = lr_bcast(sc, LR_S_LIKA), priorA = lr_bcast(sc, LR_S_PRIORA);
     double priorPoiA = lr_bcast(sc, LR_S_PRIORPOIA);
@@ -404,8 +435,6 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     int n_acc = lr_bcast_i(isc, LR_I_ACCEPTED);
     uint64_t next_sample = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_HI) << 32);
     int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
-    // log-likelihood of the pending proposal: tile partials summed in tile order
-    const double lik_sum = lr_wave_sum(part);
     LR_SSTAMP(1);
 
     if (mode == 1) {
@@ -423,7 +452,7 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
         const double lik = gibbs ? likA : lik_sum + constP;
         const double u = lr_pair(rng, it, LR_P_ACCEPT, 0).a;
         const bool ok = gibbs || (!invalid && (lik - likA + priorP - priorA + hasting >= log(u)));
-        if (lane == LR_S_LIK_P) S[LR_ROW_SCALARS * LR_ROW + lane] = invalid ? -INFINITY : lik;
+        lik_p = invalid ? -INFINITY : lik;
         if (ok) {
             L = pL0, M = pM0, tL = ptL0, tM = ptM0, eL = peL0, eM = peM0;
             KL = lr_bcast_i(isc, LR_I_PKL), KM = lr_bcast_i(isc, LR_I_PKM);
@@ -576,17 +605,14 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     LR_SSTAMP(5);
     // ---- lookup tables of the proposal ----
     const double constP = lr_build_tables_segments(&scratch, peL, peM, PKL, PKM, a.br_length, a.log_br, cfg.model,
-                                                   n_bins, a.n_cls, a.H, lr_chain_table(a, c), lane,
+                                                   n_bins, a.n_cls, a.H, table, lane,
                                                    a.unit != 0, cfg.frac_birth, cfg.frac_death);
 
     LR_SSTAMP(6);
-    // ---- store ----
-    S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
-    S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
-    S[LR_ROW_PL * LR_ROW + lane] = pL, S[LR_ROW_PM * LR_ROW + lane] = pM;
-    S[LR_ROW_PTL * LR_ROW + lane] = ptL, S[LR_ROW_PTM * LR_ROW + lane] = ptM;
-    I[LR_IROW_EL * LR_ROW + lane] = eL, I[LR_IROW_EM * LR_ROW + lane] = eM;
-    I[LR_IROW_PEL * LR_ROW + lane] = peL, I[LR_IROW_PEM * LR_ROW + lane] = peM;
+    // ---- back into the state registers ----
+    st.L = L, st.M = M, st.tL = tL, st.tM = tM;
+    st.pL = pL, st.pM = pM, st.ptL = ptL, st.ptM = ptM;
+    st.eL = eL, st.eM = eM, st.peL = peL, st.peM = peM;
     {
         // scalar slots: branch-free select chains (a switch over the lane id runs every case under its own exec mask)
         double so = 0.0;
@@ -601,10 +627,11 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
         so = (lane == LR_S_PRIORPOI_P) ? priorPoi : so;
         so = (lane == LR_S_CONST_P) ? constP : so;
         so = (lane == LR_S_CONST_A) ? constA : so;
+        so = (lane == LR_S_LIK_P) ? lik_p : so;
         so = (lane == LR_S_LOG_G0) ? lg0 : so;
         so = (lane == LR_S_LOG_G1) ? lg1 : so;
         so = (lane == LR_S_LOG_POI) ? lpoi : so;
-        if (lane <= LR_S_LOG_POI && lane != LR_S_LIK_P) S[LR_ROW_SCALARS * LR_ROW + lane] = so;
+        st.sc = so;
         int io = 0;
         io = (lane == LR_I_KL) ? KL : io;
         io = (lane == LR_I_KM) ? KM : io;
@@ -619,12 +646,25 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
         io = (lane == LR_I_NEXT_LO) ? (int)(uint32_t)next_sample : io;
         io = (lane == LR_I_NEXT_HI) ? (int)(uint32_t)(next_sample >> 32) : io;
         io = (lane == LR_I_SLOT) ? trace_slot : io;
-        if (lane <= LR_I_SLOT) I[LR_IROW_SCALARS * LR_ROW + lane] = io;
+        st.isc = io;
     }
     LR_SSTAMP(7);
 #ifdef LR_DIAG
     if (lane == 0 && c < 4096) lr_diag_step[c * 12 + 8] = move_kind;
 #endif
+}
+
+// the step of chain c with its state in global memory: load, sum the tile partials in tile order, step, store
+__device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mode, int c, int lane,
+                                                   lr_seg_scratch* scratch_p) {
+    LR_SSTAMP(0);
+    lr_chain_regs st;
+    lr_chain_load(st, a, c, lane);
+    double part = 0.0;
+    for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * a.cfg.n_chains + c];
+    const double lik_sum = lr_wave_sum(part);
+    lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c));
+    lr_chain_store(st, a, c, lane);
 }
 
 #define LR_STEP_WAVES (LR_SCAN_THREADS / LR_WAVE)

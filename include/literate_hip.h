@@ -139,7 +139,7 @@ typedef struct lr_mcmc_config {
      * dataset the reference ships: 0 and 0.5).  The fractions are then folded into the lookup
      * tables (8-byte entries, half the LDS traffic per lineage).  0 = general times.            */
     int32_t unit_resolution;
-    int32_t reserved0;
+    int32_t engine_mode;      /* 0 = auto, 1 = launch-per-iteration engine (fused, pipelined), 2 = persistent kernel */
     double frac_birth;
     double frac_death;
 } lr_mcmc_config;
@@ -149,6 +149,7 @@ typedef struct lr_mcmc_layout {
     int64_t state_f64;    /* [C, LR_STATE_ROWS, LR_ROW] doubles  (rows: see LR_ROW_* below)  */
     int64_t state_i32;    /* [C, LR_ISTATE_ROWS, LR_ROW] int32                                */
     int64_t bin_consts;   /* [n_bins] doubles: log(br_length) (models 0/1)                    */
+    int64_t lineage_idx;  /* [n padded to 8] uint16: packed table indices (birth | death << 8) of the lineages */
     int64_t tables;       /* [C, table_stride] double2                                        */
     int64_t partials;     /* [tiles, C] doubles                                               */
     int64_t trace;        /* [n_trace_slots, C, LR_TRACE_W] doubles                           */
@@ -159,6 +160,8 @@ typedef struct lr_mcmc_layout {
     int32_t trace_width;
     int32_t n_parts;      /* independent chain partitions, each on its own stream                  */
     int32_t pipelined;    /* 1: each partition runs the fused scan|step schedule over two halves   */
+    int32_t persistent;   /* 1: lr_mcmc_steps uses the persistent two-chains-per-block kernel       */
+    int32_t reserved1;
 } lr_mcmc_layout;
 
 /* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */

@@ -27,14 +27,14 @@ class McmcConfig(C.Structure):
                 ("const_rates", c_i32), ("const_death_rate", c_i32), ("use_rate_HP", c_i32), ("s_freq", c_i32),
                 ("n_trace_slots", c_i32), ("poisson_HP", c_f64), ("update_fraction", c_f64), ("t0", c_f64),
                 ("start_time", c_f64), ("end_time", c_f64), ("seed", C.c_uint64), ("chain_offset", c_i64),
-                ("unit_resolution", c_i32), ("reserved0", c_i32), ("frac_birth", c_f64), ("frac_death", c_f64)]
+                ("unit_resolution", c_i32), ("engine_mode", c_i32), ("frac_birth", c_f64), ("frac_death", c_f64)]
 
 
 class McmcLayout(C.Structure):
-    _fields_ = [("state_f64", c_i64), ("state_i32", c_i64), ("bin_consts", c_i64), ("tables", c_i64),
+    _fields_ = [("state_f64", c_i64), ("state_i32", c_i64), ("bin_consts", c_i64), ("lineage_idx", c_i64), ("tables", c_i64),
                 ("partials", c_i64), ("trace", c_i64), ("total_bytes", c_i64), ("table_stride", c_i32),
                 ("tiles", c_i32), ("chains_per_block", c_i32), ("trace_width", c_i32), ("n_parts", c_i32),
-                ("pipelined", c_i32)]
+                ("pipelined", c_i32), ("persistent", c_i32), ("reserved1", c_i32)]
 
 
 # name -> (restype, argtypes); exactly the symbols include/literate_hip.h declares (+ the RNG debug hook)

@@ -129,6 +129,8 @@ struct lr_engine {
     bool initialised;
     int n_parts;
     lr_part part[LR_MAX_PARTS];
+    bool persistent;          // use lr_persist_kernel in lr_mcmc_steps
+    long long n8;             // 16-byte groups of packed lineage indices
     hipEvent_t fork;
 };
 
@@ -381,9 +383,7 @@ struct lr_chain_regs {
     int isc;                    // LR_IROW_SCALARS
 };
 
-__device__ __forceinline__ void lr_chain_load(lr_chain_regs& r, const lr_step_args& a, int c, int lane) {
-    const double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
-    const int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+__device__ __forceinline__ void lr_chain_load(lr_chain_regs& r, const double* S, const int* I, int lane) {
     r.L = S[LR_ROW_L * LR_ROW + lane], r.M = S[LR_ROW_M * LR_ROW + lane];
     r.tL = S[LR_ROW_TL * LR_ROW + lane], r.tM = S[LR_ROW_TM * LR_ROW + lane];
     r.pL = S[LR_ROW_PL * LR_ROW + lane], r.pM = S[LR_ROW_PM * LR_ROW + lane];
@@ -394,9 +394,7 @@ __device__ __forceinline__ void lr_chain_load(lr_chain_regs& r, const lr_step_ar
     r.isc = I[LR_IROW_SCALARS * LR_ROW + lane];
 }
 
-__device__ __forceinline__ void lr_chain_store(const lr_chain_regs& r, const lr_step_args& a, int c, int lane) {
-    double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
-    int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+__device__ __forceinline__ void lr_chain_store(const lr_chain_regs& r, double* S, int* I, int lane) {
     S[LR_ROW_L * LR_ROW + lane] = r.L, S[LR_ROW_M * LR_ROW + lane] = r.M;
     S[LR_ROW_TL * LR_ROW + lane] = r.tL, S[LR_ROW_TM * LR_ROW + lane] = r.tM;
     S[LR_ROW_PL * LR_ROW + lane] = r.pL, S[LR_ROW_PM * LR_ROW + lane] = r.pM;
@@ -659,12 +657,14 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
                                                    lr_seg_scratch* scratch_p) {
     LR_SSTAMP(0);
     lr_chain_regs st;
-    lr_chain_load(st, a, c, lane);
+    double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
+    int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+    lr_chain_load(st, S, I, lane);
     double part = 0.0;
     for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * a.cfg.n_chains + c];
     const double lik_sum = lr_wave_sum(part);
     lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c));
-    lr_chain_store(st, a, c, lane);
+    lr_chain_store(st, S, I, lane);
 }
 
 #define LR_STEP_WAVES (LR_SCAN_THREADS / LR_WAVE)
@@ -718,6 +718,147 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
     else
         lr_scan_fast_body<CB, H>(lds, tile, group * CB, f.ts, f.te, f.n, f.t0, f.n_bins, tables, f.scan_n, f.chunk,
                                  partials, a.cfg.n_chains);
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent engine for unit-resolution data and many chains (>= one pair of chains per block slot).
+//
+// One 512-thread block owns TWO chains for the whole call and iterates inside the kernel: all 8 waves
+// scan every lineage against the pair's lookup table in LDS, the sums are reduced in the block, then waves
+// 0 and 1 run the chain step of "their" chain on register-resident state and rebuild the table in LDS while
+// the others wait at the barrier.  No launch per iteration, no inter-block communication at all (a block
+// never needs another block's data), state and tables touch global memory only at entry and exit.
+// The lineages are read as one packed uint16 per lineage (table indices of its birth and death bins,
+// lr_pack_lineages_kernel), 8 lineages per 16-byte load: 200 KB per pass for 100k lineages, L2 resident.
+// ------------------------------------------------------------------------------------------
+#define LR_PERSIST_THREADS 512
+
+__global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n,
+                                        long long n_pad, double t0, int n_bins, unsigned short* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    unsigned short v = 0;  // padding: entries (0, 0) = "outside the window" on both sides, contributes 0
+    if (i < n) {
+        const int a = min(max(__double2int_rz(floor(ts[i]) - t0), -1), n_bins);
+        const int b = min(max(__double2int_rz(ceil(te[i]) - t0), 0), n_bins + 1);
+        v = (unsigned short)((a + 1) | (b << 8));
+    }
+    out[i] = v;
+}
+
+// the chain step of the persistent kernel as a real call: its ~120 live registers then do not add to the scan
+// loop's, and both fit the 128-VGPR budget of 4 waves per SIMD without spilling
+__device__ __attribute__((noinline)) void lr_persist_step(const lr_step_args* a, int c, int lane,
+                                                          lr_seg_scratch* scratch, double* st_f64, int* st_i32,
+                                                          double lik, double2* table) {
+    lr_chain_regs st;
+    lr_chain_load(st, st_f64, st_i32, lane);
+    lr_chain_step_core(st, *a, 0, c, lane, scratch, lik, table);
+    lr_chain_store(st, st_f64, st_i32, lane);
+}
+
+template <int H>
+__global__ __launch_bounds__(LR_PERSIST_THREADS, 4) void lr_persist_kernel(lr_step_args a,
+                                                                        const uint4* __restrict__ idx8, long long n8,
+                                                                        long long n_iters, int prio_shift) {
+    __shared__ double2 tab[2 * H];  // the pair table: S' entries [0,H), E' entries [H,2H); (.x, .y) = (chain 0, chain 1)
+    __shared__ double red[LR_PERSIST_THREADS / LR_WAVE][2];
+    __shared__ lr_seg_scratch scratch[2];
+    // the two chains' state rows live in LDS between iterations (registers are needed by the step itself)
+    __shared__ double st_f64[2][LR_STATE_ROWS * LR_ROW];
+    __shared__ int st_i32[2][LR_ISTATE_ROWS * LR_ROW];
+    const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    const int c0 = blockIdx.x * 2;
+    const int c = c0 + wave;
+    const bool stepper = (wave < 2) && (c < a.cfg.n_chains);
+    double2* gpair = lr_chain_table(a, c0);  // the pair (c0, c0+1) shares one table in the unit layout
+    if (stepper) {
+        const double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
+        const int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+        for (int r = 0; r < LR_STATE_ROWS; ++r) st_f64[wave][r * LR_ROW + lane] = S[r * LR_ROW + lane];
+        for (int r = 0; r < LR_ISTATE_ROWS; ++r) st_i32[wave][r * LR_ROW + lane] = I[r * LR_ROW + lane];
+    }
+    for (int i = tid; i < 2 * H; i += LR_PERSIST_THREADS) tab[i] = gpair[i];
+    __syncthreads();
+    const char* lbase = reinterpret_cast<const char*>(tab);
+    const int grp = (blockIdx.x >> 8) & 1;
+    for (long long iter = 0; iter < n_iters; ++iter) {
+        // Two blocks share a CU; the one dispatched second is the younger wave on every SIMD and loses issue
+        // arbitration to its older neighbour all the time (+30 % per iteration, measured).  Both read the same
+        // 100 MHz clock, so slicing it gives them complementary priorities that even the two out
+        // (MI355X_MICROARCH.md "Two waves per SIMD" item 4; block id >= 256 = second dispatch: speed only).
+        if (prio_shift > 0) {
+            if (((wall_clock64() >> prio_shift) + grp) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#ifdef LR_DIAG
+        d_t0 = wall_clock64();
+#endif
+        double acc0 = 0.0, acc1 = 0.0;
+        {
+            // 8 lineages per 16-byte load, the next load in flight while the current one is scored
+            long long i = tid;
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (i < n8) w = idx8[i];
+            while (i < n8) {
+                const uint4 cur = w;
+                const long long nx = i + LR_PERSIST_THREADS;
+                if (nx < n8) w = idx8[nx];
+                const unsigned int words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned int v = words[k];
+                    const double2 S0 = *reinterpret_cast<const double2*>(lbase + ((v << 4) & 0xff0u));
+                    const double2 E0 = *reinterpret_cast<const double2*>(lbase + ((v >> 4) & 0xff0u) + H * 16);
+                    const double2 S1 = *reinterpret_cast<const double2*>(lbase + ((v >> 12) & 0xff0u));
+                    const double2 E1 = *reinterpret_cast<const double2*>(lbase + ((v >> 20) & 0xff0u) + H * 16);
+                    acc0 += S0.x + E0.x;
+                    acc1 += S0.y + E0.y;
+                    acc0 += S1.x + E1.x;
+                    acc1 += S1.y + E1.y;
+                }
+                i = nx;
+            }
+        }
+#ifdef LR_DIAG
+        d_t1 = wall_clock64();
+#endif
+        const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
+        if (lane == 0) red[wave][0] = s0, red[wave][1] = s1;
+        __syncthreads();  // every scan is done: sums visible, table free to be rebuilt
+#ifdef LR_DIAG
+        d_t2 = wall_clock64();
+#endif
+        if (stepper) {
+            double lik = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < LR_PERSIST_THREADS / LR_WAVE; ++w2) lik += red[w2][wave];
+            lr_persist_step(&a, c, lane, &scratch[wave], st_f64[wave], st_i32[wave], lik,
+                            reinterpret_cast<double2*>(reinterpret_cast<double*>(tab) + wave));
+        }
+        __syncthreads();  // new tables ready
+#ifdef LR_DIAG
+        d_scan += d_t1 - d_t0, d_red += d_t2 - d_t1, d_step += wall_clock64() - d_t2;
+#endif
+    }
+#ifdef LR_DIAG
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long* o = lr_diag_step + 4096 * 12 - 4096 + (blockIdx.x * 8 + wave) % 4096;
+        (void)o;
+    }
+    if (tid == 0 && blockIdx.x < 340) {
+        lr_diag_step[blockIdx.x * 12 + 9] = d_scan, lr_diag_step[blockIdx.x * 12 + 10] = d_red;
+        lr_diag_step[blockIdx.x * 12 + 11] = d_step;
+    }
+    if (tid == 0 && blockIdx.x < 1024) lr_diag_step[2048 * 12 + blockIdx.x * 2 + 1] = wall_clock64();
+#endif
+    if (stepper) {
+        double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
+        int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+        for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = st_f64[wave][r * LR_ROW + lane];
+        for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = st_i32[wave][r * LR_ROW + lane];
+    }
+    for (int i = tid; i < 2 * H; i += LR_PERSIST_THREADS) gpair[i] = tab[i];  // pending tables back to global
 }
 
 // log(br_length) once per engine (data constant used by models 0/1)
@@ -838,6 +979,25 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     return LR_OK;
 }
 
+// Persistent engine (lr_persist_kernel): needs unit-resolution tables with byte-sized indices and an
+// instantiated table size.  cfg->engine_mode 1 / 2 force the launch-based / persistent engine (2 still needs the
+// prerequisites); auto picks the persistent kernel unless the chains are too few for the lineage count: a block
+// scans ALL lineages for its two chains, so with few chains and very long inputs the tiled launch-based scan,
+// which spreads one chain group over many CUs, is faster.
+static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
+    static const int env = lr_env_int("LR_PERSIST", -1);   // debugging override: 0 off, 1 on
+    if (env == 0 || cfg->engine_mode == 1) return false;
+    if (!p.unit || cfg->n_bins + 1 > 255 || p.cb < 2) return false;
+    if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264) return false;
+    if (env == 1 || cfg->engine_mode == 2) return true;
+    const double n = (double)cfg->n_lineages, c = (double)cfg->n_chains;
+    const int blocks = (cfg->n_chains + 1) / 2;
+    const double rounds = (double)((blocks + 511) / 512);
+    const double t_persist = rounds * (n * 2.0 * (blocks > 256 ? 2.0 : 1.0) / 2.2e10) + 6e-6;
+    const double t_launch = n * c / 5e12 + 14e-6;
+    return t_persist <= t_launch;
+}
+
 static int lr_check_cfg(const lr_mcmc_config* cfg) {
     if (!cfg) return LR_ERR_NULL;
     if (cfg->n_lineages < 1 || cfg->n_chains < 1 || cfg->s_freq < 1 || cfg->n_trace_slots < 0) return LR_ERR_SIZE;
@@ -860,6 +1020,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->state_f64 = o, o += lr_align_up64(C * LR_STATE_ROWS * LR_ROW * 8, 256);
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
     out->bin_consts = o, o += lr_align_up64((long long)cfg->n_bins * 8, 256);
+    out->lineage_idx = o, o += lr_align_up64(lr_align_up64(cfg->n_lineages, 8) * 2, 256);
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
     out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
@@ -874,6 +1035,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
         out->n_parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined);
         out->pipelined = pipelined[0] ? 1 : 0;
     }
+    out->persistent = lr_persist_eligible(cfg, p) ? 1 : 0;
     return LR_OK;
 }
 
@@ -896,6 +1058,8 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
     e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, lr_fused_supported(e->plan), base, hA, pipelined);
+    e->persistent = lr_persist_eligible(cfg, e->plan);
+    e->n8 = lr_align_up64(cfg->n_lineages, 8) / 8;
     e->fork = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
         lr_part& q = e->part[p];
@@ -962,6 +1126,12 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
     const lr_step_args a = lr_make_args(e);
     hipLaunchKernelGGL(lr_log_br_kernel, dim3((e->cfg.n_bins + 127) / 128), dim3(128), 0, stream, e->br_length,
                        e->cfg.n_bins, (double*)(e->ws + e->lay.bin_consts));
+    if (e->persistent) {
+        const long long n_pad = e->n8 * 8;
+        hipLaunchKernelGGL(lr_pack_lineages_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, stream, e->ts,
+                           e->te, (long long)e->cfg.n_lineages, n_pad, e->cfg.t0, e->cfg.n_bins,
+                           (unsigned short*)(e->ws + e->lay.lineage_idx));
+    }
     hipLaunchKernelGGL(lr_chain_init_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, L, M, tL, tM, KL, KM,
                        kmax);
     int rc = (int)hipGetLastError();
@@ -1108,6 +1278,24 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
     if (n_iters == 0) return LR_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const lr_step_args a = lr_make_args(e);
+    if (e->persistent) {
+        const uint4* idx8 = (const uint4*)(e->ws + e->lay.lineage_idx);
+        const int blocks = (e->cfg.n_chains + 1) / 2;
+        static const int prio = lr_env_int("LR_PERSIST_PRIO", 12);   // clock bits per priority slice, 0 = off
+        for (int64_t done = 0; done < n_iters;) {
+            const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
+            switch (e->plan.H) {
+                case 40: hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, a, idx8, e->n8, (long long)n, prio); break;
+                case 72: hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, a, idx8, e->n8, (long long)n, prio); break;
+                case 136: hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, a, idx8, e->n8, (long long)n, prio); break;
+                default: hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, a, idx8, e->n8, (long long)n, prio); break;
+            }
+            const int rc = (int)hipGetLastError();
+            if (rc) return rc;
+            done += n;
+        }
+        return LR_OK;
+    }
     if (e->n_parts == 1) return lr_run_part(e, a, e->part[0], n_iters, stream);
     // fork: every partition's stream waits for the caller's stream, runs its own sequence, and is joined back
     hipError_t he = hipEventRecord(e->fork, stream);

@@ -13,7 +13,7 @@ from . import _hip, ops
 class ChainEngine:
     def __init__(self, ts, te, n_chains, model=0, seed=1, const_rates=0, const_death_rate=0, use_rate_HP=1,
                  poisson_HP=0.0, update_fraction=0.75, s_freq=1000, n_trace_slots=0, chain_offset=0,
-                 device=None, stats=None, sort_lineages=True, unit_resolution=None):
+                 device=None, stats=None, sort_lineages=True, unit_resolution=None, engine="auto"):
         """ts/te: lineage birth/death times (death_jitter already added, LRF:471).
 
         stats: optional (t0, n_bins, br_length) if the caller already binned the data; otherwise the
@@ -60,6 +60,7 @@ class ChainEngine:
             s_freq=int(s_freq), n_trace_slots=int(n_trace_slots), poisson_HP=float(poisson_HP),
             update_fraction=float(update_fraction), t0=self.t0, start_time=self.start_time, end_time=self.end_time,
             seed=int(seed), chain_offset=int(chain_offset), unit_resolution=int(self.unit_resolution),
+            engine_mode={"auto": 0, "launch": 1, "persistent": 2}[engine],
             frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0)
         self.layout = _hip.McmcLayout()
         _hip.check(self.lib.lr_mcmc_query_layout(C.byref(self.cfg), C.byref(self.layout)), "lr_mcmc_query_layout")

@@ -30,14 +30,16 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
 @pytest.mark.parametrize("model,kw", [(0, {}), (2, {}), (1, {}), (3, {}),
                                        (0, dict(const_rates=1)), (0, dict(const_death_rate=1)),
                                        (2, dict(use_rate_HP=0, Poisson_HP=2.5)),
-                                       (0, dict(unit_resolution=False)), (1, dict(unit_resolution=False))])
+                                       (0, dict(unit_resolution=False)), (1, dict(unit_resolution=False)),
+                                       (0, dict(engine="launch")), (2, dict(engine="launch")),
+                                       (1, dict(engine="persistent"))])
 def test_engine_follows_oracle_trajectory(G, model, kw):
     from literate_amd.engine import ChainEngine, split_trace_row
     name, seed, n_it, C, off = "example_TBP", 2024, 1500, 6, 40
     kw = dict(kw)
     ekw = dict(const_rates=kw.get("const_rates", 0), const_death_rate=kw.get("const_death_rate", 0),
                use_rate_HP=kw.get("use_rate_HP", 1), poisson_HP=kw.get("Poisson_HP", 0.0),
-               unit_resolution=kw.pop("unit_resolution", None))
+               unit_resolution=kw.pop("unit_resolution", None), engine=kw.pop("engine", "auto"))
     eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=model, seed=seed, s_freq=1,
                       n_trace_slots=n_it, chain_offset=off, **ekw)
     # binning done by the engine's own kernel must equal the reference's
@@ -65,6 +67,14 @@ def test_engine_follows_oracle_trajectory(G, model, kw):
 
 @pytest.mark.parametrize("unit", [True, False])
 def test_pipelined_partitioned_engine_follows_oracle(G, unit):
+    _pipelined_case(G, unit, "launch")
+
+
+def test_persistent_engine_follows_oracle(G):
+    _pipelined_case(G, True, "auto")
+
+
+def _pipelined_case(G, unit, engine):
     """64 chains: two stream partitions, each software-pipelined in two halves (fused scan|step launches,
     hipGraph replays).  Chains from every half of every partition are compared with the oracle loop, and the
     engine layout is checked to really be the pipelined one.  unit=True: unit-resolution tables (8-byte
@@ -72,9 +82,10 @@ def test_pipelined_partitioned_engine_follows_oracle(G, unit):
     from literate_amd.engine import ChainEngine, split_trace_row
     name, seed, n_it, C = "metal_bands", 404, 400, 64
     eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=2, seed=seed, s_freq=1, n_trace_slots=n_it,
-                      unit_resolution=unit)
+                      unit_resolution=unit, engine=engine)
     assert eng.unit_resolution == unit and eng.layout.chains_per_block == (16 if unit else 8)
     assert eng.layout.n_parts == 2 and eng.layout.pipelined == 1
+    assert eng.layout.persistent == (0 if engine == "launch" else 1)
     eng.init()
     eng.steps(150); eng.steps(1); eng.steps(249)        # graph replays + prologue/epilogue launches, three calls
     tr = eng.trace_rows()
@@ -256,8 +267,11 @@ def test_cfg5_ddrate_50k_lineages_256_states():
     assert n_checked > C // 2
 
 
-@pytest.mark.parametrize("n_bins,unit", [(60, None), (134, None), (135, None), (200, False), (300, None)])
-def test_engine_shapes_bins(n_bins, unit):
+@pytest.mark.parametrize("n_bins,unit,engine", [(60, None, "auto"), (60, None, "launch"), (134, None, "auto"),
+                                                (134, None, "launch"), (135, None, "auto"), (135, None, "launch"),
+                                                (200, False, "auto"), (253, None, "auto"), (254, None, "auto"),
+                                                (300, None, "auto")])
+def test_engine_shapes_bins(n_bins, unit, engine):
     """Table half-stride classes (H = 72, 136, 264) and the generic kernel beyond them (n_bins = 300),
     unit-resolution and general tables: a few chains against the oracle loop on synthetic data."""
     import torch
@@ -270,7 +284,7 @@ def test_engine_shapes_bins(n_bins, unit):
     ts, te, _ = synth.make_lineages(4000, n_bins=n_bins, n_shifts=5, seed=n_bins)
     ts = np.concatenate([[0.0], ts]); te = np.concatenate([[float(n_bins) + 0.5], te])   # pin the window to n_bins
     n_it, seed, C = 120, 7, 37
-    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, unit_resolution=unit)
+    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, unit_resolution=unit, engine=engine)
     assert eng.n_bins == n_bins
     eng.init(); eng.steps(n_it)
     tr = eng.trace_rows()
@@ -285,7 +299,8 @@ def test_engine_shapes_bins(n_bins, unit):
     eng.close()
 
 
-def test_engine_chain_count_shapes(G):
+@pytest.mark.parametrize("engine", ["launch", "auto"])
+def test_engine_chain_count_shapes(G, engine):
     """Any number of chains: single partition / two partitions, pipelined or not, ragged last block.  The same
     global chains must walk the same path in every engine shape (sums differ only by their tile partition)."""
     from literate_amd.engine import ChainEngine
@@ -295,7 +310,8 @@ def test_engine_chain_count_shapes(G):
     first = ref.trace_rows()[:, 0]
     ref.close()
     for C in (1, 2, 5, 16, 17, 31, 32, 33, 47, 100, 129):
-        eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=2, seed=3, s_freq=1, n_trace_slots=n_it)
+        eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=2, seed=3, s_freq=1, n_trace_slots=n_it,
+                          engine=engine)
         eng.init(); eng.steps(25); eng.steps(n_it - 25)
         tr = eng.trace_rows()
         assert np.allclose(tr[:, 0], first, rtol=1e-10, atol=1e-9, equal_nan=True), C

@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one RJMCMC iteration of every chain on this GPU: one scan of the lineage arrays
-scoring all pending proposals + the per-chain accept / trace / next-proposal step (fused and software
-pipelined over two halves of the chains: lr_fused_iter_kernel).  Workload (config.workload) = BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages,
+scoring all pending proposals + the per-chain accept / trace / next-proposal step.  For this workload the
+engine is the persistent kernel lr_persist_kernel: one launch runs all K iterations, a block owns two chains.  Workload (config.workload) = BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages,
 128 unit bins, 20 true shifts per process, 1024 chains per GPU; chains shard across ranks with no
 data-path collective (weak scaling), lineage arrays are replicated; the sampled trace rows are
 gathered over RCCL once at the end of the timed region.  Inputs are resident in HBM before timing.
@@ -133,32 +133,45 @@ def main():
         total_chains = chains * world
         value = args.steps * n_lin * total_chains / elapsed
         # ---- roofline ------------------------------------------------------------------------------------
-        # Dominant kernel = the lineage scan.  Inside the engine it runs as the scan blocks of
-        # lr_fused_iter_kernel (beside the chain-step blocks of the other half, 2 partitions in flight), which
-        # HIP events cannot bracket launch by launch under graph replay; the SAME block body is therefore timed
-        # live as the stand-alone lr_scan_*_kernel over all chains: `reps` back-to-back launches bracketed by
-        # HIP events recorded on the launch stream (lr_mcmc_time_scan).
         cb = eng.layout.chains_per_block
         n_parts, pipelined = eng.layout.n_parts, bool(eng.layout.pipelined)
-        scan_ms = eng.time_scan(reps=50)
-        groups = -(-chains // cb)
-        alg_bytes = 16.0 * n_lin * groups                   # 16 B x N x ceil(C/Cb) per launch
-        achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
-        # engine-level view: device time of n_ev more iterations (HIP events around lr_mcmc_steps)
-        n_ev = 200
-        ev_ms = eng.timed_steps(n_ev)
-        lps = 2 if pipelined else 1
+        persistent = bool(eng.layout.persistent)
         unit = bool(eng.unit_resolution)
-        kname = ("lr_scan_unit_kernel<%d,136>" if unit else "lr_scan_fast_kernel<%d,136>") % cb
         # physical limiter: LDS gather rate, 256 B/clk/CU; bytes gathered per (lineage, chain) pair: 16 (unit) / 32
         lds_peak_pairs = 256 * 2.4e9 * 256 / (16 if unit else 32)
+        scan_ms = eng.time_scan(reps=50)   # stand-alone tiled scan of all chains (launch-based engine's body)
+        if persistent:
+            # Dominant kernel = lr_persist_kernel: ONE launch runs n_ev iterations of every chain (a 512-thread
+            # block owns two chains and reads the packed lineage indices, 2 B per lineage, once per iteration).
+            # Timed live with HIP events recorded on its stream around that single launch (lr_mcmc_time_steps).
+            n_ev = 2000
+            kernel_ms = eng.timed_steps(n_ev)
+            kname = "lr_persist_kernel<136>"
+            pairs_per_launch = float(n_ev) * n_lin * chains
+            passes = n_ev * ((chains + 1) // 2)                     # lineage passes: one per block per iteration
+            alg_bytes = 2.0 * n_lin * passes                        # bytes of lineage data the launch reads
+            conv_bytes = 16.0 * n_lin * passes                      # SURVEY 8(d) convention: 16 B x N x ceil(C/Cb), Cb = 2
+            ms_per_iter_ev = kernel_ms / n_ev
+            cb_pass = 2
+        else:
+            # launch-based engine: the lineage scan runs as the scan blocks of lr_fused_iter_kernel, which HIP
+            # events cannot bracket launch by launch under graph replay; the SAME block body is timed live as the
+            # stand-alone lr_scan_*_kernel over all chains (lr_mcmc_time_scan, back-to-back launches)
+            n_ev = 200
+            ms_per_iter_ev = eng.timed_steps(n_ev) / n_ev
+            kernel_ms = scan_ms
+            kname = ("lr_scan_unit_kernel<%d,136>" if unit else "lr_scan_fast_kernel<%d,136>") % cb
+            pairs_per_launch = float(n_lin) * chains
+            alg_bytes = conv_bytes = 16.0 * n_lin * (-(-chains // cb))
+            cb_pass = cb
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("workload") == args.workload and tj.get("chains") == chains and tj.get("kernel") == kname:
-                traffic = tj.get("hbm_bytes_per_launch")
+                traffic = tj.get("hbm_bytes_per_iteration", 0.0) * (n_ev if persistent else 1)
         out = {
             "metric": "RJMCMC iters/sec x lineages (lineage-log-lik evals/s, summed over chains)",
             "value": value, "unit": "lineage-log-lik evals/s", "n_gpus": world, "steps": args.steps,
@@ -171,17 +184,20 @@ def main():
                        "iters_per_s_per_chain": args.steps / elapsed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kname, "kernel_ms": scan_ms, "pairs_per_launch": n_lin * chains,
-                         "chains_per_pass_Cb": cb, "algorithmic_bytes_per_launch": alg_bytes,
-                         "effective_GBs_unamortised": 16.0 * n_lin * chains / (scan_ms * 1e-3) / 1e9,
-                         "kernel_evals_per_s": n_lin * chains / (scan_ms * 1e-3),
+                         "kernel": kname, "kernel_ms": kernel_ms, "iterations_per_launch": n_ev if persistent else 1,
+                         "pairs_per_launch": pairs_per_launch, "chains_per_pass_Cb": cb_pass,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "bytes_per_lineage_per_pass": 2 if persistent else 16,
+                         "achieved_GBs_16B_convention": conv_bytes / (kernel_ms * 1e-3) / 1e9,
+                         "effective_GBs_unamortised": 16.0 * pairs_per_launch / (kernel_ms * 1e-3) / 1e9,
+                         "kernel_evals_per_s": pairs_per_launch / (kernel_ms * 1e-3),
                          "physical_bound": "lds", "lds_peak_evals_per_s": lds_peak_pairs,
-                         "lds_frac_kernel": n_lin * chains / (scan_ms * 1e-3) / lds_peak_pairs,
+                         "lds_frac_kernel": pairs_per_launch / (kernel_ms * 1e-3) / lds_peak_pairs,
                          "lds_frac_engine": value / world / lds_peak_pairs,
-                         "engine": {"kernel": "lr_fused_iter_kernel<%d,136,%s>" % (cb, "true" if unit else "false"),
-                                    "partitions_in_flight": n_parts, "launches_per_step_per_partition": lps,
-                                    "device_ms_per_step_hip_events": ev_ms / n_ev,
-                                    "unit_resolution_tables": unit}},
+                         "engine": {"persistent": persistent, "partitions_in_flight": 1 if persistent else n_parts,
+                                    "device_ms_per_step_hip_events": ms_per_iter_ev,
+                                    "unit_resolution_tables": unit,
+                                    "tiled_scan_kernel_ms_all_chains": scan_ms}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ts, te, eng.t0, eng.n_bins, eng.br_length.cpu().numpy())

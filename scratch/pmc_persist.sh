@@ -1,0 +1,9 @@
+#!/bin/bash
+export TMPDIR=/tmp
+out=$1; mkdir -p $out
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline > $out/stats_bench.json 2> $out/stats.err < /dev/null || echo "stats pass failed"
+for c in FETCH_SIZE WRITE_SIZE "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE"; do
+  tag=$(echo $c | cut -d" " -f1)
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$tag -- python3 scratch/prof_persist.py > $out/$tag.log 2>&1 < /dev/null || echo "$tag pass failed"
+done
+python3 scratch/pmc_summary.py $out < /dev/null

@@ -173,7 +173,8 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
                                                        const double* __restrict__ br_length,
                                                        const double* __restrict__ log_br, int model, int n_bins,
                                                        int n_cls, int H, double2* __restrict__ tab, int lane,
-                                                       bool unit = false, double fs0 = 0.0, double fe0 = 0.0) {
+                                                       bool unit = false, double fs0 = 0.0, double fe0 = 0.0,
+                                                       int es = 2) {
     // unit-resolution layout: tab points at this chain's component of its pair table, entries 2 doubles apart
     double* tabd = reinterpret_cast<double*>(tab);
     const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
@@ -214,8 +215,8 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
             R = (model == 0) ? lam + mu : mu;
         }
         if (unit) {
-            tabd[2 * (b + 1)] = (logB + cum) + fs0 * R;
-            tabd[2 * (H + b + 1)] = (logD - cum) - fe0 * R;
+            tabd[es * (b + 1)] = (logB + cum) + fs0 * R;
+            tabd[es * (H + b + 1)] = (logD - cum) - fe0 * R;
         } else {
             tab[b + 1] = make_double2(logB + cum, R);
             tab[H + b + 1] = make_double2(logD - cum, -R);
@@ -229,8 +230,8 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
     }
     if (lane == 0) {
         if (unit) {
-            tabd[0] = 0.0, tabd[2 * H] = 0.0;
-            tabd[2 * (n_bins + 1)] = totR, tabd[2 * (H + n_bins + 1)] = -totR;
+            tabd[0] = 0.0, tabd[es * H] = 0.0;
+            tabd[es * (n_bins + 1)] = totR, tabd[es * (H + n_bins + 1)] = -totR;
         } else {
             tab[0] = make_double2(0.0, 0.0);
             tab[H] = make_double2(0.0, 0.0);
@@ -256,7 +257,7 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
                                                                 int KM, const double* __restrict__ br_length,
                                                                 const double* __restrict__ log_br, int model,
                                                                 int n_bins, int H, double2* __restrict__ tab,
-                                                                int lane, bool unit, double fs0, double fe0) {
+                                                                int lane, bool unit, double fs0, double fe0, int es) {
     double* tabd = reinterpret_cast<double*>(tab);
     const int b0 = lane * P;
     int segL[P], segM[P];
@@ -304,8 +305,8 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
         const int b = b0 + p;
         if (b < n_bins) {
             if (unit) {
-                tabd[2 * (b + 1)] = (logB[p] + cum) + fs0 * R[p];
-                tabd[2 * (H + b + 1)] = (logD[p] - cum) - fe0 * R[p];
+                tabd[es * (b + 1)] = (logB[p] + cum) + fs0 * R[p];
+                tabd[es * (H + b + 1)] = (logD[p] - cum) - fe0 * R[p];
             } else {
                 tab[b + 1] = make_double2(logB[p] + cum, R[p]);
                 tab[H + b + 1] = make_double2(logD[p] - cum, -R[p]);
@@ -315,8 +316,8 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
     }
     if (lane == 0) {
         if (unit) {
-            tabd[0] = 0.0, tabd[2 * H] = 0.0;
-            tabd[2 * (n_bins + 1)] = totR, tabd[2 * (H + n_bins + 1)] = -totR;
+            tabd[0] = 0.0, tabd[es * H] = 0.0;
+            tabd[es * (n_bins + 1)] = totR, tabd[es * (H + n_bins + 1)] = -totR;
         } else {
             tab[0] = make_double2(0.0, 0.0);
             tab[H] = make_double2(0.0, 0.0);
@@ -332,15 +333,15 @@ __device__ __forceinline__ double lr_build_tables_segments(const lr_seg_scratch*
                                                            const double* __restrict__ br_length,
                                                            const double* __restrict__ log_br, int model, int n_bins,
                                                            int n_cls, int H, double2* __restrict__ tab, int lane,
-                                                           bool unit, double fs0, double fe0) {
+                                                           bool unit, double fs0, double fe0, int es = 2) {
     if (n_cls == 1 && n_bins <= 2 * LR_WAVE)
         return lr_build_tables_segments_fast<2>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
-                                                fs0, fe0);
+                                                fs0, fe0, es);
     if (n_cls == 1 && n_bins <= 4 * LR_WAVE)
         return lr_build_tables_segments_fast<4>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
-                                                fs0, fe0);
+                                                fs0, fe0, es);
     return lr_build_tables_segments_wave(sc, KL, KM, br_length, log_br, model, n_bins, n_cls, H, tab, lane, unit, fs0,
-                                         fe0);
+                                         fe0, es);
 }
 
 // stage one chain's segments in the wave's LDS scratch; log of all rates in ONE call
@@ -410,7 +411,8 @@ __device__ __forceinline__ void lr_chain_store(const lr_chain_regs& r, double* S
 // tables at `table` (global memory or LDS; see lr_chain_table for the addressing).
 // mode: 0 = regular step, 1 = finish init (adopt the evaluated initial state, then propose iteration 0)
 __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
-                                                   lr_seg_scratch* scratch_p, double lik_sum, double2* table) {
+                                                   lr_seg_scratch* scratch_p, double lik_sum, double2* table,
+                                                   int table_es = 2) {
     lr_seg_scratch& scratch = *scratch_p;
     const lr_mcmc_config& cfg = a.cfg;
     const int C = cfg.n_chains, n_bins = cfg.n_bins;
@@ -604,7 +606,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
     // ---- lookup tables of the proposal ----
     const double constP = lr_build_tables_segments(&scratch, peL, peM, PKL, PKM, a.br_length, a.log_br, cfg.model,
                                                    n_bins, a.n_cls, a.H, table, lane,
-                                                   a.unit != 0, cfg.frac_birth, cfg.frac_death);
+                                                   a.unit != 0, cfg.frac_birth, cfg.frac_death, table_es);
 
     LR_SSTAMP(6);
     // ---- back into the state registers ----
@@ -750,10 +752,10 @@ __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const dou
 // loop's, and both fit the 128-VGPR budget of 4 waves per SIMD without spilling
 __device__ __attribute__((noinline)) void lr_persist_step(const lr_step_args* a, int c, int lane,
                                                           lr_seg_scratch* scratch, double* st_f64, int* st_i32,
-                                                          double lik, double2* table) {
+                                                          double lik, double2* table, int table_es) {
     lr_chain_regs st;
     lr_chain_load(st, st_f64, st_i32, lane);
-    lr_chain_step_core(st, *a, 0, c, lane, scratch, lik, table);
+    lr_chain_step_core(st, *a, 0, c, lane, scratch, lik, table, table_es);
     lr_chain_store(st, st_f64, st_i32, lane);
 }
 
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, 4) void lr_persist_kernel(lr_st
 #pragma unroll
             for (int w2 = 0; w2 < LR_PERSIST_THREADS / LR_WAVE; ++w2) lik += red[w2][wave];
             lr_persist_step(&a, c, lane, &scratch[wave], st_f64[wave], st_i32[wave], lik,
-                            reinterpret_cast<double2*>(reinterpret_cast<double*>(tab) + wave));
+                            reinterpret_cast<double2*>(reinterpret_cast<double*>(tab) + wave), 2);
         }
         __syncthreads();  // new tables ready
 #ifdef LR_DIAG

@@ -150,6 +150,7 @@ typedef struct lr_mcmc_layout {
     int64_t state_i32;    /* [C, LR_ISTATE_ROWS, LR_ROW] int32                                */
     int64_t bin_consts;   /* [n_bins] doubles: log(br_length) (models 0/1)                    */
     int64_t lineage_idx;  /* [n padded to 8] uint16: packed table indices (birth | death << 8) of the lineages */
+    int64_t args_blob;    /* 1 KiB: kernel arguments of the persistent engine, kept in device memory          */
     int64_t tables;       /* [C, table_stride] double2                                        */
     int64_t partials;     /* [tiles, C] doubles                                               */
     int64_t trace;        /* [n_trace_slots, C, LR_TRACE_W] doubles                           */

@@ -31,7 +31,7 @@ class McmcConfig(C.Structure):
 
 
 class McmcLayout(C.Structure):
-    _fields_ = [("state_f64", c_i64), ("state_i32", c_i64), ("bin_consts", c_i64), ("lineage_idx", c_i64), ("tables", c_i64),
+    _fields_ = [("state_f64", c_i64), ("state_i32", c_i64), ("bin_consts", c_i64), ("lineage_idx", c_i64), ("args_blob", c_i64), ("tables", c_i64),
                 ("partials", c_i64), ("trace", c_i64), ("total_bytes", c_i64), ("table_stride", c_i32),
                 ("tiles", c_i32), ("chains_per_block", c_i32), ("trace_width", c_i32), ("n_parts", c_i32),
                 ("pipelined", c_i32), ("persistent", c_i32), ("reserved1", c_i32)]

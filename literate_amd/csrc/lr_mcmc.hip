@@ -733,7 +733,12 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
 // The lineages are read as one packed uint16 per lineage (table indices of its birth and death bins,
 // lr_pack_lineages_kernel), 8 lineages per 16-byte load: 200 KB per pass for 100k lineages, L2 resident.
 // ------------------------------------------------------------------------------------------
+#ifndef LR_PERSIST_THREADS
 #define LR_PERSIST_THREADS 512
+#endif
+#ifndef LR_PERSIST_MINWAVES
+#define LR_PERSIST_MINWAVES 4
+#endif
 
 __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n,
                                         long long n_pad, double t0, int n_bins, unsigned short* __restrict__ out) {
@@ -760,9 +765,11 @@ __device__ __attribute__((noinline)) void lr_persist_step(const lr_step_args* a,
 }
 
 template <int H>
-__global__ __launch_bounds__(LR_PERSIST_THREADS, 4) void lr_persist_kernel(lr_step_args a,
-                                                                        const uint4* __restrict__ idx8, long long n8,
-                                                                        long long n_iters, int prio_shift) {
+__global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_persist_kernel(
+    const lr_step_args* __restrict__ ap /* in global memory: taking the address of a by-value kernel argument would
+                                           copy it to scratch */,
+    const uint4* __restrict__ idx8, long long n8, long long n_iters, int prio_shift) {
+    const lr_step_args& a = *ap;
     __shared__ double2 tab[2 * H];  // the pair table: S' entries [0,H), E' entries [H,2H); (.x, .y) = (chain 0, chain 1)
     __shared__ double red[LR_PERSIST_THREADS / LR_WAVE][2];
     __shared__ lr_seg_scratch scratch[2];
@@ -835,7 +842,7 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, 4) void lr_persist_kernel(lr_st
             double lik = 0.0;
 #pragma unroll
             for (int w2 = 0; w2 < LR_PERSIST_THREADS / LR_WAVE; ++w2) lik += red[w2][wave];
-            lr_persist_step(&a, c, lane, &scratch[wave], st_f64[wave], st_i32[wave], lik,
+            lr_persist_step(ap, c, lane, &scratch[wave], st_f64[wave], st_i32[wave], lik,
                             reinterpret_cast<double2*>(reinterpret_cast<double*>(tab) + wave), 2);
         }
         __syncthreads();  // new tables ready
@@ -861,6 +868,10 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, 4) void lr_persist_kernel(lr_st
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = st_i32[wave][r * LR_ROW + lane];
     }
     for (int i = tid; i < 2 * H; i += LR_PERSIST_THREADS) gpair[i] = tab[i];  // pending tables back to global
+}
+
+__global__ void lr_store_args_kernel(lr_step_args a, lr_step_args* dst) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = a;
 }
 
 // log(br_length) once per engine (data constant used by models 0/1)
@@ -1023,6 +1034,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
     out->bin_consts = o, o += lr_align_up64((long long)cfg->n_bins * 8, 256);
     out->lineage_idx = o, o += lr_align_up64(lr_align_up64(cfg->n_lineages, 8) * 2, 256);
+    out->args_blob = o, o += 1024;   // lr_step_args of the persistent kernel
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
     out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
@@ -1129,6 +1141,8 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
     hipLaunchKernelGGL(lr_log_br_kernel, dim3((e->cfg.n_bins + 127) / 128), dim3(128), 0, stream, e->br_length,
                        e->cfg.n_bins, (double*)(e->ws + e->lay.bin_consts));
     if (e->persistent) {
+        static_assert(sizeof(lr_step_args) <= 1024, "args blob too small");
+        hipLaunchKernelGGL(lr_store_args_kernel, dim3(1), dim3(64), 0, stream, a, (lr_step_args*)(e->ws + e->lay.args_blob));
         const long long n_pad = e->n8 * 8;
         hipLaunchKernelGGL(lr_pack_lineages_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, stream, e->ts,
                            e->te, (long long)e->cfg.n_lineages, n_pad, e->cfg.t0, e->cfg.n_bins,
@@ -1282,15 +1296,16 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
     const lr_step_args a = lr_make_args(e);
     if (e->persistent) {
         const uint4* idx8 = (const uint4*)(e->ws + e->lay.lineage_idx);
+        const lr_step_args* ap = (const lr_step_args*)(e->ws + e->lay.args_blob);
         const int blocks = (e->cfg.n_chains + 1) / 2;
         static const int prio = lr_env_int("LR_PERSIST_PRIO", 12);   // clock bits per priority slice, 0 = off
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
             switch (e->plan.H) {
-                case 40: hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, a, idx8, e->n8, (long long)n, prio); break;
-                case 72: hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, a, idx8, e->n8, (long long)n, prio); break;
-                case 136: hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, a, idx8, e->n8, (long long)n, prio); break;
-                default: hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, a, idx8, e->n8, (long long)n, prio); break;
+                case 40: hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 72: hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 136: hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                default: hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
             }
             const int rc = (int)hipGetLastError();
             if (rc) return rc;

@@ -6,7 +6,9 @@
 
 A "step" = one RJMCMC iteration of every chain on this GPU: one scan of the lineage arrays
 scoring all pending proposals + the per-chain accept / trace / next-proposal step.  For this workload the
-engine is the persistent kernel lr_persist_kernel: one launch runs all K iterations, a block owns two chains.  Workload (config.workload) = BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages,
+engine is the persistent kernel lr_persist4_kernel: one launch runs all K iterations, a 1024-thread block owns four
+chains (two pairs in ping-pong: one pair's step hides under the other pair's scan).  Workload (config.workload) =
+BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages,
 128 unit bins, 20 true shifts per process, 1024 chains per GPU; chains shard across ranks with no
 data-path collective (weak scaling), lineage arrays are replicated; the sampled trace rows are
 gathered over RCCL once at the end of the timed region.  Inputs are resident in HBM before timing.
@@ -33,11 +35,11 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(ts, te, t0, n_bins, br, budget_s=12.0):
-    """numpy port (oracle.per_lineage_loglik: O(N) gather form of get_BDlik) on ONE host core:
-    a bounded sample of the same workload - the same lineages, as many chain states as fit the budget."""
+def _per_lineage_worker(job):
+    """One host core: the numpy per-lineage evaluator on the same lineages for `budget_s` seconds."""
+    ts, te, t0, n_bins, br, budget_s, seed = job
     from oracle import literate_oracle as lo
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     pre = lo.lineage_bins(ts, te, t0, n_bins)          # index/fraction pass is data-only: not re-timed
     n_eval, t_start = 0, time.perf_counter()
     while True:
@@ -47,10 +49,39 @@ def cpu_baseline(ts, te, t0, n_bins, br, budget_s=12.0):
         n_eval += 1
         el = time.perf_counter() - t_start
         if el > budget_s:
-            break
-    return dict(value=n_eval * len(ts) / el, unit="lineage-log-lik evals/s", cores=1, kind="port",
-                sample="%d chain states x %d lineages (same synthetic lineages, model 0), %.1f s of numpy on 1 core"
-                       % (n_eval, len(ts), el))
+            return n_eval, el
+
+
+def cpu_baseline(ts, te, t0, n_bins, stats, start_time, end_time, budget_s=10.0):
+    """CPU numbers beside the GPU one, all from the numpy port under oracle/, bounded to ~25 s:
+    value      : per-lineage evaluator (oracle.per_lineage_loglik: O(N) gather form of get_BDlik) on ONE core,
+    all_cores  : the same evaluator, one process per host core (fresh interpreters, no GPU),
+    reference_loop : the reference's own algorithm - the whole RJMCMC iteration on binned sufficient statistics,
+                 O(n_bins) per iteration, one chain on one core - as iterations/s and iterations/s x lineages."""
+    import multiprocessing as mp
+    br = stats["br"]
+    n_eval, el = _per_lineage_worker((ts, te, t0, n_bins, br, budget_s, 0))
+    out = dict(value=n_eval * len(ts) / el, unit="lineage-log-lik evals/s", cores=1, kind="port",
+               sample="%d chain states x %d lineages (same synthetic lineages, model 0), %.1f s of numpy on 1 core"
+                      % (n_eval, len(ts), el))
+    try:
+        cores = min(len(os.sched_getaffinity(0)), 16)
+    except AttributeError:
+        cores = min(os.cpu_count() or 1, 16)
+    if cores > 1:
+        with mp.get_context("spawn").Pool(cores) as pool:
+            res = pool.map(_per_lineage_worker, [(ts, te, t0, n_bins, br, 6.0, 100 + i) for i in range(cores)])
+        out["all_cores"] = dict(value=sum(n for n, _ in res) * len(ts) / max(e for _, e in res), cores=cores,
+                                sample="one process per core, 6 s each")
+    from oracle import mcmc_oracle as mo
+    n_it = 20000
+    t_start = time.perf_counter()
+    mo.run_mcmc(stats, start_time, end_time, mo.Settings(model_BDI=0),
+                mo.PhiloxDraws(2026, 0), n_it, 100)
+    el = time.perf_counter() - t_start
+    out["reference_loop"] = dict(iters_per_s=n_it / el, iters_per_s_x_lineages=n_it / el * len(ts), cores=1,
+                                 sample="%d RJMCMC iterations of one chain on binned statistics, %.1f s" % (n_it, el))
+    return out
 
 
 def main():
@@ -115,7 +146,9 @@ def main():
 
     barrier()
     t_begin = time.perf_counter()
-    eng.steps(args.steps)
+    # the K timed iterations, also bracketed by HIP events on the launch stream (roofline.kernel_ms for the persistent
+    # engine: the timed region IS its kernel, ceil(K/4096) launches)
+    region_kernel_ms = eng.timed_steps(args.steps)
     gather_traces()
     barrier()
     elapsed = time.perf_counter() - t_begin
@@ -143,10 +176,14 @@ def main():
         if persistent:
             # Dominant kernel = lr_persist_kernel: ONE launch runs n_ev iterations of every chain (a 512-thread
             # block owns two chains and reads the packed lineage indices, 2 B per lineage, once per iteration).
-            # Timed live with HIP events recorded on its stream around that single launch (lr_mcmc_time_steps).
-            n_ev = 2000
-            kernel_ms = eng.timed_steps(n_ev)
-            kname = "lr_persist_kernel<136>"
+            # Timed live with HIP events recorded on its stream around the launches of the timed region itself
+            # (lr_mcmc_time_steps); a launch runs at most 4096 iterations.
+            launches = -(-args.steps // 4096)
+            n_ev = args.steps / launches                            # iterations per launch (average)
+            kernel_ms = region_kernel_ms / launches
+            # layout.persistent == 2: four chains per 1024-thread block, the two pairs scanned in turn (each pair still
+            # one pass over the packed indices per iteration); 1: two chains per 512-thread block
+            kname = "lr_persist4_kernel<136>" if eng.layout.persistent == 2 else "lr_persist_kernel<136>"
             pairs_per_launch = float(n_ev) * n_lin * chains
             passes = n_ev * ((chains + 1) // 2)                     # lineage passes: one per block per iteration
             alg_bytes = 2.0 * n_lin * passes                        # bytes of lineage data the launch reads
@@ -194,13 +231,15 @@ def main():
                          "physical_bound": "lds", "lds_peak_evals_per_s": lds_peak_pairs,
                          "lds_frac_kernel": pairs_per_launch / (kernel_ms * 1e-3) / lds_peak_pairs,
                          "lds_frac_engine": value / world / lds_peak_pairs,
-                         "engine": {"persistent": persistent, "partitions_in_flight": 1 if persistent else n_parts,
+                         "engine": {"persistent": persistent, "chains_per_block": 2 * eng.layout.persistent if persistent else cb,
+                                    "partitions_in_flight": 1 if persistent else n_parts,
                                     "device_ms_per_step_hip_events": ms_per_iter_ev,
                                     "unit_resolution_tables": unit,
                                     "tiled_scan_kernel_ms_all_chains": scan_ms}},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ts, te, eng.t0, eng.n_bins, eng.br_length.cpu().numpy())
+            stats = dict(sp=eng.sp_events.cpu().numpy(), ex=eng.ex_events.cpu().numpy(), br=eng.br_length.cpu().numpy())
+            out["cpu_baseline"] = cpu_baseline(ts, te, eng.t0, eng.n_bins, stats, eng.start_time, eng.end_time)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

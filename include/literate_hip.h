@@ -161,7 +161,7 @@ typedef struct lr_mcmc_layout {
     int32_t trace_width;
     int32_t n_parts;      /* independent chain partitions, each on its own stream                  */
     int32_t pipelined;    /* 1: each partition runs the fused scan|step schedule over two halves   */
-    int32_t persistent;   /* 1: lr_mcmc_steps uses the persistent two-chains-per-block kernel       */
+    int32_t persistent;   /* 0: launch-per-iteration engine; 1 / 2: persistent kernel, 2 / 4 chains per block */
     int32_t reserved1;
 } lr_mcmc_layout;
 

@@ -753,6 +753,36 @@ __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const dou
     out[i] = v;
 }
 
+// Scan of all lineages against ONE pair table by `n_scan` threads (this thread is number `sid`): the inner loop
+// of the persistent engines.  8 lineages per 16-byte load, next load in flight while the current one is scored.
+template <int H>
+__device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
+                                                     long long n8, long long sid, int n_scan, double* acc0_,
+                                                     double* acc1_) {
+    double acc0 = *acc0_, acc1 = *acc1_;
+    long long i = sid;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n8) w = idx8[i];
+    while (i < n8) {
+        const uint4 cur = w;
+        const long long nx = i + n_scan;
+        if (nx < n8) w = idx8[nx];
+        const unsigned int words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned int v = words[k];
+            const double2 s0 = *reinterpret_cast<const double2*>(lbase + ((v << 4) & 0xff0u));
+            const double2 e0 = *reinterpret_cast<const double2*>(lbase + ((v >> 4) & 0xff0u) + H * 16);
+            const double2 s1 = *reinterpret_cast<const double2*>(lbase + ((v >> 12) & 0xff0u));
+            const double2 e1 = *reinterpret_cast<const double2*>(lbase + ((v >> 20) & 0xff0u) + H * 16);
+            acc0 += (s0.x + e0.x) + (s1.x + e1.x);
+            acc1 += (s0.y + e0.y) + (s1.y + e1.y);
+        }
+        i = nx;
+    }
+    *acc0_ = acc0, *acc1_ = acc1;
+}
+
 // the chain step of the persistent kernel as a real call: its ~120 live registers then do not add to the scan
 // loop's, and both fit the 128-VGPR budget of 4 waves per SIMD without spilling
 __device__ __attribute__((noinline)) void lr_persist_step(const lr_step_args* a, int c, int lane,
@@ -804,31 +834,7 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
         d_t0 = wall_clock64();
 #endif
         double acc0 = 0.0, acc1 = 0.0;
-        {
-            // 8 lineages per 16-byte load, the next load in flight while the current one is scored
-            long long i = tid;
-            uint4 w = make_uint4(0u, 0u, 0u, 0u);
-            if (i < n8) w = idx8[i];
-            while (i < n8) {
-                const uint4 cur = w;
-                const long long nx = i + LR_PERSIST_THREADS;
-                if (nx < n8) w = idx8[nx];
-                const unsigned int words[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned int v = words[k];
-                    const double2 S0 = *reinterpret_cast<const double2*>(lbase + ((v << 4) & 0xff0u));
-                    const double2 E0 = *reinterpret_cast<const double2*>(lbase + ((v >> 4) & 0xff0u) + H * 16);
-                    const double2 S1 = *reinterpret_cast<const double2*>(lbase + ((v >> 12) & 0xff0u));
-                    const double2 E1 = *reinterpret_cast<const double2*>(lbase + ((v >> 20) & 0xff0u) + H * 16);
-                    acc0 += S0.x + E0.x;
-                    acc1 += S0.y + E0.y;
-                    acc0 += S1.x + E1.x;
-                    acc1 += S1.y + E1.y;
-                }
-                i = nx;
-            }
-        }
+        lr_persist_scan_pair<H>(lbase, idx8, n8, tid, LR_PERSIST_THREADS, &acc0, &acc1);
 #ifdef LR_DIAG
         d_t1 = wall_clock64();
 #endif
@@ -868,6 +874,79 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = st_i32[wave][r * LR_ROW + lane];
     }
     for (int i = tid; i < 2 * H; i += LR_PERSIST_THREADS) gpair[i] = tab[i];  // pending tables back to global
+}
+
+// Four chains per 1024-thread block (one block per CU), two pairs in ping-pong: while waves 0 and 1 run the chain
+// steps of one pair, waves 2..15 scan the lineages for the OTHER pair, so the latency-bound step always hides
+// under a scan of the same block and the LDS pipe never waits for it.  Used when there are enough chains to give
+// every CU four (cfg4: 1024 chains = 256 blocks).
+#define LR_P4_THREADS 1024
+#define LR_P4_SCANNERS ((LR_P4_THREADS / LR_WAVE - 2) * LR_WAVE)
+template <int H>
+__global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
+                                                                       const uint4* __restrict__ idx8, long long n8,
+                                                                       long long n_iters) {
+    const lr_step_args& a = *ap;
+    constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners
+    __shared__ double2 tab[2][2 * H];                     // pair tables
+    __shared__ double red[2][NW][2];                      // [pair][scanner wave][chain of the pair]
+    __shared__ lr_seg_scratch scratch[2];
+    __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
+    __shared__ int st_i32[4][LR_ISTATE_ROWS * LR_ROW];
+    const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    const int c0 = blockIdx.x * 4;
+    const int C = a.cfg.n_chains;
+    if (wave < 4 && c0 + wave < C) {
+        const int c = c0 + wave;
+        const double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
+        const int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+        for (int r = 0; r < LR_STATE_ROWS; ++r) st_f64[wave][r * LR_ROW + lane] = S[r * LR_ROW + lane];
+        for (int r = 0; r < LR_ISTATE_ROWS; ++r) st_i32[wave][r * LR_ROW + lane] = I[r * LR_ROW + lane];
+    }
+    double2* g0 = lr_chain_table(a, c0);
+    double2* g1 = lr_chain_table(a, c0 + 2);             // tables are allocated for whole groups of cb >= 4 chains
+    for (int i = tid; i < 2 * H; i += LR_P4_THREADS) tab[0][i] = g0[i], tab[1][i] = g1[i];
+    __syncthreads();
+    const bool scanner = wave >= 2;
+    const int sid = tid - 2 * LR_WAVE;
+    // prologue: pair 0's pending proposal is scanned so that phase A can step it
+    if (scanner) {
+        double s0 = 0.0, s1 = 0.0;
+        lr_persist_scan_pair<H>(reinterpret_cast<const char*>(tab[0]), idx8, n8, sid, LR_P4_SCANNERS, &s0, &s1);
+        s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
+        if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
+    }
+    __syncthreads();
+    for (long long iter = 0; iter < n_iters; ++iter) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            // phase ph: steppers advance pair `ph`, scanners score pair `1 - ph`
+            if (scanner) {
+                double s0 = 0.0, s1 = 0.0;
+                lr_persist_scan_pair<H>(reinterpret_cast<const char*>(tab[1 - ph]), idx8, n8, sid, LR_P4_SCANNERS, &s0, &s1);
+                s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
+                if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
+            } else {
+                const int c = c0 + 2 * ph + wave;
+                if (c < C) {
+                    double lik = 0.0;
+#pragma unroll
+                    for (int w2 = 2; w2 < NW; ++w2) lik += red[ph][w2][wave];
+                    lr_persist_step(ap, c, lane, &scratch[wave], st_f64[2 * ph + wave], st_i32[2 * ph + wave], lik,
+                                    reinterpret_cast<double2*>(reinterpret_cast<double*>(tab[ph]) + wave), 2);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (wave < 4 && c0 + wave < C) {
+        const int c = c0 + wave;
+        double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
+        int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+        for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = st_f64[wave][r * LR_ROW + lane];
+        for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = st_i32[wave][r * LR_ROW + lane];
+    }
+    for (int i = tid; i < 2 * H; i += LR_P4_THREADS) g0[i] = tab[0][i], g1[i] = tab[1][i];
 }
 
 __global__ void lr_store_args_kernel(lr_step_args a, lr_step_args* dst) {
@@ -1011,6 +1090,23 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     return t_persist <= t_launch;
 }
 
+// Which persistent kernel: 1 = two chains per 512-thread block (lr_persist_kernel), 2 = four chains per 1024-thread
+// block in ping-pong (lr_persist4_kernel).  The four-chain block hides the chain step under the other pair's scan but
+// scans with 14 of its 16 waves, so it wins only while a step is a sizeable part of a scan (measured on cfg4-like
+// data: ahead for 30k..200k lineages, behind outside), and it fills the chip in rounds of 1024 chains where the
+// two-chain kernel's remainder round is cheaper when at most 512 chains are left (C = 1536: 29.4 vs 33.5 us).
+// Model in units of one full round: t4 = ceil(C/1024), t2 = 1.06 floor(C/1024) + (0.77 | 1.06 for the remainder).
+static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
+    if (!lr_persist_eligible(cfg, p)) return 0;
+    static const int p4_env = lr_env_int("LR_PERSIST4", -1);
+    if (p.cb < 4) return 1;                 // tables are laid out per group of cb chains; a quad must not straddle
+    if (p4_env >= 0) return p4_env ? 2 : 1;
+    const int C = cfg->n_chains, rem = C % 1024;
+    const double t4 = (double)((C + 1023) / 1024);
+    const double t2 = 1.06 * (C / 1024) + (rem == 0 ? 0.0 : (rem <= 512 ? 0.77 : 1.06));
+    return (cfg->n_lineages >= 40000 && cfg->n_lineages <= 200000 && t4 < t2) ? 2 : 1;
+}
+
 static int lr_check_cfg(const lr_mcmc_config* cfg) {
     if (!cfg) return LR_ERR_NULL;
     if (cfg->n_lineages < 1 || cfg->n_chains < 1 || cfg->s_freq < 1 || cfg->n_trace_slots < 0) return LR_ERR_SIZE;
@@ -1049,7 +1145,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
         out->n_parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined);
         out->pipelined = pipelined[0] ? 1 : 0;
     }
-    out->persistent = lr_persist_eligible(cfg, p) ? 1 : 0;
+    out->persistent = lr_persist_variant(cfg, p);
     return LR_OK;
 }
 
@@ -1298,14 +1394,15 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         const uint4* idx8 = (const uint4*)(e->ws + e->lay.lineage_idx);
         const lr_step_args* ap = (const lr_step_args*)(e->ws + e->lay.args_blob);
         const int blocks = (e->cfg.n_chains + 1) / 2;
+        const bool p4 = e->lay.persistent == 2;
         static const int prio = lr_env_int("LR_PERSIST_PRIO", 12);   // clock bits per priority slice, 0 = off
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
             switch (e->plan.H) {
-                case 40: hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                case 72: hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                case 136: hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                default: hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
             }
             const int rc = (int)hipGetLastError();
             if (rc) return rc;

@@ -85,7 +85,7 @@ def _pipelined_case(G, unit, engine):
                       unit_resolution=unit, engine=engine)
     assert eng.unit_resolution == unit and eng.layout.chains_per_block == (16 if unit else 8)
     assert eng.layout.n_parts == 2 and eng.layout.pipelined == 1
-    assert eng.layout.persistent == (0 if engine == "launch" else 1)
+    assert (eng.layout.persistent > 0) == (engine != "launch")
     eng.init()
     eng.steps(150); eng.steps(1); eng.steps(249)        # graph replays + prologue/epilogue launches, three calls
     tr = eng.trace_rows()

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     cfg.unit_resolution, cfg.frac_death = 1, 0.5                  # unit-resolution tables: 8-byte entries, 16 chains/block
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
     assert lay.chains_per_block == 16 and lay.table_stride == 136 and lay.pipelined == 1
-    assert lay.persistent == 1 and lay.lineage_idx > 0           # auto: persistent engine for 1024 chains x 100k
+    assert lay.persistent == 2 and lay.lineage_idx > 0           # auto: four-chain persistent kernel for 1024 chains x 100k
     cfg.engine_mode = 1
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0
     cfg.engine_mode, cfg.n_chains, cfg.n_lineages = 0, 16, 10_000_000   # few chains, huge input: tiled launches

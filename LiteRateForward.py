@@ -44,6 +44,8 @@ def build_parser():
     p.add_argument('-out', type=str, help='output tag', default="", metavar="")
     p.add_argument('-rev_se', type=int, help='reversed order of ts and te in input file', default=0, metavar=0)
     p.add_argument('--chains', type=int, default=1, help='total number of independent chains')
+    p.add_argument('--checkpoint', type=str, default="", help='file the run is saved to after every print block and '
+                   'resumed from if it exists (same data and flags; extension to the reference, which cannot resume)')
     p.add_argument('--init_shifts', type=int, default=0, help='initial number of rate shifts per process')
     return p
 
@@ -133,12 +135,22 @@ def main(argv=None):
         eng.init(L, M, [t] * eng.n_chains, [t] * eng.n_chains)
     else:
         eng.init()
-    t_start = time.time()
     done = 0
+    ckpt = (args.checkpoint + (".rank%d" % rank if world > 1 else "")) if args.checkpoint else ""
+    if ckpt and not ckpt.endswith(".npz"):
+        ckpt += ".npz"
+    if ckpt and os.path.exists(ckpt):
+        eng.load(ckpt)
+        done = eng.iterations
+        if rank == 0:
+            print("resumed from %s at iteration %d" % (ckpt, done))
+    t_start = time.time()
     while done < args.n:
         n = min(args.p * max(1, 50000 // max(args.p, 1)), args.n - done)
         eng.steps(n)
         done += n
+        if ckpt:
+            eng.save(ckpt)
         if rank == 0:
             snap = eng.snapshot()
             print(done, snap["likA"][0], snap["priorA"][0])

@@ -129,12 +129,12 @@ def main():
     eng.init()
     eng.steps(args.warmup)
 
+    from literate_amd.dist import gather_traces as gather_rows
+
     def gather_traces():
-        heads = eng.trace[:, :, :13].contiguous()       # log-posterior trace rows sampled so far
-        if world > 1:
-            gathered = [torch.empty_like(heads) for _ in range(world)] if rank == 0 else None
-            dist.gather(heads, gathered, dst=0)          # RCCL over xGMI
-        return heads
+        # log-posterior trace rows sampled so far, gathered to rank 0 over RCCL / xGMI (literate_amd/dist.py; the same
+        # function runs under gloo in tests/test_host_cpu.py)
+        return gather_rows(eng.trace[:, :, :13], total_chains=chains * world)
 
     gather_traces()     # untimed: loads the copy kernel and sets up the RCCL communicator (one-off costs)
 

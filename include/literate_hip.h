@@ -234,6 +234,14 @@ int lr_mcmc_create(const lr_mcmc_config* cfg /* host */, const double* ts, const
 int lr_mcmc_init(lr_engine* e, const double* L, const double* M, const double* tL,
                  const double* tM, const int32_t* KL, const int32_t* KM, int32_t kmax, void* stream);
 int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream);
+/* Resume (no reference counterpart: the reference cannot resume).  Between two lr_mcmc_steps
+ * calls the whole run - accepted states, pending proposals and their tables, iteration counters, trace rows -
+ * is the workspace; the Philox draws are addressed by (seed, chain, iteration), so a run continued from a copy of
+ * the workspace is bit-identical to an uninterrupted one.  The caller copies a workspace saved from an engine
+ * with the SAME configuration (hence the same lr_mcmc_layout) into this engine's workspace, then calls this
+ * instead of lr_mcmc_init: it rebuilds what holds device addresses or derives from the data (argument blob,
+ * log(br_length), packed lineage indices) and leaves the chains alone.                                          */
+int lr_mcmc_restore(lr_engine* e, void* stream);
 /* measurement hook (bench.py roofline): average duration in ms of `reps` back-to-back launches of
  * the engine's lineage-scan kernel on `stream`, timed with HIP events recorded on that stream.
  * Blocks until the launches finish; re-scores the pending proposal, so chain state is unchanged. */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "lr_mcmc_steps": (c_i32, [c_vp, c_i64, c_vp]),
     "lr_mcmc_time_scan": (c_i32, [c_vp, c_i32, C.POINTER(C.c_float), c_vp]),
     "lr_mcmc_time_steps": (c_i32, [c_vp, c_i64, C.POINTER(C.c_float), c_vp]),
+    "lr_mcmc_restore": (c_i32, [c_vp, c_vp]),
     "lr_mcmc_destroy": (c_i32, [c_vp]),
     "lr_debug_draws": (c_i32, [C.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
 }

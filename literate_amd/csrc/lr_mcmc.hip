@@ -1227,13 +1227,8 @@ static int lr_enqueue_step_range(const lr_engine* e, const lr_step_args& a, int 
     return (int)hipGetLastError();
 }
 
-extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, const double* tL, const double* tM,
-                            const int32_t* KL, const int32_t* KM, int32_t kmax, void* stream_) {
-    if (!e) return LR_ERR_NULL;
-    if (L && (!M || !tL || !tM || !KL || !KM)) return LR_ERR_NULL;
-    if (L && (kmax < 1 || kmax > LR_KMAX)) return LR_ERR_SIZE;
-    hipStream_t stream = (hipStream_t)stream_;
-    const lr_step_args a = lr_make_args(e);
+// everything in the workspace that holds device addresses or derives from the data alone
+static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipStream_t stream) {
     hipLaunchKernelGGL(lr_log_br_kernel, dim3((e->cfg.n_bins + 127) / 128), dim3(128), 0, stream, e->br_length,
                        e->cfg.n_bins, (double*)(e->ws + e->lay.bin_consts));
     if (e->persistent) {
@@ -1244,6 +1239,27 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
                            e->te, (long long)e->cfg.n_lineages, n_pad, e->cfg.t0, e->cfg.n_bins,
                            (unsigned short*)(e->ws + e->lay.lineage_idx));
     }
+}
+
+extern "C" int lr_mcmc_restore(lr_engine* e, void* stream_) {
+    if (!e) return LR_ERR_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const lr_step_args a = lr_make_args(e);
+    lr_prepare_constants(e, a, stream);
+    const int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    e->initialised = true;
+    return LR_OK;
+}
+
+extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, const double* tL, const double* tM,
+                            const int32_t* KL, const int32_t* KM, int32_t kmax, void* stream_) {
+    if (!e) return LR_ERR_NULL;
+    if (L && (!M || !tL || !tM || !KL || !KM)) return LR_ERR_NULL;
+    if (L && (kmax < 1 || kmax > LR_KMAX)) return LR_ERR_SIZE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const lr_step_args a = lr_make_args(e);
+    lr_prepare_constants(e, a, stream);
     hipLaunchKernelGGL(lr_chain_init_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, L, M, tL, tM, KL, KM,
                        kmax);
     int rc = (int)hipGetLastError();

@@ -140,6 +140,42 @@ class ChainEngine:
         self.iterations += int(n)
         return float(ms.value)
 
+    # ---- checkpoint / resume (no reference counterpart) ----
+    _CFG_KEYS = ("n_lineages", "n_bins", "n_chains", "model", "const_rates", "const_death_rate", "use_rate_HP",
+                 "s_freq", "n_trace_slots", "poisson_HP", "update_fraction", "t0", "start_time", "end_time", "seed",
+                 "chain_offset", "unit_resolution", "frac_birth", "frac_death")
+
+    def _signature(self):
+        sig = {k: getattr(self.cfg, k) for k in self._CFG_KEYS}
+        sig.update({"layout_" + f: getattr(self.layout, f) for f, _ in self.layout._fields_})
+        return sig
+
+    def save(self, path):
+        """Write the run (all chain states, pending proposals, trace rows, iteration count) to `path` (.npz).
+        The workspace IS the run between two steps() calls; draws are addressed by (seed, chain, iteration), so a
+        run resumed with load() continues bit-identically."""
+        import torch
+        torch.cuda.synchronize(self.device)
+        sig = self._signature()
+        np.savez(path, workspace=self.workspace.cpu().numpy(), iterations=np.int64(self.iterations),
+                 sig_keys=np.array(list(sig.keys())), sig_vals=np.array([float(v) for v in sig.values()]))
+
+    def load(self, path):
+        """Resume from save(): the engine must have been created on the same data with the same settings."""
+        import torch
+        with np.load(path) as z:
+            saved = dict(zip([str(k) for k in z["sig_keys"]], z["sig_vals"]))
+            mine = self._signature()
+            bad = [k for k in mine if k not in saved or float(mine[k]) != float(saved[k])]
+            if bad or len(saved) != len(mine):
+                raise ValueError("checkpoint was written by a different configuration: " + ", ".join(bad))
+            ws = torch.from_numpy(z["workspace"])
+            if ws.numel() != self.workspace.numel():
+                raise ValueError("checkpoint workspace size differs")
+            self.workspace.copy_(ws.to(self.device))
+            self.iterations = int(z["iterations"])
+        _hip.check(self.lib.lr_mcmc_restore(self.handle, _hip.stream_ptr()), "lr_mcmc_restore")
+
     def close(self):
         if getattr(self, "handle", None) is not None:
             self.lib.lr_mcmc_destroy(self.handle)

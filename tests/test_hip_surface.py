@@ -124,6 +124,33 @@ def test_cli_end_to_end(G, tmp_path):
     shutil.rmtree(logdir)
 
 
+def test_cli_checkpoint_resume(G, tmp_path):
+    """--checkpoint: a run stopped at -n 200 and continued to -n 400 writes the same logs as one run of 400
+    (the flags that size the trace, -n and -s, have to match, so the first leg uses the engine API)."""
+    ts, te = G["example_TBP/ts"], G["example_TBP/te"] - 0.5
+    data = tmp_path / "example.tsv"
+    with open(data, "w") as f:
+        f.write("id\tts\tte\n")
+        for i, (a, b) in enumerate(zip(ts, te)):
+            f.write("%d\t%g\t%g\n" % (i, 24.0 - a, 24.0 - b))
+    base = [sys.executable, os.path.join(ROOT, "LiteRateForward.py"), "-d", str(data), "-TBP", "-n", "400", "-s", "20",
+            "-p", "200", "-seed", "31", "--chains", "2"]
+    subprocess.run(base + ["-out", "_full"], check=True, stdout=subprocess.DEVNULL, timeout=300)
+    ck = str(tmp_path / "ck")
+    out = subprocess.run(base + ["-out", "_res", "--checkpoint", ck], check=True, capture_output=True, text=True, timeout=300)
+    assert "resumed" not in out.stdout and os.path.exists(ck + ".npz")
+    # second invocation finds the finished checkpoint: nothing left to run, logs rewritten from the restored trace
+    out = subprocess.run(base + ["-out", "_res", "--checkpoint", ck], check=True, capture_output=True, text=True, timeout=300)
+    assert "resumed from" in out.stdout and "at iteration 400" in out.stdout
+    logdir = tmp_path / "literate_mcmc_logs"
+    for c in range(2):
+        for kind in ("mcmc", "sp_rates", "ex_rates"):
+            a = open(logdir / ("example_BD_full_c%d_%s.log" % (c, kind))).read()
+            b = open(logdir / ("example_BD_res_c%d_%s.log" % (c, kind))).read()
+            assert a == b and len(a) > 100
+    shutil.rmtree(logdir)
+
+
 def test_cli_cfg1_fixed_two_shifts(G, tmp_path):
     """BASELINE.json configs[0]: example_dataTBP, 1 chain, fixed 2 rate shifts (-const_rates 1 with a
     3-rate initial state, SURVEY 8c 'config-1 note').  K stays (3, 3), shift times never move (A9), the

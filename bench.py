@@ -202,6 +202,18 @@ def main():
             alg_bytes = conv_bytes = 16.0 * n_lin * (-(-chains // cb))
             cb_pass = cb
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # yardstick beside the nominal 8 TB/s: device-to-device copy of 1 GiB, read + write bytes
+        src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        ev1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2.0 * src.numel() / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        del src, dst
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
@@ -221,6 +233,7 @@ def main():
                        "iters_per_s_per_chain": args.steps / elapsed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "hbm_copy_GBs_measured": copy_gbs,
                          "kernel": kname, "kernel_ms": kernel_ms, "iterations_per_launch": n_ev if persistent else 1,
                          "pairs_per_launch": pairs_per_launch, "chains_per_pass_Cb": cb_pass,
                          "algorithmic_bytes_per_launch": alg_bytes,

@@ -112,6 +112,20 @@ int lr_dd_rates(const double* args, const double* DT, int32_t n_bins, int32_t n_
                 double* birth_rates, double* death_rates, double* niche, double* niche_frac,
                 void* stream);
 
+/* ---- the reference's other rate maps onto the same per-bin likelihood ---------
+ * lr_ddv2_rates replaces the rate half of DDRatev2.py likelihood_function (DDRatev2.py:73-104):
+ * args [C,9] = [l_f,l_mul,k,x0,div_0,L,m_mul,nuB,nuD]; m_birth 0..2, m_death <=0 (rates of 1) / 1 / 2.
+ * lr_trend_rates replaces trend_rate.py likelihood_function's rate half (trend_rate.py:73-88):
+ * args [C,6] = [l_min,m_min,alpha,beta,delta,gamma], trend [n_bins] = the normalised covariate
+ * (parse_trend_data, trend_rate.py:58-69).  Likelihood half: lr_bd_loglik_batch(model 2).     */
+int lr_ddv2_rates(const double* args, const double* DT, int32_t n_bins, int32_t n_chains,
+                  int32_t m_birth, int32_t m_death,
+                  double* birth_rates, double* death_rates, double* niche, double* niche_frac,
+                  void* stream);
+int lr_trend_rates(const double* args, const double* trend, int32_t n_bins, int32_t n_chains,
+                   int32_t const_birth, int32_t const_death,
+                   double* birth_rates, double* death_rates, void* stream);
+
 /* ---- A11: fused multi-chain RJMCMC --------------------------------------------------------
  * Replaces runMCMC (LRF:216-373) for n_chains independent chains.  Per iteration: one scan of
  * the lineage arrays scoring every chain's proposal, then one chain-step kernel (reduce,

@@ -50,6 +50,8 @@ SIGNATURES = {
                                     c_vp]),
     "lr_log_priors": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_f64, c_vp, c_vp, c_vp, c_vp]),
     "lr_dd_rates": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "lr_ddv2_rates": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "lr_trend_rates": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "lr_mcmc_query_layout": (c_i32, [C.POINTER(McmcConfig), C.POINTER(McmcLayout)]),
     "lr_mcmc_create": (c_i32, [C.POINTER(McmcConfig), c_vp, c_vp, c_vp, c_vp, c_i64, C.POINTER(c_vp)]),
     "lr_mcmc_init": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),

@@ -191,4 +191,88 @@ extern "C" int lr_dd_rates(const double* args, const double* DT, int32_t n_bins,
     return (int)hipGetLastError();
 }
 
-extern "C" int lr_version(void) { return 100; }
+// ------------------------------------------------------------------------------------------
+// the other rate maps of the reference that feed the same per-bin likelihood.
+// DDRatev2.py:55-104 (9 parameters) and trend_rate.py:73-88 (6 parameters + a per-bin covariate).
+// ------------------------------------------------------------------------------------------
+__global__ void lr_ddv2_rates_kernel(const double* __restrict__ args, const double* __restrict__ DT, int n_bins,
+                                     int m_birth, int m_death, double* __restrict__ birth, double* __restrict__ death,
+                                     double* __restrict__ niche_o, double* __restrict__ frac_o) {
+    const int c = blockIdx.y;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bins) return;
+    const double* a = args + (size_t)c * 9;
+    const double l_f = a[0], l_mul = a[1], k = a[2], x0 = a[3], div_0 = a[4], L = a[5], m_mul = a[6], nuB = a[7],
+                 nuD = a[8];
+    const double x = (double)b, dt = DT[b];
+    const double SMALL = 0.000000000000001;
+    double niche = 1.0, frac = 1.0, br, dr;
+    if (m_birth == 0) {
+        br = 1.0 * l_f * l_mul;                                            // DDRatev2.py:77
+    } else {
+        niche = (m_birth == 1) ? 1.0 * (L + div_0) : div_0 + L / pow(1.0 + exp(-k * (x - x0)), 1.0 / 1.0);
+        frac = dt / niche;
+        const double rate_max = l_f + l_f * l_mul;                         // get_brates, DDRatev2.py:61-65
+        br = rate_max - (rate_max - l_f) * pow(frac, nuB);
+        if (br <= 0.0) br = SMALL;
+    }
+    if (m_death <= 0) {
+        dr = 1.0;                                                          // np.ones, DDRatev2.py:91
+    } else {
+        niche = (m_death == 1) ? 1.0 * (L + div_0) : div_0 + L / pow(1.0 + exp(-k * (x - x0)), 1.0 / 1.0);
+        frac = dt / niche;
+        const double rate_min = l_f - l_f * m_mul;                         // get_drates on l_f, DDRatev2.py:67-71, 99
+        dr = rate_min + (l_f - rate_min) * pow(frac, nuD);
+        if (dr <= 0.0) dr = SMALL;
+    }
+    const size_t o = (size_t)c * n_bins + b;
+    birth[o] = br, death[o] = dr, niche_o[o] = niche, frac_o[o] = frac;
+}
+
+extern "C" int lr_ddv2_rates(const double* args, const double* DT, int32_t n_bins, int32_t n_chains, int32_t m_birth,
+                             int32_t m_death, double* birth_rates, double* death_rates, double* niche,
+                             double* niche_frac, void* stream_) {
+    if (!args || !DT || !birth_rates || !death_rates || !niche || !niche_frac) return LR_ERR_NULL;
+    if (n_bins < 1 || n_chains < 1 || n_chains > 65535) return LR_ERR_SIZE;
+    if (m_birth < 0 || m_birth > 2 || m_death < -2 || m_death > 2) return LR_ERR_MODEL;
+    dim3 grid((n_bins + 127) / 128, n_chains);
+    hipLaunchKernelGGL(lr_ddv2_rates_kernel, grid, dim3(128), 0, (hipStream_t)stream_, args, DT, n_bins, m_birth,
+                       m_death, birth_rates, death_rates, niche, niche_frac);
+    return (int)hipGetLastError();
+}
+
+__global__ void lr_trend_rates_kernel(const double* __restrict__ args, const double* __restrict__ trend, int n_bins,
+                                      int const_birth, int const_death, double* __restrict__ birth,
+                                      double* __restrict__ death) {
+    const int c = blockIdx.y;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bins) return;
+    const double* a = args + (size_t)c * 6;
+    const double l_min = a[0], m_min = a[1], alpha = a[2], beta = a[3], delta = a[4], gamma = a[5];
+    const double t = trend[b];
+    const double SMALL = 0.000000000000001;
+    double br = 1.0 * l_min, dr = 1.0 * m_min;
+    if (!const_birth) {
+        br = l_min + alpha * pow(t, delta);                                // trend_rate.py:79
+        if (br <= 0.0) br = SMALL;
+    }
+    if (!const_death) {
+        dr = m_min + beta * pow(t, gamma);                                 // trend_rate.py:86
+        if (dr <= 0.0) dr = SMALL;
+    }
+    const size_t o = (size_t)c * n_bins + b;
+    birth[o] = br, death[o] = dr;
+}
+
+extern "C" int lr_trend_rates(const double* args, const double* trend, int32_t n_bins, int32_t n_chains,
+                              int32_t const_birth, int32_t const_death, double* birth_rates, double* death_rates,
+                              void* stream_) {
+    if (!args || !trend || !birth_rates || !death_rates) return LR_ERR_NULL;
+    if (n_bins < 1 || n_chains < 1 || n_chains > 65535) return LR_ERR_SIZE;
+    dim3 grid((n_bins + 127) / 128, n_chains);
+    hipLaunchKernelGGL(lr_trend_rates_kernel, grid, dim3(128), 0, (hipStream_t)stream_, args, trend, n_bins,
+                       const_birth, const_death, birth_rates, death_rates);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lr_version(void) { return 101; }

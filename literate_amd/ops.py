@@ -151,6 +151,40 @@ def dd_rates(args, DT, m_birth=2, m_death=2):
     return tuple(outs)
 
 
+def ddv2_rates(args, DT, m_birth=2, m_death=2):
+    """DDRatev2 per-bin (birth, death, niche, niche_frac), each [C,n_bins] (DDRatev2.py:73-104); args [C,9]."""
+    torch = _torch()
+    lib = _hip.load()
+    args, DT = _dev(args, torch.float64), _dev(DT, torch.float64)
+    if args.dim() == 1:
+        args = args[None, :]
+    if args.shape[1] != 9:
+        raise ValueError("DDRatev2 takes 9 parameters per state")
+    C, n_bins = args.shape[0], DT.numel()
+    outs = [torch.empty((C, n_bins), dtype=torch.float64, device=args.device) for _ in range(4)]
+    rc = lib.lr_ddv2_rates(_hip.ptr(args), _hip.ptr(DT), n_bins, C, m_birth, m_death, *[_hip.ptr(o) for o in outs],
+                           _hip.stream_ptr())
+    _hip.check(rc, "lr_ddv2_rates")
+    return tuple(outs)
+
+
+def trend_rates(args, trend, const_birth=False, const_death=False):
+    """trend_rate.py:73-88 per-bin (birth, death), each [C,n_bins]; args [C,6], trend = normalised covariate."""
+    torch = _torch()
+    lib = _hip.load()
+    args, trend = _dev(args, torch.float64), _dev(trend, torch.float64)
+    if args.dim() == 1:
+        args = args[None, :]
+    if args.shape[1] != 6:
+        raise ValueError("trend_rate takes 6 parameters per state")
+    C, n_bins = args.shape[0], trend.numel()
+    outs = [torch.empty((C, n_bins), dtype=torch.float64, device=args.device) for _ in range(2)]
+    rc = lib.lr_trend_rates(_hip.ptr(args), _hip.ptr(trend), n_bins, C, int(bool(const_birth)), int(bool(const_death)),
+                            *[_hip.ptr(o) for o in outs], _hip.stream_ptr())
+    _hip.check(rc, "lr_trend_rates")
+    return tuple(outs)
+
+
 def debug_draws(seed, chain, it, purpose, idx, kind, shape):
     """Device RNG probe: kind 0 u_a, 1 u_b, 2 normal, 3 gamma(shape) at (it, purpose, idx)."""
     torch = _torch()

@@ -485,3 +485,106 @@ def dd_calc_prior(args, prior_k0_l, origin, present):
     if origin + args[2] >= present:
         p = -np.inf
     return p
+
+
+# ----------------------------------------------------------------------------
+# the other rate maps that feed the same per-bin likelihood
+# ----------------------------------------------------------------------------
+def ddv2_rates(args, DT, time_range, m_birth=2, m_death=2):
+    """DDRatev2.py:79-104 (get_logistic :55-56 with nu = 1, get_const_K :58-59, get_brates :61-65, get_drates
+    :67-71): rates move linearly in niche_frac**nu between a floor rate and a multiple of it.  As written there:
+    the death map is built from l_f (not a death parameter), m_death <= 0 gives death rates of exactly 1, and
+    m_birth == 0 gives l_f * l_mul."""
+    l_f, l_mul, k, x0, div_0, L, m_mul, nuB, nuD = args
+    n = len(DT)
+
+    def logistic():
+        return div_0 + L / ((1 + np.exp(-k * (time_range - x0))) ** (1 / 1))
+
+    def floor_rates(r):
+        r = np.array(r, dtype=float)
+        r[r <= 0] = SMALL_NUMBER
+        return r
+
+    niche = np.ones(n)
+    niche_frac = np.ones(n)
+    if m_birth == 0:
+        birth = np.ones(n) * l_f * l_mul
+    else:
+        niche = np.ones(n) * (L + div_0) if m_birth == 1 else logistic()
+        niche_frac = DT / niche
+        rate_max = l_f + l_f * l_mul
+        birth = floor_rates(rate_max - (rate_max - l_f) * (niche_frac ** nuB))
+    if m_death <= 0:
+        death = np.ones(n)
+    else:
+        niche = np.ones(n) * (L + div_0) if m_death == 1 else logistic()
+        niche_frac = DT / niche
+        rate_min = l_f - l_f * m_mul
+        death = floor_rates(rate_min + (l_f - rate_min) * (niche_frac ** nuD))
+    return birth, death, niche, niche_frac
+
+
+def ddv2_likelihood_function(args, N_SPEC, N_EXTI, DT, time_range, m_birth=2, m_death=2):
+    """DDRatev2.py:73-111: [lik[2], birth_rates, death_rates, niche, niche_frac]."""
+    birth, death, niche, niche_frac = ddv2_rates(args, DT, time_range, m_birth, m_death)
+    birth_lik = np.sum(np.log(birth) * N_SPEC - birth * DT)
+    death_lik = np.sum(np.log(death) * N_EXTI - death * DT)
+    return [np.array([birth_lik, death_lik]), birth, death, niche, niche_frac]
+
+
+def normalise_trend(trend, rm_first_bin=0):
+    """parse_trend_data, trend_rate.py:58-69, after the column has been read: drop the last bin (and the first with
+    rm_first_bin), min-max scale to [0, 1], zeros become SMALL_NUMBER."""
+    t = np.array(trend, dtype=float)[:-1]
+    if rm_first_bin:
+        t = t[1:]
+    t = (t - np.min(t)) / (np.max(t) - np.min(t))
+    t[t == 0] = SMALL_NUMBER
+    return t
+
+
+def trend_rates(args, TREND, const_birth=False, const_death=False):
+    """trend_rate.py:73-88: rate_b = r_min + slope * TREND_b ** exponent, floored to SMALL_NUMBER."""
+    l_min, m_min, alpha, beta, delta, gamma = args
+    n = len(TREND)
+    if const_birth:
+        birth = np.ones(n) * l_min
+    else:
+        birth = l_min + alpha * TREND ** delta
+        birth[birth <= 0.0] = SMALL_NUMBER
+    if const_death:
+        death = np.ones(n) * m_min
+    else:
+        death = m_min + beta * TREND ** gamma
+        death[death <= 0.0] = SMALL_NUMBER
+    return birth, death
+
+
+def _gamma_logpdf(x, a, scale, loc=0.0):
+    """scipy.stats.gamma.logpdf(x, a, scale=scale, loc=loc) in closed form."""
+    y = (x - loc) / scale
+    if y < 0:
+        return -np.inf
+    if y == 0:
+        return -np.log(scale) if a == 1 else (-np.inf if a > 1 else np.inf)
+    return (a - 1.0) * np.log(y) - y - math.lgamma(a) - np.log(scale)
+
+
+def trend_calc_prior(args):
+    """trend_rate.py:93-100."""
+    p = _gamma_logpdf(args[0], 1, 10, .001)
+    p += _gamma_logpdf(args[1], 1, 10, .001)
+    p += _norm_logpdf(args[2] / 5.0) - np.log(5.0)
+    p += _norm_logpdf(args[3] / 5.0) - np.log(5.0)
+    p += _gamma_logpdf(args[4], 3, .5)
+    p += _gamma_logpdf(args[5], 3, .5)
+    return p
+
+
+def trend_likelihood_function(args, N_SPEC, N_EXTI, DT, TREND, const_birth=False, const_death=False):
+    """trend_rate.py:72-91: [lik[2], birth_rates, death_rates]."""
+    birth, death = trend_rates(args, TREND, const_birth, const_death)
+    birth_lik = np.sum(np.log(birth) * N_SPEC - birth * DT)
+    death_lik = np.sum(np.log(death) * N_EXTI - death * DT)
+    return [np.array([birth_lik, death_lik]), birth, death]

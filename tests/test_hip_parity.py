@@ -280,6 +280,34 @@ def test_dd_rates_and_likelihood_golden(ops, G, golden_dir):
         assert np.allclose(lik[ok], ref[ok], rtol=REL)
 
 
+def test_ddv2_and_trend_rate_maps_golden(ops, G, golden_dir):
+    """lr_ddv2_rates / lr_trend_rates against the reference's own outputs (DDRatev2.py, trend_rate.py
+    run in the build container), and their likelihood halves through the per-lineage Keiding scan."""
+    D = np.load(os.path.join(golden_dir, "ratemaps.npz"))
+    ts, te = G["metal_bands/lib_ts"], G["metal_bands/lib_te"]
+    origin = np.load(os.path.join(golden_dir, "ddrate.npz"))["meta"][0]
+    for mb, md in ((2, 2), (1, 1), (0, 0), (2, -1), (1, 2)):
+        key = "ddv2_mb%d_md%d" % (mb, md)
+        b, d, ni, nf = ops.ddv2_rates(D[key + "/args"], D["DT"], mb, md)
+        for got, name in ((b, "birth"), (d, "death"), (ni, "niche"), (nf, "niche_frac")):
+            assert np.allclose(_np(got), D[key + "/" + name], rtol=1e-12, equal_nan=True), (key, name)
+        ref = D[key + "/lik"].sum(1)
+        ok = np.isfinite(ref)
+        lik = _np(ops.bd_loglik_batch(ts, te, origin, b, d, 2))
+        assert ok.sum() >= 5 and np.allclose(lik[ok], ref[ok], rtol=REL)
+    for cb, cd in ((0, 0), (1, 0), (0, 1)):
+        key = "trend_cb%d_cd%d" % (cb, cd)
+        b, d = ops.trend_rates(D[key + "/args"], D["TREND"], cb, cd)
+        assert np.allclose(_np(b), D[key + "/birth"], rtol=1e-12, equal_nan=True)
+        assert np.allclose(_np(d), D[key + "/death"], rtol=1e-12, equal_nan=True)
+        ref = D[key + "/lik"].sum(1)
+        ok = np.isfinite(ref)
+        lik = _np(ops.bd_loglik_batch(ts, te, origin, b, d, 2))
+        assert ok.sum() >= 5 and np.allclose(lik[ok], ref[ok], rtol=REL)
+    with pytest.raises(ValueError):
+        ops.trend_rates(np.zeros((2, 5)), D["TREND"])
+
+
 def test_device_rng_matches_oracle_stream(ops):
     from oracle import philox as px
     rng = np.random.default_rng(3)

@@ -207,6 +207,31 @@ def test_ddrate_likelihood_and_prior(golden_dir):
             assert lo.dd_calc_prior(args, k0, origin, present) == pytest.approx(D[key + "/prior"][j], rel=1e-12)
 
 
+def test_ddratev2_and_trend_rate_maps(golden_dir):
+    """DDRatev2.py:73-111 and trend_rate.py:58-100 restatements against the reference's outputs."""
+    D = np.load(os.path.join(golden_dir, "ratemaps.npz"))
+    for mb, md in ((2, 2), (1, 1), (0, 0), (2, -1), (1, 2)):
+        key = "ddv2_mb%d_md%d" % (mb, md)
+        for j, args in enumerate(D[key + "/args"]):
+            with np.errstate(all="ignore"):
+                lik, b, d, ni, nf = lo.ddv2_likelihood_function(args, D["N_SPEC"], D["N_EXTI"], D["DT"],
+                                                                D["TIME_RANGE"], mb, md)
+            for got, name in ((b, "birth"), (d, "death"), (ni, "niche"), (nf, "niche_frac")):
+                assert np.allclose(got, D[key + "/" + name][j], rtol=1e-13, equal_nan=True), (key, j, name)
+            assert np.allclose(lik, D[key + "/lik"][j], rtol=1e-12, equal_nan=True)
+    trend = lo.normalise_trend(D["trend_raw"])
+    assert np.array_equal(trend, D["TREND"])
+    for cb, cd in ((0, 0), (1, 0), (0, 1)):
+        key = "trend_cb%d_cd%d" % (cb, cd)
+        for j, args in enumerate(D[key + "/args"]):
+            with np.errstate(all="ignore"):
+                lik, b, d = lo.trend_likelihood_function(args, D["N_SPEC"], D["N_EXTI"], D["DT"], trend, cb, cd)
+            assert np.allclose(b, D[key + "/birth"][j], rtol=1e-13, equal_nan=True)
+            assert np.allclose(d, D[key + "/death"][j], rtol=1e-13, equal_nan=True)
+            assert np.allclose(lik, D[key + "/lik"][j], rtol=1e-12, equal_nan=True)
+            assert lo.trend_calc_prior(args) == pytest.approx(D[key + "/prior"][j], rel=1e-12)
+
+
 TRAJ = ["example_TBP_m0_s42", "example_TBP_m2_s7", "example_TBP_m1_s3", "example_TBP_m3_s9",
         "example_TBP_m0_s11_const_rates1", "example_TBP_m0_s12_const_death_rate1",
         "example_TBP_m0_s13_use_rate_HP0_Poisson_prior2.5", "metal_bands_m2_s5"]

@@ -236,6 +236,46 @@ def test_cfg3_synthetic_10k_lineages_256_chains(G):
     eng.close()
 
 
+def test_cfg4_full_size_1024_chains_100k_lineages():
+    """BASELINE.json configs[3] at FULL size on one GPU (the bench workload: 1024 chains x 100k lineages, the
+    four-chain persistent kernel).  (i) chains from the first / a middle / the last block walk the oracle loop's
+    trajectory row by row; (ii) size-independent property over ALL chains: the accepted log-likelihood the engine
+    carries equals an independent evaluation of the accepted state by lr_bd_loglik_batch (another kernel, per-bin
+    rates expanded on the host with the oracle's get_rate_index); (iii) every chain has moved."""
+    from literate_amd import ops, synth
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import literate_oracle as lo
+    from oracle import mcmc_oracle as mo
+    ts, te, _ = synth.make_lineages(100_000, n_bins=128, n_shifts=20, seed=0)
+    n_it, seed, C = 150, 2026, 1024
+    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it)
+    assert eng.layout.persistent == 2 and eng.unit_resolution
+    t0, sp, ex, br = lo.bin_events_cli(ts, te)
+    assert np.array_equal(eng.sp_events.cpu().numpy(), sp) and np.array_equal(eng.ex_events.cpu().numpy(), ex)
+    assert np.array_equal(eng.br_length.cpu().numpy(), br)
+    eng.init(); eng.steps(100); eng.steps(n_it - 100)
+    tr = eng.trace_rows()
+    stats = dict(sp=sp, ex=ex, br=br)
+    for c in (0, 1, 2, 3, 513, 1022, 1023):
+        with np.errstate(all="ignore"):
+            ref = mo.run_mcmc(stats, ts.min(), te.max(), mo.Settings(model_BDI=0), mo.PhiloxDraws(seed, c), n_it, 1, k_max=32)
+        for i in range(n_it):
+            head, s_row, e_row = split_trace_row(tr[i, c])
+            assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9), (c, i)
+            assert np.allclose(s_row, ref["sp"][i], rtol=1e-10) and np.allclose(e_row, ref["ex"][i], rtol=1e-10)
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it) and np.all(snap["accepted"] > 0) and np.all(np.isfinite(snap["likA"]))
+    n_bins = eng.n_bins
+    lam = np.stack([snap["L"][c][lo.get_rate_index(np.floor(snap["tL"][c]), n_bins)] for c in range(C)])
+    mu = np.stack([snap["M"][c][lo.get_rate_index(np.floor(snap["tM"][c]), n_bins)] for c in range(C)])
+    lik = ops.bd_loglik_batch(eng.ts, eng.te, eng.t0, lam, mu, 0, br_length=br).cpu().numpy()
+    assert np.allclose(lik, snap["likA"], rtol=1e-9)
+    # the same through the oracle's binned form for a sample of chains
+    for c in range(0, C, 97):
+        assert lo.calc_likelihood(0, lam[c], mu[c], stats) == pytest.approx(snap["likA"][c], rel=1e-9)
+    eng.close()
+
+
 def test_cfg5_ddrate_50k_lineages_256_states():
     """BASELINE.json configs[4]: DDRate likelihood (DD:71-107) on 50k synthetic lineages for 256 parameter
     states: lr_dd_rates + the per-lineage Keiding scan against the oracle's binned likelihood_function on

@@ -153,7 +153,8 @@ typedef struct lr_mcmc_config {
      * dataset the reference ships: 0 and 0.5).  The fractions are then folded into the lookup
      * tables (8-byte entries, half the LDS traffic per lineage).  0 = general times.            */
     int32_t unit_resolution;
-    int32_t engine_mode;      /* 0 = auto, 1 = launch-per-iteration engine (fused, pipelined), 2 = persistent kernel */
+    int32_t engine_mode;      /* 0 = auto, 1 = launch-per-iteration engine (fused, pipelined), 2 = persistent kernel,
+                               * 3 = persistent kernel with four chains per block (lr_mcmc_layout.persistent tells) */
     double frac_birth;
     double frac_death;
 } lr_mcmc_config;

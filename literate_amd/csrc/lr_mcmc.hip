@@ -1072,8 +1072,8 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
 }
 
 // Persistent engine (lr_persist_kernel): needs unit-resolution tables with byte-sized indices and an
-// instantiated table size.  cfg->engine_mode 1 / 2 force the launch-based / persistent engine (2 still needs the
-// prerequisites); auto picks the persistent kernel unless the chains are too few for the lineage count: a block
+// instantiated table size.  cfg->engine_mode 1 / 2 / 3 force the launch-based / persistent / four-chain persistent
+// engine (2 and 3 still need the prerequisites); auto picks the persistent kernel unless the chains are too few for the lineage count: a block
 // scans ALL lineages for its two chains, so with few chains and very long inputs the tiled launch-based scan,
 // which spreads one chain group over many CUs, is faster.
 static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
@@ -1081,7 +1081,7 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     if (env == 0 || cfg->engine_mode == 1) return false;
     if (!p.unit || cfg->n_bins + 1 > 255 || p.cb < 2) return false;
     if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264) return false;
-    if (env == 1 || cfg->engine_mode == 2) return true;
+    if (env == 1 || cfg->engine_mode == 2 || cfg->engine_mode == 3) return true;
     const double n = (double)cfg->n_lineages, c = (double)cfg->n_chains;
     const int blocks = (cfg->n_chains + 1) / 2;
     const double rounds = (double)((blocks + 511) / 512);
@@ -1100,6 +1100,7 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p) 
     if (!lr_persist_eligible(cfg, p)) return 0;
     static const int p4_env = lr_env_int("LR_PERSIST4", -1);
     if (p.cb < 4) return 1;                 // tables are laid out per group of cb chains; a quad must not straddle
+    if (cfg->engine_mode == 3) return 2;
     if (p4_env >= 0) return p4_env ? 2 : 1;
     const int C = cfg->n_chains, rem = C % 1024;
     const double t4 = (double)((C + 1023) / 1024);

@@ -60,7 +60,7 @@ class ChainEngine:
             s_freq=int(s_freq), n_trace_slots=int(n_trace_slots), poisson_HP=float(poisson_HP),
             update_fraction=float(update_fraction), t0=self.t0, start_time=self.start_time, end_time=self.end_time,
             seed=int(seed), chain_offset=int(chain_offset), unit_resolution=int(self.unit_resolution),
-            engine_mode={"auto": 0, "launch": 1, "persistent": 2}[engine],
+            engine_mode={"auto": 0, "launch": 1, "persistent": 2, "persistent4": 3}[engine],
             frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0)
         self.layout = _hip.McmcLayout()
         _hip.check(self.lib.lr_mcmc_query_layout(C.byref(self.cfg), C.byref(self.layout)), "lr_mcmc_query_layout")

@@ -32,7 +32,8 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        (2, dict(use_rate_HP=0, Poisson_HP=2.5)),
                                        (0, dict(unit_resolution=False)), (1, dict(unit_resolution=False)),
                                        (0, dict(engine="launch")), (2, dict(engine="launch")),
-                                       (1, dict(engine="persistent"))])
+                                       (1, dict(engine="persistent")), (0, dict(engine="persistent4")),
+                                       (2, dict(engine="persistent4"))])
 def test_engine_follows_oracle_trajectory(G, model, kw):
     from literate_amd.engine import ChainEngine, split_trace_row
     name, seed, n_it, C, off = "example_TBP", 2024, 1500, 6, 40
@@ -310,6 +311,8 @@ def test_cfg5_ddrate_50k_lineages_256_states():
 @pytest.mark.parametrize("n_bins,unit,engine", [(60, None, "auto"), (60, None, "launch"), (134, None, "auto"),
                                                 (134, None, "launch"), (135, None, "auto"), (135, None, "launch"),
                                                 (200, False, "auto"), (253, None, "auto"), (254, None, "auto"),
+                                                (60, None, "persistent4"), (134, None, "persistent4"),
+                                                (253, None, "persistent4"),
                                                 (300, None, "auto")])
 def test_engine_shapes_bins(n_bins, unit, engine):
     """Table half-stride classes (H = 72, 136, 264) and the generic kernel beyond them (n_bins = 300),
@@ -326,6 +329,8 @@ def test_engine_shapes_bins(n_bins, unit, engine):
     n_it, seed, C = 120, 7, 37
     eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, unit_resolution=unit, engine=engine)
     assert eng.n_bins == n_bins
+    if engine == "persistent4":
+        assert eng.layout.persistent == 2      # 37 chains: the last block holds one chain of four
     eng.init(); eng.steps(n_it)
     tr = eng.trace_rows()
     t0, sp, ex, br = lo.bin_events_cli(ts, te)
@@ -339,7 +344,7 @@ def test_engine_shapes_bins(n_bins, unit, engine):
     eng.close()
 
 
-@pytest.mark.parametrize("engine", ["launch", "auto"])
+@pytest.mark.parametrize("engine", ["launch", "auto", "persistent4"])
 def test_engine_chain_count_shapes(G, engine):
     """Any number of chains: single partition / two partitions, pipelined or not, ragged last block.  The same
     global chains must walk the same path in every engine shape (sums differ only by their tile partition)."""
@@ -363,7 +368,7 @@ def test_engine_chain_count_shapes(G, engine):
         eng.close(); last.close()
 
 
-@pytest.mark.parametrize("engine,C", [("launch", 24), ("persistent", 24), ("persistent", 10)])
+@pytest.mark.parametrize("engine,C", [("launch", 24), ("persistent", 24), ("persistent", 10), ("persistent4", 10)])
 def test_checkpoint_resume_is_bit_identical(G, tmp_path, engine, C):
     """save() after 130 iterations, load() into a fresh engine, 170 more: state, pending proposals and all 300
     trace rows equal an uninterrupted run bit for bit (draws are addressed by (seed, chain, iteration));

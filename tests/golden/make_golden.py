@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,traj]
+    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,traj]
     python tests/golden/make_chains.py <dataset> <model> <n> <s> <chains>   # long reference chains
 
 The reference is executed unmodified: LiteRateForward.py / DDRate.py through
@@ -341,6 +341,35 @@ def make_ratemaps(work):
     print("ratemaps.npz:", len(out), "arrays")
 
 
+def make_dd_trajectories(work):
+    """Full DDRate.py runs (reference process, fixed seed): every sampled row of its log is kept so that the
+    restated loop (oracle/dd_mcmc_oracle.py) fed the same MT19937 stream must reproduce them."""
+    out = {}
+    suffix_b = {0: "_LL", 1: "_LDD", 2: "_LDDN"}
+    for mb, md, seed, n, s in ((2, 2, 4, 4000, 10), (1, 1, 5, 3000, 10), (0, 0, 6, 3000, 10), (2, -1, 7, 3000, 10),
+                               (2, 0, 8, 3000, 10)):
+        rel, flags = DATASETS["metal_bands"]
+        d = tempfile.mkdtemp(dir=work)
+        dst = os.path.join(d, os.path.basename(rel))
+        shutil.copy(os.path.join(REF, rel), dst)
+        cmd = [sys.executable, "-B", os.path.join(REF, "DDRate.py"), "-d", dst, "-n", str(n), "-s", str(s),
+               "-seed", str(seed), "-m_birth", str(mb), "-m_death", str(md)] + flags
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+        suffix_d = "_ML" if md <= 0 else ("_MDD" if md == 1 else "_MDDN")
+        log = "%s_%s%s%s.log" % (os.path.splitext(dst)[0], seed, suffix_b[mb], suffix_d)
+        rows = np.loadtxt(log, skiprows=1, ndmin=2)
+        key = "mb%d_md%d_s%d" % (mb, md, seed)
+        # all sampled rows: the 14 scalar columns and the 3 adequacy columns; the 4 x n_bins per-bin columns
+        # (functions of the 8 parameters alone) only for the first 25 rows
+        out[key + "/head"] = rows[:, :14]
+        out[key + "/adequacy"] = rows[:, -3:]
+        out[key + "/full25"] = rows[:25]
+        out[key + "/meta"] = np.array([mb, md, seed, n, s], dtype=float)
+        print(key, rows.shape)
+    np.savez_compressed(os.path.join(HERE, "dd_trajectories.npz"), **out)
+
+
 def parse_logs(logdir, stem):
     mc = np.loadtxt(os.path.join(logdir, stem + "_mcmc.log"), skiprows=1, ndmin=2)
     rows = {}
@@ -394,7 +423,7 @@ def main():
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="lr_golden_")
-    steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps,
+    steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps, ddtraj=make_dd_trajectories,
                  traj=make_trajectories)
     for name, fn in steps.items():
         if args.only and name not in args.only.split(","):

@@ -270,3 +270,28 @@ def test_mcmc_loop_reproduces_reference_trajectory(G, golden_dir, key):
         for i, row in enumerate(out[kind]):
             assert np.allclose(row, R[i, :len(row)], rtol=1e-10)
             assert np.all(np.isnan(R[i, len(row):]))
+
+
+DD_TRAJ = ["mb2_md2_s4", "mb1_md1_s5", "mb0_md0_s6", "mb2_md-1_s7", "mb2_md0_s8"]
+
+
+@pytest.mark.parametrize("key", DD_TRAJ)
+def test_dd_mcmc_loop_reproduces_reference_trajectory(golden_dir, key):
+    """DDRate.py's sampler (DD:124-241) restated in oracle/dd_mcmc_oracle.py: fed numpy's legacy stream with the
+    reference's seed it must write the reference's own log rows (full reference runs on metal_bands)."""
+    from oracle import dd_mcmc_oracle as ddo
+    T = np.load(os.path.join(golden_dir, "dd_trajectories.npz"))
+    D = np.load(os.path.join(golden_dir, "ddrate.npz"))
+    mb, md, seed, n, s = [int(v) for v in T[key + "/meta"]]
+    origin, present, _ = D["meta"]
+    with np.errstate(all="ignore"):
+        emp = (D["N_SPEC"] / D["DT"], D["N_EXTI"] / D["DT"])
+    np.random.seed(seed)
+    rows = ddo.run_dd_mcmc(D["N_SPEC"], D["N_EXTI"], D["DT"], D["TIME_RANGE"], origin, present, mb, md,
+                           ddo.NumpyLegacyDraws(), n, s, emp=emp)
+    rows = np.array(rows)
+    assert rows.shape[0] == T[key + "/head"].shape[0]
+    assert np.allclose(rows[:, :14], T[key + "/head"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(rows[:, -3:], T[key + "/adequacy"], rtol=1e-7, atol=1e-9, equal_nan=True)
+    assert np.allclose(rows[:25], T[key + "/full25"], rtol=1e-9, atol=1e-12, equal_nan=True)
+    assert len(set(np.round(rows[:, 2], 6))) > 20          # the chain moved

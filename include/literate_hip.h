@@ -126,6 +126,13 @@ int lr_trend_rates(const double* args, const double* trend, int32_t n_bins, int3
                    int32_t const_birth, int32_t const_death,
                    double* birth_rates, double* death_rates, void* stream);
 
+/* Binned Keiding halves of C per-bin rate vectors, out[c] = sum_b log(rate[c,b]) * events[b] - rate[c,b] * DT[b]
+ * (DD:86, 101; trend_rate.py:82, 89; the same expression as BD_lik_Keiding LRF:137-148 on create_bins statistics):
+ * the likelihood_birth / likelihood_death columns of the DDRate-family logs.                                       */
+int lr_binned_keiding(const double* birth_rates, const double* death_rates, const int64_t* n_spec,
+                      const int64_t* n_exti, const double* DT, int32_t n_bins, int32_t n_chains,
+                      double* out_birth, double* out_death, void* stream);
+
 /* ---- A11: fused multi-chain RJMCMC --------------------------------------------------------
  * Replaces runMCMC (LRF:216-373) for n_chains independent chains.  Per iteration: one scan of
  * the lineage arrays scoring every chain's proposal, then one chain-step kernel (reduce,
@@ -157,6 +164,16 @@ typedef struct lr_mcmc_config {
                                * 3 = persistent kernel with four chains per block (lr_mcmc_layout.persistent tells) */
     double frac_birth;
     double frac_death;
+    /* ---- sampler 1: the DDRate.py Metropolis-Hastings loop (DD:124-241) on the same engine -------------
+     * model must be LR_MODEL_KEIDING, br_length = DT of create_bins (lib:231-257), t0 = ORIGIN, n_bins =
+     * N_TIME_BINS.  A chain's state is the parameter vector [l_max,k,x0,div_0,L,m_max,nuB,nuD] (DD:161) in
+     * lanes 0..7 of the rate row; a trace row is [it, posterior, likelihood, prior, args[8]].               */
+    int32_t sampler;          /* 0 = runMCMC (LRF), 1 = DDRate                      */
+    int32_t m_birth;          /* -m_birth (DD:25)                                   */
+    int32_t m_death;          /* -m_death (DD:26)                                   */
+    int32_t reserved0;
+    double dd_present;        /* PRESENT - as create_bins returns it (DD:36)        */
+    double dd_init_death;     /* -fix_death (DD:27, 156)                            */
 } lr_mcmc_config;
 
 /* where things live inside the engine workspace (byte offsets), for zero-copy host views */

@@ -27,7 +27,9 @@ class McmcConfig(C.Structure):
                 ("const_rates", c_i32), ("const_death_rate", c_i32), ("use_rate_HP", c_i32), ("s_freq", c_i32),
                 ("n_trace_slots", c_i32), ("poisson_HP", c_f64), ("update_fraction", c_f64), ("t0", c_f64),
                 ("start_time", c_f64), ("end_time", c_f64), ("seed", C.c_uint64), ("chain_offset", c_i64),
-                ("unit_resolution", c_i32), ("engine_mode", c_i32), ("frac_birth", c_f64), ("frac_death", c_f64)]
+                ("unit_resolution", c_i32), ("engine_mode", c_i32), ("frac_birth", c_f64), ("frac_death", c_f64),
+                ("sampler", c_i32), ("m_birth", c_i32), ("m_death", c_i32), ("reserved0", c_i32),
+                ("dd_present", c_f64), ("dd_init_death", c_f64)]
 
 
 class McmcLayout(C.Structure):
@@ -51,6 +53,7 @@ SIGNATURES = {
     "lr_log_priors": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_f64, c_vp, c_vp, c_vp, c_vp]),
     "lr_dd_rates": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "lr_ddv2_rates": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "lr_binned_keiding": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "lr_trend_rates": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "lr_mcmc_query_layout": (c_i32, [C.POINTER(McmcConfig), C.POINTER(McmcLayout)]),
     "lr_mcmc_create": (c_i32, [C.POINTER(McmcConfig), c_vp, c_vp, c_vp, c_vp, c_i64, C.POINTER(c_vp)]),

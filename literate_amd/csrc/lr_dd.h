@@ -1,0 +1,130 @@
+// lr_dd.h - DDRate (diversity-dependent rates) device arithmetic: SURVEY section 8a row A12 and the sampler
+// around it (DDRate.py:55-122, 124-241).  Shared by the stand-alone rate kernel (lr_stats.hip) and the
+// engine's DD chain step (lr_mcmc.hip), so that both evaluate the very same expressions.
+#pragma once
+#include "lr_chain.h"
+
+#define LR_DD_NPAR 8          /* [l_max, k, x0, div_0, L, m_max, nuB, nuD] (DD:161) */
+#define LR_DD_SMALL 0.000000000000001 /* SMALL_NUMBER, DD:47 */
+// draw purposes of the DD sampler in the addressed stream (oracle/dd_mcmc_oracle.py)
+#define LR_P_DD_MOVE 16
+#define LR_P_DD_SLIDE 17
+#define LR_P_DD_MULT 18
+#define LR_P_DD_ACCEPT 19
+
+struct lr_dd_params {
+    double l_max, k, x0, div_0, L, m_max, nuB, nuD;
+};
+
+// likelihood_function's rate half for ONE bin (DD:71-100): x = bin index (TIME_RANGE, lib:255), dt = DT[b]
+__device__ __forceinline__ void lr_dd_bin_rates(const lr_dd_params& p, double x, double dt, int m_birth, int m_death,
+                                                double* br_, double* dr_, double* niche_, double* frac_) {
+    double niche = 1.0, frac = 1.0, br, dr;
+    if (m_birth == 0) {
+        br = 1.0 * p.l_max;
+    } else {
+        niche = (m_birth == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / pow(1.0 + exp(-p.k * (x - p.x0)), 1.0 / 1.0);
+        frac = dt / niche;
+        br = p.l_max - p.l_max * pow(frac, p.nuB);
+        if (br <= 0.0) br = LR_DD_SMALL;
+    }
+    if (m_death <= 0) {
+        dr = 1.0 * p.m_max;
+    } else {
+        niche = (m_death == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / pow(1.0 + exp(-p.k * (x - p.x0)), 1.0 / 1.0);
+        frac = dt / niche;
+        dr = p.m_max + p.m_max * pow(frac, p.nuD);
+        if (dr <= 0.0) dr = LR_DD_SMALL;
+    }
+    *br_ = br, *dr_ = dr, *niche_ = niche, *frac_ = frac;
+}
+
+// lane j < 8 holds parameter j -> wave-uniform struct
+__device__ __forceinline__ lr_dd_params lr_dd_unpack(double v) {
+    lr_dd_params p;
+    p.l_max = lr_bcast(v, 0), p.k = lr_bcast(v, 1), p.x0 = lr_bcast(v, 2), p.div_0 = lr_bcast(v, 3);
+    p.L = lr_bcast(v, 4), p.m_max = lr_bcast(v, 5), p.nuB = lr_bcast(v, 6), p.nuD = lr_bcast(v, 7);
+    return p;
+}
+
+// per-parameter update probability of the vector multiplier move (DD:166-181), lane j < 8
+__device__ __forceinline__ double lr_dd_update_freq(int m_birth, int m_death, int lane) {
+    //                                l_max k  x0 div_0 L  m_max nuB nuD
+    double um = 0.0;
+    const int j = lane;
+    if (m_birth == 0 && m_death <= 0) um = (j == 0 || j == 5) ? 1.0 : 0.0;
+    else if (m_birth == 2 || m_death == 2) um = (j == 2) ? 0.0 : 1.0;
+    else um = (j == 0 || j >= 4) ? 1.0 : 0.0;
+    if (m_death == -1) um *= (j == 1 || j == 5) ? 0.0 : 1.0;
+    if (m_death == -2) um *= (j == 1 || j >= 5) ? 0.0 : 1.0;
+    if (j >= LR_DD_NPAR) um = 0.0;
+    const double tot = lr_wave_sum(um);
+    return um / tot;
+}
+
+// calc_prior (DD:110-122): Gamma(1, scale) and standard-normal log-densities; -inf once the midpoint passes PRESENT
+__device__ __forceinline__ double lr_dd_prior(double v, double origin, double present, double k0, double log_k0,
+                                              int lane) {
+    const double LOG10 = 2.302585092994046;           // log(10)
+    const double HALF_LOG_2PI = 0.9189385332046727;   // 0.5 log(2 pi)
+    double t = 0.0;
+    if (lane == 0 || lane == 5) t = (v < 0.0) ? -INFINITY : -v / 10.0 - LOG10;
+    if (lane == 3 || lane == 4) t = (v < 0.0) ? -INFINITY : -v / k0 - log_k0;
+    if (lane == 1 || lane == 6 || lane == 7) t = -0.5 * v * v - HALF_LOG_2PI;
+    if (lane >= LR_DD_NPAR) t = 0.0;
+    double p = lr_wave_sum(t);
+    if (origin + lr_bcast(v, 2) >= present) p = -INFINITY;
+    return p;
+}
+
+// Lookup tables (Keiding form, lr_bin_terms model >= 2) of one parameter vector straight from its per-bin rates;
+// same table formats as lr_build_tables_segments_wave (general double2 entries, or unit-resolution entries `es`
+// doubles apart).  Lane l owns bins [l*P, (l+1)*P), P <= LR_DD_MAXP.
+#define LR_DD_MAXP 4
+__device__ inline void lr_dd_build_tables_wave(const lr_dd_params& p, const double* __restrict__ DT, int m_birth,
+                                               int m_death, int n_bins, int H, double2* __restrict__ tab, int lane,
+                                               bool unit, double fs0, double fe0, int es) {
+    double* tabd = reinterpret_cast<double*>(tab);
+    const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
+    const int b0 = min(lane * P, n_bins), b1 = min(b0 + P, n_bins);
+    double br[LR_DD_MAXP], dr[LR_DD_MAXP];
+    double sumR = 0.0;
+#pragma unroll
+    for (int i = 0; i < LR_DD_MAXP; ++i) {
+        const int b = b0 + i;
+        br[i] = 1.0, dr[i] = 1.0;
+        if (i < P && b < b1) {
+            double ni, fr;
+            lr_dd_bin_rates(p, (double)b, DT[b], m_birth, m_death, &br[i], &dr[i], &ni, &fr);
+            sumR += br[i] + dr[i];
+        }
+    }
+    double totR;
+    double cum = lr_wave_exclusive_scan(sumR, lane, &totR);
+#pragma unroll
+    for (int i = 0; i < LR_DD_MAXP; ++i) {
+        const int b = b0 + i;
+        if (i < P && b < b1) {
+            const double logB = log(br[i]), logD = log(dr[i]), R = br[i] + dr[i];
+            if (unit) {
+                tabd[es * (b + 1)] = (logB + cum) + fs0 * R;
+                tabd[es * (H + b + 1)] = (logD - cum) - fe0 * R;
+            } else {
+                tab[b + 1] = make_double2(logB + cum, R);
+                tab[H + b + 1] = make_double2(logD - cum, -R);
+            }
+            cum += R;
+        }
+    }
+    if (lane == 0) {
+        if (unit) {
+            tabd[0] = 0.0, tabd[es * H] = 0.0;
+            tabd[es * (n_bins + 1)] = totR, tabd[es * (H + n_bins + 1)] = -totR;
+        } else {
+            tab[0] = make_double2(0.0, 0.0);
+            tab[H] = make_double2(0.0, 0.0);
+            tab[n_bins + 1] = make_double2(totR, 0.0);
+            tab[H + n_bins + 1] = make_double2(-totR, 0.0);
+        }
+    }
+}

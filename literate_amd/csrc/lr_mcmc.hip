@@ -9,6 +9,7 @@
 #include <new>
 
 #include "lr_chain.h"
+#include "lr_dd.h"
 #include "lr_internal.h"
 #include "lr_scan.h"
 
@@ -145,6 +146,7 @@ struct lr_step_args {
     const double* br_length;
     double log_T;           // log(end_time - start_time)
     double mult_l;          // 2 log d of the multiplier proposal (LRF:169)
+    const double* dd_consts; // DD sampler: {max(DT), log max(DT)} = PRIOR_K0_L (DD:45) and its log
     int tab_stride, n_cls, tiles, H, unit, cb;
 };
 
@@ -655,6 +657,102 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
 }
 
 // the step of chain c with its state in global memory: load, sum the tile partials in tile order, step, store
+
+// ---- DDRate sampler: one iteration of DDRate.py's loop (DD:194-239) for one chain ------------------------
+// Same pipeline position as lr_chain_step_core: decide the pending proposal with the scanned likelihood, write the
+// trace row, propose the next parameter vector, evaluate its prior and build its lookup tables.
+// State: lane j < 8 of st.L = accepted parameter j, of st.pL = proposed parameter j; scalars in st.sc / st.isc.
+__device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
+                                                double lik_sum, double2* table, int table_es = 2) {
+    const lr_mcmc_config& cfg = a.cfg;
+    const int C = cfg.n_chains;
+    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
+    const double origin = cfg.t0, present = cfg.dd_present;
+    const double k0 = a.dd_consts[0], log_k0 = a.dd_consts[1];
+    double A = st.L;
+    const double P0 = st.pL;
+    const double sc = st.sc;
+    const int isc = st.isc;
+    double likA = lr_bcast(sc, LR_S_LIKA), priorA = lr_bcast(sc, LR_S_PRIORA), lik_p = lr_bcast(sc, LR_S_LIK_P);
+    uint64_t it = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_HI) << 32);
+    int n_acc = lr_bcast_i(isc, LR_I_ACCEPTED);
+    uint64_t next_sample = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_HI) << 32);
+    int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
+    if (mode == 1) {
+        likA = lik_sum;                                                        // DD:184-186
+        priorA = lr_dd_prior(A, origin, present, k0, log_k0, lane);            // DD:192
+    } else {
+        const double hasting = lr_bcast(sc, LR_S_HASTING), priorP = lr_bcast(sc, LR_S_PRIOR_P);
+        const double u = lr_pair(rng, it, LR_P_DD_ACCEPT, 0).a;
+        const double lik = lik_sum;
+        const bool ok = ((lik - likA) + (priorP - priorA) + hasting > log(u)) || it == 0;   // DD:211
+        lik_p = lik;
+        if (ok) A = P0, likA = lik, priorA = priorP, n_acc += 1;
+        if (it == next_sample) {                                               // DD:221
+            const int slot = trace_slot;
+            trace_slot += 1;
+            next_sample += (uint64_t)cfg.s_freq;
+            if (slot < cfg.n_trace_slots) {
+                double* row = a.trace + ((size_t)slot * C + c) * LR_TRACE_W;
+                double h = __longlong_as_double(0x7ff8000000000000LL);
+                if (lane == 0) h = (double)it;
+                if (lane == 1) h = likA + priorA;
+                if (lane == 2) h = likA;
+                if (lane == 3) h = priorA;
+                const double Aj = __shfl(A, (lane - 4) & (LR_WAVE - 1));        // rare path (sampling only)
+                if (lane >= 4 && lane < 4 + LR_DD_NPAR) h = Aj;
+                for (int j = lane; j < LR_TRACE_W; j += LR_WAVE) row[j] = (j == lane) ? h : __longlong_as_double(0x7ff8000000000000LL);
+            }
+        }
+        it += 1;
+    }
+    // ---- propose iteration `it` (DD:195-207) ----
+    double P = A, hasting = 0.0;
+    int move_kind;
+    const lr_u2 rr = lr_pair(rng, it, LR_P_DD_MOVE, 0);
+    if (rr.b < 0.1 && (cfg.m_birth == 2 || cfg.m_death == 2)) {
+        // update_sliding_win(x0, m=0, M=PRESENT, d=1.5) (lib:124-128)
+        double ii = lr_bcast(A, 2) + (lr_pair(rng, it, LR_P_DD_SLIDE, 0).a - .5) * 1.5;
+        if (ii > present) ii = present - (ii - present);
+        ii = fabs(ii);
+        if (lane == 2) P = ii;
+        if (cfg.m_death == -1) {
+            const double z = lr_normal(rng, it, LR_P_DD_SLIDE, 1);              // update_normal_nobound(k, d=0.2) (lib:136-138)
+            if (lane == 1) P = A + z * 0.2;
+        }
+        move_kind = 1;
+    } else {
+        const double f = lr_dd_update_freq(cfg.m_birth, cfg.m_death, lane);
+        const lr_u2 d = lr_pair(rng, it, LR_P_DD_MULT, lane);
+        hasting = lr_wave_multiplier(P, LR_DD_NPAR, d.a < f, d.b, a.mult_l, lane);   // lib:156-165
+        move_kind = 0;
+    }
+    const double priorP = lr_dd_prior(P, origin, present, k0, log_k0, lane);
+    const lr_dd_params pp = lr_dd_unpack(P);
+    lr_dd_build_tables_wave(pp, a.br_length, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, a.unit != 0,
+                            cfg.frac_birth, cfg.frac_death, table_es);
+    st.L = A, st.pL = P;
+    {
+        double so = 0.0;
+        so = (lane == LR_S_LIKA) ? likA : so;
+        so = (lane == LR_S_PRIORA) ? priorA : so;
+        so = (lane == LR_S_HASTING) ? hasting : so;
+        so = (lane == LR_S_PRIOR_P) ? priorP : so;
+        so = (lane == LR_S_LIK_P) ? lik_p : so;
+        st.sc = so;
+        int io = 0;
+        io = (lane == LR_I_KL || lane == LR_I_KM || lane == LR_I_PKL || lane == LR_I_PKM) ? LR_DD_NPAR : io;
+        io = (lane == LR_I_IT_LO) ? (int)(uint32_t)it : io;
+        io = (lane == LR_I_IT_HI) ? (int)(uint32_t)(it >> 32) : io;
+        io = (lane == LR_I_ACCEPTED) ? n_acc : io;
+        io = (lane == LR_I_MOVE) ? move_kind : io;
+        io = (lane == LR_I_NEXT_LO) ? (int)(uint32_t)next_sample : io;
+        io = (lane == LR_I_NEXT_HI) ? (int)(uint32_t)(next_sample >> 32) : io;
+        io = (lane == LR_I_SLOT) ? trace_slot : io;
+        st.isc = io;
+    }
+}
+
 __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mode, int c, int lane,
                                                    lr_seg_scratch* scratch_p) {
     LR_SSTAMP(0);
@@ -665,7 +763,8 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     double part = 0.0;
     for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * a.cfg.n_chains + c];
     const double lik_sum = lr_wave_sum(part);
-    lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c));
+    if (a.cfg.sampler == 1) lr_dd_step_core(st, a, mode, c, lane, lik_sum, lr_chain_table(a, c));
+    else lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c));
     lr_chain_store(st, S, I, lane);
 }
 
@@ -790,7 +889,8 @@ __device__ __attribute__((noinline)) void lr_persist_step(const lr_step_args* a,
                                                           double lik, double2* table, int table_es) {
     lr_chain_regs st;
     lr_chain_load(st, st_f64, st_i32, lane);
-    lr_chain_step_core(st, *a, 0, c, lane, scratch, lik, table, table_es);
+    if (a->cfg.sampler == 1) lr_dd_step_core(st, *a, 0, c, lane, lik, table, table_es);
+    else lr_chain_step_core(st, *a, 0, c, lane, scratch, lik, table, table_es);
     lr_chain_store(st, st_f64, st_i32, lane);
 }
 
@@ -970,6 +1070,28 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
     double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
     int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
     const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
+    if (cfg.sampler == 1) {
+        // DDRate initial parameter vector (DD:151-161) or the caller's [C, kmax] rows; its tables, so that the first
+        // scan evaluates likA (DD:184-186)
+        double A = 0.0;
+        if (L0) {
+            if (lane < LR_DD_NPAR) A = L0[(size_t)c * kmax + lane];
+        } else {
+            const double x0 = cfg.dd_present - (cfg.t0 + cfg.dd_present) / 2.0;       // PRESENT - np.mean([ORIGIN, PRESENT])
+            const double init[LR_DD_NPAR] = {0.5, 1.5, x0, 10.0, 20000.0, cfg.dd_init_death, 1.0, 1.0};
+            if (lane < LR_DD_NPAR) A = init[lane];
+        }
+        const lr_dd_params pp = lr_dd_unpack(A);
+        lr_dd_build_tables_wave(pp, a.br_length, cfg.m_birth, cfg.m_death, n_bins, a.H, lr_chain_table(a, c), lane,
+                                a.unit != 0, cfg.frac_birth, cfg.frac_death, 2);
+        for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = 0.0;
+        for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = 0;
+        S[LR_ROW_L * LR_ROW + lane] = A, S[LR_ROW_PL * LR_ROW + lane] = A;
+        int io = 0;
+        if (lane == LR_I_KL || lane == LR_I_PKL || lane == LR_I_KM || lane == LR_I_PKM) io = LR_DD_NPAR;
+        I[LR_IROW_SCALARS * LR_ROW + lane] = io;
+        return;
+    }
     double L = 0.0, M = 0.0, tL = 0.0, tM = 0.0;
     int KL = 1, KM = 1;
     if (L0) {
@@ -1115,6 +1237,13 @@ static int lr_check_cfg(const lr_mcmc_config* cfg) {
     if (cfg->model < 0 || cfg->model > 3) return LR_ERR_MODEL;
     if (cfg->t0 != floor(cfg->t0)) return LR_ERR_T0;
     if (!(cfg->end_time > cfg->start_time)) return LR_ERR_SIZE;
+    if (cfg->sampler < 0 || cfg->sampler > 1) return LR_ERR_MODEL;
+    if (cfg->sampler == 1) {
+        if (cfg->model != LR_MODEL_KEIDING || cfg->m_birth < 0 || cfg->m_birth > 2 || cfg->m_death < -2 || cfg->m_death > 2)
+            return LR_ERR_MODEL;
+        if (cfg->n_bins > LR_DD_MAXP * LR_WAVE) return LR_ERR_SIZE;
+        if (!(cfg->dd_present > cfg->t0)) return LR_ERR_SIZE;
+    }
     return LR_OK;
 }
 
@@ -1129,7 +1258,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     long long o = 0;
     out->state_f64 = o, o += lr_align_up64(C * LR_STATE_ROWS * LR_ROW * 8, 256);
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
-    out->bin_consts = o, o += lr_align_up64((long long)cfg->n_bins * 8, 256);
+    out->bin_consts = o, o += lr_align_up64((long long)(cfg->n_bins + 2) * 8, 256);   // log(br) + the DD constants
     out->lineage_idx = o, o += lr_align_up64(lr_align_up64(cfg->n_lineages, 8) * 2, 256);
     out->args_blob = o, o += 1024;   // lr_step_args of the persistent kernel
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
@@ -1156,7 +1285,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     lr_mcmc_layout lay;
     int rc = lr_mcmc_query_layout(cfg, &lay);
     if (rc) return rc;
-    if ((cfg->model == LR_MODEL_BD || cfg->model == LR_MODEL_ID) && !br_length) return LR_ERR_MODEL;
+    if ((cfg->model == LR_MODEL_BD || cfg->model == LR_MODEL_ID || cfg->sampler == 1) && !br_length) return LR_ERR_MODEL;
     if (lay.total_bytes > workspace_bytes) return LR_ERR_WORKSPACE;
     lr_engine* e = new (std::nothrow) lr_engine();
     if (!e) return (int)hipErrorOutOfMemory;
@@ -1198,6 +1327,7 @@ static lr_step_args lr_make_args(const lr_engine* e) {
     a.state_f64 = (double*)(e->ws + e->lay.state_f64);
     a.state_i32 = (int*)(e->ws + e->lay.state_i32);
     a.log_br = (const double*)(e->ws + e->lay.bin_consts);
+    a.dd_consts = a.log_br + e->cfg.n_bins;
     a.log_T = log(e->cfg.end_time - e->cfg.start_time);
     a.mult_l = 2.0 * log(LR_MULT_D);
     a.tables = (double2*)(e->ws + e->lay.tables);
@@ -1228,10 +1358,22 @@ static int lr_enqueue_step_range(const lr_engine* e, const lr_step_args& a, int 
     return (int)hipGetLastError();
 }
 
+// DD sampler: PRIOR_K0_L = np.max(DT) (DD:45) and its logarithm, behind the n_bins entries of bin_consts
+__global__ void lr_dd_consts_kernel(const double* __restrict__ DT, int n_bins, double* __restrict__ out) {
+    const int lane = threadIdx.x;
+    double m = -INFINITY;
+    for (int b = lane; b < n_bins; b += LR_WAVE) m = fmax(m, DT[b]);
+    m = -lr_wave_min(-m);
+    if (lane == 0) out[0] = m, out[1] = log(m);
+}
+
 // everything in the workspace that holds device addresses or derives from the data alone
 static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipStream_t stream) {
     hipLaunchKernelGGL(lr_log_br_kernel, dim3((e->cfg.n_bins + 127) / 128), dim3(128), 0, stream, e->br_length,
                        e->cfg.n_bins, (double*)(e->ws + e->lay.bin_consts));
+    if (e->cfg.sampler == 1)
+        hipLaunchKernelGGL(lr_dd_consts_kernel, dim3(1), dim3(LR_WAVE), 0, stream, e->br_length, e->cfg.n_bins,
+                           (double*)(e->ws + e->lay.bin_consts) + e->cfg.n_bins);
     if (e->persistent) {
         static_assert(sizeof(lr_step_args) <= 1024, "args blob too small");
         hipLaunchKernelGGL(lr_store_args_kernel, dim3(1), dim3(64), 0, stream, a, (lr_step_args*)(e->ws + e->lay.args_blob));
@@ -1256,8 +1398,9 @@ extern "C" int lr_mcmc_restore(lr_engine* e, void* stream_) {
 extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, const double* tL, const double* tM,
                             const int32_t* KL, const int32_t* KM, int32_t kmax, void* stream_) {
     if (!e) return LR_ERR_NULL;
-    if (L && (!M || !tL || !tM || !KL || !KM)) return LR_ERR_NULL;
+    if (L && e->cfg.sampler == 0 && (!M || !tL || !tM || !KL || !KM)) return LR_ERR_NULL;
     if (L && (kmax < 1 || kmax > LR_KMAX)) return LR_ERR_SIZE;
+    if (L && e->cfg.sampler == 1 && kmax < LR_DD_NPAR) return LR_ERR_SIZE;
     hipStream_t stream = (hipStream_t)stream_;
     const lr_step_args a = lr_make_args(e);
     lr_prepare_constants(e, a, stream);

@@ -1,5 +1,6 @@
 // lr_stats.hip - sufficient statistics (A1/A2), rate-index expansion (A3) and DDRate rates (A12).
 #include "lr_device.h"
+#include "lr_dd.h"
 #include "lr_internal.h"
 
 // ------------------------------------------------------------------------------------------
@@ -154,27 +155,10 @@ __global__ void lr_dd_rates_kernel(const double* __restrict__ args, const double
     const int c = blockIdx.y;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_bins) return;
-    const double* a = args + (size_t)c * 8;
-    const double l_max = a[0], k = a[1], x0 = a[2], div_0 = a[3], L = a[4], m_max = a[5], nuB = a[6], nuD = a[7];
-    const double x = (double)b, dt = DT[b];
-    const double SMALL = 0.000000000000001;
-    double niche = 1.0, frac = 1.0, br, dr;
-    if (m_birth == 0) {
-        br = 1.0 * l_max;
-    } else {
-        niche = (m_birth == 1) ? 1.0 * (L + div_0) : div_0 + L / pow(1.0 + exp(-k * (x - x0)), 1.0 / 1.0);
-        frac = dt / niche;
-        br = l_max - l_max * pow(frac, nuB);
-        if (br <= 0.0) br = SMALL;
-    }
-    if (m_death <= 0) {
-        dr = 1.0 * m_max;
-    } else {
-        niche = (m_death == 1) ? 1.0 * (L + div_0) : div_0 + L / pow(1.0 + exp(-k * (x - x0)), 1.0 / 1.0);
-        frac = dt / niche;
-        dr = m_max + m_max * pow(frac, nuD);
-        if (dr <= 0.0) dr = SMALL;
-    }
+    const double* a = args + (size_t)c * LR_DD_NPAR;
+    const lr_dd_params p{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]};
+    double niche, frac, br, dr;
+    lr_dd_bin_rates(p, (double)b, DT[b], m_birth, m_death, &br, &dr, &niche, &frac);   // shared with the engine's DD step
     const size_t o = (size_t)c * n_bins + b;
     birth[o] = br, death[o] = dr, niche_o[o] = niche, frac_o[o] = frac;
 }
@@ -272,6 +256,39 @@ extern "C" int lr_trend_rates(const double* args, const double* trend, int32_t n
     dim3 grid((n_bins + 127) / 128, n_chains);
     hipLaunchKernelGGL(lr_trend_rates_kernel, grid, dim3(128), 0, (hipStream_t)stream_, args, trend, n_bins,
                        const_birth, const_death, birth_rates, death_rates);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Binned Keiding halves, sum_b log(rate_b) * events_b - rate_b * DT_b (DD:86, 101; trend_rate.py:82, 89): the
+// `likelihood_birth` / `likelihood_death` log columns of the DDRate-family samplers (the engine itself scores the
+// proposal per lineage and carries only the sum).  One wave per parameter vector, fixed summation order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LR_WAVE) void lr_binned_keiding_kernel(const double* __restrict__ birth,
+                                                                    const double* __restrict__ death,
+                                                                    const long long* __restrict__ n_spec,
+                                                                    const long long* __restrict__ n_exti,
+                                                                    const double* __restrict__ DT, int n_bins,
+                                                                    double* __restrict__ out_birth,
+                                                                    double* __restrict__ out_death) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double sb = 0.0, sd = 0.0;
+    for (int b = lane; b < n_bins; b += LR_WAVE) {
+        const double lb = birth[(size_t)c * n_bins + b], ld = death[(size_t)c * n_bins + b];
+        sb += log(lb) * (double)n_spec[b] - lb * DT[b];
+        sd += log(ld) * (double)n_exti[b] - ld * DT[b];
+    }
+    sb = lr_wave_sum(sb), sd = lr_wave_sum(sd);
+    if (lane == 0) out_birth[c] = sb, out_death[c] = sd;
+}
+
+extern "C" int lr_binned_keiding(const double* birth_rates, const double* death_rates, const int64_t* n_spec,
+                                 const int64_t* n_exti, const double* DT, int32_t n_bins, int32_t n_chains,
+                                 double* out_birth, double* out_death, void* stream_) {
+    if (!birth_rates || !death_rates || !n_spec || !n_exti || !DT || !out_birth || !out_death) return LR_ERR_NULL;
+    if (n_bins < 1 || n_chains < 1) return LR_ERR_SIZE;
+    hipLaunchKernelGGL(lr_binned_keiding_kernel, dim3(n_chains), dim3(LR_WAVE), 0, (hipStream_t)stream_, birth_rates,
+                       death_rates, (const long long*)n_spec, (const long long*)n_exti, DT, n_bins, out_birth, out_death);
     return (int)hipGetLastError();
 }
 

@@ -13,11 +13,13 @@ from . import _hip, ops
 class ChainEngine:
     def __init__(self, ts, te, n_chains, model=0, seed=1, const_rates=0, const_death_rate=0, use_rate_HP=1,
                  poisson_HP=0.0, update_fraction=0.75, s_freq=1000, n_trace_slots=0, chain_offset=0,
-                 device=None, stats=None, sort_lineages=True, unit_resolution=None, engine="auto"):
+                 device=None, stats=None, sort_lineages=True, unit_resolution=None, engine="auto", dd=None):
         """ts/te: lineage birth/death times (death_jitter already added, LRF:471).
 
         stats: optional (t0, n_bins, br_length) if the caller already binned the data; otherwise the
-        binning kernel runs here (LRF:515-523)."""
+        binning kernel runs here (LRF:515-523).
+        dd: None = the runMCMC sampler (LRF:216-373); dict(m_birth, m_death, present, init_death) = the DDRate.py
+        sampler (DD:124-241) on create_bins statistics: stats = (ORIGIN, N_TIME_BINS, DT), model 2."""
         torch = _hip.require_gpu()
         self.lib = _hip.load()
         self.device = torch.device(device or "cuda")
@@ -61,12 +63,16 @@ class ChainEngine:
             update_fraction=float(update_fraction), t0=self.t0, start_time=self.start_time, end_time=self.end_time,
             seed=int(seed), chain_offset=int(chain_offset), unit_resolution=int(self.unit_resolution),
             engine_mode={"auto": 0, "launch": 1, "persistent": 2, "persistent4": 3}[engine],
-            frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0)
+            frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0,
+            sampler=0 if dd is None else 1, m_birth=0 if dd is None else int(dd["m_birth"]),
+            m_death=0 if dd is None else int(dd["m_death"]), dd_present=0.0 if dd is None else float(dd["present"]),
+            dd_init_death=0.0 if dd is None else float(dd.get("init_death", 0.1)))
+        self.dd = dd
         self.layout = _hip.McmcLayout()
         _hip.check(self.lib.lr_mcmc_query_layout(C.byref(self.cfg), C.byref(self.layout)), "lr_mcmc_query_layout")
         self.workspace = torch.zeros(self.layout.total_bytes, dtype=torch.uint8, device=self.device)
         handle = C.c_void_p()
-        br_ptr = _hip.ptr(self.br_length) if model in (0, 1) else None
+        br_ptr = _hip.ptr(self.br_length) if (model in (0, 1) or dd is not None) else None
         _hip.check(self.lib.lr_mcmc_create(C.byref(self.cfg), _hip.ptr(self.ts), _hip.ptr(self.te), br_ptr,
                                            _hip.ptr(self.workspace), self.workspace.numel(), C.byref(handle)),
                    "lr_mcmc_create")
@@ -104,6 +110,13 @@ class ChainEngine:
         import torch
         if L is None:
             rc = self.lib.lr_mcmc_init(self.handle, None, None, None, None, None, None, 0, _hip.stream_ptr())
+        elif self.dd is not None:
+            # DDRate sampler: L = [C, 8] parameter vectors [l_max,k,x0,div_0,L,m_max,nuB,nuD] (DD:161)
+            args = np.zeros((self.n_chains, _hip.LR_KMAX))
+            args[:, :8] = np.asarray(L, dtype=float).reshape(self.n_chains, 8)
+            self._init_keep = [ops._dev(args, torch.float64, self.device)]
+            rc = self.lib.lr_mcmc_init(self.handle, _hip.ptr(self._init_keep[0]), None, None, None, None, None,
+                                       _hip.LR_KMAX, _hip.stream_ptr())
         else:
             kmax = _hip.LR_KMAX
             Ls = np.zeros((self.n_chains, kmax)); Ms = np.zeros((self.n_chains, kmax))

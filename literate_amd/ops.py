@@ -185,6 +185,25 @@ def trend_rates(args, trend, const_birth=False, const_death=False):
     return tuple(outs)
 
 
+def binned_keiding(birth, death, n_spec, n_exti, DT):
+    """(birth_lik[C], death_lik[C]) = sum_b log(rate) * events - rate * DT (DD:86, 101) for C per-bin rate vectors."""
+    torch = _torch()
+    lib = _hip.load()
+    birth, death, DT = _dev(birth, torch.float64), _dev(death, torch.float64), _dev(DT, torch.float64)
+    n_spec, n_exti = _dev(n_spec, torch.int64), _dev(n_exti, torch.int64)
+    if birth.dim() == 1:
+        birth, death = birth[None, :], death[None, :]
+    C, n_bins = birth.shape
+    if death.shape != birth.shape or DT.numel() != n_bins or n_spec.numel() != n_bins or n_exti.numel() != n_bins:
+        raise ValueError("shape mismatch")
+    ob = torch.empty(C, dtype=torch.float64, device=birth.device)
+    od = torch.empty_like(ob)
+    rc = lib.lr_binned_keiding(_hip.ptr(birth), _hip.ptr(death), _hip.ptr(n_spec), _hip.ptr(n_exti), _hip.ptr(DT),
+                               n_bins, C, _hip.ptr(ob), _hip.ptr(od), _hip.stream_ptr())
+    _hip.check(rc, "lr_binned_keiding")
+    return ob, od
+
+
 def debug_draws(seed, chain, it, purpose, idx, kind, shape):
     """Device RNG probe: kind 0 u_a, 1 u_b, 2 normal, 3 gamma(shape) at (it, purpose, idx)."""
     torch = _torch()

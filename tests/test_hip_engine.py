@@ -397,3 +397,40 @@ def test_checkpoint_resume_is_bit_identical(G, tmp_path, engine, C):
         other.load(path)
     for e in (full, b, other):
         e.close()
+
+
+@pytest.mark.parametrize("mb,md,engine", [(2, 2, "auto"), (2, 2, "launch"), (2, 2, "persistent4"), (1, 1, "auto"),
+                                          (0, 0, "auto"), (2, -1, "auto"), (2, 0, "launch"), (1, 2, "auto"),
+                                          (2, -2, "auto")])
+def test_ddrate_sampler_follows_oracle(G, golden_dir, mb, md, engine):
+    """DDRate.py's sampler (DD:124-241) on the engine (lr_mcmc_config.sampler = 1), metal_bands, 11 chains: every
+    sampled log row (scalars AND the 4 x n_bins per-bin columns) against the oracle loop fed the same Philox draws.
+    The oracle scores with the reference's binned likelihood, the engine per lineage."""
+    from literate_amd.ddrate import DDRateEngine
+    from oracle import dd_mcmc_oracle as ddo
+    D = np.load(os.path.join(golden_dir, "ddrate.npz"))
+    origin, present, _ = D["meta"]
+    ts, te = G["metal_bands/lib_ts"], G["metal_bands/lib_te"]
+    n_it, seed, C, off = 600, 909, 11, 5
+    eng = DDRateEngine(ts, te, origin, present, C, m_birth=mb, m_death=md, seed=seed, s_freq=3,
+                       n_trace_slots=n_it // 3, chain_offset=off, engine=engine)
+    assert np.array_equal(eng.n_spec, D["N_SPEC"]) and np.array_equal(eng.DT, D["DT"])
+    if engine != "auto":
+        assert (eng.layout.persistent > 0) == (engine != "launch")
+    eng.init(); eng.steps(250); eng.steps(n_it - 250)
+    with np.errstate(all="ignore"):
+        emp = (D["N_SPEC"] / D["DT"], D["N_EXTI"] / D["DT"])
+    moved = 0
+    for c in (0, 1, 6, 10):
+        ref = ddo.run_dd_mcmc(D["N_SPEC"], D["N_EXTI"], D["DT"], D["TIME_RANGE"], origin, present, mb, md,
+                              ddo.PhiloxDraws(seed, off + c), n_it, 3, emp=emp)
+        got = eng.log_rows(c, emp=emp)
+        assert len(got) == len(ref) == n_it // 3
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert g[0] == r[0]
+            assert np.allclose(g[1:-3], r[1:-3], rtol=1e-9, atol=1e-9, equal_nan=True), (c, i, g[:14], r[:14])
+            assert np.allclose(g[-3:], r[-3:], rtol=1e-7, atol=1e-9, equal_nan=True)
+        moved += len(set(np.round(np.array(ref)[:, 2], 6)))
+    assert moved > 4 * 30
+    assert np.all(eng.snapshot()["it"] == n_it)
+    eng.close()

@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,traj]
+    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,shipped,traj]
     python tests/golden/make_chains.py <dataset> <model> <n> <s> <chains>   # long reference chains
 
 The reference is executed unmodified: LiteRateForward.py / DDRate.py through
@@ -370,6 +370,21 @@ def make_dd_trajectories(work):
     np.savez_compressed(os.path.join(HERE, "dd_trajectories.npz"), **out)
 
 
+def make_shipped(work):
+    """Data files the reference ships with its example run: the single-run _div.log statistics
+    and the first rows of the shipped DDRate log with its header line."""
+    base = os.path.join(REF, "example_data/metal_bands/single_run")
+    div = np.loadtxt(os.path.join(base, "metal_bands_1_div.log"), skiprows=1)
+    np.savez_compressed(os.path.join(HERE, "shipped_metal_bands.npz"), sp=div[:, 0].astype(np.int64),
+                        ex=div[:, 1].astype(np.int64), br=div[:, 2])
+    log = os.path.join(base, "DD_Rate/all_bands_1_8898_LDDN_MDDN.log")
+    with open(log) as f:
+        header = f.readline().rstrip("\n")
+    rows = np.loadtxt(log, skiprows=1)[:12]
+    np.savez_compressed(os.path.join(HERE, "shipped_ddrate_log.npz"), header=np.array(header), rows=rows)
+    print("shipped: div", div.shape, "ddrate rows", rows.shape)
+
+
 def parse_logs(logdir, stem):
     mc = np.loadtxt(os.path.join(logdir, stem + "_mcmc.log"), skiprows=1, ndmin=2)
     rows = {}
@@ -423,7 +438,7 @@ def main():
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="lr_golden_")
-    steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps, ddtraj=make_dd_trajectories,
+    steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps, ddtraj=make_dd_trajectories, shipped=make_shipped,
                  traj=make_trajectories)
     for name, fn in steps.items():
         if args.only and name not in args.only.split(","):

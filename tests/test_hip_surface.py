@@ -151,6 +151,50 @@ def test_cli_checkpoint_resume(G, tmp_path):
     shutil.rmtree(logdir)
 
 
+def test_ddrate_cli_end_to_end_and_shipped_log_kat(G, golden_dir, tmp_path):
+    """python DDRate.py -d <metal_bands> ...: the log has the reference's header (the shipped DDRate log's own header
+    line) and its rows equal the oracle loop's (Philox draws); the HIP rate / likelihood-half kernels reproduce the
+    shipped log's per-bin columns and likelihood halves from its logged parameters."""
+    from literate_amd import ops
+    from oracle import dd_mcmc_oracle as ddo
+    from test_oracle_golden import _shipped_ddrate_rows
+    rows, s, header = _shipped_ddrate_rows(golden_dir)
+    args = np.array([r[0] for r in rows])
+    b, d, ni, nf = ops.dd_rates(args, s["br"], 2, 2)
+    lb, ld = ops.binned_keiding(b, d, s["sp"], s["ex"], s["br"])
+    for i, (_, head, cols, _) in enumerate(rows):
+        assert np.allclose(b[i].cpu().numpy(), cols[0], rtol=2e-7) and np.allclose(d[i].cpu().numpy(), cols[1], rtol=2e-7)
+        assert np.allclose(ni[i].cpu().numpy(), cols[2], rtol=2e-7) and np.allclose(nf[i].cpu().numpy(), cols[3], rtol=2e-7)
+        assert float(lb[i]) == pytest.approx(head[3], rel=1e-7) and float(ld[i]) == pytest.approx(head[4], rel=1e-7)
+    pb, pd_ = ops.binned_keiding(np.array([r[2][0] for r in rows]), np.array([r[2][1] for r in rows]), s["sp"], s["ex"], s["br"])
+    assert np.allclose(pb.cpu().numpy(), [r[1][3] for r in rows], rtol=2e-12)
+    assert np.allclose(pd_.cpu().numpy(), [r[1][4] for r in rows], rtol=2e-12)
+    # the CLI on the metal_bands lineages (AD years; te carries the 0.5 jitter in the fixture)
+    D = np.load(os.path.join(golden_dir, "ddrate.npz"))
+    ts, te = G["metal_bands/lib_ts"], G["metal_bands/lib_te"] - 0.5
+    data = tmp_path / "bands.tsv"
+    with open(data, "w") as f:
+        f.write("id\tts\tte\n")
+        for i, (a, c) in enumerate(zip(ts, te)):
+            f.write("%d\t%g\t%g\n" % (i, a, c))
+    cmd = [sys.executable, os.path.join(ROOT, "DDRate.py"), "-d", str(data), "-n", "300", "-s", "10", "-p", "100",
+           "-seed", "21", "--chains", "2"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, timeout=300)
+    origin, present, _ = D["meta"]
+    with np.errstate(all="ignore"):
+        emp = (D["N_SPEC"] / D["DT"], D["N_EXTI"] / D["DT"])
+    for c in range(2):
+        path = tmp_path / ("bands_21_LDDN_MDDN_c%d.log" % c)
+        lines = open(path).read().splitlines()
+        assert lines[0] == header
+        got = np.array([[float(v) for v in l.split("\t")] for l in lines[1:]])
+        ref = np.array(ddo.run_dd_mcmc(D["N_SPEC"], D["N_EXTI"], D["DT"], D["TIME_RANGE"], origin, present, 2, 2,
+                                       ddo.PhiloxDraws(21, c), 300, 10, emp=emp))
+        assert got.shape == ref.shape == (30, 145)
+        assert np.allclose(got[:, :-3], ref[:, :-3], rtol=1e-9, atol=1e-9)
+        assert np.allclose(got[:, -3:], ref[:, -3:], rtol=1e-7, atol=1e-9, equal_nan=True)
+
+
 def test_cli_cfg1_fixed_two_shifts(G, tmp_path):
     """BASELINE.json configs[0]: example_dataTBP, 1 chain, fixed 2 rate shifts (-const_rates 1 with a
     3-rate initial state, SURVEY 8c 'config-1 note').  K stays (3, 3), shift times never move (A9), the

@@ -152,6 +152,40 @@ def test_shipped_metal_bands_log_row_kat(golden_dir):
     assert v == pytest.approx(-621495.769068, rel=1e-11)
 
 
+def _shipped_ddrate_rows(golden_dir):
+    """(args as the sampler holds them, logged columns) of the shipped DDRate log rows; ORIGIN of that run = 1968,
+    its DT is embedded as niche_i * nicheFrac_i, its N_SPEC / N_EXTI are the shipped _div.log's."""
+    d = np.load(os.path.join(golden_dir, "shipped_ddrate_log.npz"))
+    s = np.load(os.path.join(golden_dir, "shipped_metal_bands.npz"))
+    n = len(s["sp"])
+    out = []
+    for r in d["rows"][1:]:
+        head = r[:14]
+        cols = [r[14 + k * n:14 + (k + 1) * n] for k in range(4)]
+        args = np.array([head[6], head[7], head[8] - 1968.0, head[9], head[10] - head[9], head[11], head[12], head[13]])
+        out.append((args, head, cols, cols[2] * cols[3]))
+    return out, s, str(d["header"])
+
+
+def test_shipped_ddrate_log_kat(golden_dir):
+    """Shipped DDRate run (all_bands_1_8898_LDDN_MDDN.log): from each row's logged parameters the restated
+    likelihood_function gives the row's own l_i, m_i, niche_i, nicheFrac_i (print precision) and, on the shipped
+    _div.log statistics, its likelihood_birth / likelihood_death to all printed digits."""
+    rows, s, header = _shipped_ddrate_rows(golden_dir)
+    assert len(rows) == 11
+    for args, head, cols, DT in rows:
+        assert np.allclose(DT, s["br"], rtol=1e-6)
+        lik, b, d, ni, nf = lo.dd_likelihood_function(args, s["sp"], s["ex"], s["br"], np.arange(len(DT)).astype(float), 2, 2)
+        assert np.allclose(b, cols[0], rtol=2e-7) and np.allclose(d, cols[1], rtol=2e-7)
+        assert np.allclose(ni, cols[2], rtol=2e-7) and np.allclose(nf, cols[3], rtol=2e-7)
+        # halves evaluated on the PRINTED rates reproduce the printed halves to all digits
+        lb = np.sum(np.log(cols[0]) * s["sp"] - cols[0] * s["br"])
+        ld = np.sum(np.log(cols[1]) * s["ex"] - cols[1] * s["br"])
+        assert lb == pytest.approx(head[3], rel=2e-12) and ld == pytest.approx(head[4], rel=2e-12)
+        assert lik[0] == pytest.approx(head[3], rel=1e-7) and lik[1] == pytest.approx(head[4], rel=1e-7)
+        assert head[2] == pytest.approx(head[3] + head[4], rel=1e-11) and head[1] == pytest.approx(head[2] + head[5], rel=1e-11)
+
+
 def test_add_remove_multiplier_scorers(P):
     pr = P["proposals"]
     for r in pr["add"]:

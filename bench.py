@@ -31,6 +31,8 @@ WORKLOADS = {
     # name: (lineages, n_bins, true shifts, chains per GPU, model)
     "cfg4": (100_000, 128, 20, 1024, 0),
     "cfg3": (10_000, 128, 20, 256, 0),
+    # BASELINE.json configs[4]: the DDRate.py sampler (model "dd": -m_birth 2 -m_death 2) on 50k lineages, 256 chains
+    "cfg5": (50_000, 64, 6, 256, "dd"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -116,8 +118,13 @@ def main():
         chains = args.chains
     ts, te, _ = synth.make_lineages(n_lin, n_bins=n_bins, n_shifts=n_shifts, seed=0)   # same on every rank
     n_slots = (args.steps + args.warmup) // args.sample_every + 2
-    eng = ChainEngine(ts, te, chains, model=model, seed=2026, s_freq=args.sample_every, n_trace_slots=n_slots,
-                      chain_offset=rank * chains)
+    if model == "dd":
+        from literate_amd.ddrate import DDRateEngine
+        eng = DDRateEngine(ts, te, float(ts.min()), float(te.max()), chains, m_birth=2, m_death=2, seed=2026,
+                           s_freq=args.sample_every, n_trace_slots=n_slots, chain_offset=rank * chains)
+    else:
+        eng = ChainEngine(ts, te, chains, model=model, seed=2026, s_freq=args.sample_every, n_trace_slots=n_slots,
+                          chain_offset=rank * chains)
     # bring the device out of its idle power state before anything is measured (a cold MI355X runs the first
     # tens of milliseconds at a fraction of its clock): ~0.4 s of throw-away iterations, then a fresh init so
     # that exactly W warm-up + K timed iterations follow
@@ -170,6 +177,7 @@ def main():
         n_parts, pipelined = eng.layout.n_parts, bool(eng.layout.pipelined)
         persistent = bool(eng.layout.persistent)
         unit = bool(eng.unit_resolution)
+        H = eng.layout.table_stride // (1 if unit else 2)       # table half-stride the kernels are instantiated for
         # physical limiter: LDS gather rate, 256 B/clk/CU; bytes gathered per (lineage, chain) pair: 16 (unit) / 32
         lds_peak_pairs = 256 * 2.4e9 * 256 / (16 if unit else 32)
         scan_ms = eng.time_scan(reps=50)   # stand-alone tiled scan of all chains (launch-based engine's body)
@@ -183,7 +191,7 @@ def main():
             kernel_ms = region_kernel_ms / launches
             # layout.persistent == 2: four chains per 1024-thread block, the two pairs scanned in turn (each pair still
             # one pass over the packed indices per iteration); 1: two chains per 512-thread block
-            kname = "lr_persist4_kernel<136>" if eng.layout.persistent == 2 else "lr_persist_kernel<136>"
+            kname = ("lr_persist4_kernel<%d>" if eng.layout.persistent == 2 else "lr_persist_kernel<%d>") % H
             pairs_per_launch = float(n_ev) * n_lin * chains
             passes = n_ev * ((chains + 1) // 2)                     # lineage passes: one per block per iteration
             alg_bytes = 2.0 * n_lin * passes                        # bytes of lineage data the launch reads
@@ -197,7 +205,7 @@ def main():
             n_ev = 200
             ms_per_iter_ev = eng.timed_steps(n_ev) / n_ev
             kernel_ms = scan_ms
-            kname = ("lr_scan_unit_kernel<%d,136>" if unit else "lr_scan_fast_kernel<%d,136>") % cb
+            kname = ("lr_scan_unit_kernel<%d,%d>" if unit else "lr_scan_fast_kernel<%d,%d>") % (cb, H)
             pairs_per_launch = float(n_lin) * chains
             alg_bytes = conv_bytes = 16.0 * n_lin * (-(-chains // cb))
             cb_pass = cb
@@ -227,7 +235,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: synthetic %d lineages, %d unit bins, %d true shifts, %d chains per GPU, "
-                                   "model_BDI %d, RJ prior on shifts" % (args.workload, n_lin, n_bins, n_shifts, chains, model),
+                                   "%s" % (args.workload, n_lin, n_bins, n_shifts, chains,
+                                         "DDRate sampler -m_birth 2 -m_death 2" if model == "dd"
+                                         else "model_BDI %d, RJ prior on shifts" % model),
                        "lineages": n_lin, "chains_per_gpu": chains, "chains_total": total_chains,
                        "n_bins": eng.n_bins, "sample_every": args.sample_every,
                        "iters_per_s_per_chain": args.steps / elapsed},
@@ -251,8 +261,11 @@ def main():
                                     "tiled_scan_kernel_ms_all_chains": scan_ms}},
         }
         if not args.no_cpu_baseline and world == 1:
-            stats = dict(sp=eng.sp_events.cpu().numpy(), ex=eng.ex_events.cpu().numpy(), br=eng.br_length.cpu().numpy())
-            out["cpu_baseline"] = cpu_baseline(ts, te, eng.t0, eng.n_bins, stats, eng.start_time, eng.end_time)
+            if model == "dd":
+                out["cpu_baseline"] = None     # the CPU legs below time the RJ sampler's path; cfg4 carries them
+            else:
+                stats = dict(sp=eng.sp_events.cpu().numpy(), ex=eng.ex_events.cpu().numpy(), br=eng.br_length.cpu().numpy())
+                out["cpu_baseline"] = cpu_baseline(ts, te, eng.t0, eng.n_bins, stats, eng.start_time, eng.end_time)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -921,6 +921,9 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
     __syncthreads();
     const char* lbase = reinterpret_cast<const char*>(tab);
     const int grp = (blockIdx.x >> 8) & 1;
+#ifdef LR_DIAG
+    unsigned long long d_t0 = 0, d_t1 = 0, d_t2 = 0, d_scan = 0, d_red = 0, d_step = 0;
+#endif
     for (long long iter = 0; iter < n_iters; ++iter) {
         // Two blocks share a CU; the one dispatched second is the younger wave on every SIMD and loses issue
         // arbitration to its older neighbour all the time (+30 % per iteration, measured).  Both read the same

@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,shipped,traj]
+    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,shipped,cfg1,traj]
     python tests/golden/make_chains.py <dataset> <model> <n> <s> <chains>   # long reference chains
 
 The reference is executed unmodified: LiteRateForward.py / DDRate.py through
@@ -370,6 +370,36 @@ def make_dd_trajectories(work):
     np.savez_compressed(os.path.join(HERE, "dd_trajectories.npz"), **out)
 
 
+def make_cfg1(work):
+    """BASELINE.json configs[0]: example_dataTBP, ONE chain, fixed 2 rate shifts.  The CLI cannot start with
+    shifts (SURVEY 8c, config-1 note), so the reference's own runMCMC (LRF:216-373) is called through the runpy
+    harness with a 3-rate initial state and -const_rates 1; its three logs are kept row by row."""
+    d = tempfile.mkdtemp(dir=work)
+    seed, n, s_freq = 19, 6000, 10
+    g = run_cli("LiteRateForward.py", DATASETS["example_TBP"][0],
+                ["-TBP", "-n", "0", "-seed", str(seed), "-const_rates", "1", "-s", str(s_freq)], d)
+    fn = g["runMCMC"]
+    G_ = fn.__globals__
+    G_["n_iterations"] = n
+    start, end = G_["start_time"], G_["end_time"]
+    t = np.linspace(start, end, 4)
+    L0, M0 = np.array([0.4, 0.15, 0.6]), np.array([0.1, 0.3, 0.2])
+    np.random.seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fn([L0, M0, t + 0., t + 0.])
+    for name in ("mcmc_logfile", "sp_logfile", "ex_logfile"):
+        if name in G_:
+            G_[name].flush()
+    logdir = os.path.join(d, "literate_mcmc_logs")
+    stem = os.path.splitext(os.path.basename(DATASETS["example_TBP"][0]))[0] + "_BD"
+    mc, sp, ex = parse_logs(logdir, stem)
+    out = {"mcmc": mc, "sp": pack_rows(sp), "ex": pack_rows(ex), "meta": np.array([seed, n, s_freq], dtype=float),
+           "L0": L0, "M0": M0, "times0": t}
+    np.savez_compressed(os.path.join(HERE, "cfg1_fixed_shifts.npz"), **out)
+    print("cfg1_fixed_shifts.npz:", mc.shape)
+
+
 def make_shipped(work):
     """Data files the reference ships with its example run: the single-run _div.log statistics
     and the first rows of the shipped DDRate log with its header line."""
@@ -438,7 +468,7 @@ def main():
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="lr_golden_")
-    steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps, ddtraj=make_dd_trajectories, shipped=make_shipped,
+    steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps, ddtraj=make_dd_trajectories, shipped=make_shipped, cfg1=make_cfg1,
                  traj=make_trajectories)
     for name, fn in steps.items():
         if args.only and name not in args.only.split(","):

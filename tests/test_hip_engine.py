@@ -434,3 +434,36 @@ def test_ddrate_sampler_follows_oracle(G, golden_dir, mb, md, engine):
     assert moved > 4 * 30
     assert np.all(eng.snapshot()["it"] == n_it)
     eng.close()
+
+
+def test_cfg1_fixed_two_shifts_engine_vs_reference_run(G, golden_dir):
+    """BASELINE.json configs[0] on the device: example_dataTBP, fixed 2 rate shifts (3-rate initial state of the
+    golden reference run, const_rates=1).  (i) one chain follows the oracle loop (Philox draws) row by row from that
+    state; (ii) the posterior means of the six segment rates over 64 device chains agree with the reference's own
+    runMCMC chain (tests/golden/cfg1_fixed_shifts.npz) within Monte-Carlo error."""
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import mcmc_oracle as mo
+    T = np.load(os.path.join(golden_dir, "cfg1_fixed_shifts.npz"))
+    name, C, n_it, s = "example_TBP", 64, 6000, 10
+    eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=0, seed=5, const_rates=1, s_freq=s, n_trace_slots=n_it // s)
+    init = [[T["L0"]] * C, [T["M0"]] * C, [T["times0"]] * C, [T["times0"]] * C]
+    eng.init(*init)
+    eng.steps(n_it)
+    tr = eng.trace_rows()
+    stats = dict(sp=G[name + "/sp"], ex=G[name + "/ex"], br=G[name + "/br"])
+    start, end = G[name + "/start_end"]
+    with np.errstate(all="ignore"):
+        ref = mo.run_mcmc(stats, start, end, mo.Settings(model_BDI=0, const_rates=1), mo.PhiloxDraws(5, 0), n_it, s,
+                          init=(T["L0"], T["M0"], T["times0"], T["times0"]), k_max=32)
+    for i in range(n_it // s):
+        head, sp, ex = split_trace_row(tr[i, 0])
+        assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9), i
+        assert np.allclose(sp, ref["sp"][i], rtol=1e-10) and np.allclose(ex, ref["ex"][i], rtol=1e-10)
+    burn = 100
+    K = 32
+    dev_sp = tr[burn:, :, 13:13 + 3].reshape(-1, 3).mean(0)                    # rates are the first K_MAX entries
+    dev_ex = tr[burn:, :, 13 + (2 * K - 1):13 + (2 * K - 1) + 3].reshape(-1, 3).mean(0)
+    ref_sp, ref_ex = T["sp"][burn:, :3].mean(0), T["ex"][burn:, :3].mean(0)
+    assert np.all(tr[:, :, 6] == 3) and np.all(tr[:, :, 7] == 3)
+    assert np.allclose(dev_sp, ref_sp, rtol=0.12) and np.allclose(dev_ex, ref_ex, rtol=0.12), (dev_sp, ref_sp, dev_ex, ref_ex)
+    eng.close()

@@ -329,3 +329,30 @@ def test_dd_mcmc_loop_reproduces_reference_trajectory(golden_dir, key):
     assert np.allclose(rows[:, -3:], T[key + "/adequacy"], rtol=1e-7, atol=1e-9, equal_nan=True)
     assert np.allclose(rows[:25], T[key + "/full25"], rtol=1e-9, atol=1e-12, equal_nan=True)
     assert len(set(np.round(rows[:, 2], 6))) > 20          # the chain moved
+
+
+def test_cfg1_fixed_two_shifts_reproduces_reference_runMCMC(G, golden_dir):
+    """BASELINE.json configs[0] (example_dataTBP, 1 chain, fixed 2 rate shifts, CPU): the reference's own runMCMC
+    called with a 3-rate initial state and -const_rates 1 (tests/golden/make_golden.py::make_cfg1); the restated loop
+    started from the same state on the same MT19937 stream writes the same three logs.  K stays 3 and, update_times
+    being a no-op (A9), so do the shift times."""
+    T = np.load(os.path.join(golden_dir, "cfg1_fixed_shifts.npz"))
+    seed, n, s = [int(v) for v in T["meta"]]
+    name = "example_TBP"
+    stats = dict(sp=G[name + "/sp"], ex=G[name + "/ex"], br=G[name + "/br"])
+    start, end = G[name + "/start_end"]
+    np.random.seed(seed)
+    with np.errstate(all="ignore"):
+        out = mo.run_mcmc(stats, start, end, mo.Settings(model_BDI=0, const_rates=1), mo.NumpyLegacyDraws(), n, s,
+                          init=(T["L0"], T["M0"], T["times0"], T["times0"]), emp=(G[name + "/B_EMP"], G[name + "/D_EMP"]))
+    mc, ref = np.array(out["mcmc"]), T["mcmc"]
+    assert mc.shape == ref.shape == (n // s, 16)
+    assert np.all(ref[:, 6] == 3) and np.all(ref[:, 7] == 3)
+    assert np.array_equal(mc[:, [0, 6, 7]], ref[:, [0, 6, 7]])
+    assert np.allclose(mc[:, :13], ref[:, :13], rtol=1e-9, atol=1e-9)
+    assert np.allclose(mc[:, 13:], ref[:, 13:], rtol=1e-6, atol=1e-8, equal_nan=True)
+    for kind in ("sp", "ex"):
+        for i, row in enumerate(out[kind]):
+            assert np.allclose(row, T[kind][i, :len(row)], rtol=1e-10)
+            assert np.array_equal(row[3:], T["times0"][1:3])       # the two shift times never move
+    assert len(set(np.round(mc[:, 2], 6))) > 100

@@ -313,7 +313,7 @@ def test_cfg5_ddrate_50k_lineages_256_states():
                                                 (200, False, "auto"), (253, None, "auto"), (254, None, "auto"),
                                                 (60, None, "persistent4"), (134, None, "persistent4"),
                                                 (253, None, "persistent4"),
-                                                (300, None, "auto")])
+                                                (300, None, "auto"), (1000, None, "auto")])
 def test_engine_shapes_bins(n_bins, unit, engine):
     """Table half-stride classes (H = 72, 136, 264) and the generic kernel beyond them (n_bins = 300),
     unit-resolution and general tables: a few chains against the oracle loop on synthetic data."""
@@ -467,3 +467,29 @@ def test_cfg1_fixed_two_shifts_engine_vs_reference_run(G, golden_dir):
     assert np.all(tr[:, :, 6] == 3) and np.all(tr[:, :, 7] == 3)
     assert np.allclose(dev_sp, ref_sp, rtol=0.12) and np.allclose(dev_ex, ref_ex, rtol=0.12), (dev_sp, ref_sp, dev_ex, ref_ex)
     eng.close()
+
+
+@pytest.mark.parametrize("engine", ["auto", "launch"])
+def test_engine_tiny_input_three_lineages(engine):
+    """Smallest inputs: three lineages (one extant), 9 unit bins, chains 1..5 - the scan's tile, pair and quad paths all
+    run ragged.  Rows against the oracle loop."""
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import literate_oracle as lo
+    from oracle import mcmc_oracle as mo
+    ts = np.array([0.0, 2.0, 5.0])
+    te = np.array([4.5, 9.5, 7.5])
+    t0, sp, ex, br = lo.bin_events_cli(ts, te)
+    n_it, seed = 200, 3
+    for C in (1, 2, 5):
+        eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine)
+        assert eng.n_bins == len(sp) == 9
+        eng.init(); eng.steps(n_it)
+        tr = eng.trace_rows()
+        for c in range(C):
+            with np.errstate(all="ignore"):
+                ref = mo.run_mcmc(dict(sp=sp, ex=ex, br=br), ts.min(), te.max(), mo.Settings(model_BDI=0),
+                                  mo.PhiloxDraws(seed, c), n_it, 1, k_max=32)
+            for i in range(n_it):
+                head, s_row, e_row = split_trace_row(tr[i, c])
+                assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9, equal_nan=True), (C, c, i)
+        eng.close()

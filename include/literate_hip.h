@@ -133,6 +133,21 @@ int lr_binned_keiding(const double* birth_rates, const double* death_rates, cons
                       const int64_t* n_exti, const double* DT, int32_t n_bins, int32_t n_chains,
                       double* out_birth, double* out_death, void* stream);
 
+/* ---- discrete-time birth-death lineage simulator ----------------------------------
+ * The scheme of simulateRateABC.v2.py:103-234 and of notebook 4's Simulator / Population: n_start lineages born at
+ * step 0; at every step t < n_steps each living lineage draws one uniform r (Philox keyed by (seed, lineage slot),
+ * counter (t, 24, 0)): r < lambda_t spawns a lineage born at t, lambda_t <= r < lambda_t + mu_t kills it at t.
+ * mode 0: lambda_t = lam_steps[t], mu_t = mu_steps[t] (per-step probabilities, i.e. rate / scale);
+ * mode 1: notebook-4 diversity dependence, lambda = max(0, l0 - l0 D/K), mu = max(0, m0 + m0 D/K), both / scale;
+ * mode 2: simulateRateABC.v2.py:153-154, lambda = max(0, l0 - (l0-m0) D/K), mu = max(0, m0 + (l0-m0) D/K), / scale;
+ * D = living lineages at the start of the step.  Outputs: ts/te [capacity] = birth / death STEP of every lineage
+ * (te = n_steps: extant), counters[0] = lineages, counters[1] = living at the end, counters[2] = 1 if `capacity`
+ * was hit (later births were dropped); alive_trace[n_steps] (may be NULL) = D per step.  workspace: 64 bytes.   */
+int lr_simulate_bd(const double* lam_steps, const double* mu_steps, int32_t n_steps, int32_t mode,
+                   double l0, double m0, double K, double scale, int64_t n_start, int64_t capacity,
+                   uint64_t seed, double* ts, double* te, int64_t* counters /* [4] */,
+                   int64_t* alive_trace, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- A11: fused multi-chain RJMCMC --------------------------------------------------------
  * Replaces runMCMC (LRF:216-373) for n_chains independent chains.  Per iteration: one scan of
  * the lineage arrays scoring every chain's proposal, then one chain-step kernel (reduce,

@@ -5,8 +5,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libliterate_hip.so")
-SOURCES = ["lr_stats.hip", "lr_loglik.hip", "lr_mcmc.hip"]
-HEADERS = ["lr_device.h", "lr_chain.h", "lr_internal.h", os.path.join("..", "..", "include", "literate_hip.h")]
+SOURCES = ["lr_stats.hip", "lr_loglik.hip", "lr_mcmc.hip", "lr_sim.hip"]
+HEADERS = ["lr_device.h", "lr_chain.h", "lr_dd.h", "lr_scan.h", "lr_internal.h", os.path.join("..", "..", "include", "literate_hip.h")]
 
 
 def _stale():

@@ -204,6 +204,35 @@ def binned_keiding(birth, death, n_spec, n_exti, DT):
     return ob, od
 
 
+def simulate_bd(n_start, n_steps, seed, lam_steps=None, mu_steps=None, mode=0, l0=0.0, m0=0.0, K=1.0, scale=1.0,
+                capacity=None, device=None):
+    """Discrete-time birth-death simulation on the device (simulateRateABC.v2.py:103-234 / notebook 4 Simulator).
+    Returns (ts, te, alive_trace) as device tensors: birth / death step per lineage (te = n_steps: extant), trimmed to
+    the lineages created, in slot order, and the living count per step.  Raises OverflowError when `capacity`
+    (default 64 x n_start, at least 1M) was hit."""
+    torch = _torch()
+    lib = _hip.load()
+    dev = device or "cuda"
+    capacity = int(capacity or max(64 * n_start, 1 << 20))
+    lam = None if lam_steps is None else _dev(lam_steps, torch.float64, dev)
+    mu = None if mu_steps is None else _dev(mu_steps, torch.float64, dev)
+    if mode == 0 and (lam is None or mu is None or lam.numel() < n_steps or mu.numel() < n_steps):
+        raise ValueError("mode 0 needs lam_steps and mu_steps with n_steps entries")
+    ts = torch.empty(capacity, dtype=torch.float64, device=dev)
+    te = torch.empty(capacity, dtype=torch.float64, device=dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    trace = torch.zeros(int(n_steps), dtype=torch.int64, device=dev)
+    ws = torch.zeros(64, dtype=torch.uint8, device=dev)
+    rc = lib.lr_simulate_bd(_hip.ptr(lam), _hip.ptr(mu), int(n_steps), int(mode), float(l0), float(m0), float(K),
+                            float(scale), int(n_start), capacity, int(seed) & 0xFFFFFFFFFFFFFFFF, _hip.ptr(ts), _hip.ptr(te),
+                            _hip.ptr(counters), _hip.ptr(trace), _hip.ptr(ws), ws.numel(), _hip.stream_ptr())
+    _hip.check(rc, "lr_simulate_bd")
+    n, alive, overflow, _ = [int(v) for v in counters.cpu()]
+    if overflow:
+        raise OverflowError("simulate_bd: more than %d lineages; pass a larger capacity" % capacity)
+    return ts[:n], te[:n], trace
+
+
 def debug_draws(seed, chain, it, purpose, idx, kind, shape):
     """Device RNG probe: kind 0 u_a, 1 u_b, 2 normal, 3 gamma(shape) at (it, purpose, idx)."""
     torch = _torch()

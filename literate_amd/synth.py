@@ -45,3 +45,54 @@ def make_lineages(n, n_bins=128, n_shifts=20, seed=0, jitter=0.5):
     order = np.argsort(ts, kind="stable")          # files are written in order of appearance
     truth = dict(edges_l=eL, rates_l=rL, edges_m=eM, rates_m=rM, lam_bins=lam, mu_bins=mu)
     return ts[order].astype(np.float64), (te[order] + jitter).astype(np.float64), truth
+
+
+# ---- discrete-time simulator: rate generators of notebook 4 and the device run ----------
+def rates_constant(time_len, lam, mu):
+    """Constant_Rate_Generator."""
+    return np.full(time_len, float(lam)), np.full(time_len, float(mu))
+
+
+def rates_key_innovation(time_len, lam, mu, timing_innov, mag_innov):
+    """Key_Innovation_Rate_Generator: the birth rate jumps by mag_innov from int(time_len * timing_innov) on."""
+    la = np.full(time_len, float(lam))
+    la[int(time_len * timing_innov):] += mag_innov
+    return la, np.full(time_len, float(mu))
+
+
+def rates_mass_extinction(time_len, base_la, base_mu, timing_ext, mag_ext, mag_rebound):
+    """Mass_Extinction_Rate_Generator: one bin of extra death rate, then a birth-rate rebound."""
+    k = int(time_len * timing_ext)
+    la, mu = np.full(time_len, float(base_la)), np.full(time_len, float(base_mu))
+    la[k + 1:] += mag_rebound
+    mu[k] += mag_ext
+    return la, mu
+
+
+def rates_trend(trend, lambda_0, mu_0, alpha, beta):
+    """Environmental_Trend_Rate_Generator: rate_t = base + slope * trend[t]."""
+    trend = np.asarray(trend, dtype=float)
+    return lambda_0 + alpha * trend, mu_0 + beta * trend
+
+
+def simulate(n_start, time_len, scale=1, seed=0, rates=None, dd=None, capacity=None, jitter=0.5):
+    """Run the reference's discrete-time birth-death scheme on the device (lr_simulate_bd) and return LiteRate input:
+    (ts, te) in time units (floor(step / scale), as simulateRateABC.v2.py:218 floors them; extant lineages end at
+    time_len) with death_jitter added to te, sorted by (ts, te), plus the living count per step.
+
+    rates: (lam[time_len], mu[time_len]) per time unit from a generator above (evaluated at floor(t / scale) and
+    divided by scale, like Simulator.run_simulation does);  dd: dict(mode=1|2, l0, m0, K) for diversity dependence."""
+    from . import ops
+    n_steps = int(time_len) * int(scale)
+    if dd is None:
+        lam, mu = rates
+        t = np.arange(n_steps) // int(scale)
+        ts_s, te_s, trace = ops.simulate_bd(n_start, n_steps, seed, np.asarray(lam, float)[t] / scale,
+                                            np.asarray(mu, float)[t] / scale, capacity=capacity)
+    else:
+        ts_s, te_s, trace = ops.simulate_bd(n_start, n_steps, seed, mode=int(dd["mode"]), l0=dd["l0"], m0=dd["m0"],
+                                            K=dd["K"], scale=scale, capacity=capacity)
+    ts = np.floor(ts_s.cpu().numpy() / scale)
+    te = np.floor(te_s.cpu().numpy() / scale)
+    order = np.lexsort((te, ts))
+    return ts[order], te[order] + jitter, trace.cpu().numpy()

@@ -89,3 +89,32 @@ class Stream:
             if math.log(u) < 0.5 * x * x + d - d * v + d * math.log(v):
                 return d * v
         return d
+
+
+# ---- vectorised block (numpy uint64 arithmetic) for the lineage simulator -------------------------
+P_SIM = 24      # simulator: key = (seed, lineage slot), counter = (step, P_SIM, 0) -> u_a decides birth / death
+
+
+def philox4x32_10_np(c0, c1, c2, c3, k0, k1):
+    """philox4x32_10 on numpy arrays (any broadcastable shapes); returns four uint64 arrays < 2**32."""
+    import numpy as np
+    c0, c1, c2, c3 = [np.asarray(x, dtype=np.uint64) for x in (c0, c1, c2, c3)]
+    k0, k1 = np.asarray(k0, dtype=np.uint64), np.asarray(k1, dtype=np.uint64)
+    m = np.uint64(MASK)
+    for _ in range(10):
+        p0 = np.uint64(M0) * c0
+        p1 = np.uint64(M1) * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & m
+        hi1, lo1 = p1 >> np.uint64(32), p1 & m
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & m, lo1, (hi0 ^ c3 ^ k1) & m, lo0
+        k0 = (k0 + np.uint64(W0)) & m
+        k1 = (k1 + np.uint64(W1)) & m
+    return c0, c1, c2, c3
+
+
+def uniform_a_np(it, purpose, idx, k0, k1):
+    """u_a of Stream(k0, k1).pair(it, purpose, idx), vectorised over any of the arguments."""
+    import numpy as np
+    it = np.asarray(it, dtype=np.uint64)
+    w0, w1, _, _ = philox4x32_10_np(it & np.uint64(MASK), it >> np.uint64(32), purpose, idx, k0, k1)
+    return ((w0 >> np.uint64(5)).astype(np.float64) * 67108864.0 + (w1 >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0

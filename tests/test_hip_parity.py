@@ -335,3 +335,42 @@ def test_device_rng_matches_oracle_stream(ops):
         else:
             ref = s.gamma(int(it[i]), int(purpose[i]), int(idx[i]), float(shape[i]))
             assert got[i] == pytest.approx(ref, rel=1e-12)
+
+
+@pytest.mark.parametrize("case", ["constant", "key_innovation", "mass_extinction", "dd_nb4", "dd_abc", "overflow"])
+def test_device_simulator_matches_oracle(ops, case):
+    """lr_simulate_bd against oracle/sim_oracle.py: the multiset of (birth step, death step) pairs and the
+    living count per step, bit for bit (integers), for given-rate and diversity-dependent runs."""
+    from literate_amd import synth
+    from oracle import sim_oracle as so
+    scale, T, seed = 4, 40, 77
+    n_steps = T * scale
+    t = np.arange(n_steps) // scale
+    kw = dict(mode=0)
+    if case == "constant":
+        la, mu = synth.rates_constant(T, .12, .08)
+    elif case == "key_innovation":
+        la, mu = synth.rates_key_innovation(T, .05, .05, .6, .3)
+    elif case in ("mass_extinction", "overflow"):
+        la, mu = synth.rates_mass_extinction(T, .15, .1, .4, 1.0, .08)
+    if case.startswith("dd"):
+        kw = dict(mode=1 if case == "dd_nb4" else 2, l0=.4, m0=.1, K=5000.0, scale=float(scale))
+        lam_s = mu_s = None
+    else:
+        lam_s, mu_s = la[t] / scale, mu[t] / scale
+    n_start = 800
+    if case == "overflow":
+        with pytest.raises(OverflowError):
+            ops.simulate_bd(n_start, n_steps, seed, lam_s, mu_s, capacity=1000)
+        return
+    ts, te, trace = ops.simulate_bd(n_start, n_steps, seed, lam_s, mu_s, **kw)
+    rts, rte, rtrace = so.simulate_bd(n_start, n_steps, seed, lam_s, mu_s, **kw)
+    ts, te = _np(ts), _np(te)
+    order = np.lexsort((te, ts))
+    assert len(ts) == len(rts) > n_start
+    assert np.array_equal(ts[order], rts) and np.array_equal(te[order], rte)
+    assert np.array_equal(_np(trace), rtrace)
+    # LiteRate input made from it: integer time units, jitter on te, sorted, extant at T + jitter
+    if case == "constant":
+        lts, lte, _ = synth.simulate(n_start, T, scale, seed, rates=(la, mu))
+        assert len(lts) == len(ts) and np.all(np.diff(lts) >= 0) and lte.max() == T + 0.5 and np.all(lte - 0.5 >= lts)

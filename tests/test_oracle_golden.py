@@ -356,3 +356,29 @@ def test_cfg1_fixed_two_shifts_reproduces_reference_runMCMC(G, golden_dir):
             assert np.allclose(row, T[kind][i, :len(row)], rtol=1e-10)
             assert np.array_equal(row[3:], T["times0"][1:3])       # the two shift times never move
     assert len(set(np.round(mc[:, 2], 6))) > 100
+
+
+def test_simulator_oracle_properties():
+    """oracle/sim_oracle.py (the reference simulators' per-step Bernoulli scheme): vectorised Philox equals the scalar
+    stream; conservation (living count = births - deaths so far); zero rates leave the start population extant;
+    a death rate of 1 kills everyone in the first step; the DD generators cap growth near the carrying capacity."""
+    from oracle import philox as px
+    from oracle import sim_oracle as so
+    s = px.Stream(99, 1234)
+    u = px.uniform_a_np(np.arange(6) + (1 << 33), px.P_SIM, 0, 99, 1234)
+    assert np.array_equal(u, [s.pair(int(i) + (1 << 33), px.P_SIM, 0)[0] for i in range(6)])
+    T = 60
+    ts, te, trace = so.simulate_bd(300, T, 4, np.full(T, .06), np.full(T, .05))
+    assert trace[0] == 300
+    for t in range(1, T):      # living at the start of step t = born before t - dead before t
+        assert trace[t] == np.sum(ts < t) - np.sum(te < t)
+    assert np.sum(te == T) == trace[-1] + np.sum(ts == T - 1) - np.sum(te == T - 1)
+    assert np.all(te >= ts) and np.all(np.diff(ts) >= 0)
+    ts0, te0, tr0 = so.simulate_bd(50, 10, 1, np.zeros(10), np.zeros(10))
+    assert len(ts0) == 50 and np.all(te0 == 10) and np.all(tr0 == 50)
+    ts1, te1, tr1 = so.simulate_bd(50, 5, 1, np.zeros(5), np.ones(5))
+    assert len(ts1) == 50 and np.all(te1 == 0) and tr1[1] == 0
+    for mode in (1, 2):
+        tsd, ted, trd = so.simulate_bd(200, 400, 3, mode=mode, l0=.4, m0=.1, K=2000.0, scale=4.0)
+        eq = 2000.0 * (.4 - .1) / (.4 + .1) if mode == 1 else 2000.0 / 2.0      # where lambda(D) = mu(D)
+        assert abs(trd[-50:].mean() - eq) < 0.12 * eq

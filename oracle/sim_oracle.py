@@ -1,7 +1,11 @@
 """Discrete-time birth-death lineage simulator: restatement of the scheme both of the reference's simulators use
 (simulateRateABC.v2.py:103-234 `Simulator.simulate`; notebook 4 `Simulator.run_simulation`, `Population`).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Per step t every living lineage draws one uniform r:
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED for this file: both reference simulators live in
+a plotting script / a Colab notebook that run a simulation and draw figures at import (matplotlib windows, tqdm
+notebook widgets, altair) and draw from numpy's global stream, so no reference output was generated for them; the
+scheme below is restated from their source text and the device is checked against this restatement only.
+Per step t every living lineage draws one uniform r:
 r < lambda_t -> it spawns a lineage born at t; lambda_t <= r < lambda_t + mu_t -> it dies at t (nb4: birther_indices /
 dying_indices; ABC: r_sp_indx / r_ex_indx).  Lineages born at t first act at t + 1.  Rates per step come from a
 rate generator evaluated at the scaled-down time, or from the living count (diversity dependence).

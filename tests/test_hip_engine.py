@@ -493,3 +493,34 @@ def test_engine_tiny_input_three_lineages(engine):
                 head, s_row, e_row = split_trace_row(tr[i, c])
                 assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9, equal_nan=True), (C, c, i)
         eng.close()
+
+
+def test_end_to_end_simulate_then_recover_key_innovation():
+    """Whole stack on the device: lr_simulate_bd draws a key-innovation history (birth rate 0.10 -> 0.25 at t = 24 of 40,
+    death rate 0.08, per-step Bernoulli scheme at scale 4), the RJMCMC engine samples 32 chains on the resulting
+    lineages, and the pooled posterior per-bin rates (plotRJforward.v3.py:92-139 definition) recover the history."""
+    from literate_amd import logs, synth
+    from literate_amd.engine import ChainEngine, split_trace_row
+    T, scale = 40, 4
+    la, mu = synth.rates_key_innovation(T, .10, .08, .6, .15)
+    ts, te, trace = synth.simulate(2000, T, scale, seed=11, rates=(la, mu))
+    assert 20_000 < len(ts) < 200_000 and trace[-1] > trace[0]
+    C, n_it, s = 32, 8000, 20
+    eng = ChainEngine(ts, te, C, model=0, seed=3, s_freq=s, n_trace_slots=n_it // s)
+    eng.init(); eng.steps(n_it)
+    tr = eng.trace_rows()
+    burn = (n_it // s) // 4
+    sp_bins, ex_bins = [], []
+    for c in range(C):
+        for i in range(burn, n_it // s):
+            head, sp, ex = split_trace_row(tr[i, c])
+            k_l, k_m = int(head[6]), int(head[7])
+            sp_bins.append(logs.rates_per_bin(sp[:k_l], sp[k_l:], eng.start_time, eng.n_bins))
+            ex_bins.append(logs.rates_per_bin(ex[:k_m], ex[k_m:], eng.start_time, eng.n_bins))
+    lam_hat, mu_hat = np.mean(sp_bins, 0), np.mean(ex_bins, 0)
+    assert eng.n_bins == T
+    assert np.allclose(lam_hat[3:22], .10, rtol=0.3), lam_hat
+    assert np.allclose(lam_hat[27:38], .25, rtol=0.3), lam_hat
+    assert np.allclose(mu_hat[3:38], .08, rtol=0.35), mu_hat
+    assert lam_hat[27:38].mean() > 1.8 * lam_hat[3:22].mean()
+    eng.close()

@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,shipped,cfg1,traj]
+    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,shipped,cfg1,trendtraj,traj]
     python tests/golden/make_chains.py <dataset> <model> <n> <s> <chains>   # long reference chains
 
 The reference is executed unmodified: LiteRateForward.py / DDRate.py through
@@ -400,6 +400,40 @@ def make_cfg1(work):
     print("cfg1_fixed_shifts.npz:", mc.shape)
 
 
+def make_trend_trajectories(work):
+    """Full trend_rate.py runs (reference process, fixed seed) on metal_bands with the synthetic trend column of
+    ratemaps.npz: every sampled log row."""
+    R = np.load(os.path.join(HERE, "ratemaps.npz"))
+    out = {}
+    for cb, cd, seed, n, s in ((0, 0, 4, 3000, 10), (1, 0, 5, 2000, 10), (0, 1, 6, 2000, 10)):
+        rel, flags = DATASETS["metal_bands"]
+        d = tempfile.mkdtemp(dir=work)
+        dst = os.path.join(d, os.path.basename(rel))
+        shutil.copy(os.path.join(REF, rel), dst)
+        trend_file = os.path.join(d, "trend.tsv")
+        with open(trend_file, "w") as f:
+            f.write("year\ttrend\n")
+            for i, v in enumerate(R["trend_raw"]):
+                f.write("%d\t%r\n" % (i, float(v)))
+        cmd = [sys.executable, "-B", os.path.join(REF, "trend_rate.py"), "-d", dst, "-n", str(n), "-s", str(s),
+               "-seed", str(seed), "-trend_data", trend_file, "-trend_index", "1"] + flags
+        cmd += (["-const_B", "1"] if cb else []) + (["-const_D", "1"] if cd else [])
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+        suffix = ("_CONB" if cb else "_EXPB") + ("_COND" if cd else "_EXPD")
+        log = "%s_%s%s_%s.trendrate.log" % (os.path.splitext(dst)[0], seed, suffix, 1)
+        rows = np.loadtxt(log, skiprows=1, ndmin=2)
+        key = "cb%d_cd%d_s%d" % (cb, cd, seed)
+        out[key + "/head"] = rows[:, :12]
+        out[key + "/adequacy"] = rows[:, -3:]
+        out[key + "/full25"] = rows[:25]
+        out[key + "/meta"] = np.array([cb, cd, seed, n, s], dtype=float)
+        with open(log) as f:
+            out[key + "/header"] = np.array(f.readline().rstrip("\n"))
+        print(key, rows.shape)
+    np.savez_compressed(os.path.join(HERE, "trend_trajectories.npz"), **out)
+
+
 def make_shipped(work):
     """Data files the reference ships with its example run: the single-run _div.log statistics
     and the first rows of the shipped DDRate log with its header line."""
@@ -468,7 +502,7 @@ def main():
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="lr_golden_")
-    steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps, ddtraj=make_dd_trajectories, shipped=make_shipped, cfg1=make_cfg1,
+    steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps, ddtraj=make_dd_trajectories, shipped=make_shipped, cfg1=make_cfg1, trendtraj=make_trend_trajectories,
                  traj=make_trajectories)
     for name, fn in steps.items():
         if args.only and name not in args.only.split(","):

@@ -382,3 +382,23 @@ def test_simulator_oracle_properties():
         tsd, ted, trd = so.simulate_bd(200, 400, 3, mode=mode, l0=.4, m0=.1, K=2000.0, scale=4.0)
         eq = 2000.0 * (.4 - .1) / (.4 + .1) if mode == 1 else 2000.0 / 2.0      # where lambda(D) = mu(D)
         assert abs(trd[-50:].mean() - eq) < 0.12 * eq
+
+
+@pytest.mark.parametrize("key", ["cb0_cd0_s4", "cb1_cd0_s5", "cb0_cd1_s6"])
+def test_trend_mcmc_loop_reproduces_reference_trajectory(golden_dir, key):
+    """trend_rate.py's sampler (:102-196) restated in oracle/trend_mcmc_oracle.py: on numpy's legacy stream with the
+    reference's seed it writes the reference's own log rows (full reference runs, metal_bands + a synthetic trend)."""
+    from oracle import trend_mcmc_oracle as tro
+    T = np.load(os.path.join(golden_dir, "trend_trajectories.npz"))
+    R = np.load(os.path.join(golden_dir, "ratemaps.npz"))
+    cb, cd, seed, n, s = [int(v) for v in T[key + "/meta"]]
+    with np.errstate(all="ignore"):
+        emp = (R["N_SPEC"] / R["DT"], R["N_EXTI"] / R["DT"])
+    np.random.seed(seed)
+    rows = np.array(tro.run_trend_mcmc(R["N_SPEC"], R["N_EXTI"], R["DT"], R["TREND"], tro.NumpyLegacyDraws(), n, s,
+                                       bool(cb), bool(cd), emp=emp))
+    assert rows.shape[0] == T[key + "/head"].shape[0]
+    assert np.allclose(rows[:, :12], T[key + "/head"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(rows[:, -3:], T[key + "/adequacy"], rtol=1e-7, atol=1e-9, equal_nan=True)
+    assert np.allclose(rows[:25], T[key + "/full25"], rtol=1e-9, atol=1e-12, equal_nan=True)
+    assert len(set(np.round(rows[:, 2], 6))) > 20

@@ -183,12 +183,15 @@ typedef struct lr_mcmc_config {
      * model must be LR_MODEL_KEIDING, br_length = DT of create_bins (lib:231-257), t0 = ORIGIN, n_bins =
      * N_TIME_BINS.  A chain's state is the parameter vector [l_max,k,x0,div_0,L,m_max,nuB,nuD] (DD:161) in
      * lanes 0..7 of the rate row; a trace row is [it, posterior, likelihood, prior, args[8]].               */
-    int32_t sampler;          /* 0 = runMCMC (LRF), 1 = DDRate                      */
-    int32_t m_birth;          /* -m_birth (DD:25)                                   */
-    int32_t m_death;          /* -m_death (DD:26)                                   */
+    int32_t sampler;          /* 0 = runMCMC (LRF), 1 = DDRate, 2 = trend_rate (below) */
+    int32_t m_birth;          /* -m_birth (DD:25); sampler 2: -const_B flag          */
+    int32_t m_death;          /* -m_death (DD:26); sampler 2: -const_D flag          */
     int32_t reserved0;
     double dd_present;        /* PRESENT - as create_bins returns it (DD:36)        */
     double dd_init_death;     /* -fix_death (DD:27, 156)                            */
+    /* sampler 2: the trend_rate.py loop (trend_rate.py:102-196): parameters [l_min,m_min,alpha,beta,delta,gamma],
+     * br_length = the normalised covariate TREND[n_bins] (parse_trend_data, trend_rate.py:58-69), t0 / n_bins as
+     * for sampler 1; a trace row is [it, posterior, likelihood, prior, args[6]].                              */
 } lr_mcmc_config;
 
 /* where things live inside the engine workspace (byte offsets), for zero-copy host views */

@@ -77,13 +77,13 @@ __device__ __forceinline__ double lr_dd_prior(double v, double origin, double pr
     return p;
 }
 
-// Lookup tables (Keiding form, lr_bin_terms model >= 2) of one parameter vector straight from its per-bin rates;
+// Lookup tables (Keiding form, lr_bin_terms model >= 2) straight from per-bin rates given by `rates(b, &br, &dr)`;
 // same table formats as lr_build_tables_segments_wave (general double2 entries, or unit-resolution entries `es`
 // doubles apart).  Lane l owns bins [l*P, (l+1)*P), P <= LR_DD_MAXP.
 #define LR_DD_MAXP 4
-__device__ inline void lr_dd_build_tables_wave(const lr_dd_params& p, const double* __restrict__ DT, int m_birth,
-                                               int m_death, int n_bins, int H, double2* __restrict__ tab, int lane,
-                                               bool unit, double fs0, double fe0, int es) {
+template <class F>
+__device__ __forceinline__ void lr_rates_build_tables_wave(F rates, int n_bins, int H, double2* __restrict__ tab, int lane,
+                                                           bool unit, double fs0, double fe0, int es) {
     double* tabd = reinterpret_cast<double*>(tab);
     const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
     const int b0 = min(lane * P, n_bins), b1 = min(b0 + P, n_bins);
@@ -94,8 +94,7 @@ __device__ inline void lr_dd_build_tables_wave(const lr_dd_params& p, const doub
         const int b = b0 + i;
         br[i] = 1.0, dr[i] = 1.0;
         if (i < P && b < b1) {
-            double ni, fr;
-            lr_dd_bin_rates(p, (double)b, DT[b], m_birth, m_death, &br[i], &dr[i], &ni, &fr);
+            rates(b, &br[i], &dr[i]);
             sumR += br[i] + dr[i];
         }
     }
@@ -127,4 +126,78 @@ __device__ inline void lr_dd_build_tables_wave(const lr_dd_params& p, const doub
             tab[H + n_bins + 1] = make_double2(-totR, 0.0);
         }
     }
+}
+
+__device__ inline void lr_dd_build_tables_wave(const lr_dd_params& p, const double* __restrict__ DT, int m_birth,
+                                               int m_death, int n_bins, int H, double2* __restrict__ tab, int lane,
+                                               bool unit, double fs0, double fe0, int es) {
+    lr_rates_build_tables_wave(
+        [&](int b, double* br, double* dr) {
+            double ni, fr;
+            lr_dd_bin_rates(p, (double)b, DT[b], m_birth, m_death, br, dr, &ni, &fr);
+        },
+        n_bins, H, tab, lane, unit, fs0, fe0, es);
+}
+
+// ---- trend_rate.py: rates driven by a per-bin covariate ---------------------------------------
+#define LR_TR_NPAR 6          /* [l_min, m_min, alpha, beta, delta, gamma] (trend_rate.py:74) */
+#define LR_P_TR_MOVE 32
+#define LR_P_TR_NORM 33
+#define LR_P_TR_MULT 34
+#define LR_P_TR_ACCEPT 35
+
+struct lr_trend_params {
+    double l_min, m_min, alpha, beta, delta, gamma;
+};
+
+// likelihood_function's rate half for ONE bin (trend_rate.py:73-88); t = TREND[b]
+__device__ __forceinline__ void lr_trend_bin_rates(const lr_trend_params& p, double t, int const_birth, int const_death,
+                                                   double* br_, double* dr_) {
+    double br = 1.0 * p.l_min, dr = 1.0 * p.m_min;
+    if (!const_birth) {
+        br = p.l_min + p.alpha * pow(t, p.delta);
+        if (br <= 0.0) br = LR_DD_SMALL;
+    }
+    if (!const_death) {
+        dr = p.m_min + p.beta * pow(t, p.gamma);
+        if (dr <= 0.0) dr = LR_DD_SMALL;
+    }
+    *br_ = br, *dr_ = dr;
+}
+
+__device__ __forceinline__ lr_trend_params lr_trend_unpack(double v) {
+    lr_trend_params p;
+    p.l_min = lr_bcast(v, 0), p.m_min = lr_bcast(v, 1), p.alpha = lr_bcast(v, 2), p.beta = lr_bcast(v, 3);
+    p.delta = lr_bcast(v, 4), p.gamma = lr_bcast(v, 5);
+    return p;
+}
+
+// update probabilities of the two vector moves (trend_rate.py:122-135), lane j < 6; 0/0 = nan when a mask is empty,
+// as in the reference (a nan probability never fires)
+__device__ __forceinline__ void lr_trend_update_freq(int const_birth, int const_death, int lane, double* f_mult,
+                                                     double* f_norm) {
+    double um = (lane == 0 || lane == 1 || lane == 4 || lane == 5) ? 1.0 : 0.0;
+    double un = (lane == 2 || lane == 3) ? 1.0 : 0.0;
+    if (const_birth && lane == 4) um = 0.0;
+    if (const_birth && lane == 2) un = 0.0;
+    if (const_death && lane == 5) um = 0.0;
+    if (const_death && lane == 3) un = 0.0;
+    if (lane >= LR_TR_NPAR) um = 0.0, un = 0.0;
+    *f_mult = um / lr_wave_sum(um);
+    *f_norm = un / lr_wave_sum(un);
+}
+
+// calc_prior (trend_rate.py:93-100): Gamma(1, scale 10, loc .001) on the floors, Normal(0, 5) on the slopes,
+// Gamma(3, scale .5) on the exponents; one packed log
+__device__ __forceinline__ double lr_trend_prior(double v, int lane) {
+    const double LOG10 = 2.302585092994046, HALF_LOG_2PI = 0.9189385332046727, LOG5 = 1.6094379124341003;
+    const double LOG2 = 0.6931471805599453;
+    const double y = (lane <= 1) ? (v - .001) / 10.0 : (v / .5);
+    const double ly = log((lane == 4 || lane == 5) && y > 0.0 ? y : 1.0);
+    double t = 0.0;
+    if (lane <= 1) t = (y < 0.0) ? -INFINITY : -y - LOG10;
+    if (lane == 2 || lane == 3) t = -0.5 * (v / 5.0) * (v / 5.0) - HALF_LOG_2PI - LOG5;
+    if (lane == 4 || lane == 5) t = (y <= 0.0) ? -INFINITY : 2.0 * ly - y - LOG2 + LOG2;   // - lgamma(3) - log(.5)
+    if (lane >= LR_TR_NPAR) t = 0.0;
+    return lr_wave_sum(t);
 }

@@ -658,17 +658,22 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
 
 // the step of chain c with its state in global memory: load, sum the tile partials in tile order, step, store
 
-// ---- DDRate sampler: one iteration of DDRate.py's loop (DD:194-239) for one chain ------------------------
+// ---- parametric samplers: one iteration of DDRate.py's loop (DD:194-239; sampler 1) or of trend_rate.py's
+// (trend_rate.py:160-195; sampler 2) for one chain -----------------------------------------------------------
 // Same pipeline position as lr_chain_step_core: decide the pending proposal with the scanned likelihood, write the
 // trace row, propose the next parameter vector, evaluate its prior and build its lookup tables.
-// State: lane j < 8 of st.L = accepted parameter j, of st.pL = proposed parameter j; scalars in st.sc / st.isc.
+// State: lane j < NPAR of st.L = accepted parameter j, of st.pL = proposed parameter j; scalars in st.sc / st.isc.
+// `aux` = the per-bin array the rate map needs: DT (DDRate) or the normalised covariate TREND (trend_rate).
 __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
                                                 double lik_sum, double2* table, int table_es = 2) {
     const lr_mcmc_config& cfg = a.cfg;
     const int C = cfg.n_chains;
+    const bool trend = cfg.sampler == 2;
+    const int npar = trend ? LR_TR_NPAR : LR_DD_NPAR;
     const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
     const double origin = cfg.t0, present = cfg.dd_present;
     const double k0 = a.dd_consts[0], log_k0 = a.dd_consts[1];
+    const double* aux = a.br_length;
     double A = st.L;
     const double P0 = st.pL;
     const double sc = st.sc;
@@ -679,13 +684,13 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
     uint64_t next_sample = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_HI) << 32);
     int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
     if (mode == 1) {
-        likA = lik_sum;                                                        // DD:184-186
-        priorA = lr_dd_prior(A, origin, present, k0, log_k0, lane);            // DD:192
+        likA = lik_sum;                                                        // DD:184-186, trend_rate.py:150-151
+        priorA = trend ? lr_trend_prior(A, lane) : lr_dd_prior(A, origin, present, k0, log_k0, lane);
     } else {
         const double hasting = lr_bcast(sc, LR_S_HASTING), priorP = lr_bcast(sc, LR_S_PRIOR_P);
-        const double u = lr_pair(rng, it, LR_P_DD_ACCEPT, 0).a;
+        const double u = lr_pair(rng, it, trend ? LR_P_TR_ACCEPT : LR_P_DD_ACCEPT, 0).a;
         const double lik = lik_sum;
-        const bool ok = ((lik - likA) + (priorP - priorA) + hasting > log(u)) || it == 0;   // DD:211
+        const bool ok = ((lik - likA) + (priorP - priorA) + hasting > log(u)) || it == 0;   // DD:211, trend_rate.py:176
         lik_p = lik;
         if (ok) A = P0, likA = lik, priorA = priorP, n_acc += 1;
         if (it == next_sample) {                                               // DD:221
@@ -700,37 +705,62 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
                 if (lane == 2) h = likA;
                 if (lane == 3) h = priorA;
                 const double Aj = __shfl(A, (lane - 4) & (LR_WAVE - 1));        // rare path (sampling only)
-                if (lane >= 4 && lane < 4 + LR_DD_NPAR) h = Aj;
+                if (lane >= 4 && lane < 4 + npar) h = Aj;
                 for (int j = lane; j < LR_TRACE_W; j += LR_WAVE) row[j] = (j == lane) ? h : __longlong_as_double(0x7ff8000000000000LL);
             }
         }
         it += 1;
     }
-    // ---- propose iteration `it` (DD:195-207) ----
+    // ---- propose iteration `it` ----
     double P = A, hasting = 0.0;
     int move_kind;
-    const lr_u2 rr = lr_pair(rng, it, LR_P_DD_MOVE, 0);
-    if (rr.b < 0.1 && (cfg.m_birth == 2 || cfg.m_death == 2)) {
-        // update_sliding_win(x0, m=0, M=PRESENT, d=1.5) (lib:124-128)
-        double ii = lr_bcast(A, 2) + (lr_pair(rng, it, LR_P_DD_SLIDE, 0).a - .5) * 1.5;
-        if (ii > present) ii = present - (ii - present);
-        ii = fabs(ii);
-        if (lane == 2) P = ii;
-        if (cfg.m_death == -1) {
-            const double z = lr_normal(rng, it, LR_P_DD_SLIDE, 1);              // update_normal_nobound(k, d=0.2) (lib:136-138)
-            if (lane == 1) P = A + z * 0.2;
+    if (trend) {
+        // trend_rate.py:165-169: 33 % additive normal step on the slopes, else the vector multiplier
+        const double rr = lr_pair(rng, it, LR_P_TR_MOVE, 0).a;
+        double f_mult, f_norm;
+        lr_trend_update_freq(cfg.m_birth, cfg.m_death, lane, &f_mult, &f_norm);
+        const lr_u2 d = lr_pair(rng, it, LR_P_TR_MULT, lane);
+        if (rr < .33) {
+            const double z = lr_normal(rng, it, LR_P_TR_NORM, lane);               // update_normal_nobound_vec (lib:140-146)
+            if (lane < npar && d.a < f_norm) P = A + z * .001;
+            move_kind = 1;
+        } else {
+            hasting = lr_wave_multiplier(P, npar, d.a < f_mult, d.b, a.mult_l, lane);   // lib:156-165
+            move_kind = 0;
         }
-        move_kind = 1;
     } else {
-        const double f = lr_dd_update_freq(cfg.m_birth, cfg.m_death, lane);
-        const lr_u2 d = lr_pair(rng, it, LR_P_DD_MULT, lane);
-        hasting = lr_wave_multiplier(P, LR_DD_NPAR, d.a < f, d.b, a.mult_l, lane);   // lib:156-165
-        move_kind = 0;
+        // DD:195-207
+        const lr_u2 rr = lr_pair(rng, it, LR_P_DD_MOVE, 0);
+        if (rr.b < 0.1 && (cfg.m_birth == 2 || cfg.m_death == 2)) {
+            // update_sliding_win(x0, m=0, M=PRESENT, d=1.5) (lib:124-128)
+            double ii = lr_bcast(A, 2) + (lr_pair(rng, it, LR_P_DD_SLIDE, 0).a - .5) * 1.5;
+            if (ii > present) ii = present - (ii - present);
+            ii = fabs(ii);
+            if (lane == 2) P = ii;
+            if (cfg.m_death == -1) {
+                const double z = lr_normal(rng, it, LR_P_DD_SLIDE, 1);              // update_normal_nobound(k, d=0.2) (lib:136-138)
+                if (lane == 1) P = A + z * 0.2;
+            }
+            move_kind = 1;
+        } else {
+            const double f = lr_dd_update_freq(cfg.m_birth, cfg.m_death, lane);
+            const lr_u2 d = lr_pair(rng, it, LR_P_DD_MULT, lane);
+            hasting = lr_wave_multiplier(P, npar, d.a < f, d.b, a.mult_l, lane);   // lib:156-165
+            move_kind = 0;
+        }
     }
-    const double priorP = lr_dd_prior(P, origin, present, k0, log_k0, lane);
-    const lr_dd_params pp = lr_dd_unpack(P);
-    lr_dd_build_tables_wave(pp, a.br_length, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, a.unit != 0,
-                            cfg.frac_birth, cfg.frac_death, table_es);
+    double priorP;
+    if (trend) {
+        priorP = lr_trend_prior(P, lane);
+        const lr_trend_params tp = lr_trend_unpack(P);
+        lr_rates_build_tables_wave([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
+                                   cfg.n_bins, a.H, table, lane, a.unit != 0, cfg.frac_birth, cfg.frac_death, table_es);
+    } else {
+        priorP = lr_dd_prior(P, origin, present, k0, log_k0, lane);
+        const lr_dd_params pp = lr_dd_unpack(P);
+        lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, a.unit != 0,
+                                cfg.frac_birth, cfg.frac_death, table_es);
+    }
     st.L = A, st.pL = P;
     {
         double so = 0.0;
@@ -741,7 +771,7 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
         so = (lane == LR_S_LIK_P) ? lik_p : so;
         st.sc = so;
         int io = 0;
-        io = (lane == LR_I_KL || lane == LR_I_KM || lane == LR_I_PKL || lane == LR_I_PKM) ? LR_DD_NPAR : io;
+        io = (lane == LR_I_KL || lane == LR_I_KM || lane == LR_I_PKL || lane == LR_I_PKM) ? npar : io;
         io = (lane == LR_I_IT_LO) ? (int)(uint32_t)it : io;
         io = (lane == LR_I_IT_HI) ? (int)(uint32_t)(it >> 32) : io;
         io = (lane == LR_I_ACCEPTED) ? n_acc : io;
@@ -763,7 +793,7 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     double part = 0.0;
     for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * a.cfg.n_chains + c];
     const double lik_sum = lr_wave_sum(part);
-    if (a.cfg.sampler == 1) lr_dd_step_core(st, a, mode, c, lane, lik_sum, lr_chain_table(a, c));
+    if (a.cfg.sampler != 0) lr_dd_step_core(st, a, mode, c, lane, lik_sum, lr_chain_table(a, c));
     else lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c));
     lr_chain_store(st, S, I, lane);
 }
@@ -889,7 +919,7 @@ __device__ __attribute__((noinline)) void lr_persist_step(const lr_step_args* a,
                                                           double lik, double2* table, int table_es) {
     lr_chain_regs st;
     lr_chain_load(st, st_f64, st_i32, lane);
-    if (a->cfg.sampler == 1) lr_dd_step_core(st, *a, 0, c, lane, lik, table, table_es);
+    if (a->cfg.sampler != 0) lr_dd_step_core(st, *a, 0, c, lane, lik, table, table_es);
     else lr_chain_step_core(st, *a, 0, c, lane, scratch, lik, table, table_es);
     lr_chain_store(st, st_f64, st_i32, lane);
 }
@@ -1073,25 +1103,37 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
     double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
     int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
     const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
-    if (cfg.sampler == 1) {
-        // DDRate initial parameter vector (DD:151-161) or the caller's [C, kmax] rows; its tables, so that the first
-        // scan evaluates likA (DD:184-186)
+    if (cfg.sampler != 0) {
+        // initial parameter vector of the parametric samplers (DD:151-161, trend_rate.py:141-147) or the caller's
+        // [C, kmax] rows; its tables, so that the first scan evaluates likA (DD:184-186)
+        const bool trend = cfg.sampler == 2;
+        const int npar = trend ? LR_TR_NPAR : LR_DD_NPAR;
         double A = 0.0;
         if (L0) {
-            if (lane < LR_DD_NPAR) A = L0[(size_t)c * kmax + lane];
+            if (lane < npar) A = L0[(size_t)c * kmax + lane];
+        } else if (trend) {
+            const double init[LR_TR_NPAR] = {.1, .1, 0.0, 0.0, 1.0, 1.0};
+            if (lane < npar) A = init[lane];
         } else {
             const double x0 = cfg.dd_present - (cfg.t0 + cfg.dd_present) / 2.0;       // PRESENT - np.mean([ORIGIN, PRESENT])
             const double init[LR_DD_NPAR] = {0.5, 1.5, x0, 10.0, 20000.0, cfg.dd_init_death, 1.0, 1.0};
-            if (lane < LR_DD_NPAR) A = init[lane];
+            if (lane < npar) A = init[lane];
         }
-        const lr_dd_params pp = lr_dd_unpack(A);
-        lr_dd_build_tables_wave(pp, a.br_length, cfg.m_birth, cfg.m_death, n_bins, a.H, lr_chain_table(a, c), lane,
-                                a.unit != 0, cfg.frac_birth, cfg.frac_death, 2);
+        if (trend) {
+            const lr_trend_params tp = lr_trend_unpack(A);
+            const double* aux = a.br_length;
+            lr_rates_build_tables_wave([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
+                                       n_bins, a.H, lr_chain_table(a, c), lane, a.unit != 0, cfg.frac_birth, cfg.frac_death, 2);
+        } else {
+            const lr_dd_params pp = lr_dd_unpack(A);
+            lr_dd_build_tables_wave(pp, a.br_length, cfg.m_birth, cfg.m_death, n_bins, a.H, lr_chain_table(a, c), lane,
+                                    a.unit != 0, cfg.frac_birth, cfg.frac_death, 2);
+        }
         for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = 0.0;
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = 0;
         S[LR_ROW_L * LR_ROW + lane] = A, S[LR_ROW_PL * LR_ROW + lane] = A;
         int io = 0;
-        if (lane == LR_I_KL || lane == LR_I_PKL || lane == LR_I_KM || lane == LR_I_PKM) io = LR_DD_NPAR;
+        if (lane == LR_I_KL || lane == LR_I_PKL || lane == LR_I_KM || lane == LR_I_PKM) io = npar;
         I[LR_IROW_SCALARS * LR_ROW + lane] = io;
         return;
     }
@@ -1240,11 +1282,13 @@ static int lr_check_cfg(const lr_mcmc_config* cfg) {
     if (cfg->model < 0 || cfg->model > 3) return LR_ERR_MODEL;
     if (cfg->t0 != floor(cfg->t0)) return LR_ERR_T0;
     if (!(cfg->end_time > cfg->start_time)) return LR_ERR_SIZE;
-    if (cfg->sampler < 0 || cfg->sampler > 1) return LR_ERR_MODEL;
-    if (cfg->sampler == 1) {
-        if (cfg->model != LR_MODEL_KEIDING || cfg->m_birth < 0 || cfg->m_birth > 2 || cfg->m_death < -2 || cfg->m_death > 2)
-            return LR_ERR_MODEL;
+    if (cfg->sampler < 0 || cfg->sampler > 2) return LR_ERR_MODEL;
+    if (cfg->sampler != 0) {
+        if (cfg->model != LR_MODEL_KEIDING) return LR_ERR_MODEL;
         if (cfg->n_bins > LR_DD_MAXP * LR_WAVE) return LR_ERR_SIZE;
+    }
+    if (cfg->sampler == 1) {
+        if (cfg->m_birth < 0 || cfg->m_birth > 2 || cfg->m_death < -2 || cfg->m_death > 2) return LR_ERR_MODEL;
         if (!(cfg->dd_present > cfg->t0)) return LR_ERR_SIZE;
     }
     return LR_OK;
@@ -1288,7 +1332,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     lr_mcmc_layout lay;
     int rc = lr_mcmc_query_layout(cfg, &lay);
     if (rc) return rc;
-    if ((cfg->model == LR_MODEL_BD || cfg->model == LR_MODEL_ID || cfg->sampler == 1) && !br_length) return LR_ERR_MODEL;
+    if ((cfg->model == LR_MODEL_BD || cfg->model == LR_MODEL_ID || cfg->sampler != 0) && !br_length) return LR_ERR_MODEL;
     if (lay.total_bytes > workspace_bytes) return LR_ERR_WORKSPACE;
     lr_engine* e = new (std::nothrow) lr_engine();
     if (!e) return (int)hipErrorOutOfMemory;
@@ -1403,7 +1447,7 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
     if (!e) return LR_ERR_NULL;
     if (L && e->cfg.sampler == 0 && (!M || !tL || !tM || !KL || !KM)) return LR_ERR_NULL;
     if (L && (kmax < 1 || kmax > LR_KMAX)) return LR_ERR_SIZE;
-    if (L && e->cfg.sampler == 1 && kmax < LR_DD_NPAR) return LR_ERR_SIZE;
+    if (L && e->cfg.sampler != 0 && kmax < LR_DD_NPAR) return LR_ERR_SIZE;
     hipStream_t stream = (hipStream_t)stream_;
     const lr_step_args a = lr_make_args(e);
     lr_prepare_constants(e, a, stream);

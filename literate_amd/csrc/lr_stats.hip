@@ -231,19 +231,10 @@ __global__ void lr_trend_rates_kernel(const double* __restrict__ args, const dou
     const int c = blockIdx.y;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_bins) return;
-    const double* a = args + (size_t)c * 6;
-    const double l_min = a[0], m_min = a[1], alpha = a[2], beta = a[3], delta = a[4], gamma = a[5];
-    const double t = trend[b];
-    const double SMALL = 0.000000000000001;
-    double br = 1.0 * l_min, dr = 1.0 * m_min;
-    if (!const_birth) {
-        br = l_min + alpha * pow(t, delta);                                // trend_rate.py:79
-        if (br <= 0.0) br = SMALL;
-    }
-    if (!const_death) {
-        dr = m_min + beta * pow(t, gamma);                                 // trend_rate.py:86
-        if (dr <= 0.0) dr = SMALL;
-    }
+    const double* a = args + (size_t)c * LR_TR_NPAR;
+    const lr_trend_params p{a[0], a[1], a[2], a[3], a[4], a[5]};
+    double br, dr;
+    lr_trend_bin_rates(p, trend[b], const_birth, const_death, &br, &dr);   // shared with the engine's trend step
     const size_t o = (size_t)c * n_bins + b;
     birth[o] = br, death[o] = dr;
 }

@@ -19,7 +19,9 @@ class ChainEngine:
         stats: optional (t0, n_bins, br_length) if the caller already binned the data; otherwise the
         binning kernel runs here (LRF:515-523).
         dd: None = the runMCMC sampler (LRF:216-373); dict(m_birth, m_death, present, init_death) = the DDRate.py
-        sampler (DD:124-241) on create_bins statistics: stats = (ORIGIN, N_TIME_BINS, DT), model 2."""
+        sampler (DD:124-241) on create_bins statistics: stats = (ORIGIN, N_TIME_BINS, DT), model 2;
+        dict(kind="trend", m_birth=const_B, m_death=const_D) = the trend_rate.py sampler with
+        stats = (ORIGIN, N_TIME_BINS, TREND)."""
         torch = _hip.require_gpu()
         self.lib = _hip.load()
         self.device = torch.device(device or "cuda")
@@ -64,8 +66,9 @@ class ChainEngine:
             seed=int(seed), chain_offset=int(chain_offset), unit_resolution=int(self.unit_resolution),
             engine_mode={"auto": 0, "launch": 1, "persistent": 2, "persistent4": 3}[engine],
             frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0,
-            sampler=0 if dd is None else 1, m_birth=0 if dd is None else int(dd["m_birth"]),
-            m_death=0 if dd is None else int(dd["m_death"]), dd_present=0.0 if dd is None else float(dd["present"]),
+            sampler=0 if dd is None else (2 if dd.get("kind") == "trend" else 1),
+            m_birth=0 if dd is None else int(dd["m_birth"]), m_death=0 if dd is None else int(dd["m_death"]),
+            dd_present=0.0 if dd is None else float(dd.get("present", 0.0)),
             dd_init_death=0.0 if dd is None else float(dd.get("init_death", 0.1)))
         self.dd = dd
         self.layout = _hip.McmcLayout()
@@ -111,9 +114,10 @@ class ChainEngine:
         if L is None:
             rc = self.lib.lr_mcmc_init(self.handle, None, None, None, None, None, None, 0, _hip.stream_ptr())
         elif self.dd is not None:
-            # DDRate sampler: L = [C, 8] parameter vectors [l_max,k,x0,div_0,L,m_max,nuB,nuD] (DD:161)
+            # parametric samplers: L = [C, 8] (DD:161) or [C, 6] (trend_rate.py:74) parameter vectors
+            npar = 6 if self.dd.get("kind") == "trend" else 8
             args = np.zeros((self.n_chains, _hip.LR_KMAX))
-            args[:, :8] = np.asarray(L, dtype=float).reshape(self.n_chains, 8)
+            args[:, :npar] = np.asarray(L, dtype=float).reshape(self.n_chains, npar)
             self._init_keep = [ops._dev(args, torch.float64, self.device)]
             rc = self.lib.lr_mcmc_init(self.handle, _hip.ptr(self._init_keep[0]), None, None, None, None, None,
                                        _hip.LR_KMAX, _hip.stream_ptr())

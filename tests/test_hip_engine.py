@@ -524,3 +524,36 @@ def test_end_to_end_simulate_then_recover_key_innovation():
     assert np.allclose(mu_hat[3:38], .08, rtol=0.35), mu_hat
     assert lam_hat[27:38].mean() > 1.8 * lam_hat[3:22].mean()
     eng.close()
+
+
+@pytest.mark.parametrize("cb,cd,engine", [(0, 0, "auto"), (0, 0, "launch"), (0, 0, "persistent4"), (1, 0, "auto"), (0, 1, "auto")])
+def test_trend_rate_sampler_follows_oracle(G, golden_dir, cb, cd, engine):
+    """trend_rate.py's sampler (:102-196) on the engine (lr_mcmc_config.sampler = 2), metal_bands + the fixture's
+    covariate, 9 chains: every sampled log row against the oracle loop fed the same Philox draws."""
+    from literate_amd.trendrate import TrendRateEngine, normalise_trend
+    from oracle import trend_mcmc_oracle as tro
+    R = np.load(os.path.join(golden_dir, "ratemaps.npz"))
+    D = np.load(os.path.join(golden_dir, "ddrate.npz"))
+    origin, present, _ = D["meta"]
+    trend = normalise_trend(R["trend_raw"])
+    assert np.array_equal(trend, R["TREND"])
+    ts, te = G["metal_bands/lib_ts"], G["metal_bands/lib_te"]
+    n_it, seed, C, off = 600, 411, 9, 3
+    eng = TrendRateEngine(ts, te, origin, present, trend, C, const_birth=cb, const_death=cd, seed=seed, s_freq=3,
+                          n_trace_slots=n_it // 3, chain_offset=off, engine=engine)
+    eng.init(); eng.steps(250); eng.steps(n_it - 250)
+    with np.errstate(all="ignore"):
+        emp = (R["N_SPEC"] / R["DT"], R["N_EXTI"] / R["DT"])
+    moved = 0
+    for c in (0, 4, 8):
+        ref = tro.run_trend_mcmc(R["N_SPEC"], R["N_EXTI"], R["DT"], R["TREND"], tro.PhiloxDraws(seed, off + c), n_it, 3,
+                                 bool(cb), bool(cd), emp=emp)
+        got = eng.log_rows(c, emp=emp)
+        assert len(got) == len(ref) == n_it // 3
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert g[0] == r[0]
+            assert np.allclose(g[1:-3], r[1:-3], rtol=1e-9, atol=1e-9, equal_nan=True), (c, i, g[:12], r[:12])
+            assert np.allclose(g[-3:], r[-3:], rtol=1e-7, atol=1e-9, equal_nan=True)
+        moved += len(set(np.round(np.array(ref)[:, 2], 6)))
+    assert moved > 3 * 30
+    eng.close()

@@ -195,6 +195,38 @@ def test_ddrate_cli_end_to_end_and_shipped_log_kat(G, golden_dir, tmp_path):
         assert np.allclose(got[:, -3:], ref[:, -3:], rtol=1e-7, atol=1e-9, equal_nan=True)
 
 
+def test_trend_rate_cli_end_to_end(G, golden_dir, tmp_path):
+    """python trend_rate.py -d <metal_bands> -trend_data <file> ...: the log has the reference's own header line (from a
+    reference run) and its rows equal the oracle loop's (Philox draws)."""
+    from oracle import trend_mcmc_oracle as tro
+    R = np.load(os.path.join(golden_dir, "ratemaps.npz"))
+    T = np.load(os.path.join(golden_dir, "trend_trajectories.npz"))
+    ts, te = G["metal_bands/lib_ts"], G["metal_bands/lib_te"] - 0.5
+    data = tmp_path / "bands.tsv"
+    with open(data, "w") as f:
+        f.write("id\tts\tte\n")
+        for i, (a, c) in enumerate(zip(ts, te)):
+            f.write("%d\t%g\t%g\n" % (i, a, c))
+    trend_file = tmp_path / "trend.tsv"
+    with open(trend_file, "w") as f:
+        f.write("year\ttrend\n")
+        for i, v in enumerate(R["trend_raw"]):
+            f.write("%d\t%r\n" % (i, float(v)))
+    cmd = [sys.executable, os.path.join(ROOT, "trend_rate.py"), "-d", str(data), "-n", "300", "-s", "10", "-p", "100",
+           "-seed", "23", "-trend_data", str(trend_file), "-trend_index", "1", "--chains", "2"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, timeout=300)
+    with np.errstate(all="ignore"):
+        emp = (R["N_SPEC"] / R["DT"], R["N_EXTI"] / R["DT"])
+    for c in range(2):
+        lines = open(tmp_path / ("bands_23_EXPB_EXPD_c%d_1.trendrate.log" % c)).read().splitlines()
+        assert lines[0] == str(T["cb0_cd0_s4/header"])
+        got = np.array([[float(v) for v in l.split("\t")] for l in lines[1:]])
+        ref = np.array(tro.run_trend_mcmc(R["N_SPEC"], R["N_EXTI"], R["DT"], R["TREND"], tro.PhiloxDraws(23, c), 300, 10, emp=emp))
+        assert got.shape == ref.shape == (30, 12 + 2 * len(R["DT"]) + 3)
+        assert np.allclose(got[:, :-3], ref[:, :-3], rtol=1e-9, atol=1e-9)
+        assert np.allclose(got[:, -3:], ref[:, -3:], rtol=1e-7, atol=1e-9, equal_nan=True)
+
+
 def test_cli_cfg1_fixed_two_shifts(G, tmp_path):
     """BASELINE.json configs[0]: example_dataTBP, 1 chain, fixed 2 rate shifts (-const_rates 1 with a
     3-rate initial state, SURVEY 8c 'config-1 note').  K stays (3, 3), shift times never move (A9), the

@@ -46,6 +46,8 @@ def build_parser():
     p.add_argument('--chains', type=int, default=1, help='total number of independent chains')
     p.add_argument('--checkpoint', type=str, default="", help='file the run is saved to after every print block and '
                    'resumed from if it exists (same data and flags; extension to the reference, which cannot resume)')
+    p.add_argument('--combine', type=float, default=-1.0, help='with --chains > 1: also write COMBINED_{mcmc,sp_rates,'
+                   'ex_rates,div}.log with this burn-in fraction dropped per chain (plotRJforward.v3.py combine_logs)')
     p.add_argument('--init_shifts', type=int, default=0, help='initial number of rate shifts per process')
     return p
 
@@ -167,6 +169,9 @@ def main(argv=None):
         for c in range(args.chains):
             _, paths = logs.log_paths(args.d, model, args.out, None if args.chains == 1 else c)
             logs.write_chain_logs(paths, rows[:, c], emp, eng.n_bins, args.pyrate_output, true_root_age)
+        if args.combine >= 0 and args.chains > 1:
+            files = [logs.log_paths(args.d, model, args.out, c)[1]["mcmc"] for c in range(args.chains)]
+            logs.combine_logs(files, os.path.dirname(files[0]), args.combine)
     eng.close()
     if world > 1:
         dist.destroy_process_group()

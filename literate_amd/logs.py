@@ -4,6 +4,7 @@ File names, headers and column order follow LiteRateForward.py:485-512, 321-359,
 that plotRJforward.v3.py-style consumers read them unchanged; `marginal_rates` restates
 plotRJforward.v3.py:92-139, the definition of "posterior rate marginals"."""
 import csv
+import re
 import os
 
 import numpy as np
@@ -87,6 +88,43 @@ def write_chain_logs(paths, rows, emp=None, n_bins=None, pyrate_output=False, tr
                 ex = np.concatenate([ex[:km], true_root_age - ex[km:]])
             fs.write('\t'.join(str(float(v)) for v in sp) + '\n')
             fe.write('\t'.join(str(float(v)) for v in ex) + '\n')
+
+
+def combine_logs(mcmc_files, wd, burnin_pct):
+    """plotRJforward.v3.py:307-350: pool the per-chain logs of one analysis into COMBINED_{mcmc,sp_rates,ex_rates,
+    div}.log (burn-in dropped per file, the `it` column renumbered, the div statistics averaged over the files)."""
+    mcmc_files = list(mcmc_files)
+    total, header = [], ""
+    for name in mcmc_files:
+        with open(name) as f:
+            lines = f.readlines()
+        header = lines[0]
+        total += lines[int(burnin_pct * len(lines[1:])) + 1:]
+    with open(wd + '/COMBINED_mcmc.log', 'w') as o:
+        o.write(header)
+        for i, l in enumerate(total):
+            l = l.split('\t')
+            l[0] = str(i)
+            o.write('\t'.join(l))
+    for kind in ("sp_rates", "ex_rates"):
+        total = []
+        for name in mcmc_files:
+            with open(name.replace('mcmc.log', kind + '.log')) as f:
+                lines = f.readlines()
+            total += lines[int(burnin_pct * len(lines)):]
+        with open(wd + '/COMBINED_%s.log' % kind, 'w') as o:
+            o.writelines(total)
+    divs = []
+    for name in mcmc_files:
+        div_name = name.replace('mcmc.log', 'div.log')
+        if not os.path.exists(div_name):              # one div log per data file: all chains of a run share it
+            div_name = re.sub(r'_c\d+_div\.log$', '_div.log', div_name)
+        divs.append(np.loadtxt(div_name, skiprows=1, ndmin=2))
+    mean = np.mean(np.array(divs), axis=0)
+    with open(wd + '/COMBINED_div.log', 'w') as o:
+        o.write('sp_events\tex_events\tbr_length\n')
+        for row in mean:
+            o.write('\t'.join(str(float(v)) for v in row) + '\n')
 
 
 def calcHPD(data, level=0.95):

@@ -154,6 +154,20 @@ def test_log_writers_and_marginal_rates(tmp_path):
     assert np.array_equal(a[1], b[0]) and np.array_equal(a[2], b[1]) and np.array_equal(a[4], b[3])
     logs.write_div_log(paths["div"], np.arange(3), np.arange(3), np.array([1.5, 2.0, 3.0]))
     assert open(paths["div"]).read().splitlines()[1] == "0\t0\t1.5"
+    # combine_logs (plotRJforward.v3.py:307-350): two chains pooled, 25 % burn-in per file, `it` renumbered
+    files = []
+    for c in range(2):
+        _, pc = logs.log_paths(str(data), 0, "", c)
+        logs.write_chain_logs(pc, rows[c * 20:c * 20 + 20], emp, n_bins)
+        files.append(pc["mcmc"])
+    logs.combine_logs(files, out_dir, 0.25)
+    comb = open(os.path.join(out_dir, "COMBINED_mcmc.log")).read().splitlines()
+    assert comb[0] == lines[0] and len(comb) == 1 + 2 * 15
+    assert [l.split("\t")[0] for l in comb[1:]] == [str(i) for i in range(30)]
+    assert comb[1].split("\t")[1:] == open(files[0]).read().splitlines()[6].split("\t")[1:]
+    sp_comb = open(os.path.join(out_dir, "COMBINED_sp_rates.log")).read().splitlines()
+    assert len(sp_comb) == 30 and np.array_equal(np.array(sp_comb[15].split(), float), sp_rows[25])
+    assert open(os.path.join(out_dir, "COMBINED_div.log")).read().splitlines()[3] == "2.0\t2.0\t3.0"
 
 
 def _free_port():

@@ -103,9 +103,13 @@ def test_cli_end_to_end(G, tmp_path):
         for i, (a, b) in enumerate(zip(ts, te)):
             f.write("%d\t%g\t%g\n" % (i, root - a, root - b))
     cmd = [sys.executable, os.path.join(ROOT, "LiteRateForward.py"), "-d", str(data), "-TBP", "-n", "400", "-s", "20",
-           "-p", "200", "-seed", "31", "-model_BDI", "2", "--chains", "3"]
+           "-p", "200", "-seed", "31", "-model_BDI", "2", "--chains", "3", "--combine", "0.25"]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, timeout=300)
     logdir = tmp_path / "literate_mcmc_logs"
+    comb = open(logdir / "COMBINED_mcmc.log").read().splitlines()
+    assert len(comb) == 1 + 3 * 15 and comb[1].split("\t")[0] == "0" and comb[-1].split("\t")[0] == "44"
+    assert len(open(logdir / "COMBINED_sp_rates.log").read().splitlines()) == 45
+    assert open(logdir / "COMBINED_div.log").read().splitlines()[0] == "sp_events\tex_events\tbr_length"
     div = open(logdir / "example_BDk_div.log").read().splitlines()
     assert div[0] == "sp_events\tex_events\tbr_length"
     for line, a, b, c in zip(div[1:], G["example_TBP/sp"], G["example_TBP/ex"], G["example_TBP/br"]):

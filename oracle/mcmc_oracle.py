@@ -82,7 +82,7 @@ class NumpyLegacyDraws:
 
 
 class PhiloxDraws:
-    """The device's addressed stream (literate_amd/csrc/lr_rng.h) for one chain."""
+    """The device's addressed stream (literate_amd/csrc/lr_device.h) for one chain."""
 
     def __init__(self, seed, chain):
         self.s = px.Stream(seed, chain)

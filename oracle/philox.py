@@ -11,7 +11,7 @@ per chain on a GPU; the device engine therefore defines its own stream:
 so every draw is addressed by (iteration, purpose, index) and no draw depends
 on how many draws came before it.  This file restates that scheme in
 numpy/pure Python so the oracle MCMC can be fed the identical randomness the
-HIP kernel (literate_amd/csrc/lr_rng.h) uses.  Algorithm: Salmon et al.,
+HIP kernel (literate_amd/csrc/lr_device.h) uses.  Algorithm: Salmon et al.,
 "Parallel random numbers: as easy as 1, 2, 3" (SC'11), 10 rounds.
 """
 import math
@@ -22,7 +22,7 @@ W0 = 0x9E3779B9
 W1 = 0xBB67AE85
 MASK = 0xFFFFFFFF
 
-# purposes (must match literate_amd/csrc/lr_rng.h)
+# purposes (must match literate_amd/csrc/lr_device.h)
 P_MOVE = 0      # idx 0 -> r[0], r[1] (u_a, u_b)
 P_MULT = 1      # idx j -> (binomial-uniform, multiplier-uniform) for element j
 P_TIMES = 2     # idx 0 -> (choice, random)

@@ -10,5 +10,6 @@ Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the real
 reference (``/root/reference``) in the build container and records its outputs
 on the same inputs; ``tests/test_oracle_golden.py`` checks every function here
 against those vectors and against the reference's own known-answer values
-(SURVEY.md section 4).
+(SURVEY.md section 4).  One exception: ``sim_oracle.py`` (the lineage simulator,
+a "next" row of SURVEY.md section 8f) is UNPINNED - see its header.
 """

@@ -77,6 +77,12 @@ def test_no_cpu_compute_path():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src, f
+    for f in ("LiteRateForward.py", "DDRate.py", "trend_rate.py", "literate_library.py"):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read(), f
+    with pytest.raises(_hip.HipLibraryError):
+        ops.simulate_bd(10, 4, 1, np.zeros(4), np.zeros(4))
+    with pytest.raises(_hip.HipLibraryError):
+        ops.dd_rates(np.ones(8), np.ones(5))
 
 
 def test_drop_in_surface_names():

@@ -446,6 +446,15 @@ def make_shipped(work):
         header = f.readline().rstrip("\n")
     rows = np.loadtxt(log, skiprows=1)[:12]
     np.savez_compressed(os.path.join(HERE, "shipped_ddrate_log.npz"), header=np.array(header), rows=rows)
+    # the shipped posterior summary of the 100-chain analysis (vectors of the R plotting script the reference ships)
+    import re
+    txt = open(os.path.join(REF, "example_data/metal_bands/combined_runs/metal_bands.100chains_RTT_plots.r")).read()
+    summ = {}
+    for name in ("time", "birth_rate", "birth_minHPD", "birth_maxHPD", "death_rate", "death_minHPD", "death_maxHPD",
+                 "unique", "counts"):
+        m = re.findall(r"\n" + name + r"=c\(([^)]*)\)", txt)
+        summ[name] = np.array([float(x) for x in m[0].split(",")])
+    np.savez_compressed(os.path.join(HERE, "shipped_metal_bands_100chains.npz"), **summ)
     print("shipped: div", div.shape, "ddrate rows", rows.shape)
 
 

@@ -211,6 +211,18 @@ def test_engine_posterior_matches_reference_chains(G, golden_dir, name, model, C
         assert np.allclose(mine.mean(0), ref.mean(0), rtol=0.15)
     ref_kl = [np.dot(R["c%d/K_l_hist" % c], np.arange(40)) / R["c%d/K_l_hist" % c].sum() for c in range(n_ref)]
     assert abs(np.mean(kl) - np.mean(ref_kl)) < k_tol
+    if name == "metal_bands":
+        # the posterior the reference SHIPS for this dataset (100 chains, each on its own imputation replicate of the
+        # death times - so only a loose check): per-year mean birth rate, death rate on its two plateaus, inside the
+        # shipped 95 % HPD nearly everywhere, and the same most frequent number of birth-rate shifts
+        S = np.load(os.path.join(golden_dir, "shipped_metal_bands_100chains.npz"))
+        mine_b, mine_d = sp.mean(0)[::-1], ex.mean(0)[::-1]            # marginal rates come most recent first
+        assert np.allclose(mine_b, S["birth_rate"], rtol=0.12)
+        assert np.allclose(mine_d[:10], S["death_rate"][:10], rtol=0.15) and np.allclose(mine_d[-10:], S["death_rate"][-10:], rtol=0.2)
+        inside = (mine_b >= S["birth_minHPD"]) & (mine_b <= S["birth_maxHPD"])
+        assert inside.mean() > 0.9
+        k_hist = np.bincount(np.concatenate([[int(split_trace_row(tr[i, c])[0][6]) - 1 for i in range(burn, tr.shape[0])] for c in range(0, C, 8)]))
+        assert abs(int(np.argmax(k_hist)) - int(S["unique"][np.argmax(S["counts"])])) <= 1
 
 
 def test_cfg3_synthetic_10k_lineages_256_chains(G):

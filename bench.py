@@ -31,6 +31,9 @@ WORKLOADS = {
     # name: (lineages, n_bins, true shifts, chains per GPU, model)
     "cfg4": (100_000, 128, 20, 1024, 0),
     "cfg3": (10_000, 128, 20, 256, 0),
+    # BASELINE.json configs[1]: the shipped metal_bands lineages (30,217; the fixture holds the parsed file), 128 chains,
+    # model_BDI 2 as in the reference's tutorial run
+    "cfg2": (30_217, 32, 0, 128, 2),
     # BASELINE.json configs[4]: the DDRate.py sampler (model "dd": -m_birth 2 -m_death 2) on 50k lineages, 256 chains
     "cfg5": (50_000, 64, 6, 256, "dd"),
 }
@@ -116,7 +119,12 @@ def main():
     n_lin, n_bins, n_shifts, chains, model = WORKLOADS[args.workload]
     if args.chains:
         chains = args.chains
-    ts, te, _ = synth.make_lineages(n_lin, n_bins=n_bins, n_shifts=n_shifts, seed=0)   # same on every rank
+    if args.workload == "cfg2":
+        G = np.load(os.path.join(ROOT, "tests", "golden", "binning_lik.npz"))
+        ts, te = G["metal_bands/ts"], G["metal_bands/te"]
+        n_lin = len(ts)
+    else:
+        ts, te, _ = synth.make_lineages(n_lin, n_bins=n_bins, n_shifts=n_shifts, seed=0)   # same on every rank
     n_slots = (args.steps + args.warmup) // args.sample_every + 2
     if model == "dd":
         from literate_amd.ddrate import DDRateEngine
@@ -233,7 +241,7 @@ def main():
             "metric": "RJMCMC iters/sec x lineages (lineage-log-lik evals/s, summed over chains)",
             "value": value, "unit": "lineage-log-lik evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "shipped metal_bands_1.tsv" if args.workload == "cfg2" else "synthetic",
             "config": {"workload": "%s: synthetic %d lineages, %d unit bins, %d true shifts, %d chains per GPU, "
                                    "%s" % (args.workload, n_lin, n_bins, n_shifts, chains,
                                          "DDRate sampler -m_birth 2 -m_death 2" if model == "dd"

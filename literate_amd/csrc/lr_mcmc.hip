@@ -439,6 +439,17 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
     int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
     LR_SSTAMP(1);
 
+    // The wave-uniform draws of this step in ONE Philox call (a block costs 40 quarter-rate 32-bit multiplies whether
+    // one lane needs it or all 64): lane 0 the acceptance uniform of iteration `it`, lanes 1..3 the move selector and
+    // the two RJ pairs of the iteration about to be proposed.  Same (iteration, purpose, index) addresses as the
+    // separate calls, so the stream is unchanged.
+    lr_u2 ud;
+    {
+        const uint64_t it_prop = (mode == 1) ? it : it + 1;
+        const uint32_t purpose = (lane == 0) ? LR_P_ACCEPT : (lane == 1 ? LR_P_MOVE : LR_P_RJ);
+        ud = lr_pair(rng, lane == 0 ? it : it_prop, purpose, lane == 3 ? 1u : 0u);
+    }
+
     if (mode == 1) {
         // LRF:224-230.  The initial prior uses prior_gamma's default rate b=2 (LRF:201, 227).
         likA = lik_sum + constA;
@@ -452,7 +463,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
         const double hasting = lr_bcast(sc, LR_S_HASTING), priorP = lr_bcast(sc, LR_S_PRIOR_P);
         const double priorPoiP = lr_bcast(sc, LR_S_PRIORPOI_P), constP = lr_bcast(sc, LR_S_CONST_P);
         const double lik = gibbs ? likA : lik_sum + constP;
-        const double u = lr_pair(rng, it, LR_P_ACCEPT, 0).a;
+        const double u = lr_bcast(ud.a, 0);
         const bool ok = gibbs || (!invalid && (lik - likA + priorP - priorA + hasting >= log(u)));
         lik_p = invalid ? -INFINITY : lik;
         if (ok) {
@@ -510,7 +521,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
     const double sample_shift_mu = cfg.const_death_rate ? 0.0 : 0.5;
     const double b_freq = cfg.const_death_rate ? 0.7 : 0.4, d_freq = 0.8;
     const double fL = cfg.update_fraction, fM = cfg.const_death_rate ? 1.0 : cfg.update_fraction;
-    const lr_u2 r = lr_pair(rng, it, LR_P_MOVE, 0);
+    const lr_u2 r{lr_bcast(ud.a, 1), lr_bcast(ud.b, 1)};
     if (r.a < b_freq) {
         if (r.b < .5 || KL == 1) {
             const lr_u2 d = lr_pair(rng, it, LR_P_MULT, lane);
@@ -532,12 +543,12 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
     } else if (r.a < 0.999 && cfg.const_rates == 0) {
         // RJMCMC (LRF:71-97)
         move_kind = 4;
-        const lr_u2 q = lr_pair(rng, it, LR_P_RJ, 0);
+        const lr_u2 q{lr_bcast(ud.a, 2), lr_bcast(ud.b, 2)};
         const bool sideL = q.a > sample_shift_mu;
         double R = sideL ? L : M, T = sideL ? tL : tM;
         int K = sideL ? KL : KM;
         double score = 0.0;
-        const lr_u2 q2 = lr_pair(rng, it, LR_P_RJ, 1);
+        const lr_u2 q2{lr_bcast(ud.a, 3), lr_bcast(ud.b, 3)};
         if (q.b > 0.5) {
             if (K >= LR_KMAX) {
                 invalid = 1;  // device cap on the number of rates; the reference has none
@@ -683,12 +694,21 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
     int n_acc = lr_bcast_i(isc, LR_I_ACCEPTED);
     uint64_t next_sample = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_HI) << 32);
     int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
+    // wave-uniform draws in one Philox call (see lr_chain_step_core): lane 0 acceptance uniform of `it`, lane 1 the move
+    // selector and lane 2 the sliding-window uniform of the iteration about to be proposed
+    lr_u2 ud;
+    {
+        const uint64_t it_prop = (mode == 1) ? it : it + 1;
+        const uint32_t purpose = trend ? (lane == 0 ? LR_P_TR_ACCEPT : LR_P_TR_MOVE)
+                                       : (lane == 0 ? LR_P_DD_ACCEPT : (lane == 1 ? LR_P_DD_MOVE : LR_P_DD_SLIDE));
+        ud = lr_pair(rng, lane == 0 ? it : it_prop, purpose, 0u);
+    }
     if (mode == 1) {
         likA = lik_sum;                                                        // DD:184-186, trend_rate.py:150-151
         priorA = trend ? lr_trend_prior(A, lane) : lr_dd_prior(A, origin, present, k0, log_k0, lane);
     } else {
         const double hasting = lr_bcast(sc, LR_S_HASTING), priorP = lr_bcast(sc, LR_S_PRIOR_P);
-        const double u = lr_pair(rng, it, trend ? LR_P_TR_ACCEPT : LR_P_DD_ACCEPT, 0).a;
+        const double u = lr_bcast(ud.a, 0);
         const double lik = lik_sum;
         const bool ok = ((lik - likA) + (priorP - priorA) + hasting > log(u)) || it == 0;   // DD:211, trend_rate.py:176
         lik_p = lik;
@@ -716,7 +736,7 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
     int move_kind;
     if (trend) {
         // trend_rate.py:165-169: 33 % additive normal step on the slopes, else the vector multiplier
-        const double rr = lr_pair(rng, it, LR_P_TR_MOVE, 0).a;
+        const double rr = lr_bcast(ud.a, 1);
         double f_mult, f_norm;
         lr_trend_update_freq(cfg.m_birth, cfg.m_death, lane, &f_mult, &f_norm);
         const lr_u2 d = lr_pair(rng, it, LR_P_TR_MULT, lane);
@@ -730,10 +750,10 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
         }
     } else {
         // DD:195-207
-        const lr_u2 rr = lr_pair(rng, it, LR_P_DD_MOVE, 0);
+        const lr_u2 rr{lr_bcast(ud.a, 1), lr_bcast(ud.b, 1)};
         if (rr.b < 0.1 && (cfg.m_birth == 2 || cfg.m_death == 2)) {
             // update_sliding_win(x0, m=0, M=PRESENT, d=1.5) (lib:124-128)
-            double ii = lr_bcast(A, 2) + (lr_pair(rng, it, LR_P_DD_SLIDE, 0).a - .5) * 1.5;
+            double ii = lr_bcast(A, 2) + (lr_bcast(ud.a, 2) - .5) * 1.5;
             if (ii > present) ii = present - (ii - present);
             ii = fabs(ii);
             if (lane == 2) P = ii;

@@ -242,6 +242,7 @@ typedef struct lr_mcmc_layout {
 #define LR_S_LOG_G0 12   /* cached log(Gamma_rate[0]), log(Gamma_rate[1]), log(Poi_lambda_rjHP) */
 #define LR_S_LOG_G1 13
 #define LR_S_LOG_POI 14
+#define LR_S_LOG_U 15     /* log of the acceptance uniform of the pending proposal's iteration (drawn one step early) */
 /* rows of the int32 state block */
 #define LR_IROW_EL 0     /* accepted birth bin edges (ints, relative to bin 0) [K_l+1] */
 #define LR_IROW_EM 1

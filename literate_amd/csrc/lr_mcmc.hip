@@ -349,13 +349,18 @@ __device__ __forceinline__ double lr_build_tables_segments(const lr_seg_scratch*
 // stage one chain's segments in the wave's LDS scratch; log of all rates in ONE call
 // (lanes 0..31 carry the birth rates, lanes 32..63 the death rates)
 __device__ __forceinline__ void lr_stage_segments(lr_seg_scratch* sc, double L, double M, int eL, int eM, int KL,
-                                                  int KM, int lane, double* logL, double* logM) {
+                                                  int KM, int lane, double* logL, double* logM, double extra = 1.0,
+                                                  double* log_extra = nullptr) {
     const double Mhi = __shfl(M, lane & 31, LR_WAVE);
     const bool hi = lane >= 32;
     const int j = lane & 31;
     const bool valid = hi ? (j < KM) : (j < KL);
-    const double x = valid ? (hi ? Mhi : L) : 1.0;
+    // lane 63 is free unless the death process holds LR_KMAX rates: it takes one more logarithm along (`extra`)
+    const bool free63 = KM < LR_KMAX;
+    double x = valid ? (hi ? Mhi : L) : 1.0;
+    if (lane == LR_WAVE - 1 && free63) x = extra;
     const double lx = log(x);
+    if (log_extra) *log_extra = free63 ? lr_bcast(lx, LR_WAVE - 1) : log(extra);
     sc->rate[hi][j] = x;
     sc->lograte[hi][j] = lx;
     if (lane <= LR_KMAX) sc->edge[0][lane] = eL, sc->edge[1][lane] = eM;
@@ -439,16 +444,18 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
     int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
     LR_SSTAMP(1);
 
-    // The wave-uniform draws of this step in ONE Philox call (a block costs 40 quarter-rate 32-bit multiplies whether
-    // one lane needs it or all 64): lane 0 the acceptance uniform of iteration `it`, lanes 1..3 the move selector and
-    // the two RJ pairs of the iteration about to be proposed.  Same (iteration, purpose, index) addresses as the
-    // separate calls, so the stream is unchanged.
+    // The wave-uniform draws of the iteration about to be proposed in ONE Philox call (a block costs 40 quarter-rate
+    // 32-bit multiplies whether one lane needs it or all 64): lane 0 its acceptance uniform, lane 1 the move selector,
+    // lanes 2..3 the two RJ pairs.  Same (iteration, purpose, index) addresses as separate calls would use, so the
+    // stream is unchanged.  The logarithm of the acceptance uniform rides along in the packed log of the rates below
+    // and waits in LR_S_LOG_U until the proposal is decided, one step later.
     lr_u2 ud;
     {
         const uint64_t it_prop = (mode == 1) ? it : it + 1;
         const uint32_t purpose = (lane == 0) ? LR_P_ACCEPT : (lane == 1 ? LR_P_MOVE : LR_P_RJ);
-        ud = lr_pair(rng, lane == 0 ? it : it_prop, purpose, lane == 3 ? 1u : 0u);
+        ud = lr_pair(rng, it_prop, purpose, lane == 3 ? 1u : 0u);
     }
+    const double u_next = lr_bcast(ud.a, 0);
 
     if (mode == 1) {
         // LRF:224-230.  The initial prior uses prior_gamma's default rate b=2 (LRF:201, 227).
@@ -463,8 +470,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
         const double hasting = lr_bcast(sc, LR_S_HASTING), priorP = lr_bcast(sc, LR_S_PRIOR_P);
         const double priorPoiP = lr_bcast(sc, LR_S_PRIORPOI_P), constP = lr_bcast(sc, LR_S_CONST_P);
         const double lik = gibbs ? likA : lik_sum + constP;
-        const double u = lr_bcast(ud.a, 0);
-        const bool ok = gibbs || (!invalid && (lik - likA + priorP - priorA + hasting >= log(u)));
+        const bool ok = gibbs || (!invalid && (lik - likA + priorP - priorA + hasting >= lr_bcast(sc, LR_S_LOG_U)));
         lik_p = invalid ? -INFINITY : lik;
         if (ok) {
             L = pL0, M = pM0, tL = ptL0, tM = ptM0, eL = peL0, eM = peM0;
@@ -592,8 +598,8 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
 
     LR_SSTAMP(3);
     // segments of the proposal -> LDS scratch (+ log of every rate in one call)
-    double logpL, logpM;
-    lr_stage_segments(&scratch, pL, pM, peL, peM, PKL, PKM, lane, &logpL, &logpM);
+    double logpL, logpM, log_u_next;
+    lr_stage_segments(&scratch, pL, pM, peL, peM, PKL, PKM, lane, &logpL, &logpM, u_next, &log_u_next);
 
     LR_SSTAMP(4);
     // guard against tiny time frames (LRF:290-292) and the prior of the proposal (LRF:296-304)
@@ -644,6 +650,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
         so = (lane == LR_S_LOG_G0) ? lg0 : so;
         so = (lane == LR_S_LOG_G1) ? lg1 : so;
         so = (lane == LR_S_LOG_POI) ? lpoi : so;
+        so = (lane == LR_S_LOG_U) ? log_u_next : so;
         st.sc = so;
         int io = 0;
         io = (lane == LR_I_KL) ? KL : io;

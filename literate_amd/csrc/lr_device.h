@@ -95,6 +95,23 @@ __device__ __forceinline__ double lr_wave_exclusive_scan(double v, int lane, dou
     return lr_dpp_zero<0x138 /* wave_shr:1 */, 0xf, 0xf>(incl);   // lane l <- incl[l-1], lane 0 <- 0
 }
 
+// exclusive prefix sum of 32-bit integers over the lanes (same DPP pattern)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int lr_dpp_zero_i32(int src) {
+    return __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, BANK_MASK, true);
+}
+__device__ __forceinline__ int lr_wave_exclusive_scan_i32(int x) {
+    int v = x;
+    v += lr_dpp_zero_i32<LR_DPP_ROW_SHR(1), 0xf, 0xf>(x);
+    v += lr_dpp_zero_i32<LR_DPP_ROW_SHR(2), 0xf, 0xf>(x);
+    v += lr_dpp_zero_i32<LR_DPP_ROW_SHR(3), 0xf, 0xf>(x);
+    v += lr_dpp_zero_i32<LR_DPP_ROW_SHR(4), 0xf, 0xe>(v);
+    v += lr_dpp_zero_i32<LR_DPP_ROW_SHR(8), 0xf, 0xc>(v);
+    v += lr_dpp_zero_i32<LR_DPP_ROW_BCAST15, 0xa, 0xf>(v);
+    v += lr_dpp_zero_i32<LR_DPP_ROW_BCAST31, 0xc, 0xf>(v);
+    return lr_dpp_zero_i32<0x138 /* wave_shr:1 */, 0xf, 0xf>(v);
+}
+
 // ---------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11) and the draws built on it
 // ---------------------------------------------------------------------------------------

@@ -165,6 +165,7 @@ struct lr_seg_scratch {
     double rate[2][LR_KMAX];
     double lograte[2][LR_KMAX];
     int edge[2][LR_KMAX + 1];
+    int marks[4 * LR_WAVE + 2];   // per unit bin: number of birth-rate shifts (low half) / death-rate shifts (high half)
 };
 
 // Lookup tables of one chain straight from its segments (get_rate_index + L[indL] + the table
@@ -271,15 +272,32 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
         k_b[p] = (model < 2) ? br_length[b] : 1.0;
         lk_b[p] = (model < 2) ? log_br[b] : 0.0;
     }
-    for (int j = 1; j < KL; ++j) {
-        const int e = __builtin_amdgcn_readlane(eL, j);
+    // Segment of every bin = number of shifts at or before it.  The K - 1 shift lanes drop a count on their bin in
+    // LDS (birth shifts in the low half-word, death shifts in the high one), every lane reads the counts of its own
+    // bins and one integer wave scan turns them into ranks: a fixed ~35 instructions instead of a dependent
+    // (K_l + K_m) x P compare-and-add chain (the largest single item of the chain step before).
+    {
+        int* marks = const_cast<int*>(sc->marks);
+        for (int b = lane; b <= n_bins; b += LR_WAVE) marks[b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane >= 1 && lane < KL) atomicAdd(&marks[eL], 1);
+        if (lane >= 1 && lane < KM) atomicAdd(&marks[eM], 0x10000);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        int cnt[P], tot = 0;
 #pragma unroll
-        for (int p = 0; p < P; ++p) segL[p] += (e <= b0 + p) ? 1 : 0;
-    }
-    for (int j = 1; j < KM; ++j) {
-        const int e = __builtin_amdgcn_readlane(eM, j);
+        for (int p = 0; p < P; ++p) {
+            cnt[p] = (b0 + p <= n_bins) ? marks[b0 + p] : 0;
+            tot += cnt[p];
+        }
+        int run = lr_wave_exclusive_scan_i32(tot);
 #pragma unroll
-        for (int p = 0; p < P; ++p) segM[p] += (e <= b0 + p) ? 1 : 0;
+        for (int p = 0; p < P; ++p) {
+            run += cnt[p];
+            segL[p] = run & 0xffff, segM[p] = run >> 16;
+        }
     }
     double logB[P], logD[P], R[P];
     double sumR = 0.0, csum = 0.0;

@@ -627,7 +627,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
         const double nL = lr_dpp_zero<0x130 /* wave_shl:1 */, 0xf, 0xf>(ptL);   // lane l <- element l+1
         const double nM = lr_dpp_zero<0x130, 0xf, 0xf>(ptM);
         const double dmin = fmin(lane < PKL ? fabs(nL - ptL) : 1e300, lane < PKM ? fabs(nM - ptM) : 1e300);
-        if (lr_wave_min(dmin) <= LR_MIN_ALLOWED_T) invalid = 1;
+        if (__ballot(dmin <= LR_MIN_ALLOWED_T)) invalid = 1;       // min <= 1  <=>  any <= 1: one compare, no reduction
     }
     if (!invalid) {
         // Gamma(2, g) log-densities of all rates of both processes in one reduction (LRF:296)

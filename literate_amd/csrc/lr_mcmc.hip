@@ -929,7 +929,7 @@ __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const dou
 
 // Scan of all lineages against ONE pair table by `n_scan` threads (this thread is number `sid`): the inner loop
 // of the persistent engines.  8 lineages per 16-byte load, next load in flight while the current one is scored.
-template <int H>
+template <int H, int UNROLL = 1>
 __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                      long long n8, long long sid, int n_scan, double* acc0_,
                                                      double* acc1_) {
@@ -937,6 +937,9 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
     long long i = sid;
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     if (i < n8) w = idx8[i];
+    // UNROLL = 2 saves the register rotation of the prefetched index word (+1 % on long scans) at the price of a dozen
+    // spills around the chain-step call, which the short-scan configurations feel: the four-chain kernel uses it
+#pragma unroll UNROLL
     while (i < n8) {
         const uint4 cur = w;
         const long long nx = i + n_scan;
@@ -1090,7 +1093,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     // prologue: pair 0's pending proposal is scanned so that phase A can step it
     if (scanner) {
         double s0 = 0.0, s1 = 0.0;
-        lr_persist_scan_pair<H>(reinterpret_cast<const char*>(tab[0]), idx8, n8, sid, LR_P4_SCANNERS, &s0, &s1);
+        lr_persist_scan_pair<H, 2>(reinterpret_cast<const char*>(tab[0]), idx8, n8, sid, LR_P4_SCANNERS, &s0, &s1);
         s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
         if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
     }
@@ -1101,7 +1104,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
             // phase ph: steppers advance pair `ph`, scanners score pair `1 - ph`
             if (scanner) {
                 double s0 = 0.0, s1 = 0.0;
-                lr_persist_scan_pair<H>(reinterpret_cast<const char*>(tab[1 - ph]), idx8, n8, sid, LR_P4_SCANNERS, &s0, &s1);
+                lr_persist_scan_pair<H, 2>(reinterpret_cast<const char*>(tab[1 - ph]), idx8, n8, sid, LR_P4_SCANNERS, &s0, &s1);
                 s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
                 if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
             } else {

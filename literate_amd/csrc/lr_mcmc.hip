@@ -934,16 +934,18 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
                                                      long long n8, long long sid, int n_scan, double* acc0_,
                                                      double* acc1_) {
     double acc0 = *acc0_, acc1 = *acc1_;
-    long long i = sid;
+    // 32-bit loop arithmetic (n8 = N / 8 < 2^31): a 64-bit compare and add per trip are two instructions each
+    const int n = (int)n8;
+    int i = (int)sid;
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    if (i < n8) w = idx8[i];
+    if (i < n) w = idx8[i];
     // UNROLL = 2 saves the register rotation of the prefetched index word (+1 % on long scans) at the price of a dozen
     // spills around the chain-step call, which the short-scan configurations feel: the four-chain kernel uses it
 #pragma unroll UNROLL
-    while (i < n8) {
+    while (i < n) {
         const uint4 cur = w;
-        const long long nx = i + n_scan;
-        if (nx < n8) w = idx8[nx];
+        const int nx = i + n_scan;
+        if (nx < n) w = idx8[nx];
         const unsigned int words[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1295,6 +1297,7 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     static const int env = lr_env_int("LR_PERSIST", -1);   // debugging override: 0 off, 1 on
     if (env == 0 || cfg->engine_mode == 1) return false;
     if (!p.unit || cfg->n_bins + 1 > 255 || p.cb < 2) return false;
+    if (cfg->n_lineages >= (1ll << 33)) return false;   // the scan loop counts 16-byte index groups in 32 bits
     if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264) return false;
     if (env == 1 || cfg->engine_mode == 2 || cfg->engine_mode == 3) return true;
     const double n = (double)cfg->n_lineages, c = (double)cfg->n_chains;

@@ -19,21 +19,29 @@ struct lr_dd_params {
 // likelihood_function's rate half for ONE bin (DD:71-100): x = bin index (TIME_RANGE, lib:255), dt = DT[b]
 __device__ __forceinline__ void lr_dd_bin_rates(const lr_dd_params& p, double x, double dt, int m_birth, int m_death,
                                                 double* br_, double* dr_, double* niche_, double* frac_) {
-    double niche = 1.0, frac = 1.0, br, dr;
+    // frac ** nu as exp(nu * log(frac)) with the logarithm shared by the two processes when they see the same niche
+    // (a pow call is a log and an exp plus its own special-case handling; 0 and negative fractions behave as in
+    // numpy: 0 ** nu = 0, negative ** nu = nan)
+    double niche = 1.0, frac = 1.0, br, dr, lfrac = 0.0;
+    int niche_model = 0;
     if (m_birth == 0) {
         br = 1.0 * p.l_max;
     } else {
         niche = (m_birth == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / pow(1.0 + exp(-p.k * (x - p.x0)), 1.0 / 1.0);
         frac = dt / niche;
-        br = p.l_max - p.l_max * pow(frac, p.nuB);
+        lfrac = log(frac), niche_model = m_birth;
+        br = p.l_max - p.l_max * exp(p.nuB * lfrac);
         if (br <= 0.0) br = LR_DD_SMALL;
     }
     if (m_death <= 0) {
         dr = 1.0 * p.m_max;
     } else {
-        niche = (m_death == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / pow(1.0 + exp(-p.k * (x - p.x0)), 1.0 / 1.0);
-        frac = dt / niche;
-        dr = p.m_max + p.m_max * pow(frac, p.nuD);
+        if (m_death != niche_model) {
+            niche = (m_death == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / pow(1.0 + exp(-p.k * (x - p.x0)), 1.0 / 1.0);
+            frac = dt / niche;
+            lfrac = log(frac);
+        }
+        dr = p.m_max + p.m_max * exp(p.nuD * lfrac);
         if (dr <= 0.0) dr = LR_DD_SMALL;
     }
     *br_ = br, *dr_ = dr, *niche_ = niche, *frac_ = frac;
@@ -153,13 +161,15 @@ struct lr_trend_params {
 // likelihood_function's rate half for ONE bin (trend_rate.py:73-88); t = TREND[b]
 __device__ __forceinline__ void lr_trend_bin_rates(const lr_trend_params& p, double t, int const_birth, int const_death,
                                                    double* br_, double* dr_) {
+    // TREND ** exponent as exp(exponent * log(TREND)), one logarithm for both processes (TREND is in (0, 1])
     double br = 1.0 * p.l_min, dr = 1.0 * p.m_min;
+    const double lt = (const_birth && const_death) ? 0.0 : log(t);
     if (!const_birth) {
-        br = p.l_min + p.alpha * pow(t, p.delta);
+        br = p.l_min + p.alpha * exp(p.delta * lt);
         if (br <= 0.0) br = LR_DD_SMALL;
     }
     if (!const_death) {
-        dr = p.m_min + p.beta * pow(t, p.gamma);
+        dr = p.m_min + p.beta * exp(p.gamma * lt);
         if (dr <= 0.0) dr = LR_DD_SMALL;
     }
     *br_ = br, *dr_ = dr;

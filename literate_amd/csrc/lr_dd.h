@@ -16,7 +16,8 @@ struct lr_dd_params {
     double l_max, k, x0, div_0, L, m_max, nuB, nuD;
 };
 
-// likelihood_function's rate half for ONE bin (DD:71-100): x = bin index (TIME_RANGE, lib:255), dt = DT[b]
+// likelihood_function's rate half for ONE bin (DD:71-100): x = bin index (TIME_RANGE, lib:255), dt = DT[b].
+// get_logistic (DD:55-56) raises its denominator to 1/nu with nu = 1: x ** 1.0 is x, so no pow here.
 __device__ __forceinline__ void lr_dd_bin_rates(const lr_dd_params& p, double x, double dt, int m_birth, int m_death,
                                                 double* br_, double* dr_, double* niche_, double* frac_) {
     // frac ** nu as exp(nu * log(frac)) with the logarithm shared by the two processes when they see the same niche
@@ -27,7 +28,7 @@ __device__ __forceinline__ void lr_dd_bin_rates(const lr_dd_params& p, double x,
     if (m_birth == 0) {
         br = 1.0 * p.l_max;
     } else {
-        niche = (m_birth == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / pow(1.0 + exp(-p.k * (x - p.x0)), 1.0 / 1.0);
+        niche = (m_birth == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / (1.0 + exp(-p.k * (x - p.x0)));
         frac = dt / niche;
         lfrac = log(frac), niche_model = m_birth;
         br = p.l_max - p.l_max * exp(p.nuB * lfrac);
@@ -37,7 +38,7 @@ __device__ __forceinline__ void lr_dd_bin_rates(const lr_dd_params& p, double x,
         dr = 1.0 * p.m_max;
     } else {
         if (m_death != niche_model) {
-            niche = (m_death == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / pow(1.0 + exp(-p.k * (x - p.x0)), 1.0 / 1.0);
+            niche = (m_death == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / (1.0 + exp(-p.k * (x - p.x0)));
             frac = dt / niche;
             lfrac = log(frac);
         }

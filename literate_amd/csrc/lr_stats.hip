@@ -194,7 +194,7 @@ __global__ void lr_ddv2_rates_kernel(const double* __restrict__ args, const doub
     if (m_birth == 0) {
         br = 1.0 * l_f * l_mul;                                            // DDRatev2.py:77
     } else {
-        niche = (m_birth == 1) ? 1.0 * (L + div_0) : div_0 + L / pow(1.0 + exp(-k * (x - x0)), 1.0 / 1.0);
+        niche = (m_birth == 1) ? 1.0 * (L + div_0) : div_0 + L / (1.0 + exp(-k * (x - x0)));
         frac = dt / niche;
         const double rate_max = l_f + l_f * l_mul;                         // get_brates, DDRatev2.py:61-65
         br = rate_max - (rate_max - l_f) * pow(frac, nuB);
@@ -203,7 +203,7 @@ __global__ void lr_ddv2_rates_kernel(const double* __restrict__ args, const doub
     if (m_death <= 0) {
         dr = 1.0;                                                          // np.ones, DDRatev2.py:91
     } else {
-        niche = (m_death == 1) ? 1.0 * (L + div_0) : div_0 + L / pow(1.0 + exp(-k * (x - x0)), 1.0 / 1.0);
+        niche = (m_death == 1) ? 1.0 * (L + div_0) : div_0 + L / (1.0 + exp(-k * (x - x0)));
         frac = dt / niche;
         const double rate_min = l_f - l_f * m_mul;                         // get_drates on l_f, DDRatev2.py:67-71, 99
         dr = rate_min + (l_f - rate_min) * pow(frac, nuD);

@@ -871,7 +871,9 @@ struct lr_fused_args {
 template <int CB, int H, bool UNIT>
 __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_args a, lr_fused_args f) {
     extern __shared__ double2 lds[];
-    __shared__ lr_seg_scratch scratch[LR_STEP_WAVES];
+    // the step blocks do not stage tables: their per-wave scratch lives in the same dynamic LDS (a static array on top
+    // of the tables would cost the scan blocks one resident block per CU)
+    lr_seg_scratch* scratch = reinterpret_cast<lr_seg_scratch*>(lds);
     const int bid = blockIdx.x;
     if (bid < f.step_blocks) {
         const int wave = threadIdx.x / LR_WAVE, lane = threadIdx.x & (LR_WAVE - 1);
@@ -1535,7 +1537,8 @@ template <int CB, int H, bool UNIT>
 static int lr_launch_fused(const lr_engine* e, const lr_step_args& a, const lr_fused_args& f, hipStream_t stream) {
     const int groups = (f.scan_n + CB - 1) / CB;
     const int blocks = f.step_blocks + groups * f.tiles;
-    hipLaunchKernelGGL((lr_fused_iter_kernel<CB, H, UNIT>), dim3(blocks), dim3(LR_SCAN_THREADS), e->plan.lds_bytes,
+    const size_t lds_bytes = e->plan.lds_bytes > (int)(LR_STEP_WAVES * sizeof(lr_seg_scratch)) ? (size_t)e->plan.lds_bytes : LR_STEP_WAVES * sizeof(lr_seg_scratch);
+    hipLaunchKernelGGL((lr_fused_iter_kernel<CB, H, UNIT>), dim3(blocks), dim3(LR_SCAN_THREADS), lds_bytes,
                        stream, a, f);
     return (int)hipGetLastError();
 }

@@ -6,6 +6,7 @@ from .build import LIB
 
 c_i32, c_i64, c_f64, c_vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 
+LR_ERR_NULL, LR_ERR_SIZE, LR_ERR_MODEL, LR_ERR_WORKSPACE, LR_ERR_T0, LR_ERR_STATE = -1, -2, -3, -4, -5, -6
 ERRORS = {-1: "LR_ERR_NULL", -2: "LR_ERR_SIZE", -3: "LR_ERR_MODEL", -4: "LR_ERR_WORKSPACE", -5: "LR_ERR_T0",
           -6: "LR_ERR_STATE"}
 

@@ -374,3 +374,36 @@ def test_device_simulator_matches_oracle(ops, case):
     if case == "constant":
         lts, lte, _ = synth.simulate(n_start, T, scale, seed, rates=(la, mu))
         assert len(lts) == len(ts) and np.all(np.diff(lts) >= 0) and lte.max() == T + 0.5 and np.all(lte - 0.5 >= lts)
+
+
+def test_new_entry_points_reject_bad_arguments(ops):
+    """Error behaviour of the later ABI additions: status codes, no launch (0 ok, < 0 invalid argument)."""
+    import ctypes as C
+    import torch
+    from literate_amd import _hip
+    from literate_amd.engine import ChainEngine
+    lib = _hip.load()
+    dt = torch.ones(5, dtype=torch.float64, device="cuda")
+    out = [torch.empty((2, 5), dtype=torch.float64, device="cuda") for _ in range(4)]
+    a9 = torch.ones((2, 9), dtype=torch.float64, device="cuda")
+    P = _hip.ptr
+    assert lib.lr_ddv2_rates(P(a9), P(dt), 5, 2, 3, 2, P(out[0]), P(out[1]), P(out[2]), P(out[3]), None) == _hip.LR_ERR_MODEL
+    assert lib.lr_ddv2_rates(None, P(dt), 5, 2, 2, 2, P(out[0]), P(out[1]), P(out[2]), P(out[3]), None) == _hip.LR_ERR_NULL
+    assert lib.lr_trend_rates(P(a9), P(dt), 0, 2, 0, 0, P(out[0]), P(out[1]), None) == _hip.LR_ERR_SIZE
+    i64 = torch.ones(5, dtype=torch.int64, device="cuda")
+    assert lib.lr_binned_keiding(P(out[0]), P(out[1]), P(i64), None, P(dt), 5, 2, P(out[2]), P(out[3]), None) == _hip.LR_ERR_NULL
+    ws = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+    ts = torch.empty(100, dtype=torch.float64, device="cuda")
+    assert lib.lr_simulate_bd(None, None, 4, 0, 0., 0., 1., 1., 10, 100, 1, P(ts), P(ts), P(cnt), None, P(ws), 64, None) == _hip.LR_ERR_NULL
+    assert lib.lr_simulate_bd(P(dt), P(dt), 4, 5, 0., 0., 1., 1., 10, 100, 1, P(ts), P(ts), P(cnt), None, P(ws), 64, None) == _hip.LR_ERR_MODEL
+    assert lib.lr_simulate_bd(P(dt), P(dt), 4, 0, 0., 0., 1., 1., 200, 100, 1, P(ts), P(ts), P(cnt), None, P(ws), 64, None) == _hip.LR_ERR_SIZE
+    assert lib.lr_simulate_bd(P(dt), P(dt), 4, 0, 0., 0., 1., 1., 10, 100, 1, P(ts), P(ts), P(cnt), None, P(ws), 8, None) == _hip.LR_ERR_WORKSPACE
+    assert lib.lr_mcmc_restore(None, None) == _hip.LR_ERR_NULL
+    # a parametric sampler needs the Keiding model, at most 256 bins and its per-bin array
+    with pytest.raises(ValueError, match="LR_ERR_MODEL"):
+        ChainEngine(np.array([0., 1.]), np.array([2.5, 3.5]), 2, model=0, stats=(0.0, 3, np.ones(3)),
+                    dd=dict(m_birth=2, m_death=2, present=3.5))
+    with pytest.raises(ValueError, match="LR_ERR_MODEL"):
+        ChainEngine(np.array([0., 1.]), np.array([2.5, 3.5]), 2, model=2, stats=(0.0, 3, np.ones(3)),
+                    dd=dict(m_birth=5, m_death=2, present=3.5))

@@ -66,7 +66,13 @@ def cpu_baseline(ts, te, t0, n_bins, stats, start_time, end_time, budget_s=10.0)
     import multiprocessing as mp
     br = stats["br"]
     n_eval, el = _per_lineage_worker((ts, te, t0, n_bins, br, budget_s, 0))
-    out = dict(value=n_eval * len(ts) / el, unit="lineage-log-lik evals/s", cores=1, kind="port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    out = dict(value=n_eval * len(ts) / el, unit="lineage-log-lik evals/s", cores=1, kind="port", cpu_model=cpu_model,
                sample="%d chain states x %d lineages (same synthetic lineages, model 0), %.1f s of numpy on 1 core"
                       % (n_eval, len(ts), el))
     try:

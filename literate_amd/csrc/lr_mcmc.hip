@@ -132,6 +132,8 @@ struct lr_engine {
     lr_part part[LR_MAX_PARTS];
     bool persistent;          // use lr_persist_kernel in lr_mcmc_steps
     long long n8;             // 16-byte groups of packed lineage indices
+    long long n8_alloc;       // ... allocated (zero-filled behind the data)
+    int p4_d1, p4_d1b, p4_d2; // trips handed from the youngest to the oldest scanner waves (four-chain kernel)
     hipEvent_t fork;
 };
 
@@ -912,21 +914,35 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
 #ifndef LR_PERSIST_THREADS
 #define LR_PERSIST_THREADS 512
 #endif
+// spare zero-filled 16-byte groups behind the packed lineage indices (index 0 = sentinel table entries, contribution 0):
+// room for the trips the four-chain kernel moves between waves and for its prefetch past the end
+#define LR_P4_MAX_GIVE 64
+#define LR_IDX_SPARE ((LR_P4_MAX_GIVE + 1) * 896)
 #ifndef LR_PERSIST_MINWAVES
 #define LR_PERSIST_MINWAVES 4
 #endif
 
+// p4 = 1: layout for the four-chain kernel.  Its 14 scanner waves stride over the groups (wave slot = (group % 896) /
+// 64, trip = group / 896); the last d1 trips of the youngest waves (slots 10..13) and the last d2 trips of slots 8, 9
+// are stored behind the END of the oldest waves' shares instead (slots 0..3 and 4, 5), where those simply keep
+// striding: the hand-over costs the scan loop nothing.
 __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n,
-                                        long long n_pad, double t0, int n_bins, unsigned short* __restrict__ out) {
+                                        double t0, int n_bins, int p4, int k_tot, int d1, int d1b, int d2,
+                                        unsigned short* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
-    unsigned short v = 0;  // padding: entries (0, 0) = "outside the window" on both sides, contributes 0
-    if (i < n) {
-        const int a = min(max(__double2int_rz(floor(ts[i]) - t0), -1), n_bins);
-        const int b = min(max(__double2int_rz(ceil(te[i]) - t0), 0), n_bins + 1);
-        v = (unsigned short)((a + 1) | (b << 8));
+    if (i >= n) return;
+    const int a = min(max(__double2int_rz(floor(ts[i]) - t0), -1), n_bins);
+    const int b = min(max(__double2int_rz(ceil(te[i]) - t0), 0), n_bins + 1);
+    long long g = i >> 3;
+    if (p4) {
+        const int slot = (int)(g % 896) / 64, trip = (int)(g / 896);
+        int to = -1, give = 0;
+        if (slot >= 12) to = slot - 12, give = d1;          // waves 14, 15 -> 2, 3
+        else if (slot >= 10) to = slot - 8, give = d1b;     // waves 12, 13 -> 4, 5
+        else if (slot >= 8) to = slot - 4, give = d2;       // waves 10, 11 -> 6, 7
+        if (give > 0 && trip >= k_tot - give) g += (long long)(to - slot) * 64 + (long long)give * 896;
     }
-    out[i] = v;
+    out[g * 8 + (i & 7)] = (unsigned short)((a + 1) | (b << 8));
 }
 
 // Scan of all lineages against ONE pair table by `n_scan` threads (this thread is number `sid`): the inner loop
@@ -1070,7 +1086,7 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
 template <int H>
 __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
                                                                        const uint4* __restrict__ idx8, long long n8,
-                                                                       long long n_iters) {
+                                                                       int d1, int d1b, int d2, long long n_iters) {
     const lr_step_args& a = *ap;
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners
     __shared__ double2 tab[2][2 * H];                     // pair tables
@@ -1094,10 +1110,25 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     __syncthreads();
     const bool scanner = wave >= 2;
     const int sid = tid - 2 * LR_WAVE;
+    // The SIMD issue arbiter serves its oldest wave first: with equal shares the scanner waves of a SIMD finish one
+    // after the other (5.0 / 6.4 / 7.9 / 9.5 us per phase, measured with in-kernel stamps) and the youngest runs the
+    // tail alone.  So the youngest waves (12..15) leave their last d1 trips to the oldest scanner of their SIMD
+    // (2..5) and waves 10, 11 their last d2 trips to waves 6, 7.  lr_pack_lineages_kernel stores those groups where
+    // the takers keep striding, so this is only a per-wave end of the loop: a fixed partition, the summation order -
+    // and with it bitwise reproducibility - stays.
+    const int k_tot = (int)((n8 + LR_P4_SCANNERS - 1) / LR_P4_SCANNERS);
+    int k_mine = k_tot;
+    if (wave >= 14) k_mine -= d1;
+    else if (wave >= 12) k_mine -= d1b;
+    else if (wave >= 10) k_mine -= d2;
+    else if (wave == 6 || wave == 7) k_mine += d2;
+    else if (wave == 4 || wave == 5) k_mine += d1b;
+    else if (wave == 2 || wave == 3) k_mine += d1;
+    const long long n8w = (long long)k_mine * LR_P4_SCANNERS;
     // prologue: pair 0's pending proposal is scanned so that phase A can step it
     if (scanner) {
         double s0 = 0.0, s1 = 0.0;
-        lr_persist_scan_pair<H, 2>(reinterpret_cast<const char*>(tab[0]), idx8, n8, sid, LR_P4_SCANNERS, &s0, &s1);
+        lr_persist_scan_pair<H, 2>(reinterpret_cast<const char*>(tab[0]), idx8, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
         s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
         if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
     }
@@ -1108,7 +1139,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
             // phase ph: steppers advance pair `ph`, scanners score pair `1 - ph`
             if (scanner) {
                 double s0 = 0.0, s1 = 0.0;
-                lr_persist_scan_pair<H, 2>(reinterpret_cast<const char*>(tab[1 - ph]), idx8, n8, sid, LR_P4_SCANNERS, &s0, &s1);
+                lr_persist_scan_pair<H, 2>(reinterpret_cast<const char*>(tab[1 - ph]), idx8, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
                 s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
                 if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
             } else {
@@ -1359,7 +1390,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->state_f64 = o, o += lr_align_up64(C * LR_STATE_ROWS * LR_ROW * 8, 256);
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
     out->bin_consts = o, o += lr_align_up64((long long)(cfg->n_bins + 2) * 8, 256);   // log(br) + the DD constants
-    out->lineage_idx = o, o += lr_align_up64(lr_align_up64(cfg->n_lineages, 8) * 2, 256);
+    out->lineage_idx = o, o += lr_align_up64((lr_align_up64(cfg->n_lineages, 8) / 8 + (64 + 1) * 896) * 16, 256);
     out->args_blob = o, o += 1024;   // lr_step_args of the persistent kernel
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
@@ -1400,6 +1431,18 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, lr_fused_supported(e->plan), base, hA, pipelined);
     e->persistent = lr_persist_eligible(cfg, e->plan);
     e->n8 = lr_align_up64(cfg->n_lineages, 8) / 8;
+    e->n8_alloc = e->n8 + LR_IDX_SPARE;
+    {
+        // measured optimum at 14 trips per wave (cfg4): 6 / 6 / 2 - kept as fractions of the trip count for other inputs
+        const int k_tot = (int)((e->n8 + 895) / 896);
+        static const int e1 = lr_env_int("LR_P4_D1", -1), e1b = lr_env_int("LR_P4_D1B", -1), e2 = lr_env_int("LR_P4_D2", -1);
+        // (short scans are bound by the chain step, there the equal split is left alone)
+        const int on = k_tot >= 6;
+        const int d1 = e1 >= 0 ? e1 : on * ((6 * k_tot + 7) / 14), d1b = e1b >= 0 ? e1b : on * ((6 * k_tot + 7) / 14);
+        const int d2 = e2 >= 0 ? e2 : on * ((2 * k_tot + 7) / 14);
+        auto clampd = [&](int d) { d = d < 0 ? 0 : (d > LR_P4_MAX_GIVE ? LR_P4_MAX_GIVE : d); return d >= k_tot ? k_tot - 1 : d; };
+        e->p4_d1 = clampd(d1), e->p4_d1b = clampd(d1b), e->p4_d2 = clampd(d2);
+    }
     e->fork = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
         lr_part& q = e->part[p];
@@ -1477,9 +1520,11 @@ static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipS
     if (e->persistent) {
         static_assert(sizeof(lr_step_args) <= 1024, "args blob too small");
         hipLaunchKernelGGL(lr_store_args_kernel, dim3(1), dim3(64), 0, stream, a, (lr_step_args*)(e->ws + e->lay.args_blob));
-        const long long n_pad = e->n8 * 8;
-        hipLaunchKernelGGL(lr_pack_lineages_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, stream, e->ts,
-                           e->te, (long long)e->cfg.n_lineages, n_pad, e->cfg.t0, e->cfg.n_bins,
+        // zero fill (padding entries (0, 0) = "outside the window" on both sides, contribution 0), then the lineages
+        (void)hipMemsetAsync(e->ws + e->lay.lineage_idx, 0, (size_t)e->n8_alloc * 16, stream);
+        hipLaunchKernelGGL(lr_pack_lineages_kernel, dim3((unsigned)((e->cfg.n_lineages + 255) / 256)), dim3(256), 0, stream,
+                           e->ts, e->te, (long long)e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins,
+                           e->lay.persistent == 2 ? 1 : 0, (int)((e->n8 + 895) / 896), e->p4_d1, e->p4_d1b, e->p4_d2,
                            (unsigned short*)(e->ws + e->lay.lineage_idx));
     }
 }
@@ -1660,10 +1705,10 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
             switch (e->plan.H) {
-                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4_d1, e->p4_d1b, e->p4_d2, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4_d1, e->p4_d1b, e->p4_d2, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4_d1, e->p4_d1b, e->p4_d2, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4_d1, e->p4_d1b, e->p4_d2, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
             }
             const int rc = (int)hipGetLastError();
             if (rc) return rc;

@@ -5,6 +5,8 @@
 // one wave per chain: reduce the tile partials in order, Metropolis-Hastings accept, write the
 // trace row, draw the next proposal from the chain's Philox stream, build its lookup tables].
 // Iterations are captured in a hipGraph so the host only replays it.
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <new>
 
@@ -119,6 +121,12 @@ struct lr_part {
     int graph_units;
 };
 
+// Four-chain kernel: delta[s] = trips scanner slot s (wave s + 2) scores beyond (+) or short of (-) the equal share
+// k_tot; the deltas sum to zero.  The trips given up are stored, in slot / trip order, behind the takers' own shares.
+struct lr_p4_shares {
+    int delta[14];
+};
+
 struct lr_engine {
     lr_mcmc_config cfg;
     lr_mcmc_layout lay;
@@ -133,7 +141,7 @@ struct lr_engine {
     bool persistent;          // use lr_persist_kernel in lr_mcmc_steps
     long long n8;             // 16-byte groups of packed lineage indices
     long long n8_alloc;       // ... allocated (zero-filled behind the data)
-    int p4_d1, p4_d1b, p4_d2; // trips handed from the youngest to the oldest scanner waves (four-chain kernel)
+    lr_p4_shares p4;          // per scanner wave: trips more (+) or fewer (-) than the equal share (four-chain kernel)
     hipEvent_t fork;
 };
 
@@ -923,11 +931,11 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
 #endif
 
 // p4 = 1: layout for the four-chain kernel.  Its 14 scanner waves stride over the groups (wave slot = (group % 896) /
-// 64, trip = group / 896); the last d1 trips of the youngest waves (slots 10..13) and the last d2 trips of slots 8, 9
-// are stored behind the END of the oldest waves' shares instead (slots 0..3 and 4, 5), where those simply keep
-// striding: the hand-over costs the scan loop nothing.
+// 64, trip = group / 896) and do not all score the same number of trips (lr_p4_shares): the trips a slot gives up,
+// taken in slot / trip order, are stored as the extra trips of the taking slots, in slot / trip order, where those
+// waves simply keep striding.  The hand-over costs the scan loop nothing.
 __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n,
-                                        double t0, int n_bins, int p4, int k_tot, int d1, int d1b, int d2,
+                                        double t0, int n_bins, int p4, int k_tot, lr_p4_shares sh,
                                         unsigned short* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -935,12 +943,18 @@ __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const dou
     const int b = min(max(__double2int_rz(ceil(te[i]) - t0), 0), n_bins + 1);
     long long g = i >> 3;
     if (p4) {
-        const int slot = (int)(g % 896) / 64, trip = (int)(g / 896);
-        int to = -1, give = 0;
-        if (slot >= 12) to = slot - 12, give = d1;          // waves 14, 15 -> 2, 3
-        else if (slot >= 10) to = slot - 8, give = d1b;     // waves 12, 13 -> 4, 5
-        else if (slot >= 8) to = slot - 4, give = d2;       // waves 10, 11 -> 6, 7
-        if (give > 0 && trip >= k_tot - give) g += (long long)(to - slot) * 64 + (long long)give * 896;
+        const int slot = (int)(g % 896) / 64, trip = (int)(g / 896), lane = (int)(g % 64);
+        if (sh.delta[slot] < 0 && trip >= k_tot + sh.delta[slot]) {
+            int r = trip - (k_tot + sh.delta[slot]);                     // rank of this trip among all given trips
+            for (int q = 0; q < slot; ++q) r += sh.delta[q] < 0 ? -sh.delta[q] : 0;
+            int to = 0;
+            for (; to < 14; ++to) {
+                const int extra = sh.delta[to] > 0 ? sh.delta[to] : 0;
+                if (r < extra) break;
+                r -= extra;
+            }
+            g = (long long)(k_tot + r) * 896 + to * 64 + lane;
+        }
     }
     out[g * 8 + (i & 7)] = (unsigned short)((a + 1) | (b << 8));
 }
@@ -1037,6 +1051,9 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
         double acc0 = 0.0, acc1 = 0.0;
         lr_persist_scan_pair<H>(lbase, idx8, n8, tid, LR_PERSIST_THREADS, &acc0, &acc1);
 #ifdef LR_DIAG
+        if (lane == 0 && blockIdx.x < 512) atomicAdd(&lr_diag_step[20000 + blockIdx.x * 8 + wave], wall_clock64() - d_t0);
+#endif
+#ifdef LR_DIAG
         d_t1 = wall_clock64();
 #endif
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
@@ -1086,7 +1103,7 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
 template <int H>
 __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
                                                                        const uint4* __restrict__ idx8, long long n8,
-                                                                       int d1, int d1b, int d2, long long n_iters) {
+                                                                       lr_p4_shares sh, long long n_iters) {
     const lr_step_args& a = *ap;
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners
     __shared__ double2 tab[2][2 * H];                     // pair tables
@@ -1111,19 +1128,13 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     const bool scanner = wave >= 2;
     const int sid = tid - 2 * LR_WAVE;
     // The SIMD issue arbiter serves its oldest wave first: with equal shares the scanner waves of a SIMD finish one
-    // after the other (5.0 / 6.4 / 7.9 / 9.5 us per phase, measured with in-kernel stamps) and the youngest runs the
-    // tail alone.  So the youngest waves (12..15) leave their last d1 trips to the oldest scanner of their SIMD
-    // (2..5) and waves 10, 11 their last d2 trips to waves 6, 7.  lr_pack_lineages_kernel stores those groups where
-    // the takers keep striding, so this is only a per-wave end of the loop: a fixed partition, the summation order -
-    // and with it bitwise reproducibility - stays.
+    // after the other (5.0 / 6.4 / 7.9 / 9.5 us per phase, measured with in-kernel stamps), the youngest runs the tail
+    // alone, and SIMDs 0, 1 carry the stepper waves on top.  So the waves get unequal shares (lr_p4_shares) chosen to
+    // make them finish together.  lr_pack_lineages_kernel stores the moved groups where the takers keep striding, so
+    // this is only a per-wave end of the loop: a fixed partition, the summation order - and with it bitwise
+    // reproducibility - stays.
     const int k_tot = (int)((n8 + LR_P4_SCANNERS - 1) / LR_P4_SCANNERS);
-    int k_mine = k_tot;
-    if (wave >= 14) k_mine -= d1;
-    else if (wave >= 12) k_mine -= d1b;
-    else if (wave >= 10) k_mine -= d2;
-    else if (wave == 6 || wave == 7) k_mine += d2;
-    else if (wave == 4 || wave == 5) k_mine += d1b;
-    else if (wave == 2 || wave == 3) k_mine += d1;
+    const int k_mine = k_tot + (scanner ? sh.delta[wave - 2] : 0);
     const long long n8w = (long long)k_mine * LR_P4_SCANNERS;
     // prologue: pair 0's pending proposal is scanned so that phase A can step it
     if (scanner) {
@@ -1139,7 +1150,13 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
             // phase ph: steppers advance pair `ph`, scanners score pair `1 - ph`
             if (scanner) {
                 double s0 = 0.0, s1 = 0.0;
+#ifdef LR_DIAG
+                const unsigned long long dq0 = wall_clock64();
+#endif
                 lr_persist_scan_pair<H, 2>(reinterpret_cast<const char*>(tab[1 - ph]), idx8, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
+#ifdef LR_DIAG
+                if (lane == 0 && blockIdx.x < 64) atomicAdd(&lr_diag_step[20000 + blockIdx.x * 16 + wave], wall_clock64() - dq0);
+#endif
                 s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
                 if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
             } else {
@@ -1433,15 +1450,32 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->n8 = lr_align_up64(cfg->n_lineages, 8) / 8;
     e->n8_alloc = e->n8 + LR_IDX_SPARE;
     {
-        // measured optimum at 14 trips per wave (cfg4): 6 / 6 / 2 - kept as fractions of the trip count for other inputs
+        // Shares of the 14 scanner waves, tuned on cfg4 (14 trips per wave) with in-kernel stamps until the waves of a
+        // phase finish together: per wave pair (2,3) (4,5) ... (14,15) the trips beyond / short of the equal share.
+        // The SIMD arbiter serves its oldest wave first and SIMDs 0, 1 also host the stepper waves, hence the shape.
+        // Kept as fractions of the trip count for other inputs; short scans (bound by the chain step) stay equal.
+        static const char* env = getenv("LR_P4_SHARES");       // "d2,d4,d6,d8,d10,d12,d14" for 14 trips
+        int base[7] = {6, 6, 2, 0, -2, -6, -6};
+        if (env) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
         const int k_tot = (int)((e->n8 + 895) / 896);
-        static const int e1 = lr_env_int("LR_P4_D1", -1), e1b = lr_env_int("LR_P4_D1B", -1), e2 = lr_env_int("LR_P4_D2", -1);
-        // (short scans are bound by the chain step, there the equal split is left alone)
-        const int on = k_tot >= 6;
-        const int d1 = e1 >= 0 ? e1 : on * ((6 * k_tot + 7) / 14), d1b = e1b >= 0 ? e1b : on * ((6 * k_tot + 7) / 14);
-        const int d2 = e2 >= 0 ? e2 : on * ((2 * k_tot + 7) / 14);
-        auto clampd = [&](int d) { d = d < 0 ? 0 : (d > LR_P4_MAX_GIVE ? LR_P4_MAX_GIVE : d); return d >= k_tot ? k_tot - 1 : d; };
-        e->p4_d1 = clampd(d1), e->p4_d1b = clampd(d1b), e->p4_d2 = clampd(d2);
+        int sum = 0;
+        for (int j = 0; j < 7; ++j) {
+            int d = (k_tot >= 6) ? (int)lrint((double)base[j] * k_tot / 14.0) : 0;
+            if (d < -(k_tot - 1)) d = -(k_tot - 1);
+            if (d > LR_P4_MAX_GIVE) d = LR_P4_MAX_GIVE;
+            e->p4.delta[2 * j] = e->p4.delta[2 * j + 1] = d;
+            sum += d;
+        }
+        // make the deltas sum to zero exactly: trim the largest takers / givers
+        for (int guard = 0; sum != 0 && guard < 64; ++guard) {
+            int pick = 0;
+            for (int j = 1; j < 7; ++j)
+                if (sum > 0 ? e->p4.delta[2 * j] > e->p4.delta[2 * pick] : e->p4.delta[2 * j] < e->p4.delta[2 * pick]) pick = j;
+            const int step = sum > 0 ? -1 : 1;
+            e->p4.delta[2 * pick] += step, e->p4.delta[2 * pick + 1] += step;
+            sum += step;
+        }
+        if (sum != 0) for (int j = 0; j < 14; ++j) e->p4.delta[j] = 0;
     }
     e->fork = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
@@ -1524,7 +1558,7 @@ static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipS
         (void)hipMemsetAsync(e->ws + e->lay.lineage_idx, 0, (size_t)e->n8_alloc * 16, stream);
         hipLaunchKernelGGL(lr_pack_lineages_kernel, dim3((unsigned)((e->cfg.n_lineages + 255) / 256)), dim3(256), 0, stream,
                            e->ts, e->te, (long long)e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins,
-                           e->lay.persistent == 2 ? 1 : 0, (int)((e->n8 + 895) / 896), e->p4_d1, e->p4_d1b, e->p4_d2,
+                           e->lay.persistent == 2 ? 1 : 0, (int)((e->n8 + 895) / 896), e->p4,
                            (unsigned short*)(e->ws + e->lay.lineage_idx));
     }
 }
@@ -1705,10 +1739,10 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
             switch (e->plan.H) {
-                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4_d1, e->p4_d1b, e->p4_d2, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4_d1, e->p4_d1b, e->p4_d2, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4_d1, e->p4_d1b, e->p4_d2, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4_d1, e->p4_d1b, e->p4_d2, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
             }
             const int rc = (int)hipGetLastError();
             if (rc) return rc;

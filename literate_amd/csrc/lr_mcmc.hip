@@ -1135,7 +1135,11 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     // reproducibility - stays.
     const int k_tot = (int)((n8 + LR_P4_SCANNERS - 1) / LR_P4_SCANNERS);
     const int k_mine = k_tot + (scanner ? sh.delta[wave - 2] : 0);
-    const long long n8w = (long long)k_mine * LR_P4_SCANNERS;
+    // equal shares (short scans): the true end, so that the ragged last trip costs only the lanes that have a group
+    bool any_shift = false;
+#pragma unroll
+    for (int q = 0; q < 14; ++q) any_shift |= sh.delta[q] != 0;
+    const long long n8w = any_shift ? (long long)k_mine * LR_P4_SCANNERS : n8;
     // prologue: pair 0's pending proposal is scanned so that phase A can step it
     if (scanner) {
         double s0 = 0.0, s1 = 0.0;

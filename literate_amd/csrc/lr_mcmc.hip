@@ -1365,7 +1365,7 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
 // Which persistent kernel: 1 = two chains per 512-thread block (lr_persist_kernel), 2 = four chains per 1024-thread
 // block in ping-pong (lr_persist4_kernel).  The four-chain block hides the chain step under the other pair's scan but
 // scans with 14 of its 16 waves, so it wins only while a step is a sizeable part of a scan (measured on cfg4-like
-// data: ahead for 25k..200k lineages, behind outside), and it fills the chip in rounds of 1024 chains where the
+// data: ahead for 25k..1M lineages since its waves got unequal shares, behind below), and it fills the chip in rounds of 1024 chains where the
 // two-chain kernel's remainder round is cheaper when at most 512 chains are left (C = 1536: 29.4 vs 33.5 us).
 // Model in units of one full round: t4 = ceil(C/1024), t2 = 1.06 floor(C/1024) + (0.77 | 1.06 for the remainder).
 static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
@@ -1377,7 +1377,7 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p) 
     const int C = cfg->n_chains, rem = C % 1024;
     const double t4 = (double)((C + 1023) / 1024);
     const double t2 = 1.06 * (C / 1024) + (rem == 0 ? 0.0 : (rem <= 512 ? 0.77 : 1.06));
-    return (cfg->n_lineages >= 25000 && cfg->n_lineages <= 200000 && t4 < t2) ? 2 : 1;
+    return (cfg->n_lineages >= 25000 && cfg->n_lineages <= 1000000 && t4 < t2) ? 2 : 1;
 }
 
 static int lr_check_cfg(const lr_mcmc_config* cfg) {

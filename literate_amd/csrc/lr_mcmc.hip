@@ -124,7 +124,8 @@ struct lr_part {
 // Four-chain kernel: delta[s] = trips scanner slot s (wave s + 2) scores beyond (+) or short of (-) the equal share
 // k_tot; the deltas sum to zero.  The trips given up are stored, in slot / trip order, behind the takers' own shares.
 struct lr_p4_shares {
-    int delta[14];
+    int delta[16];
+    int n_slots;          // scanner waves striding over the groups: 14 (four-chain kernel) or 8 (two-chain kernel)
 };
 
 struct lr_engine {
@@ -943,17 +944,18 @@ __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const dou
     const int b = min(max(__double2int_rz(ceil(te[i]) - t0), 0), n_bins + 1);
     long long g = i >> 3;
     if (p4) {
-        const int slot = (int)(g % 896) / 64, trip = (int)(g / 896), lane = (int)(g % 64);
+        const int stride = sh.n_slots * 64;
+        const int slot = (int)(g % stride) / 64, trip = (int)(g / stride), lane = (int)(g % 64);
         if (sh.delta[slot] < 0 && trip >= k_tot + sh.delta[slot]) {
             int r = trip - (k_tot + sh.delta[slot]);                     // rank of this trip among all given trips
             for (int q = 0; q < slot; ++q) r += sh.delta[q] < 0 ? -sh.delta[q] : 0;
             int to = 0;
-            for (; to < 14; ++to) {
+            for (; to < sh.n_slots; ++to) {
                 const int extra = sh.delta[to] > 0 ? sh.delta[to] : 0;
                 if (r < extra) break;
                 r -= extra;
             }
-            g = (long long)(k_tot + r) * 896 + to * 64 + lane;
+            g = (long long)(k_tot + r) * stride + to * 64 + lane;
         }
     }
     out[g * 8 + (i & 7)] = (unsigned short)((a + 1) | (b << 8));
@@ -1010,7 +1012,7 @@ template <int H>
 __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_persist_kernel(
     const lr_step_args* __restrict__ ap /* in global memory: taking the address of a by-value kernel argument would
                                            copy it to scratch */,
-    const uint4* __restrict__ idx8, long long n8, long long n_iters, int prio_shift) {
+    const uint4* __restrict__ idx8, long long n8, lr_p4_shares sh, long long n_iters, int prio_shift) {
     const lr_step_args& a = *ap;
     __shared__ double2 tab[2 * H];  // the pair table: S' entries [0,H), E' entries [H,2H); (.x, .y) = (chain 0, chain 1)
     __shared__ double red[LR_PERSIST_THREADS / LR_WAVE][2];
@@ -1032,6 +1034,8 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
     for (int i = tid; i < 2 * H; i += LR_PERSIST_THREADS) tab[i] = gpair[i];
     __syncthreads();
     const char* lbase = reinterpret_cast<const char*>(tab);
+    // unequal shares of the waves (see lr_persist4_kernel): older waves 0..3 take trips from the younger 4..7
+    const long long n8w = sh.delta[0] != 0 ? ((n8 + LR_PERSIST_THREADS - 1) / LR_PERSIST_THREADS + sh.delta[wave]) * LR_PERSIST_THREADS : n8;
     const int grp = (blockIdx.x >> 8) & 1;
 #ifdef LR_DIAG
     unsigned long long d_t0 = 0, d_t1 = 0, d_t2 = 0, d_scan = 0, d_red = 0, d_step = 0;
@@ -1049,7 +1053,7 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
         d_t0 = wall_clock64();
 #endif
         double acc0 = 0.0, acc1 = 0.0;
-        lr_persist_scan_pair<H>(lbase, idx8, n8, tid, LR_PERSIST_THREADS, &acc0, &acc1);
+        lr_persist_scan_pair<H>(lbase, idx8, n8w, tid, LR_PERSIST_THREADS, &acc0, &acc1);
 #ifdef LR_DIAG
         if (lane == 0 && blockIdx.x < 512) atomicAdd(&lr_diag_step[20000 + blockIdx.x * 8 + wave], wall_clock64() - d_t0);
 #endif
@@ -1459,27 +1463,40 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
         // The SIMD arbiter serves its oldest wave first and SIMDs 0, 1 also host the stepper waves, hence the shape.
         // Kept as fractions of the trip count for other inputs; short scans (bound by the chain step) stay equal.
         static const char* env = getenv("LR_P4_SHARES");       // "d2,d4,d6,d8,d10,d12,d14" for 14 trips
-        int base[7] = {6, 6, 2, 0, -2, -6, -6};
-        if (env) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
-        const int k_tot = (int)((e->n8 + 895) / 896);
-        int sum = 0;
-        for (int j = 0; j < 7; ++j) {
-            int d = (k_tot >= 6) ? (int)lrint((double)base[j] * k_tot / 14.0) : 0;
-            if (d < -(k_tot - 1)) d = -(k_tot - 1);
+        static const int env2 = lr_env_int("LR_P2_SHARE", 0);   // two-chain kernel: trips per 24 moved from waves 4..7 to 0..3 (no gain measured: off)
+        for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
+        if (e->lay.persistent == 2) {
+            e->p4.n_slots = 14;
+            int base[7] = {6, 6, 2, 0, -2, -6, -6};
+            if (env) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
+            const int k_tot = (int)((e->n8 + 895) / 896);
+            int sum = 0;
+            for (int j = 0; j < 7; ++j) {
+                int d = (k_tot >= 6) ? (int)lrint((double)base[j] * k_tot / 14.0) : 0;
+                if (d < -(k_tot - 1)) d = -(k_tot - 1);
+                if (d > LR_P4_MAX_GIVE) d = LR_P4_MAX_GIVE;
+                e->p4.delta[2 * j] = e->p4.delta[2 * j + 1] = d;
+                sum += d;
+            }
+            // make the deltas sum to zero exactly: trim the largest takers / givers
+            for (int guard = 0; sum != 0 && guard < 64; ++guard) {
+                int pick = 0;
+                for (int j = 1; j < 7; ++j)
+                    if (sum > 0 ? e->p4.delta[2 * j] > e->p4.delta[2 * pick] : e->p4.delta[2 * j] < e->p4.delta[2 * pick]) pick = j;
+                const int step = sum > 0 ? -1 : 1;
+                e->p4.delta[2 * pick] += step, e->p4.delta[2 * pick + 1] += step;
+                sum += step;
+            }
+            if (sum != 0) for (int j = 0; j < 14; ++j) e->p4.delta[j] = 0;
+        } else {
+            // two-chain kernel: 8 waves, two per SIMD; the younger four (4..7) trail the older four by ~10 % on long scans,
+            // but with two unsynchronised blocks per CU moving trips between them bought nothing (16.3 us either way)
+            e->p4.n_slots = 8;
+            const int k_tot = (int)((e->n8 + 511) / 512);
+            int d = (k_tot >= 12) ? (int)lrint((double)env2 * k_tot / 24.0) : 0;
             if (d > LR_P4_MAX_GIVE) d = LR_P4_MAX_GIVE;
-            e->p4.delta[2 * j] = e->p4.delta[2 * j + 1] = d;
-            sum += d;
+            for (int j = 0; j < 4; ++j) e->p4.delta[j] = d, e->p4.delta[4 + j] = -d;
         }
-        // make the deltas sum to zero exactly: trim the largest takers / givers
-        for (int guard = 0; sum != 0 && guard < 64; ++guard) {
-            int pick = 0;
-            for (int j = 1; j < 7; ++j)
-                if (sum > 0 ? e->p4.delta[2 * j] > e->p4.delta[2 * pick] : e->p4.delta[2 * j] < e->p4.delta[2 * pick]) pick = j;
-            const int step = sum > 0 ? -1 : 1;
-            e->p4.delta[2 * pick] += step, e->p4.delta[2 * pick + 1] += step;
-            sum += step;
-        }
-        if (sum != 0) for (int j = 0; j < 14; ++j) e->p4.delta[j] = 0;
     }
     e->fork = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
@@ -1562,7 +1579,7 @@ static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipS
         (void)hipMemsetAsync(e->ws + e->lay.lineage_idx, 0, (size_t)e->n8_alloc * 16, stream);
         hipLaunchKernelGGL(lr_pack_lineages_kernel, dim3((unsigned)((e->cfg.n_lineages + 255) / 256)), dim3(256), 0, stream,
                            e->ts, e->te, (long long)e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins,
-                           e->lay.persistent == 2 ? 1 : 0, (int)((e->n8 + 895) / 896), e->p4,
+                           1, (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64)), e->p4,
                            (unsigned short*)(e->ws + e->lay.lineage_idx));
     }
 }
@@ -1743,10 +1760,10 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
             switch (e->plan.H) {
-                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
-                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, (long long)n, prio); break;
+                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); break;
+                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); break;
+                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); break;
+                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); break;
             }
             const int rc = (int)hipGetLastError();
             if (rc) return rc;

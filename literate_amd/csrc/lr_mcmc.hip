@@ -1371,7 +1371,8 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
 // scans with 14 of its 16 waves, so it wins only while a step is a sizeable part of a scan (measured on cfg4-like
 // data: ahead for 25k..1M lineages since its waves got unequal shares, behind below), and it fills the chip in rounds of 1024 chains where the
 // two-chain kernel's remainder round is cheaper when at most 512 chains are left (C = 1536: 29.4 vs 33.5 us).
-// Model in units of one full round: t4 = ceil(C/1024), t2 = 1.06 floor(C/1024) + (0.77 | 1.06 for the remainder).
+// Model in units of one full round (15.2 us on cfg4): t4 = ceil(C/1024), t2 = 1.08 floor(C/1024) + (0.82 | 1.08 for
+// the remainder).
 static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
     if (!lr_persist_eligible(cfg, p)) return 0;
     static const int p4_env = lr_env_int("LR_PERSIST4", -1);
@@ -1380,7 +1381,7 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p) 
     if (p4_env >= 0) return p4_env ? 2 : 1;
     const int C = cfg->n_chains, rem = C % 1024;
     const double t4 = (double)((C + 1023) / 1024);
-    const double t2 = 1.06 * (C / 1024) + (rem == 0 ? 0.0 : (rem <= 512 ? 0.77 : 1.06));
+    const double t2 = 1.08 * (C / 1024) + (rem == 0 ? 0.0 : (rem <= 512 ? 0.82 : 1.08));
     return (cfg->n_lineages >= 25000 && cfg->n_lineages <= 1000000 && t4 < t2) ? 2 : 1;
 }
 

@@ -117,10 +117,18 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    # LR_DIST_BACKEND=gloo: rehearsal of the multi-rank path on ONE GPU (all ranks on device 0, host-staged gather);
+    # the real thing is one rank per GPU over RCCL
+    backend = os.environ.get("LR_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n_lin, n_bins, n_shifts, chains, model = WORKLOADS[args.workload]
     if args.chains:
@@ -174,7 +182,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -23,7 +23,7 @@ def gather_traces(local, total_chains=None, dst=0, group=None):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if total_chains is None:
-        n = torch.tensor([local.shape[1]], device=local.device)
+        n = torch.tensor([local.shape[1]], device="cpu" if dist.get_backend(group) == "gloo" else local.device)
         dist.all_reduce(n, group=group)
         total_chains = int(n.item())
     n_max = -(-total_chains // world)
@@ -31,9 +31,13 @@ def gather_traces(local, total_chains=None, dst=0, group=None):
     if local.shape[1] < n_max:
         pad = torch.cat([local, local.new_full((local.shape[0], n_max - local.shape[1], local.shape[2]), float("nan"))], 1)
     pad = pad.contiguous()
+    # gloo (CPU tests, single-GPU rehearsals of the multi-rank path) gathers host tensors only
+    device = pad.device
+    if dist.get_backend(group) == "gloo" and pad.is_cuda:
+        pad = pad.cpu()
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    parts = [bufs[r][:, :shard_chains(total_chains, world, r)[1]] for r in range(world)]
+    parts = [bufs[r][:, :shard_chains(total_chains, world, r)[1]].to(device) for r in range(world)]
     return torch.cat(parts, 1)

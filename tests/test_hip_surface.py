@@ -231,6 +231,24 @@ def test_trend_rate_cli_end_to_end(G, golden_dir, tmp_path):
         assert np.allclose(got[:, -3:], ref[:, -3:], rtol=1e-7, atol=1e-9, equal_nan=True)
 
 
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """bench.py's multi-rank path (chain offsets per rank, barrier + max-over-ranks timing, gather of the sampled
+    rows to rank 0, one JSON line from rank 0) rehearsed with two ranks on ONE GPU: LR_DIST_BACKEND=gloo maps all
+    ranks to device 0 and stages the gather through the host.  The real runs use one rank per GPU over RCCL."""
+    import json
+    env = dict(os.environ, LR_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "300", "--warmup", "50",
+           "--chains", "64", "--workload", "cfg3", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=300, env=env).stdout
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["chains_total"] == 128 and b["config"]["chains_per_gpu"] == 64
+    assert b["scaling"] == "weak" and b["value"] > 0 and b["cpu_baseline"] is None
+    assert b["value"] == pytest.approx(300 * b["config"]["lineages"] * 128 / (b["ms_per_step"] * 1e-3 * 300))
+
+
 def test_cli_cfg1_fixed_two_shifts(G, tmp_path):
     """BASELINE.json configs[0]: example_dataTBP, 1 chain, fixed 2 rate shifts (-const_rates 1 with a
     3-rate initial state, SURVEY 8c 'config-1 note').  K stays (3, 3), shift times never move (A9), the

@@ -213,7 +213,7 @@ def main():
             kernel_ms = region_kernel_ms / launches
             # layout.persistent == 2: four chains per 1024-thread block, the two pairs scanned in turn (each pair still
             # one pass over the packed indices per iteration); 1: two chains per 512-thread block
-            kname = ("lr_persist4_kernel<%d>" if eng.layout.persistent == 2 else "lr_persist_kernel<%d>") % H
+            kname = "lr_persist4_kernel<%d>" % H if eng.layout.persistent == 2 else "lr_persist_kernel<%d, %d>" % (H, eng.layout.reserved1)
             pairs_per_launch = float(n_ev) * n_lin * chains
             passes = n_ev * ((chains + 1) // 2)                     # lineage passes: one per block per iteration
             alg_bytes = 2.0 * n_lin * passes                        # bytes of lineage data the launch reads

@@ -212,7 +212,7 @@ typedef struct lr_mcmc_layout {
     int32_t n_parts;      /* independent chain partitions, each on its own stream                  */
     int32_t pipelined;    /* 1: each partition runs the fused scan|step schedule over two halves   */
     int32_t persistent;   /* 0: launch-per-iteration engine; 1 / 2: persistent kernel, 2 / 4 chains per block */
-    int32_t reserved1;
+    int32_t reserved1;    /* threads per block of the persistent kernel (512 / 1024), 0 for the launch-based engine */
 } lr_mcmc_layout;
 
 /* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */

@@ -1008,14 +1008,16 @@ __device__ __attribute__((noinline)) void lr_persist_step(const lr_step_args* a,
     lr_chain_store(st, st_f64, st_i32, lane);
 }
 
-template <int H>
-__global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_persist_kernel(
+// T = threads per block: 512 (two blocks share a CU) or, when there are no more blocks than CUs anyway (at most 512
+// chains), 1024 - all 16 waves of the CU scan the one pair.
+template <int H, int T>
+__global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
     const lr_step_args* __restrict__ ap /* in global memory: taking the address of a by-value kernel argument would
                                            copy it to scratch */,
     const uint4* __restrict__ idx8, long long n8, lr_p4_shares sh, long long n_iters, int prio_shift) {
     const lr_step_args& a = *ap;
     __shared__ double2 tab[2 * H];  // the pair table: S' entries [0,H), E' entries [H,2H); (.x, .y) = (chain 0, chain 1)
-    __shared__ double red[LR_PERSIST_THREADS / LR_WAVE][2];
+    __shared__ double red[T / LR_WAVE][2];
     __shared__ lr_seg_scratch scratch[2];
     // the two chains' state rows live in LDS between iterations (registers are needed by the step itself)
     __shared__ double st_f64[2][LR_STATE_ROWS * LR_ROW];
@@ -1031,11 +1033,11 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
         for (int r = 0; r < LR_STATE_ROWS; ++r) st_f64[wave][r * LR_ROW + lane] = S[r * LR_ROW + lane];
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) st_i32[wave][r * LR_ROW + lane] = I[r * LR_ROW + lane];
     }
-    for (int i = tid; i < 2 * H; i += LR_PERSIST_THREADS) tab[i] = gpair[i];
+    for (int i = tid; i < 2 * H; i += T) tab[i] = gpair[i];
     __syncthreads();
     const char* lbase = reinterpret_cast<const char*>(tab);
     // unequal shares of the waves (see lr_persist4_kernel): older waves 0..3 take trips from the younger 4..7
-    const long long n8w = sh.delta[0] != 0 ? ((n8 + LR_PERSIST_THREADS - 1) / LR_PERSIST_THREADS + sh.delta[wave]) * LR_PERSIST_THREADS : n8;
+    const long long n8w = sh.delta[0] != 0 ? ((n8 + T - 1) / T + sh.delta[wave]) * T : n8;
     const int grp = (blockIdx.x >> 8) & 1;
 #ifdef LR_DIAG
     unsigned long long d_t0 = 0, d_t1 = 0, d_t2 = 0, d_scan = 0, d_red = 0, d_step = 0;
@@ -1053,7 +1055,7 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
         d_t0 = wall_clock64();
 #endif
         double acc0 = 0.0, acc1 = 0.0;
-        lr_persist_scan_pair<H>(lbase, idx8, n8w, tid, LR_PERSIST_THREADS, &acc0, &acc1);
+        lr_persist_scan_pair<H>(lbase, idx8, n8w, tid, T, &acc0, &acc1);
 #ifdef LR_DIAG
         if (lane == 0 && blockIdx.x < 512) atomicAdd(&lr_diag_step[20000 + blockIdx.x * 8 + wave], wall_clock64() - d_t0);
 #endif
@@ -1069,7 +1071,7 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
         if (stepper) {
             double lik = 0.0;
 #pragma unroll
-            for (int w2 = 0; w2 < LR_PERSIST_THREADS / LR_WAVE; ++w2) lik += red[w2][wave];
+            for (int w2 = 0; w2 < T / LR_WAVE; ++w2) lik += red[w2][wave];
             lr_persist_step(ap, c, lane, &scratch[wave], st_f64[wave], st_i32[wave], lik,
                             reinterpret_cast<double2*>(reinterpret_cast<double*>(tab) + wave), 2);
         }
@@ -1095,7 +1097,7 @@ __global__ __launch_bounds__(LR_PERSIST_THREADS, LR_PERSIST_MINWAVES) void lr_pe
         for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = st_f64[wave][r * LR_ROW + lane];
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = st_i32[wave][r * LR_ROW + lane];
     }
-    for (int i = tid; i < 2 * H; i += LR_PERSIST_THREADS) gpair[i] = tab[i];  // pending tables back to global
+    for (int i = tid; i < 2 * H; i += T) gpair[i] = tab[i];  // pending tables back to global
 }
 
 // Four chains per 1024-thread block (one block per CU), two pairs in ping-pong: while waves 0 and 1 run the chain
@@ -1433,6 +1435,11 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
         out->pipelined = pipelined[0] ? 1 : 0;
     }
     out->persistent = lr_persist_variant(cfg, p);
+    {
+        static const int wide_env = lr_env_int("LR_PERSIST_WIDE", -1);
+        const bool wide = wide_env >= 0 ? wide_env != 0 : ((cfg->n_chains + 1) / 2 <= 256 && cfg->n_lineages >= 20000);
+        out->reserved1 = out->persistent == 2 ? 1024 : (out->persistent == 1 ? (wide ? 1024 : 512) : 0);   // threads per persistent block
+    }
     return LR_OK;
 }
 
@@ -1492,11 +1499,26 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
         } else {
             // two-chain kernel: 8 waves, two per SIMD; the younger four (4..7) trail the older four by ~10 % on long scans,
             // but with two unsynchronised blocks per CU moving trips between them bought nothing (16.3 us either way)
-            e->p4.n_slots = 8;
-            const int k_tot = (int)((e->n8 + 511) / 512);
+            const bool wide2 = e->lay.reserved1 == 1024;
+            e->p4.n_slots = wide2 ? 16 : 8;
+            const int k_tot = (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64));
             int d = (k_tot >= 12) ? (int)lrint((double)env2 * k_tot / 24.0) : 0;
             if (d > LR_P4_MAX_GIVE) d = LR_P4_MAX_GIVE;
-            for (int j = 0; j < 4; ++j) e->p4.delta[j] = d, e->p4.delta[4 + j] = -d;
+            if (e->p4.n_slots == 8)
+                for (int j = 0; j < 4; ++j) e->p4.delta[j] = d, e->p4.delta[4 + j] = -d;
+            if (e->p4.n_slots == 16 && k_tot >= 6) {
+                // wide variant: ONE block per CU, four scanner waves per SIMD - the oldest-first pattern of the four-chain
+                // kernel: waves 0..3 / 4..7 take trips from 12..15 / 8..11 (per 12 trips)
+                static const char* envw = getenv("LR_P2W_SHARES");
+                int a = 5, b = 2;
+                if (envw) sscanf(envw, "%d,%d", &a, &b);
+                int da = (int)lrint((double)a * k_tot / 12.0), db = (int)lrint((double)b * k_tot / 12.0);
+                if (da > LR_P4_MAX_GIVE) da = LR_P4_MAX_GIVE;
+                if (db > LR_P4_MAX_GIVE) db = LR_P4_MAX_GIVE;
+                if (da > k_tot - 1) da = k_tot - 1;
+                if (db > k_tot - 1) db = k_tot - 1;
+                for (int j = 0; j < 4; ++j) e->p4.delta[j] = da, e->p4.delta[4 + j] = db, e->p4.delta[8 + j] = -db, e->p4.delta[12 + j] = -da;
+            }
         }
     }
     e->fork = nullptr;
@@ -1758,13 +1780,17 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         const int blocks = (e->cfg.n_chains + 1) / 2;
         const bool p4 = e->lay.persistent == 2;
         static const int prio = lr_env_int("LR_PERSIST_PRIO", 12);   // clock bits per priority slice, 0 = off
+        // one block per CU at most: give it the whole CU (16 waves on the one pair)
+        static const int wide_env = lr_env_int("LR_PERSIST_WIDE", -1);
+        const bool wide = e->lay.reserved1 == 1024;   // (short scans keep 512: the 16-wave barrier costs more than it buys)
+        (void)wide_env;
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
             switch (e->plan.H) {
-                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<40>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); break;
-                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<72>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); break;
-                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<136>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); break;
-                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else hipLaunchKernelGGL(lr_persist_kernel<264>, dim3(blocks), dim3(LR_PERSIST_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); break;
+                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else { if (wide) hipLaunchKernelGGL((lr_persist_kernel<40, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); else hipLaunchKernelGGL((lr_persist_kernel<40, 512>), dim3(blocks), dim3(512), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); } break;
+                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else { if (wide) hipLaunchKernelGGL((lr_persist_kernel<72, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); else hipLaunchKernelGGL((lr_persist_kernel<72, 512>), dim3(blocks), dim3(512), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); } break;
+                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else { if (wide) hipLaunchKernelGGL((lr_persist_kernel<136, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); else hipLaunchKernelGGL((lr_persist_kernel<136, 512>), dim3(blocks), dim3(512), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); } break;
+                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else { if (wide) hipLaunchKernelGGL((lr_persist_kernel<264, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); else hipLaunchKernelGGL((lr_persist_kernel<264, 512>), dim3(blocks), dim3(512), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); } break;
             }
             const int rc = (int)hipGetLastError();
             if (rc) return rc;

@@ -4,22 +4,34 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one RJMCMC iteration of every chain on this GPU: one scan of the lineage arrays
-scoring all pending proposals + the per-chain accept / trace / next-proposal step.  For this workload the
-engine is the persistent kernel lr_persist4_kernel: one launch runs all K iterations, a 1024-thread block owns four
-chains (two pairs in ping-pong: one pair's step hides under the other pair's scan).  Workload (config.workload) =
-BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages,
-128 unit bins, 20 true shifts per process, 1024 chains per GPU; chains shard across ranks with no
-data-path collective (weak scaling), lineage arrays are replicated; the sampled trace rows are
-gathered over RCCL once at the end of the timed region.  Inputs are resident in HBM before timing.
+A "step" = one RJMCMC iteration of every chain on this GPU: one scan of the lineages scoring all pending proposals
++ the per-chain accept / trace / next-proposal step, all inside the persistent engine kernel (one launch runs the K
+timed iterations).  Workload (config.workload) = BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages, 128 unit
+bins, 20 true shifts per process, 1024 chains per GPU; chains shard across ranks with no data-path collective (weak
+scaling), lineage arrays are replicated; the sampled trace rows are gathered over RCCL once at the end of the timed
+region.  Inputs are resident in HBM before timing.
 
-value = iterations x lineages x chains / time (one unit = one lineage's contribution to one
-chain's proposed-state log-likelihood: "iters/sec x lineages" of BASELINE.json, summed over chains).
+value = iterations x lineages x chains / time (one unit = one lineage's contribution to one chain's proposed-state
+log-likelihood: "iters/sec x lineages" of BASELINE.json, summed over chains).
+
+Beside the headline the line carries
+  roofline      - the dominant kernel against its physical bound (the LDS gather rate), with the
+                  HBM figures SURVEY 8(d) asks for as side fields and the HBM traffic measured by a rocprofv3 --pmc
+                  child run of the same launch (null + the reason when the profiler is not usable);
+  configs       - the other BASELINE configurations (cfg2, cfg3, cfg5), cfg4 on general (non-integer) lineage times,
+                  and cfg4 exactly as BASELINE.json words it (1024 chains over 8 GPUs = a 128-chain shard);
+  strong_scaling- for N > 1: the same 1024 chains in total, sharded over the N ranks, timed the same way;
+  cpu_baseline  - the numpy port (oracle/) on the host cores of the same box.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,18 +40,84 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (lineages, n_bins, true shifts, chains per GPU, model)
-    "cfg4": (100_000, 128, 20, 1024, 0),
-    "cfg3": (10_000, 128, 20, 256, 0),
+    # name: (lineages, n_bins, true shifts, chains per GPU, model, general times)
+    "cfg4": (100_000, 128, 20, 1024, 0, False),
+    "cfg3": (10_000, 128, 20, 256, 0, False),
     # BASELINE.json configs[1]: the shipped metal_bands lineages (30,217; the fixture holds the parsed file), 128 chains,
     # model_BDI 2 as in the reference's tutorial run
-    "cfg2": (30_217, 32, 0, 128, 2),
+    "cfg2": (30_217, 32, 0, 128, 2, False),
     # BASELINE.json configs[4]: the DDRate.py sampler (model "dd": -m_birth 2 -m_death 2) on 50k lineages, 256 chains
-    "cfg5": (50_000, 64, 6, 256, "dd"),
+    "cfg5": (50_000, 64, 6, 256, "dd", False),
+    # cfg4 with continuous (non-integer) birth / death times: the per-lineage form of BDIx:124-160 proper
+    "cfg4_general": (100_000, 128, 20, 1024, 0, True),
+    # BASELINE.json configs[3] as worded: 1024 chains over 8 GPUs = 128 chains on each
+    "cfg4_shard128": (100_000, 128, 20, 128, 0, False),
 }
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+LDS_PEAK_GBS = 256 * 256 * 2.4e9 / 1e9     # 256 B/clk/CU x 256 CUs x 2.4 GHz = 157,286 GB/s (MI355X_MICROARCH.md, LDS)
 
 
+def make_workload(name):
+    """-> (ts, te, n_bins requested, model, label)"""
+    n_lin, n_bins, n_shifts, _, model, general = WORKLOADS[name]
+    from literate_amd import synth
+    if name == "cfg2":
+        G = np.load(os.path.join(ROOT, "tests", "golden", "binning_lik.npz"))
+        return G["metal_bands/ts"], G["metal_bands/te"], model, "shipped metal_bands_1.tsv, 30217 lineages"
+    ts, te, _ = synth.make_lineages(n_lin, n_bins=n_bins, n_shifts=n_shifts, seed=0)   # same on every rank
+    label = "synthetic %d lineages, %d unit bins, %d true shifts" % (n_lin, n_bins, n_shifts)
+    if general:
+        # continuous times: births anywhere inside their year, deaths anywhere inside theirs (same bins, same events)
+        rng = np.random.default_rng(7)
+        ts = ts + rng.uniform(0.0, 1.0, len(ts)) * 0.999
+        te = np.maximum(np.ceil(te) - 1.0 + rng.uniform(1e-3, 0.999, len(te)), ts + 1e-3)
+        label += ", continuous times"
+    return ts, te, model, label
+
+
+def make_engine(name, ts, te, model, chains, chain_offset, s_freq, n_slots, engine="auto"):
+    if model == "dd":
+        from literate_amd.ddrate import DDRateEngine
+        return DDRateEngine(ts, te, float(ts.min()), float(te.max()), chains, m_birth=2, m_death=2, seed=2026,
+                            s_freq=s_freq, n_trace_slots=n_slots, chain_offset=chain_offset, engine=engine)
+    from literate_amd.engine import ChainEngine
+    return ChainEngine(ts, te, chains, model=model, seed=2026, s_freq=s_freq, n_trace_slots=n_slots,
+                       chain_offset=chain_offset, engine=engine)
+
+
+def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
+    """LDS-roofline figures of `n_iters` iterations that took `kernel_ms` of device time."""
+    unit = bool(eng.unit_resolution)
+    lds_bytes_per_eval = 16 if unit else 32          # two 8-byte / two 16-byte table entries per (lineage, chain)
+    evals = float(n_iters) * n_lin * chains
+    achieved = evals * lds_bytes_per_eval / (kernel_ms * 1e-3) / 1e9
+    return dict(kernel=eng.kernel_name(), us_per_iter=kernel_ms / n_iters * 1e3, evals_per_s=evals / (kernel_ms * 1e-3),
+                lds_bytes_per_eval=lds_bytes_per_eval, lds_GBs=achieved, lds_frac=achieved / LDS_PEAK_GBS,
+                unit_resolution_tables=unit, persistent=int(eng.layout.persistent),
+                threads_per_block=int(eng.layout.reserved1))
+
+
+def side_config(name, steps, warmup):
+    """One of the other configurations, ~1 s: device time of `steps` iterations (HIP events on the launch stream)."""
+    import torch
+    ts, te, model, label = make_workload(name)
+    chains = WORKLOADS[name][3]
+    eng = make_engine(name, ts, te, model, chains, 0, 100, (steps + warmup) // 100 + 2)
+    eng.init()
+    eng.steps(warmup)
+    torch.cuda.synchronize()
+    ms = eng.timed_steps(steps)
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == steps + warmup) and np.all(np.isfinite(snap["likA"])), name
+    out = dict(workload="%s: %s, %d chains, %s" % (name, label, chains,
+                                                    "DDRate sampler -m_birth 2 -m_death 2" if model == "dd" else "model_BDI %d" % model),
+               lineages=len(ts), chains=chains, steps=steps, iters_per_s_per_chain=steps / (ms * 1e-3))
+    out.update(kernel_figures(eng, len(ts), chains, steps, ms))
+    eng.close()
+    return out
+
+
+# ---- CPU legs (oracle/ = the checker, timed as the reported baseline) -------------------------------------------
 def _per_lineage_worker(job):
     """One host core: the numpy per-lineage evaluator on the same lineages for `budget_s` seconds."""
     ts, te, t0, n_bins, br, budget_s, seed = job
@@ -57,6 +135,14 @@ def _per_lineage_worker(job):
             return n_eval, el
 
 
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except (OSError, StopIteration):
+        return "unknown"
+
+
 def cpu_baseline(ts, te, t0, n_bins, stats, start_time, end_time, budget_s=10.0):
     """CPU numbers beside the GPU one, all from the numpy port under oracle/, bounded to ~25 s:
     value      : per-lineage evaluator (oracle.per_lineage_loglik: O(N) gather form of get_BDlik) on ONE core,
@@ -66,13 +152,8 @@ def cpu_baseline(ts, te, t0, n_bins, stats, start_time, end_time, budget_s=10.0)
     import multiprocessing as mp
     br = stats["br"]
     n_eval, el = _per_lineage_worker((ts, te, t0, n_bins, br, budget_s, 0))
-    cpu_model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
-    except (OSError, StopIteration):
-        pass
-    out = dict(value=n_eval * len(ts) / el, unit="lineage-log-lik evals/s", cores=1, kind="port", cpu_model=cpu_model,
+    out = dict(value=n_eval * len(ts) / el, unit="lineage-log-lik evals/s", cores=1, kind="port",
+               cpu_model=cpu_model_name(),
                sample="%d chain states x %d lineages (same synthetic lineages, model 0), %.1f s of numpy on 1 core"
                       % (n_eval, len(ts), el))
     try:
@@ -95,6 +176,78 @@ def cpu_baseline(ts, te, t0, n_bins, stats, start_time, end_time, budget_s=10.0)
     return out
 
 
+def cpu_baseline_dd(ts, te, budget_s=4.0):
+    """cfg5's CPU leg: DDRate.py's own loop (one chain, binned create_bins statistics; oracle/dd_mcmc_oracle.py) on
+    one core, as iterations/s and iterations/s x lineages."""
+    from oracle import dd_mcmc_oracle as do
+    from oracle import literate_oracle as lo
+    origin, present, n_spec, n_exti, DT, n_time_bins, time_range = lo.create_bins(float(ts.min()), float(te.max()), ts, te, 0)
+    n_it = 400
+    t_start = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t_start < budget_s:
+        do.run_dd_mcmc(n_spec, n_exti, DT, time_range, origin, present, 2, 2, do.NumpyLegacyDraws(), n_it, 100)
+        done += n_it
+    el = time.perf_counter() - t_start
+    return dict(value=done / el * len(ts), unit="lineage-log-lik evals/s", cores=1, kind="port",
+                iters_per_s=done / el, cpu_model=cpu_model_name(),
+                sample="%d iterations of DDRate.py's loop (one chain, binned statistics, -m_birth 2 -m_death 2), %.1f s of "
+                       "numpy on 1 core; value = iterations/s x %d lineages" % (done, el, len(ts)))
+
+
+# ---- HBM traffic of the dominant kernel: rocprofv3 --pmc child runs of the same launch ----------------------------
+def pmc_child(args):
+    """--pmc-child: exactly one engine launch of `steps` iterations on the named workload, nothing else."""
+    import torch
+    ts, te, model, _ = make_workload(args.workload)
+    chains = args.chains or WORKLOADS[args.workload][3]
+    eng = make_engine(args.workload, ts, te, model, chains, 0, args.sample_every,
+                      args.steps // args.sample_every + 2, engine=args.engine)
+    eng.init()
+    eng.steps(args.steps)
+    torch.cuda.synchronize()
+    eng.close()
+
+
+def measure_traffic(workload, chains, steps, kname, engine, sample_every):
+    """HBM bytes of ONE launch of the dominant kernel, the way MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE and
+    WRITE_SIZE in separate --pmc passes, FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B), both in KiB.
+    Returns (bytes or None, note)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    steps = min(steps, 4096)                      # one launch
+    vals = {}
+    base = kname.split("<")[0]
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="lr_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload, "--chains", str(chains),
+               "--steps", str(steps), "--engine", engine, "--sample-every", str(sample_every)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, timeout=150)
+        except (subprocess.TimeoutExpired, OSError) as ex:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 --pmc %s: %s" % (counter, type(ex).__name__)
+        rows = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                rows += [x for x in csv.DictReader(fh) if x.get("Counter_Name") == counter and base in x.get("Kernel_Name", "")]
+        shutil.rmtree(d, ignore_errors=True)
+        if r.returncode != 0 or not rows:
+            return None, "rocprofv3 --pmc %s: rc %d, %d rows for %s" % (counter, r.returncode, len(rows), base)
+        # the engine's launch of `steps` iterations is the longest dispatch of that kernel: the largest counter value
+        vals[counter] = max(float(x["Counter_Value"]) for x in rows)
+    hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return hbm * 1.0, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over one %d-iteration launch of %s: "
+                       "FETCH_SIZE %.1f KiB x 2 (gfx950 correction) + WRITE_SIZE %.1f KiB"
+                       % (steps, kname, vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,14 +255,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: the workload's chains on EVERY GPU; strong: that many chains in total, sharded over the ranks")
+    ap.add_argument("--engine", default="auto", choices=("auto", "launch", "persistent", "persistent4"))
     ap.add_argument("--sample-every", type=int, default=100, help="trace sampling frequency (-s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (cfg2, cfg3, cfg5, ...)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     import torch
     import torch.distributed as dist
-    from literate_amd import synth
-    from literate_amd.engine import ChainEngine
+    from literate_amd.dist import gather_traces as gather_rows
+    from literate_amd.dist import shard_chains
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,42 +291,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    n_lin, n_bins, n_shifts, chains, model = WORKLOADS[args.workload]
-    if args.chains:
-        chains = args.chains
-    if args.workload == "cfg2":
-        G = np.load(os.path.join(ROOT, "tests", "golden", "binning_lik.npz"))
-        ts, te = G["metal_bands/ts"], G["metal_bands/te"]
-        n_lin = len(ts)
-    else:
-        ts, te, _ = synth.make_lineages(n_lin, n_bins=n_bins, n_shifts=n_shifts, seed=0)   # same on every rank
-    n_slots = (args.steps + args.warmup) // args.sample_every + 2
-    if model == "dd":
-        from literate_amd.ddrate import DDRateEngine
-        eng = DDRateEngine(ts, te, float(ts.min()), float(te.max()), chains, m_birth=2, m_death=2, seed=2026,
-                           s_freq=args.sample_every, n_trace_slots=n_slots, chain_offset=rank * chains)
-    else:
-        eng = ChainEngine(ts, te, chains, model=model, seed=2026, s_freq=args.sample_every, n_trace_slots=n_slots,
-                          chain_offset=rank * chains)
-    # bring the device out of its idle power state before anything is measured (a cold MI355X runs the first
-    # tens of milliseconds at a fraction of its clock): ~0.4 s of throw-away iterations, then a fresh init so
-    # that exactly W warm-up + K timed iterations follow
-    eng.init()
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.4:
-        eng.steps(256)
-        torch.cuda.synchronize()
-    eng.init()
-    eng.steps(args.warmup)
-
-    from literate_amd.dist import gather_traces as gather_rows
-
-    def gather_traces():
-        # log-posterior trace rows sampled so far, gathered to rank 0 over RCCL / xGMI (literate_amd/dist.py; the same
-        # function runs under gloo in tests/test_host_cpu.py)
-        return gather_rows(eng.trace[:, :, :13], total_chains=chains * world)
-
-    gather_traces()     # untimed: loads the copy kernel and sets up the RCCL communicator (one-off costs)
+    ts, te, model, label = make_workload(args.workload)
+    n_lin = len(ts)
+    n_bins_req, n_shifts = WORKLOADS[args.workload][1], WORKLOADS[args.workload][2]
+    base_chains = args.chains or WORKLOADS[args.workload][3]
 
     def barrier():
         torch.cuda.synchronize()
@@ -173,65 +302,81 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t_begin = time.perf_counter()
-    # the K timed iterations, also bracketed by HIP events on the launch stream (roofline.kernel_ms for the persistent
-    # engine: the timed region IS its kernel, ceil(K/4096) launches)
-    region_kernel_ms = eng.timed_steps(args.steps)
-    gather_traces()
-    barrier()
-    elapsed = time.perf_counter() - t_begin
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(scaling):
+        """W warm-up + exactly K timed iterations of this rank's shard; returns the figures of the region."""
+        if scaling == "weak":
+            offset, chains = rank * base_chains, base_chains
+            total = base_chains * world
+        else:
+            offset, chains = shard_chains(base_chains, world, rank)
+            total = base_chains
+        n_slots = (args.steps + args.warmup) // args.sample_every + 2
+        eng = make_engine(args.workload, ts, te, model, chains, offset, args.sample_every, n_slots, engine=args.engine)
+        # bring the device out of its idle power state before anything is measured (a cold MI355X runs the first
+        # tens of milliseconds at a fraction of its clock): ~0.4 s of throw-away iterations, then a fresh init so
+        # that exactly W warm-up + K timed iterations follow
+        eng.init()
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.4:
+            eng.steps(256)
+            torch.cuda.synchronize()
+        eng.init()
+        eng.steps(args.warmup)
 
-    # sanity: the chains ran and hold finite posteriors
-    snap = eng.snapshot()
-    assert np.all(snap["it"] == args.steps + args.warmup) and np.all(np.isfinite(snap["likA"]))
-    assert snap["accepted"].min() > 0
+        def gather_traces():
+            # log-posterior trace rows sampled so far, gathered to rank 0 over RCCL / xGMI (literate_amd/dist.py; the
+            # same function runs under gloo in tests/test_host_cpu.py)
+            return gather_rows(eng.trace[:, :, :13], total_chains=total)
 
+        gather_traces()     # untimed: loads the copy kernel and sets up the RCCL communicator (one-off costs)
+        barrier()
+        t_begin = time.perf_counter()
+        # the K timed iterations, also bracketed by HIP events on the launch stream (roofline.kernel_ms for the
+        # persistent engine: the timed region IS its kernel, ceil(K/4096) launches)
+        region_kernel_ms = eng.timed_steps(args.steps)
+        gather_traces()
+        barrier()
+        elapsed = time.perf_counter() - t_begin
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # sanity: the chains ran and hold finite posteriors
+        snap = eng.snapshot()
+        assert np.all(snap["it"] == args.steps + args.warmup) and np.all(np.isfinite(snap["likA"]))
+        assert snap["accepted"].min() > 0
+        return eng, chains, total, elapsed, region_kernel_ms
+
+    eng, chains, total_chains, elapsed, region_kernel_ms = timed_region(args.scaling)
+    value = args.steps * n_lin * total_chains / elapsed
+
+    out = None
     if rank == 0:
-        total_chains = chains * world
-        value = args.steps * n_lin * total_chains / elapsed
-        # ---- roofline ------------------------------------------------------------------------------------
-        cb = eng.layout.chains_per_block
-        n_parts, pipelined = eng.layout.n_parts, bool(eng.layout.pipelined)
         persistent = bool(eng.layout.persistent)
         unit = bool(eng.unit_resolution)
-        H = eng.layout.table_stride // (1 if unit else 2)       # table half-stride the kernels are instantiated for
-        # physical limiter: LDS gather rate, 256 B/clk/CU; bytes gathered per (lineage, chain) pair: 16 (unit) / 32
-        lds_peak_pairs = 256 * 2.4e9 * 256 / (16 if unit else 32)
-        scan_ms = eng.time_scan(reps=50)   # stand-alone tiled scan of all chains (launch-based engine's body)
+        cb = eng.layout.chains_per_block
+        kname = eng.kernel_name()
         if persistent:
-            # Dominant kernel = lr_persist_kernel: ONE launch runs n_ev iterations of every chain (a 512-thread
-            # block owns two chains and reads the packed lineage indices, 2 B per lineage, once per iteration).
-            # Timed live with HIP events recorded on its stream around the launches of the timed region itself
+            # Dominant kernel = the persistent engine kernel: ONE launch runs n_ev iterations of every chain.  Timed
+            # live with HIP events recorded on its stream around the launches of the timed region itself
             # (lr_mcmc_time_steps); a launch runs at most 4096 iterations.
             launches = -(-args.steps // 4096)
             n_ev = args.steps / launches                            # iterations per launch (average)
             kernel_ms = region_kernel_ms / launches
-            # layout.persistent == 2: four chains per 1024-thread block, the two pairs scanned in turn (each pair still
-            # one pass over the packed indices per iteration); 1: two chains per 512-thread block
-            kname = "lr_persist4_kernel<%d>" % H if eng.layout.persistent == 2 else "lr_persist_kernel<%d, %d>" % (H, eng.layout.reserved1)
-            pairs_per_launch = float(n_ev) * n_lin * chains
-            passes = n_ev * ((chains + 1) // 2)                     # lineage passes: one per block per iteration
-            alg_bytes = 2.0 * n_lin * passes                        # bytes of lineage data the launch reads
-            conv_bytes = 16.0 * n_lin * passes                      # SURVEY 8(d) convention: 16 B x N x ceil(C/Cb), Cb = 2
-            ms_per_iter_ev = kernel_ms / n_ev
+            passes = n_ev * ((chains + 1) // 2)                     # lineage passes: one per chain pair per iteration
             cb_pass = 2
         else:
             # launch-based engine: the lineage scan runs as the scan blocks of lr_fused_iter_kernel, which HIP
             # events cannot bracket launch by launch under graph replay; the SAME block body is timed live as the
             # stand-alone lr_scan_*_kernel over all chains (lr_mcmc_time_scan, back-to-back launches)
-            n_ev = 200
-            ms_per_iter_ev = eng.timed_steps(n_ev) / n_ev
-            kernel_ms = scan_ms
-            kname = ("lr_scan_unit_kernel<%d,%d>" if unit else "lr_scan_fast_kernel<%d,%d>") % (cb, H)
-            pairs_per_launch = float(n_lin) * chains
-            alg_bytes = conv_bytes = 16.0 * n_lin * (-(-chains // cb))
+            n_ev = 1
+            kernel_ms = eng.time_scan(reps=50)
+            kname = ("lr_scan_unit_kernel<%d, %d>" if unit else "lr_scan_fast_kernel<%d, %d>") % (
+                cb, eng.layout.table_stride // (1 if unit else 2))
+            passes = -(-chains // cb)
             cb_pass = cb
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        fig = kernel_figures(eng, n_lin, chains, n_ev, kernel_ms)
+        conv_bytes = 16.0 * n_lin * passes                          # SURVEY 8(d): 16 B x N x ceil(C/Cb) per iteration
         # yardstick beside the nominal 8 TB/s (SURVEY 8d): device-to-device copy of 1 GiB, read + write bytes
         src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(src)
@@ -244,54 +389,90 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 10 * 2.0 * src.numel() / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
         del src, dst
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("workload") == args.workload and tj.get("chains") == chains and tj.get("kernel") == kname:
-                traffic = tj.get("hbm_bytes_per_iteration", 0.0) * (n_ev if persistent else 1)
+        hbm = {"peak_GBs": HBM_PEAK_GBS, "copy_GBs_measured": copy_gbs,
+               "algorithmic_GBs_16B_convention": conv_bytes / (kernel_ms * 1e-3) / 1e9,
+               "chains_per_pass_Cb": cb_pass,
+               "note": "SURVEY 8(d) prices a lineage pass at 16 B (fp64 ts + te) x N x ceil(C/Cb); the engine reads the "
+                       "lineages as packed table indices that stay in L2 (and scores Cb chains per pass from LDS), so this "
+                       "figure may exceed the HBM peak: HBM is not what the kernel works against - see traffic / "
+                       "measured_GBs for the bytes that really reach HBM"}
         out = {
             "metric": "RJMCMC iters/sec x lineages (lineage-log-lik evals/s, summed over chains)",
             "value": value, "unit": "lineage-log-lik evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "shipped metal_bands_1.tsv" if args.workload == "cfg2" else "synthetic",
-            "config": {"workload": "%s: synthetic %d lineages, %d unit bins, %d true shifts, %d chains per GPU, "
-                                   "%s" % (args.workload, n_lin, n_bins, n_shifts, chains,
-                                         "DDRate sampler -m_birth 2 -m_death 2" if model == "dd"
-                                         else "model_BDI %d, RJ prior on shifts" % model),
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "shipped metal_bands_1.tsv" if args.workload == "cfg2" else "synthetic",
+            "config": {"workload": "%s: %s, %d chains %s, %s" % (
+                           args.workload, label, base_chains, "per GPU" if args.scaling == "weak" else "in total",
+                           "DDRate sampler -m_birth 2 -m_death 2" if model == "dd" else "model_BDI %d, RJ prior on shifts" % model),
                        "lineages": n_lin, "chains_per_gpu": chains, "chains_total": total_chains,
                        "n_bins": eng.n_bins, "sample_every": args.sample_every,
                        "iters_per_s_per_chain": args.steps / elapsed},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "hbm_copy_GBs_measured": copy_gbs,
-                         "kernel": kname, "kernel_ms": kernel_ms, "iterations_per_launch": n_ev if persistent else 1,
-                         "pairs_per_launch": pairs_per_launch, "chains_per_pass_Cb": cb_pass,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_lineage_per_pass": 2 if persistent else 16,
-                         "achieved_GBs_16B_convention": conv_bytes / (kernel_ms * 1e-3) / 1e9,
-                         "effective_GBs_unamortised": 16.0 * pairs_per_launch / (kernel_ms * 1e-3) / 1e9,
-                         "kernel_evals_per_s": pairs_per_launch / (kernel_ms * 1e-3),
-                         "physical_bound": "lds", "lds_peak_evals_per_s": lds_peak_pairs,
-                         "lds_frac_kernel": pairs_per_launch / (kernel_ms * 1e-3) / lds_peak_pairs,
-                         "lds_frac_engine": value / world / lds_peak_pairs,
-                         "engine": {"persistent": persistent, "chains_per_block": 2 * eng.layout.persistent if persistent else cb,
-                                    "partitions_in_flight": 1 if persistent else n_parts,
-                                    "device_ms_per_step_hip_events": ms_per_iter_ev,
-                                    "unit_resolution_tables": unit,
-                                    "tiled_scan_kernel_ms_all_chains": scan_ms}},
+            "roofline": {"bound": "lds", "achieved": fig["lds_GBs"], "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                         "frac": fig["lds_frac"], "traffic": None, "traffic_note": "not measured",
+                         "kernel": kname, "kernel_ms": kernel_ms, "iterations_per_launch": n_ev,
+                         "evals_per_launch": float(n_ev) * n_lin * chains,
+                         "lds_bytes_per_eval": fig["lds_bytes_per_eval"],
+                         "kernel_evals_per_s": fig["evals_per_s"],
+                         "frac_engine": value / world * fig["lds_bytes_per_eval"] / 1e9 / LDS_PEAK_GBS,
+                         "bound_note": "LDS gather bandwidth: per (lineage, chain) the scan gathers %d B of lookup-table "
+                                       "entries from LDS (256 B/clk/CU x 256 CU x 2.4 GHz); no MFMA in a gather/scan/reduce"
+                                       % fig["lds_bytes_per_eval"],
+                         "hbm": hbm,
+                         "engine": {"persistent": fig["persistent"], "threads_per_block": fig["threads_per_block"],
+                                    "chains_per_block": 2 * eng.layout.persistent if persistent else cb,
+                                    "unit_resolution_tables": unit, "us_per_iter_device": fig["us_per_iter"]}},
         }
-        if not args.no_cpu_baseline and world == 1:
+    eng.close()
+    del eng
+
+    # ---- N > 1: the configuration as BASELINE.json words it (the chains in total, sharded) -----------------------
+    if world > 1 and args.scaling == "weak":
+        eng2, chains2, total2, elapsed2, kms2 = timed_region("strong")
+        if rank == 0:
+            out["strong_scaling"] = {"chains_total": total2, "chains_per_gpu": chains2,
+                                     "value": args.steps * n_lin * total2 / elapsed2, "unit": out["unit"],
+                                     "ms_per_step": elapsed2 / args.steps * 1e3, "kernel": eng2.kernel_name(),
+                                     "kernel_ms": kms2}
+        eng2.close()
+        del eng2
+
+    if rank == 0 and world == 1:
+        r = out["roofline"]
+        if not args.no_pmc:
+            traffic, note = measure_traffic(args.workload, chains, args.steps if r["iterations_per_launch"] > 1 else 64,
+                                            r["kernel"], args.engine, args.sample_every)
+            if traffic is not None and r["iterations_per_launch"] > 1:
+                traffic *= r["iterations_per_launch"] / min(args.steps, 4096)
+            r["traffic"], r["traffic_note"] = traffic, note
+            if traffic is not None:
+                r["hbm"]["measured_GBs"] = traffic / (r["kernel_ms"] * 1e-3) / 1e9
+                r["hbm"]["measured_frac_of_peak"] = r["hbm"]["measured_GBs"] / HBM_PEAK_GBS
+        if not args.no_configs:
+            cfgs = {}
+            for name in ("cfg2", "cfg3", "cfg5", "cfg4_general", "cfg4_shard128"):
+                if name == args.workload:
+                    continue
+                cfgs[name] = side_config(name, 2000, 300)
+            out["configs"] = cfgs
+        if not args.no_cpu_baseline:
             if model == "dd":
-                out["cpu_baseline"] = None     # the CPU legs below time the RJ sampler's path; cfg4 carries them
+                out["cpu_baseline"] = cpu_baseline_dd(ts, te, budget_s=15.0)
             else:
-                stats = dict(sp=eng.sp_events.cpu().numpy(), ex=eng.ex_events.cpu().numpy(), br=eng.br_length.cpu().numpy())
-                out["cpu_baseline"] = cpu_baseline(ts, te, eng.t0, eng.n_bins, stats, eng.start_time, eng.end_time)
+                e0 = make_engine(args.workload, ts, te, model, 2, 0, 100, 2)
+                stats = dict(sp=e0.sp_events.cpu().numpy(), ex=e0.ex_events.cpu().numpy(), br=e0.br_length.cpu().numpy())
+                t0, nb, st, en = e0.t0, e0.n_bins, e0.start_time, e0.end_time
+                e0.close()
+                out["cpu_baseline"] = cpu_baseline(ts, te, t0, nb, stats, st, en)
+            if "configs" in out and "cfg5" in out["configs"]:
+                ts5, te5, _, _ = make_workload("cfg5")
+                out["configs"]["cfg5"]["cpu_baseline"] = cpu_baseline_dd(ts5, te5)
         else:
             out["cpu_baseline"] = None
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -299,6 +299,8 @@ int lr_mcmc_restore(lr_engine* e, void* stream);
 int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms /* host */, void* stream);
 /* lr_mcmc_steps(n_iters) bracketed by HIP events on `stream`; blocks; *total_ms = elapsed device time. */
 int lr_mcmc_time_steps(lr_engine* e, int64_t n_iters, float* total_ms /* host */, void* stream);
+/* measurement hook: name of the kernel lr_mcmc_steps spends its time in, as a kernel trace prints it (n >= 64). */
+int lr_mcmc_describe(const lr_engine* e, char* buf /* host */, int32_t n);
 int lr_mcmc_destroy(lr_engine* e);
 
 #ifdef __cplusplus

@@ -65,6 +65,7 @@ SIGNATURES = {
     "lr_mcmc_time_scan": (c_i32, [c_vp, c_i32, C.POINTER(C.c_float), c_vp]),
     "lr_mcmc_time_steps": (c_i32, [c_vp, c_i64, C.POINTER(C.c_float), c_vp]),
     "lr_mcmc_restore": (c_i32, [c_vp, c_vp]),
+    "lr_mcmc_describe": (c_i32, [c_vp, C.c_char_p, c_i32]),
     "lr_mcmc_destroy": (c_i32, [c_vp]),
     "lr_debug_draws": (c_i32, [C.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
 }
@@ -112,6 +113,16 @@ def ptr(t):
     return None if t is None else c_vp(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """torch's current HIP stream on `device` (None = the current device) as a void*."""
     import torch
-    return c_vp(torch.cuda.current_stream().cuda_stream)
+    return c_vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+def launch(fn, device, *args):
+    """Call an ABI entry point whose last argument is the stream: on `device`'s current torch stream, with `device`
+    made current for the call (a launch on another device's stream is an error in HIP, and the library's own
+    streams / events / graphs are created on the current device)."""
+    import torch
+    with torch.cuda.device(device):
+        return fn(*args, stream_ptr(device))

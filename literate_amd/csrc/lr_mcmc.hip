@@ -926,7 +926,8 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
 // spare zero-filled 16-byte groups behind the packed lineage indices (index 0 = sentinel table entries, contribution 0):
 // room for the trips the four-chain kernel moves between waves and for its prefetch past the end
 #define LR_P4_MAX_GIVE 64
-#define LR_IDX_SPARE ((LR_P4_MAX_GIVE + 1) * 896)
+// sized for the widest stride (16 scanner waves x 64 lanes): the takers' extra trips reach group (k_tot + give) * stride
+#define LR_IDX_SPARE ((LR_P4_MAX_GIVE + 2) * 1024)
 #ifndef LR_PERSIST_MINWAVES
 #define LR_PERSIST_MINWAVES 4
 #endif
@@ -1418,7 +1419,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->state_f64 = o, o += lr_align_up64(C * LR_STATE_ROWS * LR_ROW * 8, 256);
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
     out->bin_consts = o, o += lr_align_up64((long long)(cfg->n_bins + 2) * 8, 256);   // log(br) + the DD constants
-    out->lineage_idx = o, o += lr_align_up64((lr_align_up64(cfg->n_lineages, 8) / 8 + (64 + 1) * 896) * 16, 256);
+    out->lineage_idx = o, o += lr_align_up64((lr_align_up64(cfg->n_lineages, 8) / 8 + LR_IDX_SPARE) * 16, 256);
     out->args_blob = o, o += 1024;   // lr_step_args of the persistent kernel
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
@@ -1520,6 +1521,15 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
                 for (int j = 0; j < 4; ++j) e->p4.delta[j] = da, e->p4.delta[4 + j] = db, e->p4.delta[8 + j] = -db, e->p4.delta[12 + j] = -da;
             }
         }
+    }
+    {
+        // the takers' extra trips must stay inside the zero-filled spare behind the packed indices
+        const long long stride = (long long)e->p4.n_slots * 64;
+        const long long k_tot = (e->n8 + stride - 1) / stride;
+        int dmax = 0;
+        for (int j = 0; j < 16; ++j) dmax = e->p4.delta[j] > dmax ? e->p4.delta[j] : dmax;
+        if ((k_tot + dmax + 1) * stride > e->n8_alloc)
+            for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
     }
     e->fork = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
@@ -1724,20 +1734,21 @@ static int lr_run_units(lr_engine* e, const lr_step_args& a, lr_part& q, int64_t
         if (!q.graph_exec) {
             // capture G units once; the kernels read the iteration number from device memory, so the
             // same graph is valid for every replay
-            hipStream_t cs;
+            hipStream_t cs = nullptr;
+            hipGraph_t graph = nullptr;
             hipError_t he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
             if (he != hipSuccess) return (int)he;
-            hipGraph_t graph;
-            he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-            if (he != hipSuccess) return (int)he;
             int rc = LR_OK;
-            for (int i = 0; i < G && rc == LR_OK; ++i) rc = lr_enqueue_unit(e, a, q, cs);
-            he = hipStreamEndCapture(cs, &graph);
-            if (rc) return rc;
-            if (he != hipSuccess) return (int)he;
-            he = hipGraphInstantiate(&q.graph_exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
+            he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+            if (he == hipSuccess) {
+                for (int i = 0; i < G && rc == LR_OK; ++i) rc = lr_enqueue_unit(e, a, q, cs);
+                he = hipStreamEndCapture(cs, &graph);       // always ended, so that the stream leaves capture mode
+            }
+            if (he == hipSuccess && rc == LR_OK) he = hipGraphInstantiate(&q.graph_exec, graph, nullptr, nullptr, 0);
+            // the capture stream and the graph are released on every path
+            if (graph) (void)hipGraphDestroy(graph);
             (void)hipStreamDestroy(cs);
+            if (rc) return rc;
             if (he != hipSuccess) return (int)he;
             q.graph_units = G;
         }
@@ -1823,7 +1834,10 @@ extern "C" int lr_mcmc_time_steps(lr_engine* e, int64_t n_iters, float* total_ms
     hipError_t he = hipEventCreate(&t0);
     if (he != hipSuccess) return (int)he;
     he = hipEventCreate(&t1);
-    if (he != hipSuccess) return (int)he;
+    if (he != hipSuccess) {
+        (void)hipEventDestroy(t0);
+        return (int)he;
+    }
     int rc = (int)hipEventRecord(t0, stream);
     if (rc == LR_OK) rc = lr_mcmc_steps(e, n_iters, stream_);
     if (rc == LR_OK) rc = (int)hipEventRecord(t1, stream);
@@ -1845,7 +1859,10 @@ extern "C" int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms, void
     hipError_t he = hipEventCreate(&t0);
     if (he != hipSuccess) return (int)he;
     he = hipEventCreate(&t1);
-    if (he != hipSuccess) return (int)he;
+    if (he != hipSuccess) {
+        (void)hipEventDestroy(t0);
+        return (int)he;
+    }
     int rc = lr_enqueue_scan(e, stream);  // warm
     if (rc == LR_OK) rc = (int)hipEventRecord(t0, stream);
     for (int i = 0; i < reps && rc == LR_OK; ++i) rc = lr_enqueue_scan(e, stream);
@@ -1857,6 +1874,23 @@ extern "C" int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms, void
     (void)hipEventDestroy(t1);
     *avg_ms = ms / reps;
     return rc;
+}
+
+// name of the kernel lr_mcmc_steps spends its time in, as rocprofv3's kernel trace prints it (without arguments)
+extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
+    if (!e || !buf) return LR_ERR_NULL;
+    if (n < 64) return LR_ERR_SIZE;
+    if (e->persistent) {
+        if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d>", e->plan.H);
+        else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
+    } else if (e->part[0].pipelined) {
+        snprintf(buf, (size_t)n, "lr_fused_iter_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");
+    } else if (e->plan.fast) {
+        snprintf(buf, (size_t)n, "%s<%d, %d>", e->plan.unit ? "lr_scan_unit_kernel" : "lr_scan_fast_kernel", e->plan.cb, e->plan.H);
+    } else {
+        snprintf(buf, (size_t)n, "lr_scan_kernel<%d>", e->plan.cb);
+    }
+    return LR_OK;
 }
 
 extern "C" int lr_mcmc_destroy(lr_engine* e) {

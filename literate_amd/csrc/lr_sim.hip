@@ -32,9 +32,12 @@ __global__ void lr_sim_init_kernel(double* __restrict__ ts, double* __restrict__
 }
 
 __global__ void lr_sim_prepare_kernel(const double* __restrict__ lam_steps, const double* __restrict__ mu_steps, int t,
-                                      int mode, double l0, double m0, double K, double scale,
-                                      const long long* __restrict__ counters, lr_sim_step* __restrict__ step,
+                                      int mode, double l0, double m0, double K, double scale, long long capacity,
+                                      long long* __restrict__ counters, lr_sim_step* __restrict__ step,
                                       long long* __restrict__ alive_trace) {
+    // after an overflow the allocation counter runs past the capacity (the dropped births still took slot numbers):
+    // clamp it here, so that the next step never visits - or hands out - a slot outside ts/te
+    if (counters[0] > capacity) counters[0] = capacity;
     const long long alive = counters[1];
     double lt, mt;
     if (mode == 0) {
@@ -137,7 +140,7 @@ extern "C" int lr_simulate_bd(const double* lam_steps, const double* mu_steps, i
     if (blocks > 2048) blocks = 2048;     // 8 blocks per CU, 64 items per thread and round
     for (int t = 0; t < n_steps; ++t) {
         hipLaunchKernelGGL(lr_sim_prepare_kernel, dim3(1), dim3(1), 0, stream, lam_steps, mu_steps, t, mode, l0, m0, K,
-                           scale, (const long long*)counters, step, (long long*)alive_trace);
+                           scale, (long long)capacity, (long long*)counters, step, (long long*)alive_trace);
         hipLaunchKernelGGL(lr_sim_step_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ts, te, t, n_steps,
                            (long long)capacity, (unsigned long long)seed, step, (long long*)counters);
     }

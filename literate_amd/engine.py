@@ -4,6 +4,8 @@ All chain state lives in one torch uint8 workspace in HBM whose layout the C ABI
 (lr_mcmc_query_layout); this class only creates views on it and calls lr_mcmc_*.
 """
 import ctypes as C
+import hashlib
+import os
 
 import numpy as np
 
@@ -76,12 +78,23 @@ class ChainEngine:
         self.workspace = torch.zeros(self.layout.total_bytes, dtype=torch.uint8, device=self.device)
         handle = C.c_void_p()
         br_ptr = _hip.ptr(self.br_length) if (model in (0, 1) or dd is not None) else None
-        _hip.check(self.lib.lr_mcmc_create(C.byref(self.cfg), _hip.ptr(self.ts), _hip.ptr(self.te), br_ptr,
-                                           _hip.ptr(self.workspace), self.workspace.numel(), C.byref(handle)),
-                   "lr_mcmc_create")
+        with torch.cuda.device(self.device):      # the library creates its streams / events on the current device
+            _hip.check(self.lib.lr_mcmc_create(C.byref(self.cfg), _hip.ptr(self.ts), _hip.ptr(self.te), br_ptr,
+                                               _hip.ptr(self.workspace), self.workspace.numel(), C.byref(handle)),
+                       "lr_mcmc_create")
         self.handle = handle
         self.n_chains = int(n_chains)
         self.iterations = 0
+        self._hash = None
+
+    @property
+    def _data_hash(self):
+        """sha1 of the lineage arrays as the engine holds them (sorted): identifies the data in a checkpoint."""
+        if self._hash is None:
+            h = hashlib.sha1(self.ts.cpu().numpy().tobytes())
+            h.update(self.te.cpu().numpy().tobytes())
+            self._hash = h.hexdigest()
+        return self._hash
 
     # ---- views on the workspace ----
     def _view(self, off, dtype, shape):
@@ -112,15 +125,15 @@ class ChainEngine:
         chain (ragged allowed: pass 2-D arrays padded with anything plus K inferred from times)."""
         import torch
         if L is None:
-            rc = self.lib.lr_mcmc_init(self.handle, None, None, None, None, None, None, 0, _hip.stream_ptr())
+            rc = _hip.launch(self.lib.lr_mcmc_init, self.device, self.handle, None, None, None, None, None, None, 0)
         elif self.dd is not None:
             # parametric samplers: L = [C, 8] (DD:161) or [C, 6] (trend_rate.py:74) parameter vectors
             npar = 6 if self.dd.get("kind") == "trend" else 8
             args = np.zeros((self.n_chains, _hip.LR_KMAX))
             args[:, :npar] = np.asarray(L, dtype=float).reshape(self.n_chains, npar)
             self._init_keep = [ops._dev(args, torch.float64, self.device)]
-            rc = self.lib.lr_mcmc_init(self.handle, _hip.ptr(self._init_keep[0]), None, None, None, None, None,
-                                       _hip.LR_KMAX, _hip.stream_ptr())
+            rc = _hip.launch(self.lib.lr_mcmc_init, self.device, self.handle, _hip.ptr(self._init_keep[0]), None, None, None,
+                             None, None, _hip.LR_KMAX)
         else:
             kmax = _hip.LR_KMAX
             Ls = np.zeros((self.n_chains, kmax)); Ms = np.zeros((self.n_chains, kmax))
@@ -134,25 +147,31 @@ class ChainEngine:
             dev = [ops._dev(x, torch.float64, self.device) for x in (Ls, Ms, tLs, tMs)]
             dk = [ops._dev(x, torch.int32, self.device) for x in (KL, KM)]
             self._init_keep = dev + dk
-            rc = self.lib.lr_mcmc_init(self.handle, *[_hip.ptr(x) for x in dev + dk], kmax, _hip.stream_ptr())
+            rc = _hip.launch(self.lib.lr_mcmc_init, self.device, self.handle, *[_hip.ptr(x) for x in dev + dk], kmax)
         _hip.check(rc, "lr_mcmc_init")
         self.iterations = 0
 
     def steps(self, n):
-        _hip.check(self.lib.lr_mcmc_steps(self.handle, int(n), _hip.stream_ptr()), "lr_mcmc_steps")
+        _hip.check(_hip.launch(self.lib.lr_mcmc_steps, self.device, self.handle, int(n)), "lr_mcmc_steps")
         self.iterations += int(n)
 
     def time_scan(self, reps=20):
         """Average duration (ms) of the lineage-scan kernel, HIP events on the launch stream."""
         ms = C.c_float(0.0)
-        _hip.check(self.lib.lr_mcmc_time_scan(self.handle, int(reps), C.byref(ms), _hip.stream_ptr()),
+        _hip.check(_hip.launch(self.lib.lr_mcmc_time_scan, self.device, self.handle, int(reps), C.byref(ms)),
                    "lr_mcmc_time_scan")
         return float(ms.value)
+
+    def kernel_name(self):
+        """Name of the kernel steps() spends its time in, as rocprofv3's kernel trace prints it."""
+        buf = C.create_string_buffer(128)
+        _hip.check(self.lib.lr_mcmc_describe(self.handle, buf, 128), "lr_mcmc_describe")
+        return buf.value.decode()
 
     def timed_steps(self, n):
         """steps(n) bracketed by HIP events on the launch stream; returns elapsed device ms (blocks)."""
         ms = C.c_float(0.0)
-        _hip.check(self.lib.lr_mcmc_time_steps(self.handle, int(n), C.byref(ms), _hip.stream_ptr()),
+        _hip.check(_hip.launch(self.lib.lr_mcmc_time_steps, self.device, self.handle, int(n), C.byref(ms)),
                    "lr_mcmc_time_steps")
         self.iterations += int(n)
         return float(ms.value)
@@ -160,11 +179,15 @@ class ChainEngine:
     # ---- checkpoint / resume (no reference counterpart) ----
     _CFG_KEYS = ("n_lineages", "n_bins", "n_chains", "model", "const_rates", "const_death_rate", "use_rate_HP",
                  "s_freq", "n_trace_slots", "poisson_HP", "update_fraction", "t0", "start_time", "end_time", "seed",
-                 "chain_offset", "unit_resolution", "frac_birth", "frac_death")
+                 "chain_offset", "unit_resolution", "frac_birth", "frac_death", "sampler", "m_birth", "m_death",
+                 "dd_present", "dd_init_death", "engine_mode")
 
     def _signature(self):
-        sig = {k: getattr(self.cfg, k) for k in self._CFG_KEYS}
-        sig.update({"layout_" + f: getattr(self.layout, f) for f, _ in self.layout._fields_})
+        """What a checkpoint must agree on: every configuration field, the workspace layout and a hash of the lineages.
+        Values are kept as strings (repr), so 64-bit seeds and offsets compare exactly."""
+        sig = {k: repr(getattr(self.cfg, k)) for k in self._CFG_KEYS}
+        sig.update({"layout_" + f: repr(getattr(self.layout, f)) for f, _ in self.layout._fields_})
+        sig["data_sha1"] = self._data_hash
         return sig
 
     def save(self, path):
@@ -174,16 +197,22 @@ class ChainEngine:
         import torch
         torch.cuda.synchronize(self.device)
         sig = self._signature()
-        np.savez(path, workspace=self.workspace.cpu().numpy(), iterations=np.int64(self.iterations),
-                 sig_keys=np.array(list(sig.keys())), sig_vals=np.array([float(v) for v in sig.values()]))
+        # written beside the target and renamed over it: a kill during save() leaves the previous checkpoint intact
+        path = str(path)
+        if not path.endswith(".npz"):
+            path += ".npz"
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, workspace=self.workspace.cpu().numpy(), iterations=np.int64(self.iterations),
+                 sig_keys=np.array(list(sig.keys())), sig_vals=np.array(list(sig.values())))
+        os.replace(tmp, path)
 
     def load(self, path):
         """Resume from save(): the engine must have been created on the same data with the same settings."""
         import torch
         with np.load(path) as z:
-            saved = dict(zip([str(k) for k in z["sig_keys"]], z["sig_vals"]))
+            saved = dict(zip([str(k) for k in z["sig_keys"]], [str(v) for v in z["sig_vals"]]))
             mine = self._signature()
-            bad = [k for k in mine if k not in saved or float(mine[k]) != float(saved[k])]
+            bad = [k for k in mine if k not in saved or mine[k] != saved[k]]
             if bad or len(saved) != len(mine):
                 raise ValueError("checkpoint was written by a different configuration: " + ", ".join(bad))
             ws = torch.from_numpy(z["workspace"])
@@ -191,7 +220,7 @@ class ChainEngine:
                 raise ValueError("checkpoint workspace size differs")
             self.workspace.copy_(ws.to(self.device))
             self.iterations = int(z["iterations"])
-        _hip.check(self.lib.lr_mcmc_restore(self.handle, _hip.stream_ptr()), "lr_mcmc_restore")
+        _hip.check(_hip.launch(self.lib.lr_mcmc_restore, self.device, self.handle), "lr_mcmc_restore")
 
     def close(self):
         if getattr(self, "handle", None) is not None:

@@ -17,7 +17,8 @@ def _torch():
 def _dev(x, dtype, device=None):
     torch = _torch()
     if isinstance(x, torch.Tensor):
-        t = x.to(device=device or "cuda", dtype=dtype)
+        # a tensor that already lives on a GPU stays there unless the caller names another device
+        t = x.to(device=device or (x.device if x.is_cuda else "cuda"), dtype=dtype)
     else:
         t = torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(device or "cuda")
     return t.contiguous()
@@ -39,8 +40,9 @@ def bin_events(ts, te, win_lo, win_hi):
     (precompute_events / get_br, lib:74-85, for all windows in one launch)."""
     torch = _torch()
     lib = _hip.load()
-    ts, te = _dev(ts, torch.float64), _dev(te, torch.float64)
-    lo, hi = _dev(win_lo, torch.float64), _dev(win_hi, torch.float64)
+    ts = _dev(ts, torch.float64)
+    te = _dev(te, torch.float64, ts.device)
+    lo, hi = _dev(win_lo, torch.float64, ts.device), _dev(win_hi, torch.float64, ts.device)
     n, w = ts.numel(), lo.numel()
     if te.numel() != n or hi.numel() != w:
         raise ValueError("ts/te or window arrays differ in length")
@@ -51,8 +53,8 @@ def bin_events(ts, te, win_lo, win_hi):
     if nbytes < 0:
         _hip.check(int(nbytes), "lr_bin_events_workspace_bytes")
     ws = _workspace(nbytes, ts.device)
-    rc = lib.lr_bin_events(_hip.ptr(ts), _hip.ptr(te), n, _hip.ptr(lo), _hip.ptr(hi), w, _hip.ptr(sp), _hip.ptr(ex),
-                           _hip.ptr(br), _hip.ptr(ws), ws.numel(), _hip.stream_ptr())
+    rc = _hip.launch(lib.lr_bin_events, ts.device, _hip.ptr(ts), _hip.ptr(te), n, _hip.ptr(lo), _hip.ptr(hi), w, _hip.ptr(sp), _hip.ptr(ex),
+                           _hip.ptr(br), _hip.ptr(ws), ws.numel())
     _hip.check(rc, "lr_bin_events")
     return sp, ex, br
 
@@ -67,8 +69,7 @@ def expand_rates(rates, times, K, n_bins, mode=0):
     if times.shape != (C, kmax + 1) or K.shape != (C,):
         raise ValueError("shape mismatch: rates [C,kmax], times [C,kmax+1], K [C]")
     out = torch.empty((C, n_bins), dtype=torch.float64, device=rates.device)
-    rc = lib.lr_expand_rates(_hip.ptr(rates), _hip.ptr(times), _hip.ptr(K), kmax, C, n_bins, mode, _hip.ptr(out),
-                             _hip.stream_ptr())
+    rc = _hip.launch(lib.lr_expand_rates, rates.device, _hip.ptr(rates), _hip.ptr(times), _hip.ptr(K), kmax, C, n_bins, mode, _hip.ptr(out))
     _hip.check(rc, "lr_expand_rates")
     return out
 
@@ -78,14 +79,15 @@ def bd_loglik_batch(ts, te, t0, lam_bins, mu_bins, model=2, br_length=None, end_
     BDIx:124-146).  ts/te are scanned once per group of chains."""
     torch = _torch()
     lib = _hip.load()
-    ts, te = _dev(ts, torch.float64), _dev(te, torch.float64)
-    lam, mu = _dev(lam_bins, torch.float64), _dev(mu_bins, torch.float64)
+    ts = _dev(ts, torch.float64)
+    te = _dev(te, torch.float64, ts.device)
+    lam, mu = _dev(lam_bins, torch.float64, ts.device), _dev(mu_bins, torch.float64, ts.device)
     if lam.dim() == 1:
         lam, mu = lam[None, :], mu[None, :]
     C, n_bins = lam.shape
     if mu.shape != lam.shape or te.numel() != ts.numel():
         raise ValueError("shape mismatch")
-    br = None if br_length is None else _dev(br_length, torch.float64)
+    br = None if br_length is None else _dev(br_length, torch.float64, ts.device)
     if br is not None and br.numel() != n_bins:
         raise ValueError("br_length must have n_bins entries")
     out = torch.empty(C, dtype=torch.float64, device=ts.device)
@@ -93,9 +95,8 @@ def bd_loglik_batch(ts, te, t0, lam_bins, mu_bins, model=2, br_length=None, end_
     if nbytes < 0:
         _hip.check(int(nbytes), "lr_bd_loglik_workspace_bytes")
     ws = _workspace(nbytes, ts.device)
-    rc = lib.lr_bd_loglik_batch(_hip.ptr(ts), _hip.ptr(te), ts.numel(), float(t0), n_bins, _hip.ptr(lam), _hip.ptr(mu),
-                                C, model, _hip.ptr(br), float(end_time), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
-                                _hip.stream_ptr())
+    rc = _hip.launch(lib.lr_bd_loglik_batch, ts.device, _hip.ptr(ts), _hip.ptr(te), ts.numel(), float(t0), n_bins, _hip.ptr(lam), _hip.ptr(mu),
+                                C, model, _hip.ptr(br), float(end_time), _hip.ptr(out), _hip.ptr(ws), ws.numel())
     _hip.check(rc, "lr_bd_loglik_batch")
     return out
 
@@ -114,9 +115,9 @@ def rj_propose_score(rates, times, K, move, index, draws, mult_d=1.1):
     o_r, o_t = torch.empty_like(rates), torch.empty_like(times)
     o_k = torch.empty_like(K)
     o_s = torch.empty(C, dtype=torch.float64, device=rates.device)
-    rc = lib.lr_rj_propose_score(_hip.ptr(rates), _hip.ptr(times), _hip.ptr(K), kmax, C, _hip.ptr(move), _hip.ptr(index),
+    rc = _hip.launch(lib.lr_rj_propose_score, rates.device, _hip.ptr(rates), _hip.ptr(times), _hip.ptr(K), kmax, C, _hip.ptr(move), _hip.ptr(index),
                                  _hip.ptr(draws), float(mult_d), _hip.ptr(o_r), _hip.ptr(o_t), _hip.ptr(o_k),
-                                 _hip.ptr(o_s), _hip.stream_ptr())
+                                 _hip.ptr(o_s))
     _hip.check(rc, "lr_rj_propose_score")
     return o_r, o_t, o_k, o_s
 
@@ -130,8 +131,7 @@ def log_priors(rates, K, shape, gamma_rate, poi_rate=None):
     g = _dev(gamma_rate, torch.float64)
     p = None if poi_rate is None else _dev(poi_rate, torch.float64)
     out = torch.empty(C, dtype=torch.float64, device=rates.device)
-    rc = lib.lr_log_priors(_hip.ptr(rates), _hip.ptr(K), kmax, C, float(shape), _hip.ptr(g), _hip.ptr(p), _hip.ptr(out),
-                           _hip.stream_ptr())
+    rc = _hip.launch(lib.lr_log_priors, rates.device, _hip.ptr(rates), _hip.ptr(K), kmax, C, float(shape), _hip.ptr(g), _hip.ptr(p), _hip.ptr(out))
     _hip.check(rc, "lr_log_priors")
     return out
 
@@ -145,8 +145,7 @@ def dd_rates(args, DT, m_birth=2, m_death=2):
         args = args[None, :]
     C, n_bins = args.shape[0], DT.numel()
     outs = [torch.empty((C, n_bins), dtype=torch.float64, device=args.device) for _ in range(4)]
-    rc = lib.lr_dd_rates(_hip.ptr(args), _hip.ptr(DT), n_bins, C, m_birth, m_death, *[_hip.ptr(o) for o in outs],
-                         _hip.stream_ptr())
+    rc = _hip.launch(lib.lr_dd_rates, args.device, _hip.ptr(args), _hip.ptr(DT), n_bins, C, m_birth, m_death, *[_hip.ptr(o) for o in outs])
     _hip.check(rc, "lr_dd_rates")
     return tuple(outs)
 
@@ -162,8 +161,7 @@ def ddv2_rates(args, DT, m_birth=2, m_death=2):
         raise ValueError("DDRatev2 takes 9 parameters per state")
     C, n_bins = args.shape[0], DT.numel()
     outs = [torch.empty((C, n_bins), dtype=torch.float64, device=args.device) for _ in range(4)]
-    rc = lib.lr_ddv2_rates(_hip.ptr(args), _hip.ptr(DT), n_bins, C, m_birth, m_death, *[_hip.ptr(o) for o in outs],
-                           _hip.stream_ptr())
+    rc = _hip.launch(lib.lr_ddv2_rates, args.device, _hip.ptr(args), _hip.ptr(DT), n_bins, C, m_birth, m_death, *[_hip.ptr(o) for o in outs])
     _hip.check(rc, "lr_ddv2_rates")
     return tuple(outs)
 
@@ -179,8 +177,8 @@ def trend_rates(args, trend, const_birth=False, const_death=False):
         raise ValueError("trend_rate takes 6 parameters per state")
     C, n_bins = args.shape[0], trend.numel()
     outs = [torch.empty((C, n_bins), dtype=torch.float64, device=args.device) for _ in range(2)]
-    rc = lib.lr_trend_rates(_hip.ptr(args), _hip.ptr(trend), n_bins, C, int(bool(const_birth)), int(bool(const_death)),
-                            *[_hip.ptr(o) for o in outs], _hip.stream_ptr())
+    rc = _hip.launch(lib.lr_trend_rates, args.device, _hip.ptr(args), _hip.ptr(trend), n_bins, C, int(bool(const_birth)), int(bool(const_death)),
+                            *[_hip.ptr(o) for o in outs])
     _hip.check(rc, "lr_trend_rates")
     return tuple(outs)
 
@@ -198,8 +196,8 @@ def binned_keiding(birth, death, n_spec, n_exti, DT):
         raise ValueError("shape mismatch")
     ob = torch.empty(C, dtype=torch.float64, device=birth.device)
     od = torch.empty_like(ob)
-    rc = lib.lr_binned_keiding(_hip.ptr(birth), _hip.ptr(death), _hip.ptr(n_spec), _hip.ptr(n_exti), _hip.ptr(DT),
-                               n_bins, C, _hip.ptr(ob), _hip.ptr(od), _hip.stream_ptr())
+    rc = _hip.launch(lib.lr_binned_keiding, birth.device, _hip.ptr(birth), _hip.ptr(death), _hip.ptr(n_spec), _hip.ptr(n_exti), _hip.ptr(DT),
+                               n_bins, C, _hip.ptr(ob), _hip.ptr(od))
     _hip.check(rc, "lr_binned_keiding")
     return ob, od
 
@@ -223,9 +221,9 @@ def simulate_bd(n_start, n_steps, seed, lam_steps=None, mu_steps=None, mode=0, l
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     trace = torch.zeros(int(n_steps), dtype=torch.int64, device=dev)
     ws = torch.zeros(64, dtype=torch.uint8, device=dev)
-    rc = lib.lr_simulate_bd(_hip.ptr(lam), _hip.ptr(mu), int(n_steps), int(mode), float(l0), float(m0), float(K),
+    rc = _hip.launch(lib.lr_simulate_bd, ts.device, _hip.ptr(lam), _hip.ptr(mu), int(n_steps), int(mode), float(l0), float(m0), float(K),
                             float(scale), int(n_start), capacity, int(seed) & 0xFFFFFFFFFFFFFFFF, _hip.ptr(ts), _hip.ptr(te),
-                            _hip.ptr(counters), _hip.ptr(trace), _hip.ptr(ws), ws.numel(), _hip.stream_ptr())
+                            _hip.ptr(counters), _hip.ptr(trace), _hip.ptr(ws), ws.numel())
     _hip.check(rc, "lr_simulate_bd")
     n, alive, overflow, _ = [int(v) for v in counters.cpu()]
     if overflow:
@@ -241,7 +239,7 @@ def debug_draws(seed, chain, it, purpose, idx, kind, shape):
     purpose, idx, kind = _dev(purpose, torch.int32), _dev(idx, torch.int32), _dev(kind, torch.int32)
     shape = _dev(shape, torch.float64)
     out = torch.empty(it.numel(), dtype=torch.float64, device=it.device)
-    rc = lib.lr_debug_draws(int(seed), int(chain), _hip.ptr(it), _hip.ptr(purpose), _hip.ptr(idx), _hip.ptr(kind),
-                            _hip.ptr(shape), it.numel(), _hip.ptr(out), _hip.stream_ptr())
+    rc = _hip.launch(lib.lr_debug_draws, it.device, int(seed), int(chain), _hip.ptr(it), _hip.ptr(purpose), _hip.ptr(idx), _hip.ptr(kind),
+                            _hip.ptr(shape), it.numel(), _hip.ptr(out))
     _hip.check(rc, "lr_debug_draws")
     return out

@@ -175,8 +175,9 @@ typedef struct lr_mcmc_config {
      * dataset the reference ships: 0 and 0.5).  The fractions are then folded into the lookup
      * tables (8-byte entries, half the LDS traffic per lineage).  0 = general times.            */
     int32_t unit_resolution;
-    int32_t engine_mode;      /* 0 = auto, 1 = launch-per-iteration engine (fused, pipelined), 2 = persistent kernel,
-                               * 3 = persistent kernel with four chains per block (lr_mcmc_layout.persistent tells) */
+    int32_t engine_mode;      /* 0 = auto, 1 = launch-per-iteration engine (fused, pipelined), 2 = a persistent kernel
+                               * (the library picks which), 3 = four chains per block, 4 = two chains per block,
+                               * 5 = speculative team kernel (lr_mcmc_layout.persistent tells what runs)               */
     double frac_birth;
     double frac_death;
     /* ---- sampler 1: the DDRate.py Metropolis-Hastings loop (DD:124-241) on the same engine -------------
@@ -186,7 +187,7 @@ typedef struct lr_mcmc_config {
     int32_t sampler;          /* 0 = runMCMC (LRF), 1 = DDRate, 2 = trend_rate (below) */
     int32_t m_birth;          /* -m_birth (DD:25); sampler 2: -const_B flag          */
     int32_t m_death;          /* -m_death (DD:26); sampler 2: -const_D flag          */
-    int32_t reserved0;
+    int32_t team_request;     /* speculative kernel: blocks per chain pair, 0 = the library chooses (1, 2, 4 or 8)   */
     double dd_present;        /* PRESENT - as create_bins returns it (DD:36)        */
     double dd_init_death;     /* -fix_death (DD:27, 156)                            */
     /* sampler 2: the trend_rate.py loop (trend_rate.py:102-196): parameters [l_min,m_min,alpha,beta,delta,gamma],
@@ -211,8 +212,13 @@ typedef struct lr_mcmc_layout {
     int32_t trace_width;
     int32_t n_parts;      /* independent chain partitions, each on its own stream                  */
     int32_t pipelined;    /* 1: each partition runs the fused scan|step schedule over two halves   */
-    int32_t persistent;   /* 0: launch-per-iteration engine; 1 / 2: persistent kernel, 2 / 4 chains per block */
+    int32_t persistent;   /* 0: launch-per-iteration engine; 1 / 2: persistent kernel, 2 / 4 chains per block;
+                           * 3: speculative team kernel (a chain pair per team of team_blocks blocks)             */
     int32_t reserved1;    /* threads per block of the persistent kernel (512 / 1024), 0 for the launch-based engine */
+    int64_t status;       /* engine status word (uint32): 0 ok, 1 = a team exchange of the speculative kernel timed out */
+    int64_t xchg;         /* partial-sum exchange granules of the speculative kernel's teams (team_blocks > 1)        */
+    int32_t team_blocks;  /* blocks (= CUs) that share one chain pair, each scanning 1/team_blocks of the lineages     */
+    int32_t reserved2;
 } lr_mcmc_layout;
 
 /* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */
@@ -299,6 +305,9 @@ int lr_mcmc_restore(lr_engine* e, void* stream);
 int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms /* host */, void* stream);
 /* lr_mcmc_steps(n_iters) bracketed by HIP events on `stream`; blocks; *total_ms = elapsed device time. */
 int lr_mcmc_time_steps(lr_engine* e, int64_t n_iters, float* total_ms /* host */, void* stream);
+/* Blocks until `stream` is idle and copies the engine status word to *status (host): 0 = ok, 1 = a team exchange of the
+ * speculative kernel timed out (its blocks were not all resident within two seconds) and the run is void.          */
+int lr_mcmc_status(lr_engine* e, int32_t* status /* host */, void* stream);
 /* measurement hook: name of the kernel lr_mcmc_steps spends its time in, as a kernel trace prints it (n >= 64). */
 int lr_mcmc_describe(const lr_engine* e, char* buf /* host */, int32_t n);
 int lr_mcmc_destroy(lr_engine* e);

@@ -29,7 +29,7 @@ class McmcConfig(C.Structure):
                 ("n_trace_slots", c_i32), ("poisson_HP", c_f64), ("update_fraction", c_f64), ("t0", c_f64),
                 ("start_time", c_f64), ("end_time", c_f64), ("seed", C.c_uint64), ("chain_offset", c_i64),
                 ("unit_resolution", c_i32), ("engine_mode", c_i32), ("frac_birth", c_f64), ("frac_death", c_f64),
-                ("sampler", c_i32), ("m_birth", c_i32), ("m_death", c_i32), ("reserved0", c_i32),
+                ("sampler", c_i32), ("m_birth", c_i32), ("m_death", c_i32), ("team_request", c_i32),
                 ("dd_present", c_f64), ("dd_init_death", c_f64)]
 
 
@@ -37,7 +37,8 @@ class McmcLayout(C.Structure):
     _fields_ = [("state_f64", c_i64), ("state_i32", c_i64), ("bin_consts", c_i64), ("lineage_idx", c_i64), ("args_blob", c_i64), ("tables", c_i64),
                 ("partials", c_i64), ("trace", c_i64), ("total_bytes", c_i64), ("table_stride", c_i32),
                 ("tiles", c_i32), ("chains_per_block", c_i32), ("trace_width", c_i32), ("n_parts", c_i32),
-                ("pipelined", c_i32), ("persistent", c_i32), ("reserved1", c_i32)]
+                ("pipelined", c_i32), ("persistent", c_i32), ("reserved1", c_i32), ("status", c_i64), ("xchg", c_i64),
+                ("team_blocks", c_i32), ("reserved2", c_i32)]
 
 
 # name -> (restype, argtypes); exactly the symbols include/literate_hip.h declares (+ the RNG debug hook)
@@ -66,6 +67,7 @@ SIGNATURES = {
     "lr_mcmc_time_steps": (c_i32, [c_vp, c_i64, C.POINTER(C.c_float), c_vp]),
     "lr_mcmc_restore": (c_i32, [c_vp, c_vp]),
     "lr_mcmc_describe": (c_i32, [c_vp, C.c_char_p, c_i32]),
+    "lr_mcmc_status": (c_i32, [c_vp, C.POINTER(c_i32), c_vp]),
     "lr_mcmc_destroy": (c_i32, [c_vp]),
     "lr_debug_draws": (c_i32, [C.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
 }

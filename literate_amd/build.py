@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libliterate_hip.so")
 SOURCES = ["lr_stats.hip", "lr_loglik.hip", "lr_mcmc.hip", "lr_sim.hip"]
-HEADERS = ["lr_device.h", "lr_chain.h", "lr_dd.h", "lr_scan.h", "lr_internal.h", os.path.join("..", "..", "include", "literate_hip.h")]
+HEADERS = ["lr_device.h", "lr_chain.h", "lr_dd.h", "lr_scan.h", "lr_step.h", "lr_spec.h", "lr_internal.h", os.path.join("..", "..", "include", "literate_hip.h")]
 
 
 def _stale():

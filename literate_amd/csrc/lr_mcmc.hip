@@ -14,6 +14,8 @@
 #include "lr_dd.h"
 #include "lr_internal.h"
 #include "lr_scan.h"
+#include "lr_spec.h"
+#include "lr_step.h"
 
 // ------------------------------------------------------------------------------------------
 // explicit-draw scorers (parity with reference-generated vectors)
@@ -146,714 +148,6 @@ struct lr_engine {
     hipEvent_t fork;
 };
 
-struct lr_step_args {
-    lr_mcmc_config cfg;
-    double* state_f64;
-    int* state_i32;
-    const double* log_br;   // [n_bins] log(br_length) (models 0/1)
-    double2* tables;
-    const double* partials;
-    double* trace;
-    const double* br_length;
-    double log_T;           // log(end_time - start_time)
-    double mult_l;          // 2 log d of the multiplier proposal (LRF:169)
-    const double* dd_consts; // DD sampler: {max(DT), log max(DT)} = PRIOR_K0_L (DD:45) and its log
-    int tab_stride, n_cls, tiles, H, unit, cb;
-};
-
-// where chain c's lookup table starts.  General layout: chain-major, tab_stride double2 per chain.
-// Unit-resolution layout: groups of cb chains, inside a group [pair][2H] double2 = (even chain, odd chain);
-// the returned pointer addresses this chain's component, consecutive entries are 2 doubles apart.
-__device__ __forceinline__ double2* lr_chain_table(const lr_step_args& a, int c) {
-    if (!a.unit) return a.tables + (size_t)c * a.tab_stride;
-    const int l = c % a.cb;
-    double* base = reinterpret_cast<double*>(a.tables + (size_t)(c - l) * a.tab_stride);
-    return reinterpret_cast<double2*>(base + (size_t)(l >> 1) * (4 * a.H) + (l & 1));
-}
-
-// per-wave LDS scratch: segment rates, their logs and integer edges of both processes
-struct lr_seg_scratch {
-    double rate[2][LR_KMAX];
-    double lograte[2][LR_KMAX];
-    int edge[2][LR_KMAX + 1];
-    int marks[4 * LR_WAVE + 2];   // per unit bin: number of birth-rate shifts (low half) / death-rate shifts (high half)
-};
-
-// Lookup tables of one chain straight from its segments (get_rate_index + L[indL] + the table
-// builder of lr_device.h in one go, no per-bin transcendental): bin b of process p takes segment
-// j with edge[p][j] <= b < edge[p][j+1].  Model conventions as lr_bin_terms, with
-// log(k*lam) taken as log k + log lam (log_br = log k is a data constant).
-__device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc, int KL, int KM,
-                                                       const double* __restrict__ br_length,
-                                                       const double* __restrict__ log_br, int model, int n_bins,
-                                                       int n_cls, int H, double2* __restrict__ tab, int lane,
-                                                       bool unit = false, double fs0 = 0.0, double fe0 = 0.0,
-                                                       int es = 2) {
-    // unit-resolution layout: tab points at this chain's component of its pair table, entries 2 doubles apart
-    double* tabd = reinterpret_cast<double*>(tab);
-    const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
-    const int b0 = min(lane * P, n_bins), b1 = min(b0 + P, n_bins);
-    int sl0 = 0, sm0 = 0;
-    while (sl0 + 1 < KL && sc->edge[0][sl0 + 1] <= b0) ++sl0;
-    while (sm0 + 1 < KM && sc->edge[1][sm0 + 1] <= b0) ++sm0;
-    double sumR = 0.0, sumRl = 0.0, csum = 0.0;
-    int sl = sl0, sm = sm0;
-    for (int b = b0; b < b1; ++b) {
-        while (sl + 1 < KL && sc->edge[0][sl + 1] <= b) ++sl;
-        while (sm + 1 < KM && sc->edge[1][sm + 1] <= b) ++sm;
-        const double lam = sc->rate[0][sl], mu = sc->rate[1][sm];
-        const bool live = (model >= 2) || (br_length[b] > 0.0);
-        double R = 0.0;
-        if (live) R = (model == 1) ? mu : lam + mu;
-        sumR += R;
-        if (model >= 2) sumRl += lam;
-        if (model == 1 && live) csum -= lam;
-    }
-    double totR, totRl = 0.0;
-    double cum = lr_wave_exclusive_scan(sumR, lane, &totR);
-    double cuml = 0.0;
-    if (n_cls == 2) cuml = lr_wave_exclusive_scan(sumRl, lane, &totRl);
-    sl = sl0, sm = sm0;
-    for (int b = b0; b < b1; ++b) {
-        while (sl + 1 < KL && sc->edge[0][sl + 1] <= b) ++sl;
-        while (sm + 1 < KM && sc->edge[1][sm + 1] <= b) ++sm;
-        const double lam = sc->rate[0][sl], mu = sc->rate[1][sm];
-        const double llam = sc->lograte[0][sl], lmu = sc->lograte[1][sm];
-        double logB = 0.0, logD = 0.0, R = 0.0;
-        if (model >= 2) {
-            logB = llam, logD = lmu, R = lam + mu;
-        } else if (br_length[b] > 0.0) {
-            const double lk = log_br[b];
-            logB = (model == 0) ? lk + llam : llam;
-            logD = lmu + lk;
-            R = (model == 0) ? lam + mu : mu;
-        }
-        if (unit) {
-            tabd[es * (b + 1)] = (logB + cum) + fs0 * R;
-            tabd[es * (H + b + 1)] = (logD - cum) - fe0 * R;
-        } else {
-            tab[b + 1] = make_double2(logB + cum, R);
-            tab[H + b + 1] = make_double2(logD - cum, -R);
-        }
-        cum += R;
-        if (n_cls == 2) {
-            tab[2 * H + b + 1] = make_double2(logB + cuml, lam);
-            tab[3 * H + b + 1] = make_double2(-cuml, -lam);
-            cuml += lam;
-        }
-    }
-    if (lane == 0) {
-        if (unit) {
-            tabd[0] = 0.0, tabd[es * H] = 0.0;
-            tabd[es * (n_bins + 1)] = totR, tabd[es * (H + n_bins + 1)] = -totR;
-        } else {
-            tab[0] = make_double2(0.0, 0.0);
-            tab[H] = make_double2(0.0, 0.0);
-            tab[n_bins + 1] = make_double2(totR, 0.0);
-            tab[H + n_bins + 1] = make_double2(-totR, 0.0);
-        }
-        if (n_cls == 2) {
-            tab[2 * H] = make_double2(0.0, 0.0);
-            tab[3 * H] = make_double2(0.0, 0.0);
-            tab[2 * H + n_bins + 1] = make_double2(totRl, 0.0);
-            tab[3 * H + n_bins + 1] = make_double2(-totRl, 0.0);
-        }
-    }
-    return lr_wave_sum(csum);
-}
-
-// Same tables for the common shape (one table class, at most 4 bins per lane, i.e. n_bins <= 256) in ONE pass
-// with everything in registers: the segment of a bin is the number of interior edges <= bin, counted by
-// broadcasting the K-1 edges with v_readlane (edges live in lanes: lane j holds edge j); rates and their logs
-// come from the LDS scratch with independent reads; one DPP scan gives the cumulative exposure.
-template <int P>
-__device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scratch* sc, int eL, int eM, int KL,
-                                                                int KM, const double* __restrict__ br_length,
-                                                                const double* __restrict__ log_br, int model,
-                                                                int n_bins, int H, double2* __restrict__ tab,
-                                                                int lane, bool unit, double fs0, double fe0, int es) {
-    double* tabd = reinterpret_cast<double*>(tab);
-    const int b0 = lane * P;
-    int segL[P], segM[P];
-    double k_b[P], lk_b[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        segL[p] = 0, segM[p] = 0;
-        const int b = min(b0 + p, n_bins - 1);
-        k_b[p] = (model < 2) ? br_length[b] : 1.0;
-        lk_b[p] = (model < 2) ? log_br[b] : 0.0;
-    }
-    // Segment of every bin = number of shifts at or before it.  The K - 1 shift lanes drop a count on their bin in
-    // LDS (birth shifts in the low half-word, death shifts in the high one), every lane reads the counts of its own
-    // bins and one integer wave scan turns them into ranks: a fixed ~35 instructions instead of a dependent
-    // (K_l + K_m) x P compare-and-add chain (the largest single item of the chain step before).
-    {
-        int* marks = const_cast<int*>(sc->marks);
-        for (int b = lane; b <= n_bins; b += LR_WAVE) marks[b] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (lane >= 1 && lane < KL) atomicAdd(&marks[eL], 1);
-        if (lane >= 1 && lane < KM) atomicAdd(&marks[eM], 0x10000);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        int cnt[P], tot = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            cnt[p] = (b0 + p <= n_bins) ? marks[b0 + p] : 0;
-            tot += cnt[p];
-        }
-        int run = lr_wave_exclusive_scan_i32(tot);
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            run += cnt[p];
-            segL[p] = run & 0xffff, segM[p] = run >> 16;
-        }
-    }
-    double logB[P], logD[P], R[P];
-    double sumR = 0.0, csum = 0.0;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const double lam = sc->rate[0][segL[p]], mu = sc->rate[1][segM[p]];
-        const double llam = sc->lograte[0][segL[p]], lmu = sc->lograte[1][segM[p]];
-        logB[p] = 0.0, logD[p] = 0.0, R[p] = 0.0;
-        if (b0 + p < n_bins) {
-            if (model >= 2) {
-                logB[p] = llam, logD[p] = lmu, R[p] = lam + mu;
-            } else if (k_b[p] > 0.0) {
-                logB[p] = (model == 0) ? lk_b[p] + llam : llam;
-                logD[p] = lmu + lk_b[p];
-                R[p] = (model == 0) ? lam + mu : mu;
-                if (model == 1) csum -= lam;
-            }
-        }
-        sumR += R[p];
-    }
-    double totR;
-    double cum = lr_wave_exclusive_scan(sumR, lane, &totR);
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const int b = b0 + p;
-        if (b < n_bins) {
-            if (unit) {
-                tabd[es * (b + 1)] = (logB[p] + cum) + fs0 * R[p];
-                tabd[es * (H + b + 1)] = (logD[p] - cum) - fe0 * R[p];
-            } else {
-                tab[b + 1] = make_double2(logB[p] + cum, R[p]);
-                tab[H + b + 1] = make_double2(logD[p] - cum, -R[p]);
-            }
-        }
-        cum += R[p];
-    }
-    if (lane == 0) {
-        if (unit) {
-            tabd[0] = 0.0, tabd[es * H] = 0.0;
-            tabd[es * (n_bins + 1)] = totR, tabd[es * (H + n_bins + 1)] = -totR;
-        } else {
-            tab[0] = make_double2(0.0, 0.0);
-            tab[H] = make_double2(0.0, 0.0);
-            tab[n_bins + 1] = make_double2(totR, 0.0);
-            tab[H + n_bins + 1] = make_double2(-totR, 0.0);
-        }
-    }
-    return (model == 1) ? lr_wave_sum(csum) : 0.0;
-}
-
-// dispatcher: fast one-pass builder when the shape allows, general two-pass builder otherwise
-__device__ __forceinline__ double lr_build_tables_segments(const lr_seg_scratch* sc, int eL, int eM, int KL, int KM,
-                                                           const double* __restrict__ br_length,
-                                                           const double* __restrict__ log_br, int model, int n_bins,
-                                                           int n_cls, int H, double2* __restrict__ tab, int lane,
-                                                           bool unit, double fs0, double fe0, int es = 2) {
-    if (n_cls == 1 && n_bins <= 2 * LR_WAVE)
-        return lr_build_tables_segments_fast<2>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
-                                                fs0, fe0, es);
-    if (n_cls == 1 && n_bins <= 4 * LR_WAVE)
-        return lr_build_tables_segments_fast<4>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
-                                                fs0, fe0, es);
-    return lr_build_tables_segments_wave(sc, KL, KM, br_length, log_br, model, n_bins, n_cls, H, tab, lane, unit, fs0,
-                                         fe0, es);
-}
-
-// stage one chain's segments in the wave's LDS scratch; log of all rates in ONE call
-// (lanes 0..31 carry the birth rates, lanes 32..63 the death rates)
-__device__ __forceinline__ void lr_stage_segments(lr_seg_scratch* sc, double L, double M, int eL, int eM, int KL,
-                                                  int KM, int lane, double* logL, double* logM, double extra = 1.0,
-                                                  double* log_extra = nullptr) {
-    const double Mhi = __shfl(M, lane & 31, LR_WAVE);
-    const bool hi = lane >= 32;
-    const int j = lane & 31;
-    const bool valid = hi ? (j < KM) : (j < KL);
-    // lane 63 is free unless the death process holds LR_KMAX rates: it takes one more logarithm along (`extra`)
-    const bool free63 = KM < LR_KMAX;
-    double x = valid ? (hi ? Mhi : L) : 1.0;
-    if (lane == LR_WAVE - 1 && free63) x = extra;
-    const double lx = log(x);
-    if (log_extra) *log_extra = free63 ? lr_bcast(lx, LR_WAVE - 1) : log(extra);
-    sc->rate[hi][j] = x;
-    sc->lograte[hi][j] = lx;
-    if (lane <= LR_KMAX) sc->edge[0][lane] = eL, sc->edge[1][lane] = eM;
-    *logL = lx;                                        // valid on lanes < 32
-    *logM = __shfl(lx, 32 + (lane & 31), LR_WAVE);     // lane j gets log M[j]
-    // the scratch is private to this wave; LDS operations of one wave execute in order, the fence keeps
-    // the compiler from moving the reads of lr_build_tables_segments_wave above these writes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-#ifdef LR_DIAG
-static __device__ unsigned long long lr_diag_step[4096 * 12];
-#define LR_SSTAMP(k) if (lane == 0 && c < 4096) lr_diag_step[c * 12 + (k)] = wall_clock64()
-#else
-#define LR_SSTAMP(k)
-#endif
-
-// mode: 0 = regular step (accept pending proposal, then propose), 1 = finish init (adopt the
-// evaluated initial state as accepted, then propose iteration 0)
-// chain state as it lives in the registers of the chain's wave (lane j holds element j of every row)
-struct lr_chain_regs {
-    double L, M, tL, tM;        // accepted rates / shift times
-    double pL, pM, ptL, ptM;    // pending proposal
-    double sc;                  // LR_ROW_SCALARS (lane s holds scalar s)
-    int eL, eM, peL, peM;       // integer bin edges, accepted / proposed
-    int isc;                    // LR_IROW_SCALARS
-};
-
-__device__ __forceinline__ void lr_chain_load(lr_chain_regs& r, const double* S, const int* I, int lane) {
-    r.L = S[LR_ROW_L * LR_ROW + lane], r.M = S[LR_ROW_M * LR_ROW + lane];
-    r.tL = S[LR_ROW_TL * LR_ROW + lane], r.tM = S[LR_ROW_TM * LR_ROW + lane];
-    r.pL = S[LR_ROW_PL * LR_ROW + lane], r.pM = S[LR_ROW_PM * LR_ROW + lane];
-    r.ptL = S[LR_ROW_PTL * LR_ROW + lane], r.ptM = S[LR_ROW_PTM * LR_ROW + lane];
-    r.sc = S[LR_ROW_SCALARS * LR_ROW + lane];
-    r.eL = I[LR_IROW_EL * LR_ROW + lane], r.eM = I[LR_IROW_EM * LR_ROW + lane];
-    r.peL = I[LR_IROW_PEL * LR_ROW + lane], r.peM = I[LR_IROW_PEM * LR_ROW + lane];
-    r.isc = I[LR_IROW_SCALARS * LR_ROW + lane];
-}
-
-__device__ __forceinline__ void lr_chain_store(const lr_chain_regs& r, double* S, int* I, int lane) {
-    S[LR_ROW_L * LR_ROW + lane] = r.L, S[LR_ROW_M * LR_ROW + lane] = r.M;
-    S[LR_ROW_TL * LR_ROW + lane] = r.tL, S[LR_ROW_TM * LR_ROW + lane] = r.tM;
-    S[LR_ROW_PL * LR_ROW + lane] = r.pL, S[LR_ROW_PM * LR_ROW + lane] = r.pM;
-    S[LR_ROW_PTL * LR_ROW + lane] = r.ptL, S[LR_ROW_PTM * LR_ROW + lane] = r.ptM;
-    S[LR_ROW_SCALARS * LR_ROW + lane] = r.sc;
-    I[LR_IROW_EL * LR_ROW + lane] = r.eL, I[LR_IROW_EM * LR_ROW + lane] = r.eM;
-    I[LR_IROW_PEL * LR_ROW + lane] = r.peL, I[LR_IROW_PEM * LR_ROW + lane] = r.peM;
-    I[LR_IROW_SCALARS * LR_ROW + lane] = r.isc;
-}
-
-// One chain step on register-resident state: accept the pending proposal given its log-likelihood sum
-// (lik_sum, without the model constant), write the trace row, draw the next proposal and build its lookup
-// tables at `table` (global memory or LDS; see lr_chain_table for the addressing).
-// mode: 0 = regular step, 1 = finish init (adopt the evaluated initial state, then propose iteration 0)
-__device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
-                                                   lr_seg_scratch* scratch_p, double lik_sum, double2* table,
-                                                   int table_es = 2) {
-    lr_seg_scratch& scratch = *scratch_p;
-    const lr_mcmc_config& cfg = a.cfg;
-    const int C = cfg.n_chains, n_bins = cfg.n_bins;
-    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
-    double L = st.L, M = st.M, tL = st.tL, tM = st.tM;
-    const double pL0 = st.pL, pM0 = st.pM, ptL0 = st.ptL, ptM0 = st.ptM;
-    const double sc = st.sc;
-    int eL = st.eL, eM = st.eM;
-    const int peL0 = st.peL, peM0 = st.peM;
-    const int isc = st.isc;
-    double lik_p = lr_bcast(sc, LR_S_LIK_P);
-
-    double likA = lr_bcast(sc, LR_S_LIKA), priorA = lr_bcast(sc, LR_S_PRIORA);
-    double priorPoiA = lr_bcast(sc, LR_S_PRIORPOIA);
-    double g0 = lr_bcast(sc, LR_S_GRATE_L), g1 = lr_bcast(sc, LR_S_GRATE_M), poi = lr_bcast(sc, LR_S_POI);
-    double lg0 = lr_bcast(sc, LR_S_LOG_G0), lg1 = lr_bcast(sc, LR_S_LOG_G1), lpoi = lr_bcast(sc, LR_S_LOG_POI);
-    double constA = lr_bcast(sc, LR_S_CONST_A);
-    int KL = lr_bcast_i(isc, LR_I_KL), KM = lr_bcast_i(isc, LR_I_KM);
-    uint64_t it = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_HI) << 32);
-    int n_acc = lr_bcast_i(isc, LR_I_ACCEPTED);
-    uint64_t next_sample = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_HI) << 32);
-    int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
-    LR_SSTAMP(1);
-
-    // The wave-uniform draws of the iteration about to be proposed in ONE Philox call (a block costs 40 quarter-rate
-    // 32-bit multiplies whether one lane needs it or all 64): lane 0 its acceptance uniform, lane 1 the move selector,
-    // lanes 2..3 the two RJ pairs.  Same (iteration, purpose, index) addresses as separate calls would use, so the
-    // stream is unchanged.  The logarithm of the acceptance uniform rides along in the packed log of the rates below
-    // and waits in LR_S_LOG_U until the proposal is decided, one step later.
-    lr_u2 ud;
-    {
-        const uint64_t it_prop = (mode == 1) ? it : it + 1;
-        const uint32_t purpose = (lane == 0) ? LR_P_ACCEPT : (lane == 1 ? LR_P_MOVE : LR_P_RJ);
-        ud = lr_pair(rng, it_prop, purpose, lane == 3 ? 1u : 0u);
-    }
-    const double u_next = lr_bcast(ud.a, 0);
-
-    if (mode == 1) {
-        // LRF:224-230.  The initial prior uses prior_gamma's default rate b=2 (LRF:201, 227).
-        likA = lik_sum + constA;
-        priorA = lr_wave_prior_gamma(L, KL, LR_GAMMA_SHAPE, 2.0, lane) + lr_wave_prior_gamma(M, KM, LR_GAMMA_SHAPE, 2.0, lane);
-        priorA += -a.log_T * (KL - 1 + KM - 1);
-        priorPoiA = lr_poisson_prior(KL, poi, lpoi) + lr_poisson_prior(KM, poi, lpoi);
-        priorA += priorPoiA;
-    } else {
-        // ---- Metropolis-Hastings accept of iteration `it` (LRF:305-319) ----
-        const int gibbs = lr_bcast_i(isc, LR_I_GIBBS), invalid = lr_bcast_i(isc, LR_I_INVALID);
-        const double hasting = lr_bcast(sc, LR_S_HASTING), priorP = lr_bcast(sc, LR_S_PRIOR_P);
-        const double priorPoiP = lr_bcast(sc, LR_S_PRIORPOI_P), constP = lr_bcast(sc, LR_S_CONST_P);
-        const double lik = gibbs ? likA : lik_sum + constP;
-        const bool ok = gibbs || (!invalid && (lik - likA + priorP - priorA + hasting >= lr_bcast(sc, LR_S_LOG_U)));
-        lik_p = invalid ? -INFINITY : lik;
-        if (ok) {
-            L = pL0, M = pM0, tL = ptL0, tM = ptM0, eL = peL0, eM = peM0;
-            KL = lr_bcast_i(isc, LR_I_PKL), KM = lr_bcast_i(isc, LR_I_PKM);
-            likA = lik, priorA = priorP, priorPoiA = priorPoiP, constA = constP;
-            n_acc += 1;
-        }
-        // ---- trace row (LRF:321-359) ----
-        // `it % s_freq == 0` kept as a running (next sample, slot) pair: no 64-bit division on the device
-        if (it == next_sample) {
-            const int slot = trace_slot;
-            trace_slot += 1;
-            next_sample += (uint64_t)cfg.s_freq;
-            if (slot < cfg.n_trace_slots) {
-                double* row = a.trace + ((size_t)slot * C + c) * LR_TRACE_W;
-                const double meanL = lr_wave_sum(lane < KL ? L : 0.0) / KL;
-                const double meanM = lr_wave_sum(lane < KM ? M : 0.0) / KM;
-                double h = 0.0;
-                switch (lane) {
-                    case 0: h = (double)it; break;
-                    case 1: h = likA + priorA; break;
-                    case 2: h = likA; break;
-                    case 3: h = priorA; break;
-                    case 4: h = meanL; break;
-                    case 5: h = meanM; break;
-                    case 6: h = KL; break;
-                    case 7: h = KM; break;
-                    case 8: h = cfg.start_time; break;
-                    case 9: h = cfg.end_time; break;
-                    case 10: h = g0; break;
-                    case 11: h = g1; break;
-                    case 12: h = poi; break;
-                }
-                if (lane < LR_TRACE_HEAD) row[lane] = h;
-                const double nan = __longlong_as_double(0x7ff8000000000000LL);
-                double* rl = row + LR_TRACE_HEAD;
-                double* rm = rl + (2 * LR_KMAX - 1);
-                if (lane < LR_KMAX) rl[lane] = lane < KL ? L : nan, rm[lane] = lane < KM ? M : nan;
-                if (lane >= 1 && lane < LR_KMAX) {
-                    rl[LR_KMAX + lane - 1] = lane < KL ? tL : nan;
-                    rm[LR_KMAX + lane - 1] = lane < KM ? tM : nan;
-                }
-            }
-        }
-        it += 1;
-    }
-
-    LR_SSTAMP(2);
-    // ---- propose iteration `it` (LRF:234-287) ----
-    double pL = L, pM = M, ptL = tL, ptM = tM;
-    int peL = eL, peM = eM, PKL = KL, PKM = KM;
-    double hasting = 0.0, priorPoi = 0.0;
-    int gibbs = 0, invalid = 0, move_kind;
-    const double sample_shift_mu = cfg.const_death_rate ? 0.0 : 0.5;
-    const double b_freq = cfg.const_death_rate ? 0.7 : 0.4, d_freq = 0.8;
-    const double fL = cfg.update_fraction, fM = cfg.const_death_rate ? 1.0 : cfg.update_fraction;
-    const lr_u2 r{lr_bcast(ud.a, 1), lr_bcast(ud.b, 1)};
-    if (r.a < b_freq) {
-        if (r.b < .5 || KL == 1) {
-            const lr_u2 d = lr_pair(rng, it, LR_P_MULT, lane);
-            hasting = lr_wave_multiplier(pL, KL, d.a < fL, d.b, a.mult_l, lane);
-            move_kind = 0;
-        } else {
-            peL = lr_wave_edges(tL, 0);  // update_times leaves the times unchanged (LRF:178-195)
-            move_kind = 1;
-        }
-    } else if (r.a < d_freq) {
-        if (r.b < .5 || KM == 1) {
-            const lr_u2 d = lr_pair(rng, it, LR_P_MULT, lane);
-            hasting = lr_wave_multiplier(pM, KM, d.a < fM, d.b, a.mult_l, lane);
-            move_kind = 2;
-        } else {
-            peM = lr_wave_edges(tM, 0);
-            move_kind = 3;
-        }
-    } else if (r.a < 0.999 && cfg.const_rates == 0) {
-        // RJMCMC (LRF:71-97)
-        move_kind = 4;
-        const lr_u2 q{lr_bcast(ud.a, 2), lr_bcast(ud.b, 2)};
-        const bool sideL = q.a > sample_shift_mu;
-        double R = sideL ? L : M, T = sideL ? tL : tM;
-        int K = sideL ? KL : KM;
-        double score = 0.0;
-        const lr_u2 q2{lr_bcast(ud.a, 3), lr_bcast(ud.b, 3)};
-        if (q.b > 0.5) {
-            if (K >= LR_KMAX) {
-                invalid = 1;  // device cap on the number of rates; the reference has none
-            } else {
-                const int ind = min((int)(q2.a * K), K - 1);
-                const double delta = q2.b * (lr_bcast(T, ind + 1) - lr_bcast(T, ind));
-                double ga, gb;
-                lr_wave_gamma2(rng, it, LR_P_BETA_A, LR_SHAPE_BETA_RJ, LR_P_BETA_B, LR_SHAPE_BETA_RJ, lane, &ga, &gb);
-                score = lr_wave_add_shift(R, T, K, ind, delta, ga / (ga + gb), lane);
-            }
-        } else if (K > 1) {
-            const int idx = 1 + min((int)(q2.a * (K - 1)), K - 2);
-            score = lr_wave_remove_shift(R, T, K, idx, lane);
-        }
-        hasting = score;
-        const int E = lr_wave_edges(T, 0);
-        if (sideL) pL = R, ptL = T, PKL = K, peL = E;
-        else pM = R, ptM = T, PKM = K, peM = E;
-        priorPoi = lr_poisson_prior(PKL, poi, lpoi) + lr_poisson_prior(PKM, poi, lpoi);
-    } else {
-        // Gibbs draws of the hyper-parameters (LRF:283-287, 99-108, 210-213)
-        move_kind = 5;
-        double gl = 0.0, gm = 0.0, gp = 0.0, dummy;
-        if (cfg.use_rate_HP)
-            lr_wave_gamma2(rng, it, LR_P_GIBBS_L, LR_HP_GAMMA_SHAPE + LR_GAMMA_SHAPE * KL, LR_P_GIBBS_M,
-                           LR_HP_GAMMA_SHAPE + LR_GAMMA_SHAPE * KM, lane, &gl, &gm);
-        if (cfg.poisson_HP == 0.0)
-            lr_wave_gamma2(rng, it, LR_P_GIBBS_POI, LR_RJHP_SHAPE + KL + KM, LR_P_GIBBS_POI, LR_RJHP_SHAPE + KL + KM, lane,
-                           &gp, &dummy);
-        if (cfg.poisson_HP == 0.0) poi = gp * (1. / (LR_RJHP_RATE + 2));
-        if (cfg.use_rate_HP) {
-            const double sL = lr_wave_sum(lane < KL ? L : 0.0), sM = lr_wave_sum(lane < KM ? M : 0.0);
-            g0 = gl * (1. / (LR_HP_GAMMA_RATE + sL));
-            g1 = gm * (1. / (LR_HP_GAMMA_RATE + sM));
-        }
-        // one packed log for the three cached logarithms
-        const double lx = log(lane == 0 ? g0 : (lane == 1 ? g1 : (lane == 2 ? poi : 1.0)));
-        lg0 = lr_bcast(lx, 0), lg1 = lr_bcast(lx, 1), lpoi = lr_bcast(lx, 2);
-        gibbs = 1;
-    }
-
-    LR_SSTAMP(3);
-    // segments of the proposal -> LDS scratch (+ log of every rate in one call)
-    double logpL, logpM, log_u_next;
-    lr_stage_segments(&scratch, pL, pM, peL, peM, PKL, PKM, lane, &logpL, &logpM, u_next, &log_u_next);
-
-    LR_SSTAMP(4);
-    // guard against tiny time frames (LRF:290-292) and the prior of the proposal (LRF:296-304)
-    double priorP = -INFINITY;
-    {
-        // one reduction for both processes: min over all segment lengths
-        const double nL = lr_dpp_zero<0x130 /* wave_shl:1 */, 0xf, 0xf>(ptL);   // lane l <- element l+1
-        const double nM = lr_dpp_zero<0x130, 0xf, 0xf>(ptM);
-        const double dmin = fmin(lane < PKL ? fabs(nL - ptL) : 1e300, lane < PKM ? fabs(nM - ptM) : 1e300);
-        if (__ballot(dmin <= LR_MIN_ALLOWED_T)) invalid = 1;       // min <= 1  <=>  any <= 1: one compare, no reduction
-    }
-    if (!invalid) {
-        // Gamma(2, g) log-densities of all rates of both processes in one reduction (LRF:296)
-        const double vL = (lane < PKL) ? (logpL + lg0) - pL * g0 + lg0 : 0.0;
-        const double vM = (lane < PKM) ? (logpM + lg1) - pM * g1 + lg1 : 0.0;
-        priorP = lr_wave_sum(vL + vM);
-        priorP += -a.log_T * (PKL - 1 + PKM - 1);
-        if (priorPoi != 0.0) priorP += priorPoi;
-        else priorP += priorPoiA, priorPoi = priorPoiA;
-    }
-
-    LR_SSTAMP(5);
-    // ---- lookup tables of the proposal ----
-    const double constP = lr_build_tables_segments(&scratch, peL, peM, PKL, PKM, a.br_length, a.log_br, cfg.model,
-                                                   n_bins, a.n_cls, a.H, table, lane,
-                                                   a.unit != 0, cfg.frac_birth, cfg.frac_death, table_es);
-
-    LR_SSTAMP(6);
-    // ---- back into the state registers ----
-    st.L = L, st.M = M, st.tL = tL, st.tM = tM;
-    st.pL = pL, st.pM = pM, st.ptL = ptL, st.ptM = ptM;
-    st.eL = eL, st.eM = eM, st.peL = peL, st.peM = peM;
-    {
-        // scalar slots: branch-free select chains (a switch over the lane id runs every case under its own exec mask)
-        double so = 0.0;
-        so = (lane == LR_S_LIKA) ? likA : so;
-        so = (lane == LR_S_PRIORA) ? priorA : so;
-        so = (lane == LR_S_PRIORPOIA) ? priorPoiA : so;
-        so = (lane == LR_S_GRATE_L) ? g0 : so;
-        so = (lane == LR_S_GRATE_M) ? g1 : so;
-        so = (lane == LR_S_POI) ? poi : so;
-        so = (lane == LR_S_HASTING) ? hasting : so;
-        so = (lane == LR_S_PRIOR_P) ? priorP : so;
-        so = (lane == LR_S_PRIORPOI_P) ? priorPoi : so;
-        so = (lane == LR_S_CONST_P) ? constP : so;
-        so = (lane == LR_S_CONST_A) ? constA : so;
-        so = (lane == LR_S_LIK_P) ? lik_p : so;
-        so = (lane == LR_S_LOG_G0) ? lg0 : so;
-        so = (lane == LR_S_LOG_G1) ? lg1 : so;
-        so = (lane == LR_S_LOG_POI) ? lpoi : so;
-        so = (lane == LR_S_LOG_U) ? log_u_next : so;
-        st.sc = so;
-        int io = 0;
-        io = (lane == LR_I_KL) ? KL : io;
-        io = (lane == LR_I_KM) ? KM : io;
-        io = (lane == LR_I_PKL) ? PKL : io;
-        io = (lane == LR_I_PKM) ? PKM : io;
-        io = (lane == LR_I_GIBBS) ? gibbs : io;
-        io = (lane == LR_I_INVALID) ? invalid : io;
-        io = (lane == LR_I_IT_LO) ? (int)(uint32_t)it : io;
-        io = (lane == LR_I_IT_HI) ? (int)(uint32_t)(it >> 32) : io;
-        io = (lane == LR_I_ACCEPTED) ? n_acc : io;
-        io = (lane == LR_I_MOVE) ? move_kind : io;
-        io = (lane == LR_I_NEXT_LO) ? (int)(uint32_t)next_sample : io;
-        io = (lane == LR_I_NEXT_HI) ? (int)(uint32_t)(next_sample >> 32) : io;
-        io = (lane == LR_I_SLOT) ? trace_slot : io;
-        st.isc = io;
-    }
-    LR_SSTAMP(7);
-#ifdef LR_DIAG
-    if (lane == 0 && c < 4096) lr_diag_step[c * 12 + 8] = move_kind;
-#endif
-}
-
-// the step of chain c with its state in global memory: load, sum the tile partials in tile order, step, store
-
-// ---- parametric samplers: one iteration of DDRate.py's loop (DD:194-239; sampler 1) or of trend_rate.py's
-// (trend_rate.py:160-195; sampler 2) for one chain -----------------------------------------------------------
-// Same pipeline position as lr_chain_step_core: decide the pending proposal with the scanned likelihood, write the
-// trace row, propose the next parameter vector, evaluate its prior and build its lookup tables.
-// State: lane j < NPAR of st.L = accepted parameter j, of st.pL = proposed parameter j; scalars in st.sc / st.isc.
-// `aux` = the per-bin array the rate map needs: DT (DDRate) or the normalised covariate TREND (trend_rate).
-__device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
-                                                double lik_sum, double2* table, int table_es = 2) {
-    const lr_mcmc_config& cfg = a.cfg;
-    const int C = cfg.n_chains;
-    const bool trend = cfg.sampler == 2;
-    const int npar = trend ? LR_TR_NPAR : LR_DD_NPAR;
-    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
-    const double origin = cfg.t0, present = cfg.dd_present;
-    const double k0 = a.dd_consts[0], log_k0 = a.dd_consts[1];
-    const double* aux = a.br_length;
-    double A = st.L;
-    const double P0 = st.pL;
-    const double sc = st.sc;
-    const int isc = st.isc;
-    double likA = lr_bcast(sc, LR_S_LIKA), priorA = lr_bcast(sc, LR_S_PRIORA), lik_p = lr_bcast(sc, LR_S_LIK_P);
-    uint64_t it = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_HI) << 32);
-    int n_acc = lr_bcast_i(isc, LR_I_ACCEPTED);
-    uint64_t next_sample = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_HI) << 32);
-    int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
-    // wave-uniform draws in one Philox call (see lr_chain_step_core): lane 0 acceptance uniform of `it`, lane 1 the move
-    // selector and lane 2 the sliding-window uniform of the iteration about to be proposed
-    lr_u2 ud;
-    {
-        const uint64_t it_prop = (mode == 1) ? it : it + 1;
-        const uint32_t purpose = trend ? (lane == 0 ? LR_P_TR_ACCEPT : LR_P_TR_MOVE)
-                                       : (lane == 0 ? LR_P_DD_ACCEPT : (lane == 1 ? LR_P_DD_MOVE : LR_P_DD_SLIDE));
-        ud = lr_pair(rng, lane == 0 ? it : it_prop, purpose, 0u);
-    }
-    if (mode == 1) {
-        likA = lik_sum;                                                        // DD:184-186, trend_rate.py:150-151
-        priorA = trend ? lr_trend_prior(A, lane) : lr_dd_prior(A, origin, present, k0, log_k0, lane);
-    } else {
-        const double hasting = lr_bcast(sc, LR_S_HASTING), priorP = lr_bcast(sc, LR_S_PRIOR_P);
-        const double u = lr_bcast(ud.a, 0);
-        const double lik = lik_sum;
-        const bool ok = ((lik - likA) + (priorP - priorA) + hasting > log(u)) || it == 0;   // DD:211, trend_rate.py:176
-        lik_p = lik;
-        if (ok) A = P0, likA = lik, priorA = priorP, n_acc += 1;
-        if (it == next_sample) {                                               // DD:221
-            const int slot = trace_slot;
-            trace_slot += 1;
-            next_sample += (uint64_t)cfg.s_freq;
-            if (slot < cfg.n_trace_slots) {
-                double* row = a.trace + ((size_t)slot * C + c) * LR_TRACE_W;
-                double h = __longlong_as_double(0x7ff8000000000000LL);
-                if (lane == 0) h = (double)it;
-                if (lane == 1) h = likA + priorA;
-                if (lane == 2) h = likA;
-                if (lane == 3) h = priorA;
-                const double Aj = __shfl(A, (lane - 4) & (LR_WAVE - 1));        // rare path (sampling only)
-                if (lane >= 4 && lane < 4 + npar) h = Aj;
-                for (int j = lane; j < LR_TRACE_W; j += LR_WAVE) row[j] = (j == lane) ? h : __longlong_as_double(0x7ff8000000000000LL);
-            }
-        }
-        it += 1;
-    }
-    // ---- propose iteration `it` ----
-    double P = A, hasting = 0.0;
-    int move_kind;
-    if (trend) {
-        // trend_rate.py:165-169: 33 % additive normal step on the slopes, else the vector multiplier
-        const double rr = lr_bcast(ud.a, 1);
-        double f_mult, f_norm;
-        lr_trend_update_freq(cfg.m_birth, cfg.m_death, lane, &f_mult, &f_norm);
-        const lr_u2 d = lr_pair(rng, it, LR_P_TR_MULT, lane);
-        if (rr < .33) {
-            const double z = lr_normal(rng, it, LR_P_TR_NORM, lane);               // update_normal_nobound_vec (lib:140-146)
-            if (lane < npar && d.a < f_norm) P = A + z * .001;
-            move_kind = 1;
-        } else {
-            hasting = lr_wave_multiplier(P, npar, d.a < f_mult, d.b, a.mult_l, lane);   // lib:156-165
-            move_kind = 0;
-        }
-    } else {
-        // DD:195-207
-        const lr_u2 rr{lr_bcast(ud.a, 1), lr_bcast(ud.b, 1)};
-        if (rr.b < 0.1 && (cfg.m_birth == 2 || cfg.m_death == 2)) {
-            // update_sliding_win(x0, m=0, M=PRESENT, d=1.5) (lib:124-128)
-            double ii = lr_bcast(A, 2) + (lr_bcast(ud.a, 2) - .5) * 1.5;
-            if (ii > present) ii = present - (ii - present);
-            ii = fabs(ii);
-            if (lane == 2) P = ii;
-            if (cfg.m_death == -1) {
-                const double z = lr_normal(rng, it, LR_P_DD_SLIDE, 1);              // update_normal_nobound(k, d=0.2) (lib:136-138)
-                if (lane == 1) P = A + z * 0.2;
-            }
-            move_kind = 1;
-        } else {
-            const double f = lr_dd_update_freq(cfg.m_birth, cfg.m_death, lane);
-            const lr_u2 d = lr_pair(rng, it, LR_P_DD_MULT, lane);
-            hasting = lr_wave_multiplier(P, npar, d.a < f, d.b, a.mult_l, lane);   // lib:156-165
-            move_kind = 0;
-        }
-    }
-    double priorP;
-    if (trend) {
-        priorP = lr_trend_prior(P, lane);
-        const lr_trend_params tp = lr_trend_unpack(P);
-        lr_rates_build_tables_wave([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
-                                   cfg.n_bins, a.H, table, lane, a.unit != 0, cfg.frac_birth, cfg.frac_death, table_es);
-    } else {
-        priorP = lr_dd_prior(P, origin, present, k0, log_k0, lane);
-        const lr_dd_params pp = lr_dd_unpack(P);
-        lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, a.unit != 0,
-                                cfg.frac_birth, cfg.frac_death, table_es);
-    }
-    st.L = A, st.pL = P;
-    {
-        double so = 0.0;
-        so = (lane == LR_S_LIKA) ? likA : so;
-        so = (lane == LR_S_PRIORA) ? priorA : so;
-        so = (lane == LR_S_HASTING) ? hasting : so;
-        so = (lane == LR_S_PRIOR_P) ? priorP : so;
-        so = (lane == LR_S_LIK_P) ? lik_p : so;
-        st.sc = so;
-        int io = 0;
-        io = (lane == LR_I_KL || lane == LR_I_KM || lane == LR_I_PKL || lane == LR_I_PKM) ? npar : io;
-        io = (lane == LR_I_IT_LO) ? (int)(uint32_t)it : io;
-        io = (lane == LR_I_IT_HI) ? (int)(uint32_t)(it >> 32) : io;
-        io = (lane == LR_I_ACCEPTED) ? n_acc : io;
-        io = (lane == LR_I_MOVE) ? move_kind : io;
-        io = (lane == LR_I_NEXT_LO) ? (int)(uint32_t)next_sample : io;
-        io = (lane == LR_I_NEXT_HI) ? (int)(uint32_t)(next_sample >> 32) : io;
-        io = (lane == LR_I_SLOT) ? trace_slot : io;
-        st.isc = io;
-    }
-}
-
-__device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mode, int c, int lane,
-                                                   lr_seg_scratch* scratch_p) {
-    LR_SSTAMP(0);
-    lr_chain_regs st;
-    double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
-    int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
-    lr_chain_load(st, S, I, lane);
-    double part = 0.0;
-    for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * a.cfg.n_chains + c];
-    const double lik_sum = lr_wave_sum(part);
-    if (a.cfg.sampler != 0) lr_dd_step_core(st, a, mode, c, lane, lik_sum, lr_chain_table(a, c));
-    else lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c));
-    lr_chain_store(st, S, I, lane);
-}
-
 #define LR_STEP_WAVES (LR_SCAN_THREADS / LR_WAVE)
 
 // chains [chain_base, chain_base + n_sub): one wave per chain, LR_STEP_WAVES chains per block
@@ -960,41 +254,6 @@ __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const dou
         }
     }
     out[g * 8 + (i & 7)] = (unsigned short)((a + 1) | (b << 8));
-}
-
-// Scan of all lineages against ONE pair table by `n_scan` threads (this thread is number `sid`): the inner loop
-// of the persistent engines.  8 lineages per 16-byte load, next load in flight while the current one is scored.
-template <int H, int UNROLL = 1>
-__device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
-                                                     long long n8, long long sid, int n_scan, double* acc0_,
-                                                     double* acc1_) {
-    double acc0 = *acc0_, acc1 = *acc1_;
-    // 32-bit loop arithmetic (n8 = N / 8 < 2^31): a 64-bit compare and add per trip are two instructions each
-    const int n = (int)n8;
-    int i = (int)sid;
-    uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    if (i < n) w = idx8[i];
-    // UNROLL = 2 saves the register rotation of the prefetched index word (+1 % on long scans) at the price of a dozen
-    // spills around the chain-step call, which the short-scan configurations feel: the four-chain kernel uses it
-#pragma unroll UNROLL
-    while (i < n) {
-        const uint4 cur = w;
-        const int nx = i + n_scan;
-        if (nx < n) w = idx8[nx];
-        const unsigned int words[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned int v = words[k];
-            const double2 s0 = *reinterpret_cast<const double2*>(lbase + ((v << 4) & 0xff0u));
-            const double2 e0 = *reinterpret_cast<const double2*>(lbase + ((v >> 4) & 0xff0u) + H * 16);
-            const double2 s1 = *reinterpret_cast<const double2*>(lbase + ((v >> 12) & 0xff0u));
-            const double2 e1 = *reinterpret_cast<const double2*>(lbase + ((v >> 20) & 0xff0u) + H * 16);
-            acc0 += (s0.x + e0.x) + (s1.x + e1.x);
-            acc1 += (s0.y + e0.y) + (s1.y + e1.y);
-        }
-        i = nx;
-    }
-    *acc0_ = acc0, *acc1_ = acc1;
 }
 
 // the chain step of the persistent kernel as a real call: its ~120 live registers then do not add to the scan
@@ -1349,6 +608,41 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     return LR_OK;
 }
 
+static int lr_device_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+
+// Speculative team kernel (lr_spec.h): one 1024-thread block per CU, a chain pair owned by a team of k blocks.  Model of
+// an iteration in microseconds (MI355X, measured pieces): candidate build 2.6 (RJ) / 4.0 (parametric samplers),
+// 0.55 per scan trip of the 12 scanner waves (768 lanes x 8 lineages), 1.5 for the team exchange, 0.5 for the two
+// barriers + decision + table copy.  Returns the modelled time and the best team size in *k (0 = not applicable).
+static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out) {
+    const int pairs = (cfg->n_chains + 1) / 2;
+    const int cus = lr_device_cus();
+    *k_out = 0;
+    if (pairs > cus) return 1e30;
+    static const int k_env0 = lr_env_int("LR_SPEC_TEAM", 0);
+    const int k_env = cfg->team_request > 0 ? cfg->team_request : k_env0;
+    const double n8 = (double)((cfg->n_lineages + 7) / 8);
+    const double t_cand = cfg->sampler ? 4.0 : 2.6;
+    double best = 1e30;
+    for (int k = 1; k <= LR_TEAM_MAX; k *= 2) {
+        if (pairs * k > cus) break;
+        if (k_env > 0 && k != k_env) continue;
+        const double trips = ceil(n8 / k / 768.0);
+        const double t_scan = trips * 0.55 + (k > 1 ? 1.5 : 0.0);
+        const double t = (t_scan > t_cand ? t_scan : t_cand) + 0.5;
+        if (t < best - 0.05) best = t, *k_out = k;
+    }
+    return best;
+}
+
 // Persistent engine (lr_persist_kernel): needs unit-resolution tables with byte-sized indices and an
 // instantiated table size.  cfg->engine_mode 1 / 2 / 3 force the launch-based / persistent / four-chain persistent
 // engine (2 and 3 still need the prerequisites); auto picks the persistent kernel unless the chains are too few for the lineage count: a block
@@ -1360,11 +654,14 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     if (!p.unit || cfg->n_bins + 1 > 255 || p.cb < 2) return false;
     if (cfg->n_lineages >= (1ll << 33)) return false;   // the scan loop counts 16-byte index groups in 32 bits
     if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264) return false;
-    if (env == 1 || cfg->engine_mode == 2 || cfg->engine_mode == 3) return true;
+    if (env == 1 || cfg->engine_mode >= 2) return true;
     const double n = (double)cfg->n_lineages, c = (double)cfg->n_chains;
     const int blocks = (cfg->n_chains + 1) / 2;
     const double rounds = (double)((blocks + 511) / 512);
-    const double t_persist = rounds * (n * 2.0 * (blocks > 256 ? 2.0 : 1.0) / 2.2e10) + 6e-6;
+    double t_persist = rounds * (n * 2.0 * (blocks > 256 ? 2.0 : 1.0) / 2.2e10) + 6e-6;
+    int k = 0;
+    const double t_spec = lr_spec_model(cfg, &k) * 1e-6;      // few chains: a team of CUs per chain pair
+    if (k > 0 && t_spec < t_persist) t_persist = t_spec;
     const double t_launch = n * c / 5e12 + 14e-6;
     return t_persist <= t_launch;
 }
@@ -1376,11 +673,25 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
 // two-chain kernel's remainder round is cheaper when at most 512 chains are left (C = 1536: 29.4 vs 33.5 us).
 // Model in units of one full round (15.2 us on cfg4): t4 = ceil(C/1024), t2 = 1.08 floor(C/1024) + (0.82 | 1.08 for
 // the remainder).
-static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
+static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k = nullptr) {
+    if (team_k) *team_k = 0;
     if (!lr_persist_eligible(cfg, p)) return 0;
     static const int p4_env = lr_env_int("LR_PERSIST4", -1);
+    static const int spec_env = lr_env_int("LR_SPEC", -1);
+    int k = 0;
+    const double t_spec = lr_spec_model(cfg, &k);
+    if (k > 0 && cfg->engine_mode != 3 && cfg->engine_mode != 4 && spec_env != 0) {
+        // the two-chain kernel with all 16 waves scanning wins only on long scans without room for a team
+        const double t_wide = ceil((double)((cfg->n_lineages + 7) / 8) / 1024.0) * 0.55 + 4.3;
+        if (cfg->engine_mode == 5 || spec_env == 1 || t_spec <= t_wide) {
+            if (team_k) *team_k = k;
+            return 3;
+        }
+    }
+    if (cfg->engine_mode == 5) return 0;
     if (p.cb < 4) return 1;                 // tables are laid out per group of cb chains; a quad must not straddle
     if (cfg->engine_mode == 3) return 2;
+    if (cfg->engine_mode == 4) return 1;
     if (p4_env >= 0) return p4_env ? 2 : 1;
     const int C = cfg->n_chains, rem = C % 1024;
     const double t4 = (double)((C + 1023) / 1024);
@@ -1424,6 +735,13 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
     out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
+    int team_k = 0;
+    out->persistent = lr_persist_variant(cfg, p, &team_k);
+    out->team_blocks = team_k;
+    out->reserved2 = 0;
+    out->status = o, o += 256;   // engine status word
+    // team exchange granules of the speculative kernel: [2 parities][pairs][LR_TEAM_MAX][LR_SPEC_GRANULES] x 8 bytes
+    out->xchg = o, o += (team_k > 1) ? lr_align_up64(2ll * ((C + 1) / 2) * LR_TEAM_MAX * LR_SPEC_GRANULES * 8, 256) : 0;
     out->total_bytes = o;
     out->table_stride = p.tab_stride;
     out->tiles = p.tiles;
@@ -1435,11 +753,10 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
         out->n_parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined);
         out->pipelined = pipelined[0] ? 1 : 0;
     }
-    out->persistent = lr_persist_variant(cfg, p);
     {
         static const int wide_env = lr_env_int("LR_PERSIST_WIDE", -1);
         const bool wide = wide_env >= 0 ? wide_env != 0 : ((cfg->n_chains + 1) / 2 <= 256 && cfg->n_lineages >= 20000);
-        out->reserved1 = out->persistent == 2 ? 1024 : (out->persistent == 1 ? (wide ? 1024 : 512) : 0);   // threads per persistent block
+        out->reserved1 = out->persistent == 3 ? LR_SPEC_THREADS : (out->persistent == 2 ? 1024 : (out->persistent == 1 ? (wide ? 1024 : 512) : 0));   // threads per persistent block
     }
     return LR_OK;
 }
@@ -1463,7 +780,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
     e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, lr_fused_supported(e->plan), base, hA, pipelined);
-    e->persistent = lr_persist_eligible(cfg, e->plan);
+    e->persistent = lay.persistent != 0;
     e->n8 = lr_align_up64(cfg->n_lineages, 8) / 8;
     e->n8_alloc = e->n8 + LR_IDX_SPARE;
     {
@@ -1474,7 +791,9 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
         static const char* env = getenv("LR_P4_SHARES");       // "d2,d4,d6,d8,d10,d12,d14" for 14 trips
         static const int env2 = lr_env_int("LR_P2_SHARE", 0);   // two-chain kernel: trips per 24 moved from waves 4..7 to 0..3 (no gain measured: off)
         for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
-        if (e->lay.persistent == 2) {
+        if (e->lay.persistent == 3) {
+            e->p4.n_slots = 12;      // speculative kernel: plain layout, every scanner wave strides over its block's slice
+        } else if (e->lay.persistent == 2) {
             e->p4.n_slots = 14;
             int base[7] = {6, 6, 2, 0, -2, -6, -6};
             if (env) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
@@ -1795,6 +1114,38 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         static const int wide_env = lr_env_int("LR_PERSIST_WIDE", -1);
         const bool wide = e->lay.reserved1 == 1024;   // (short scans keep 512: the 16-wave barrier costs more than it buys)
         (void)wide_env;
+        if (e->lay.persistent == 3) {
+            lr_spec_args x;
+            x.xchg = (unsigned long long*)(e->ws + e->lay.xchg);
+            x.status = (unsigned int*)(e->ws + e->lay.status);
+            x.team_blocks = e->lay.team_blocks, x.n_teams = blocks;
+            const size_t xbytes = (size_t)2 * blocks * LR_TEAM_MAX * LR_SPEC_GRANULES * 8;
+            for (int64_t done = 0; done < n_iters;) {
+                const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
+                // epochs count from 1 inside every launch: all granules start at zero (Guideline 16, "Re-initialise every call")
+                if (x.team_blocks > 1) {
+                    const hipError_t he = hipMemsetAsync(x.xchg, 0, xbytes, stream);
+                    if (he != hipSuccess) return (int)he;
+                }
+                const dim3 grid((unsigned)(blocks * x.team_blocks)), blk(LR_SPEC_THREADS);
+#define LR_SPEC_LAUNCH(HH)                                                                                                  \
+    if (e->cfg.sampler == 0)                                                                                                \
+        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, true>), grid, blk, 0, stream, a, idx8, e->n8, x, (long long)n); \
+    else                                                                                                                    \
+        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, false>), grid, blk, 0, stream, a, idx8, e->n8, x, (long long)n)
+                switch (e->plan.H) {
+                    case 40: LR_SPEC_LAUNCH(40); break;
+                    case 72: LR_SPEC_LAUNCH(72); break;
+                    case 136: LR_SPEC_LAUNCH(136); break;
+                    default: LR_SPEC_LAUNCH(264); break;
+                }
+#undef LR_SPEC_LAUNCH
+                const int rc = (int)hipGetLastError();
+                if (rc) return rc;
+                done += n;
+            }
+            return LR_OK;
+        }
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
             switch (e->plan.H) {
@@ -1876,12 +1227,22 @@ extern "C" int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms, void
     return rc;
 }
 
+extern "C" int lr_mcmc_status(lr_engine* e, int32_t* status, void* stream_) {
+    if (!e || !status) return LR_ERR_NULL;
+    unsigned int v = 0;
+    hipError_t he = hipMemcpyAsync(&v, e->ws + e->lay.status, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream_);
+    if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream_);
+    *status = (int32_t)v;
+    return (int)he;
+}
+
 // name of the kernel lr_mcmc_steps spends its time in, as rocprofv3's kernel trace prints it (without arguments)
 extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
     if (!e || !buf) return LR_ERR_NULL;
     if (n < 64) return LR_ERR_SIZE;
     if (e->persistent) {
-        if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d>", e->plan.H);
+        if (e->lay.persistent == 3) snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
+        else if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d>", e->plan.H);
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
     } else if (e->part[0].pipelined) {
         snprintf(buf, (size_t)n, "lr_fused_iter_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");
@@ -1909,5 +1270,13 @@ extern "C" int lr_mcmc_destroy(lr_engine* e) {
 #ifdef LR_DIAG
 extern "C" int lr_diag_dump_step(unsigned long long* host_out, int n_words) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lr_diag_step), (size_t)n_words * 8);
+}
+extern "C" int lr_diag_dump_seg(unsigned long long* host_out, int n_words, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lr_diag_seg), (size_t)n_words * 8);
+    if (reset) {
+        static unsigned long long zeros[64 * 16];
+        rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(lr_diag_seg), zeros, sizeof(zeros));
+    }
+    return rc;
 }
 #endif

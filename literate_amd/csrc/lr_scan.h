@@ -290,3 +290,42 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_unit_kernel(const dou
     lr_scan_unit_body<CB, H>(lds, tile, group * CB, ts, te, n, t0, n_bins, tables, n_chains, chunk, partials,
                              partial_stride);
 }
+
+// ------------------------------------------------------------------------------------------
+// persistent engines: the lineages as packed table indices (lr_pack_lineages_kernel), tables resident in LDS
+// ------------------------------------------------------------------------------------------
+// Scan of all lineages against ONE pair table by `n_scan` threads (this thread is number `sid`): the inner loop
+// of the persistent engines.  8 lineages per 16-byte load, next load in flight while the current one is scored.
+template <int H, int UNROLL = 1>
+__device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
+                                                     long long n8, long long sid, int n_scan, double* acc0_,
+                                                     double* acc1_) {
+    double acc0 = *acc0_, acc1 = *acc1_;
+    // 32-bit loop arithmetic (n8 = N / 8 < 2^31): a 64-bit compare and add per trip are two instructions each
+    const int n = (int)n8;
+    int i = (int)sid;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n) w = idx8[i];
+    // UNROLL = 2 saves the register rotation of the prefetched index word (+1 % on long scans) at the price of a dozen
+    // spills around the chain-step call, which the short-scan configurations feel: the four-chain kernel uses it
+#pragma unroll UNROLL
+    while (i < n) {
+        const uint4 cur = w;
+        const int nx = i + n_scan;
+        if (nx < n) w = idx8[nx];
+        const unsigned int words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned int v = words[k];
+            const double2 s0 = *reinterpret_cast<const double2*>(lbase + ((v << 4) & 0xff0u));
+            const double2 e0 = *reinterpret_cast<const double2*>(lbase + ((v >> 4) & 0xff0u) + H * 16);
+            const double2 s1 = *reinterpret_cast<const double2*>(lbase + ((v >> 12) & 0xff0u));
+            const double2 e1 = *reinterpret_cast<const double2*>(lbase + ((v >> 20) & 0xff0u) + H * 16);
+            acc0 += (s0.x + e0.x) + (s1.x + e1.x);
+            acc1 += (s0.y + e0.y) + (s1.y + e1.y);
+        }
+        i = nx;
+    }
+    *acc0_ = acc0, *acc1_ = acc1;
+}
+

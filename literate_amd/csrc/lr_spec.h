@@ -1,0 +1,635 @@
+// lr_spec.h - the speculative team engine: persistent kernel for shards with at most one chain pair per CU.
+//
+// The chain step is a serial fp64 stream of ~3 us that needs the lineage scan for ONE bit (accept / reject).  So it is
+// taken off the critical path by speculation: while the scanner waves score the pending proposal P, two candidate
+// waves per chain build the NEXT proposal for both outcomes - Q0 from the accepted state A (P rejected) and Q1 from P
+// (P accepted) - with their priors and lookup tables.  When the scan sums are in, every wave evaluates the
+// Metropolis-Hastings rule (a handful of flops on values in LDS), the pair table of the selected candidates is
+// copied in place and the next scan starts.  The draws are addressed by (seed, chain, iteration, purpose), so both
+// candidates consume exactly the draws the sequential loop would: trajectories are those of lr_chain_step_core.
+// Per iteration: max(candidate build, scan) + two barriers, instead of scan + step.
+//
+// Teams.  With fewer chain pairs than CUs a pair is owned by a TEAM of k blocks (k = 2, 4, 8; one block per CU).
+// Every block of the team runs the same candidate waves on the same state - a replicated state machine, so no table
+// or state ever crosses a CU boundary - and scans its own 1/k slice of the lineages.  The only exchange is the two
+// partial sums per block and iteration: 8-byte {epoch tag, 32-bit half} granules written with one agent-scope store
+// each and swept by one wave of every block until all tags carry the iteration's epoch (cdna_hip_programming.md
+// Guideline 16, form R2; parity-double-buffered, zeroed before every launch).  Every block adds the k partial sums in
+// block order, so all of them take bit-identical decisions; only block 0 of a team writes trace rows and the final
+// state.  Results never depend on dispatch order or placement; a sweep that does not complete within two seconds
+// raises the engine's status word and ends the launch (every block polls that word too).
+#pragma once
+#include "lr_scan.h"
+#include "lr_step.h"
+
+#ifndef LR_SPEC_THREADS
+#define LR_SPEC_THREADS 768   /* 12 waves: 4 candidate + 8 scanner waves, 3 per SIMD = 168 VGPRs each */
+#endif
+#ifndef LR_SPEC_SCAN_UNROLL
+#define LR_SPEC_SCAN_UNROLL 2
+#endif
+#define LR_TEAM_MAX 8
+#define LR_SPEC_GRANULES 16      /* 8-byte granules reserved per block and parity: one 128-byte line */
+#define LR_SPEC_TIMEOUT_TICKS 200000000ull   /* 2 s of the 100 MHz wall clock */
+
+// one state "as accepted" together with the bookkeeping of the proposal that led to it, in LDS
+struct lr_set {
+    double L[LR_ROW], M[LR_ROW], tL[LR_ROW], tM[LR_ROW];
+    int eL[LR_ROW], eM[LR_ROW];
+    int sgL[LR_ROW], sgM[LR_ROW];   // the table builder's bin ranks for these edges (lr_seg_cache), valid iff isc[LR_SETI_SEG]
+    double sc[16];
+    int isc[8];
+};
+#define LR_SET_HASTING 0
+#define LR_SET_PRIOR 1
+#define LR_SET_PRIORPOI 2
+#define LR_SET_CONST 3
+#define LR_SET_G0 4
+#define LR_SET_G1 5
+#define LR_SET_POI 6
+#define LR_SET_LG0 7
+#define LR_SET_LG1 8
+#define LR_SET_LPOI 9
+#define LR_SET_LOG_U 10
+#define LR_SETI_KL 0
+#define LR_SETI_KM 1
+#define LR_SETI_GIBBS 2
+#define LR_SETI_INVALID 3
+#define LR_SETI_MOVE 4
+#define LR_SETI_SEG 5
+
+// the state-independent draws of one iteration of one chain (lr_rj_draws), made one iteration ahead
+struct lr_draw_slot {
+    double sc[8];                 // log_u, r_a, r_b, q_a, q_b, q2_a, q2_b, beta
+    double x[LR_ROW], m[LR_ROW], da[LR_ROW];
+};
+
+__device__ __forceinline__ void lr_draws_store(lr_draw_slot* q, const lr_rj_draws& d, int lane) {
+    double so = d.log_u;
+    so = (lane == 1) ? d.r_a : so;
+    so = (lane == 2) ? d.r_b : so;
+    so = (lane == 3) ? d.q_a : so;
+    so = (lane == 4) ? d.q_b : so;
+    so = (lane == 5) ? d.q2_a : so;
+    so = (lane == 6) ? d.q2_b : so;
+    so = (lane == 7) ? d.beta : so;
+    if (lane < 8) q->sc[lane] = so;
+    q->x[lane] = d.x, q->m[lane] = d.m, q->da[lane] = d.da;
+}
+
+__device__ __forceinline__ void lr_draws_load(const lr_draw_slot* q, lr_rj_draws& d, int lane) {
+    const double v = q->sc[lane & 7];          // one LDS read for the eight scalars
+    d.log_u = lr_bcast(v, 0), d.r_a = lr_bcast(v, 1), d.r_b = lr_bcast(v, 2), d.q_a = lr_bcast(v, 3);
+    d.q_b = lr_bcast(v, 4), d.q2_a = lr_bcast(v, 5), d.q2_b = lr_bcast(v, 6), d.beta = lr_bcast(v, 7);
+    d.x = q->x[lane], d.m = q->m[lane], d.da = q->da[lane];
+}
+
+// draw duty of a scanner wave: the draws of iteration `it` of chain c into `out`
+__device__ __forceinline__ void lr_spec_draw(const lr_step_args& a, int c, int lane, unsigned long long it,
+                                             lr_draw_slot* out) {
+    lr_rj_draws d;
+    lr_make_rj_draws(a, c, lane, it, d);
+    lr_draws_store(out, d, lane);
+}
+
+struct lr_spec_args {
+    unsigned long long* xchg;     // [2 parities][n_teams][LR_TEAM_MAX][LR_SPEC_GRANULES] granules (k > 1)
+    unsigned int* status;         // engine status word: 0 ok, 1 = a team exchange timed out
+    int team_blocks;              // k
+    int n_teams;                  // chain pairs
+};
+
+__device__ __forceinline__ void lr_set_load(const lr_set* q, lr_rj_state& s, int lane) {
+    s.L = q->L[lane], s.M = q->M[lane], s.tL = q->tL[lane], s.tM = q->tM[lane];
+    s.eL = q->eL[lane], s.eM = q->eM[lane];
+    s.sgL = q->sgL[lane], s.sgM = q->sgM[lane];
+    const double v = q->sc[lane & 15];     // the scalars in two row reads, then register broadcasts
+    const int iv = q->isc[lane & 7];
+    s.KL = lr_bcast_i(iv, LR_SETI_KL), s.KM = lr_bcast_i(iv, LR_SETI_KM), s.sg_valid = lr_bcast_i(iv, LR_SETI_SEG);
+    s.g0 = lr_bcast(v, LR_SET_G0), s.g1 = lr_bcast(v, LR_SET_G1), s.poi = lr_bcast(v, LR_SET_POI);
+    s.lg0 = lr_bcast(v, LR_SET_LG0), s.lg1 = lr_bcast(v, LR_SET_LG1), s.lpoi = lr_bcast(v, LR_SET_LPOI);
+    s.priorPoi = lr_bcast(v, LR_SET_PRIORPOI);
+}
+
+__device__ __forceinline__ void lr_set_store(lr_set* q, const lr_rj_state& s, const lr_rj_prop& p, int lane) {
+    q->L[lane] = s.L, q->M[lane] = s.M, q->tL[lane] = s.tL, q->tM[lane] = s.tM;
+    q->eL[lane] = s.eL, q->eM[lane] = s.eM;
+    q->sgL[lane] = s.sgL, q->sgM[lane] = s.sgM;
+    double so = 0.0;
+    so = (lane == LR_SET_HASTING) ? p.hasting : so;
+    so = (lane == LR_SET_PRIOR) ? p.prior : so;
+    so = (lane == LR_SET_PRIORPOI) ? s.priorPoi : so;
+    so = (lane == LR_SET_CONST) ? p.constP : so;
+    so = (lane == LR_SET_G0) ? s.g0 : so;
+    so = (lane == LR_SET_G1) ? s.g1 : so;
+    so = (lane == LR_SET_POI) ? s.poi : so;
+    so = (lane == LR_SET_LG0) ? s.lg0 : so;
+    so = (lane == LR_SET_LG1) ? s.lg1 : so;
+    so = (lane == LR_SET_LPOI) ? s.lpoi : so;
+    so = (lane == LR_SET_LOG_U) ? p.log_u : so;
+    if (lane < 16) q->sc[lane] = so;
+    int io = 0;
+    io = (lane == LR_SETI_KL) ? s.KL : io;
+    io = (lane == LR_SETI_KM) ? s.KM : io;
+    io = (lane == LR_SETI_GIBBS) ? p.gibbs : io;
+    io = (lane == LR_SETI_INVALID) ? p.invalid : io;
+    io = (lane == LR_SETI_MOVE) ? p.move : io;
+    io = (lane == LR_SETI_SEG) ? s.sg_valid : io;
+    if (lane < 8) q->isc[lane] = io;
+}
+
+// chain state rows in global memory (include/literate_hip.h) -> the accepted set A and the pending set P
+__device__ __forceinline__ void lr_sets_from_global(const double* S, const int* I, lr_set* A, lr_set* P, int lane) {
+    A->L[lane] = S[LR_ROW_L * LR_ROW + lane], A->M[lane] = S[LR_ROW_M * LR_ROW + lane];
+    A->tL[lane] = S[LR_ROW_TL * LR_ROW + lane], A->tM[lane] = S[LR_ROW_TM * LR_ROW + lane];
+    P->L[lane] = S[LR_ROW_PL * LR_ROW + lane], P->M[lane] = S[LR_ROW_PM * LR_ROW + lane];
+    P->tL[lane] = S[LR_ROW_PTL * LR_ROW + lane], P->tM[lane] = S[LR_ROW_PTM * LR_ROW + lane];
+    A->eL[lane] = I[LR_IROW_EL * LR_ROW + lane], A->eM[lane] = I[LR_IROW_EM * LR_ROW + lane];
+    P->eL[lane] = I[LR_IROW_PEL * LR_ROW + lane], P->eM[lane] = I[LR_IROW_PEM * LR_ROW + lane];
+    A->sgL[lane] = A->sgM[lane] = P->sgL[lane] = P->sgM[lane] = 0;
+    const double sc = S[LR_ROW_SCALARS * LR_ROW + lane];
+    const int isc = I[LR_IROW_SCALARS * LR_ROW + lane];
+    // hyper-parameters: a pending Gibbs step has already put its draws into the scalar row (it is always accepted), so
+    // both sets take the row's values
+    double a = 0.0, p = 0.0;
+    a = (lane == LR_SET_PRIOR) ? lr_bcast(sc, LR_S_PRIORA) : a;
+    a = (lane == LR_SET_PRIORPOI) ? lr_bcast(sc, LR_S_PRIORPOIA) : a;
+    a = (lane == LR_SET_CONST) ? lr_bcast(sc, LR_S_CONST_A) : a;
+    p = (lane == LR_SET_HASTING) ? lr_bcast(sc, LR_S_HASTING) : p;
+    p = (lane == LR_SET_PRIOR) ? lr_bcast(sc, LR_S_PRIOR_P) : p;
+    p = (lane == LR_SET_PRIORPOI) ? lr_bcast(sc, LR_S_PRIORPOI_P) : p;
+    p = (lane == LR_SET_CONST) ? lr_bcast(sc, LR_S_CONST_P) : p;
+    p = (lane == LR_SET_LOG_U) ? lr_bcast(sc, LR_S_LOG_U) : p;
+    const double g0 = lr_bcast(sc, LR_S_GRATE_L), g1 = lr_bcast(sc, LR_S_GRATE_M), poi = lr_bcast(sc, LR_S_POI);
+    const double lg0 = lr_bcast(sc, LR_S_LOG_G0), lg1 = lr_bcast(sc, LR_S_LOG_G1), lpoi = lr_bcast(sc, LR_S_LOG_POI);
+    double h = 0.0;
+    bool hy = true;
+    switch (lane) {
+        case LR_SET_G0: h = g0; break;
+        case LR_SET_G1: h = g1; break;
+        case LR_SET_POI: h = poi; break;
+        case LR_SET_LG0: h = lg0; break;
+        case LR_SET_LG1: h = lg1; break;
+        case LR_SET_LPOI: h = lpoi; break;
+        default: hy = false;
+    }
+    if (hy) a = h, p = h;
+    if (lane < 16) A->sc[lane] = a, P->sc[lane] = p;
+    int ia = 0, ip = 0;
+    ia = (lane == LR_SETI_KL) ? lr_bcast_i(isc, LR_I_KL) : ia;
+    ia = (lane == LR_SETI_KM) ? lr_bcast_i(isc, LR_I_KM) : ia;
+    ip = (lane == LR_SETI_KL) ? lr_bcast_i(isc, LR_I_PKL) : ip;
+    ip = (lane == LR_SETI_KM) ? lr_bcast_i(isc, LR_I_PKM) : ip;
+    ip = (lane == LR_SETI_GIBBS) ? lr_bcast_i(isc, LR_I_GIBBS) : ip;
+    ip = (lane == LR_SETI_INVALID) ? lr_bcast_i(isc, LR_I_INVALID) : ip;
+    ip = (lane == LR_SETI_MOVE) ? lr_bcast_i(isc, LR_I_MOVE) : ip;
+    if (lane < 8) A->isc[lane] = ia, P->isc[lane] = ip;
+}
+
+// bookkeeping of one chain that only its clerk wave needs (wave-uniform)
+struct lr_spec_book {
+    double lik_p;
+    unsigned long long next_sample;
+    int n_acc, trace_slot;
+};
+
+__device__ __attribute__((noinline)) void lr_sets_to_global(double* S, int* I, const lr_set* A, const lr_set* P, double likA,
+                                                  unsigned long long it, const lr_spec_book& bk, bool rj, int lane) {
+    S[LR_ROW_L * LR_ROW + lane] = A->L[lane], S[LR_ROW_M * LR_ROW + lane] = A->M[lane];
+    S[LR_ROW_TL * LR_ROW + lane] = A->tL[lane], S[LR_ROW_TM * LR_ROW + lane] = A->tM[lane];
+    S[LR_ROW_PL * LR_ROW + lane] = P->L[lane], S[LR_ROW_PM * LR_ROW + lane] = P->M[lane];
+    S[LR_ROW_PTL * LR_ROW + lane] = P->tL[lane], S[LR_ROW_PTM * LR_ROW + lane] = P->tM[lane];
+    I[LR_IROW_EL * LR_ROW + lane] = A->eL[lane], I[LR_IROW_EM * LR_ROW + lane] = A->eM[lane];
+    I[LR_IROW_PEL * LR_ROW + lane] = P->eL[lane], I[LR_IROW_PEM * LR_ROW + lane] = P->eM[lane];
+    // the scalar row carries the hyper-parameters of the pending proposal (= the accepted ones unless it is a Gibbs step)
+    double so = 0.0;
+    so = (lane == LR_S_LIKA) ? likA : so;
+    so = (lane == LR_S_PRIORA) ? A->sc[LR_SET_PRIOR] : so;
+    so = (lane == LR_S_PRIORPOIA) ? A->sc[LR_SET_PRIORPOI] : so;
+    so = (lane == LR_S_GRATE_L) ? P->sc[LR_SET_G0] : so;
+    so = (lane == LR_S_GRATE_M) ? P->sc[LR_SET_G1] : so;
+    so = (lane == LR_S_POI) ? P->sc[LR_SET_POI] : so;
+    so = (lane == LR_S_HASTING) ? P->sc[LR_SET_HASTING] : so;
+    so = (lane == LR_S_PRIOR_P) ? P->sc[LR_SET_PRIOR] : so;
+    so = (lane == LR_S_PRIORPOI_P) ? P->sc[LR_SET_PRIORPOI] : so;
+    so = (lane == LR_S_CONST_P) ? P->sc[LR_SET_CONST] : so;
+    so = (lane == LR_S_CONST_A) ? A->sc[LR_SET_CONST] : so;
+    so = (lane == LR_S_LIK_P) ? bk.lik_p : so;
+    so = (lane == LR_S_LOG_G0) ? P->sc[LR_SET_LG0] : so;
+    so = (lane == LR_S_LOG_G1) ? P->sc[LR_SET_LG1] : so;
+    so = (lane == LR_S_LOG_POI) ? P->sc[LR_SET_LPOI] : so;
+    so = (lane == LR_S_LOG_U) ? P->sc[LR_SET_LOG_U] : so;
+    if (!rj && lane != LR_S_LIKA && lane != LR_S_PRIORA && lane != LR_S_HASTING && lane != LR_S_PRIOR_P &&
+        lane != LR_S_LIK_P && lane != LR_S_LOG_U)
+        so = 0.0;                                    // the parametric samplers keep the other slots zero
+    S[LR_ROW_SCALARS * LR_ROW + lane] = so;
+    int io = 0;
+    io = (lane == LR_I_KL) ? A->isc[LR_SETI_KL] : io;
+    io = (lane == LR_I_KM) ? A->isc[LR_SETI_KM] : io;
+    io = (lane == LR_I_PKL) ? P->isc[LR_SETI_KL] : io;
+    io = (lane == LR_I_PKM) ? P->isc[LR_SETI_KM] : io;
+    io = (lane == LR_I_GIBBS) ? P->isc[LR_SETI_GIBBS] : io;
+    io = (lane == LR_I_INVALID) ? P->isc[LR_SETI_INVALID] : io;
+    io = (lane == LR_I_IT_LO) ? (int)(unsigned)it : io;
+    io = (lane == LR_I_IT_HI) ? (int)(unsigned)(it >> 32) : io;
+    io = (lane == LR_I_ACCEPTED) ? bk.n_acc : io;
+    io = (lane == LR_I_MOVE) ? P->isc[LR_SETI_MOVE] : io;
+    io = (lane == LR_I_NEXT_LO) ? (int)(unsigned)bk.next_sample : io;
+    io = (lane == LR_I_NEXT_HI) ? (int)(unsigned)(bk.next_sample >> 32) : io;
+    io = (lane == LR_I_SLOT) ? bk.trace_slot : io;
+    I[LR_IROW_SCALARS * LR_ROW + lane] = io;
+}
+
+#ifdef LR_DIAG
+#define LR_XDECL() unsigned long long dg_work = 0, dg_wait1 = 0, dg_p2 = 0, dg_wait2 = 0, dg_t = 0
+#define LR_XBEGIN() dg_t = wall_clock64()
+#define LR_XSTAMP(acc) { const unsigned long long t_ = wall_clock64(); acc += t_ - dg_t; dg_t = t_; }
+#define LR_XDUMP() if (lane == 0 && blockIdx.x < 64) { unsigned long long* o = lr_diag_step + 16384 + (blockIdx.x * 16 + wave) * 4; o[0] = dg_work, o[1] = dg_wait1, o[2] = dg_p2, o[3] = dg_wait2; }
+#else
+#define LR_XDECL()
+#define LR_XBEGIN()
+#define LR_XSTAMP(acc)
+#define LR_XDUMP()
+#endif
+// trace row of the clerk, out of line: it runs once per s_freq iterations and must not cost the candidate loop registers
+__device__ __attribute__((noinline)) void lr_spec_trace(const lr_step_args* a, int c, int lane, int slot, unsigned long long it,
+                                                        double likA, const lr_set* A, int rj) {
+    if (rj) {
+        lr_rj_state s;
+        lr_set_load(A, s, lane);
+        lr_write_trace_row(*a, c, lane, slot, it, likA, A->sc[LR_SET_PRIOR], s);
+    } else {
+        lr_dd_write_trace_row(*a, c, lane, slot, it, likA, A->sc[LR_SET_PRIOR], A->L[lane]);
+    }
+}
+
+typedef __attribute__((address_space(1))) unsigned long long lr_gu64;
+typedef __attribute__((address_space(1))) unsigned int lr_gu32;
+
+// everything the block keeps in LDS
+template <int H, int NW>
+struct lr_spec_lds {
+    // Pair tables (S' entries [0,H), E' [H,2H); (.x, .y) = (chain 0, chain 1)) for every combination of outcomes, in two
+    // generations: pairs[g][d0][d1] holds candidate d0 of chain 0 beside candidate d1 of chain 1 for the iterations of
+    // parity g.  A candidate wave writes its column into the two tables that contain it, so after the decisions the
+    // scanners just switch to pairs[g][d0][d1]: no copy between the decision and the next scan.
+    double2 pairs[2][2][2][2 * H];
+    int cur_sel;                 // d0 * 2 + d1 of the pair table now being scanned
+    double red[NW][2];           // per scanner wave: partial sums of the two chains
+    unsigned int xs[LR_TEAM_MAX * 4];   // gathered partial sums of the team, as 32-bit halves
+    int abort_flag;
+    int scan_arrive;             // scanner waves that have delivered their sums, counted over the whole launch
+    int pad_[1];
+    lr_seg_scratch scratch[4];
+    lr_set sets[2][4];
+    lr_draw_slot draws[2][2];    // [chain][iteration parity]
+    double br[256], logbr[256];  // per-bin data constants of the table builders (br_length / DT / TREND and log br_length)
+};
+
+struct lr_spec_ctx {
+    const uint4* idx8;           // this block's slice of the packed lineage indices
+    long long n8;                // ... 16-byte groups in it
+    lr_spec_args x;
+    long long n_iters;
+    unsigned long long it0;      // iteration of the proposal pending at entry
+    int c0, C, team, rank;
+};
+
+// The scanner role (waves 4..NW-1): per iteration one pass over the block's slice of the lineages against the pending
+// pair table, partial sums to LDS, then the two barriers of the iteration.  Wave 4 also runs the team exchange, waves
+// 4 and 5 the draw duty.  The scanners need nothing from the decision but the new table.
+template <int H, int T, bool RJ>
+__device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE>& sm, const lr_step_args& a,
+                                                  const lr_spec_ctx& ctx, int tid) {
+    constexpr int NW = T / LR_WAVE;
+    constexpr int NSCAN = (NW - 4) * LR_WAVE;
+    const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    const int k_team = ctx.x.team_blocks;
+    constexpr bool rj = RJ;
+    // draw duty: the last two scanner waves (wave 4 runs the team exchange and should not be late)
+    const int dch = wave - (NW - 2);
+    const bool drawer = rj && dch >= 0 && ctx.c0 + dch < ctx.C;
+    const int sid = tid - 4 * LR_WAVE;
+    int sel = 0;
+    LR_XDECL();
+    for (long long iter = 0; iter < ctx.n_iters; ++iter) {
+        const unsigned long long it = ctx.it0 + (unsigned long long)iter;
+        LR_XBEGIN();
+        double acc0 = 0.0, acc1 = 0.0;
+        const char* lbase = reinterpret_cast<const char*>(sm.pairs[it & 1][sel >> 1][sel & 1]);
+        lr_persist_scan_pair<H, LR_SPEC_SCAN_UNROLL>(lbase, ctx.idx8, ctx.n8, sid, NSCAN, &acc0, &acc1);
+        const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
+        if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
+        if (k_team > 1) {
+            // The team exchange runs BEFORE the block's barrier, beside the candidate waves' tail: the scanner waves
+            // count themselves in on an LDS word (a wave's LDS operations execute in order: sums first, then the count),
+            // wave 4 waits for all of them, publishes the block's sums and sweeps the team's.
+            if (lane == 0) __hip_atomic_fetch_add(&sm.scan_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wave == 4) {
+                const int want = (NW - 4) * ((int)iter + 1);
+                while (__hip_atomic_load(&sm.scan_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
+                    __builtin_amdgcn_s_sleep(1);
+                // this block's sums in wave order, published as four {epoch, half} granules; then the sweep
+                asm volatile("" ::: "memory");     // the sums are read after the count was seen
+                const double2 rv = *reinterpret_cast<const double2*>(&sm.red[lane < NW ? lane : NW - 1][0]);
+                double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+                for (int w = 4; w < NW; ++w) b0 += lr_bcast(rv.x, w), b1 += lr_bcast(rv.y, w);
+                const unsigned int epoch = (unsigned int)iter + 1u;
+                lr_gu64* slot = (lr_gu64*)(ctx.x.xchg + ((size_t)(epoch & 1u) * ctx.x.n_teams + ctx.team) * (LR_TEAM_MAX * LR_SPEC_GRANULES));
+                if (lane < 4) {
+                    const double v = (lane < 2) ? b0 : b1;
+                    const unsigned int half = (lane & 1) ? (unsigned int)__double2hiint(v) : (unsigned int)__double2loint(v);
+                    __hip_atomic_store(slot + ctx.rank * LR_SPEC_GRANULES + lane, ((unsigned long long)epoch << 32) | half,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const bool mine = lane < 4 * k_team;
+                lr_gu64* g = slot + (lane >> 2) * LR_SPEC_GRANULES + (lane & 3);
+                unsigned long long v = (unsigned long long)epoch << 32;
+                const unsigned long long t_start = wall_clock64();
+                bool fail = false;
+                for (unsigned int spins = 0;; ++spins) {
+                    if (mine) v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((unsigned int)(v >> 32) == epoch)) break;
+                    if ((spins & 255u) == 255u) {
+                        // give up when the engine's status word is raised or after two seconds (uniform over the wave)
+                        const unsigned int st = __hip_atomic_load((lr_gu32*)ctx.x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (st != 0u || wall_clock64() - t_start > LR_SPEC_TIMEOUT_TICKS) {
+                            fail = true;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (fail) {
+                    if (lane == 0) {
+                        __hip_atomic_store((lr_gu32*)ctx.x.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sm.abort_flag = 1;
+                    }
+                } else if (mine) {
+                    sm.xs[lane] = (unsigned int)v;
+                }
+            }
+        }
+        // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
+        if (drawer) lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
+        LR_XSTAMP(dg_work);
+        __syncthreads();                                                     // B1: (team) sums and candidates are in
+        LR_XSTAMP(dg_wait1);
+        if (k_team > 1 && sm.abort_flag) return;
+        LR_XSTAMP(dg_p2);
+        __syncthreads();                                                     // B2: the decisions are taken
+        sel = sm.cur_sel;
+        LR_XSTAMP(dg_wait2);
+    }
+    LR_XDUMP();
+}
+
+// The candidate role (waves 0..3; chain = wave / 2, outcome = wave % 2): build the candidate of iteration it + 1 while
+// the others scan, then - all four waves alike, each on its own SIMD - decide both chains, copy the selected pair
+// table, turn the roles of the sets; waves 0 and 2 keep the books (acceptance count, trace rows, final state).
+template <int H, int T, bool RJ>
+__device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE>& sm, const lr_step_args& a,
+                                                  const lr_spec_ctx& ctx, int tid) {
+    constexpr int NW = T / LR_WAVE;
+    // the per-bin data constants come from their LDS copies (a global load per candidate would sit on the critical path)
+    const double* br_lds = sm.br;
+    const double* logbr_lds = sm.logbr;
+    const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    const int c = wave >> 1, k = wave & 1;
+    const int c0 = ctx.c0, C = ctx.C;
+    const int k_team = ctx.x.team_blocks;
+    constexpr bool rj = RJ;
+    const bool act1 = c0 + 1 < C;
+    const bool mine_active = c0 + c < C;
+    // run state: which of a chain's four sets plays which role (bits 0-1 A, 2-3 P, 4-5 Q0, 6-7 Q1), the accepted
+    // log-likelihoods; every candidate wave tracks both chains (all four take the same decisions)
+    int role0 = 0 | (1 << 2) | (2 << 4) | (3 << 6), role1 = role0;
+    double likA0 = 0.0, likA1 = 0.0;
+    likA0 = a.state_f64[((size_t)c0 * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA];
+    if (act1) likA1 = a.state_f64[((size_t)(c0 + 1) * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA];
+    lr_spec_book bk = {0.0, 0ull, 0, 0};
+    int sel_last = 0;
+    (void)sel_last;
+    {
+        const int cm = min(c0 + c, C - 1);
+        const int* Ic = a.state_i32 + ((size_t)cm * LR_ISTATE_ROWS + LR_IROW_SCALARS) * LR_ROW;
+        bk.n_acc = Ic[LR_I_ACCEPTED], bk.trace_slot = Ic[LR_I_SLOT];
+        bk.next_sample = (unsigned long long)(unsigned)Ic[LR_I_NEXT_LO] | ((unsigned long long)(unsigned)Ic[LR_I_NEXT_HI] << 32);
+        bk.lik_p = a.state_f64[((size_t)cm * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIK_P];
+    }
+    LR_XDECL();
+    for (long long iter = 0; iter < ctx.n_iters; ++iter) {
+        const unsigned long long it = ctx.it0 + (unsigned long long)iter;      // iteration of the pending proposal
+        LR_XBEGIN();
+        // ---- phase 1: the candidate of iteration it + 1 for outcome k of chain c ----
+        if (mine_active) {
+            const int role = c ? role1 : role0;
+            const lr_set* base = &sm.sets[c][(role >> (k ? 2 : 0)) & 3];
+            lr_set* out = &sm.sets[c][(role >> (k ? 6 : 4)) & 3];
+            // the candidate's column (component c) of the next generation's pair tables: built in the one where the other
+            // chain's outcome is 0, copied into the one where it is 1
+            const int g = (int)((it + 1) & 1);
+            double* col0 = reinterpret_cast<double*>(c ? sm.pairs[g][0][k] : sm.pairs[g][k][0]) + c;
+            double* col1 = reinterpret_cast<double*>(c ? sm.pairs[g][1][k] : sm.pairs[g][k][1]) + c;
+            double2* table = reinterpret_cast<double2*>(col0);
+            { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(8); } }
+            if (!rj) {
+                lr_dd_prop p;
+                const double P = lr_propose_dd<true>(a, c0 + c, lane, it + 1, base->L[lane], p, table, 2, br_lds);
+                out->L[lane] = P;
+                if (lane == 0) {
+                    out->sc[LR_SET_HASTING] = p.hasting, out->sc[LR_SET_PRIOR] = p.prior, out->sc[LR_SET_LOG_U] = p.log_u;
+                    out->sc[LR_SET_CONST] = 0.0;
+                    out->isc[LR_SETI_GIBBS] = 0, out->isc[LR_SETI_INVALID] = 0, out->isc[LR_SETI_MOVE] = p.move;
+                    out->isc[LR_SETI_KL] = out->isc[LR_SETI_KM] = base->isc[LR_SETI_KL];
+                }
+            } else {
+                lr_rj_state s;
+                lr_set_load(base, s, lane);
+                { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(0); } }
+                lr_rj_prop p;
+                lr_rj_draws d;
+                lr_draws_load(&sm.draws[c][(it + 1) & 1], d, lane);
+                lr_propose_rj<true>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, 2, &d, br_lds, logbr_lds);
+                lr_set_store(out, s, p, lane);
+                { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
+            }
+            LR_WAVE_LDS_ORDER();
+            for (int i = lane; i < 2 * H; i += LR_WAVE) col1[2 * i] = col0[2 * i];
+        }
+        LR_XSTAMP(dg_work);
+        __syncthreads();                                                     // B1: sums and candidates are in
+        LR_XSTAMP(dg_wait1);
+        if (k_team > 1 && sm.abort_flag) return;
+        // ---- phase 2: sums -> decisions -> selected tables ----
+        double sum0 = 0.0, sum1 = 0.0;
+        if (k_team > 1) {
+            // [block][chain] in one read per lane, summed in block order through register broadcasts
+            const double2 xv = reinterpret_cast<const double2*>(sm.xs)[lane & (LR_TEAM_MAX - 1)];
+#pragma unroll
+            for (int b = 0; b < LR_TEAM_MAX; ++b)
+                if (b < k_team) sum0 += lr_bcast(xv.x, b), sum1 += lr_bcast(xv.y, b);
+        } else {
+            // one read per lane, then a fixed-order sum over the scanner waves through register broadcasts
+            // one read per lane, then the fixed-order DPP wave sum over the scanner waves' lanes
+            // one read per lane, then a fixed pairwise tree over the scanner waves' values (short dependency chain)
+            const double2 rv = *reinterpret_cast<const double2*>(&sm.red[lane < NW ? lane : NW - 1][0]);
+            double t0[NW - 4], t1[NW - 4];
+#pragma unroll
+            for (int w = 4; w < NW; ++w) t0[w - 4] = lr_bcast(rv.x, w), t1[w - 4] = lr_bcast(rv.y, w);
+#pragma unroll
+            for (int n = NW - 4; n > 1; n = (n + 1) / 2) {
+#pragma unroll
+                for (int j = 0; j < n / 2; ++j) t0[j] = t0[2 * j] + t0[2 * j + 1], t1[j] = t1[2 * j] + t1[2 * j + 1];
+                if (n & 1) t0[n / 2] = t0[n - 1], t1[n / 2] = t1[n - 1];
+            }
+            sum0 = t0[0], sum1 = t1[0];
+        }
+        int d0 = 0, d1 = 0;
+        {
+            // the scalars both decisions need in four row reads issued together: lanes 0-15 the pending proposal's,
+            // lanes 16-31 the accepted state's
+            const int r1 = act1 ? role1 : role0;
+            const int cc1 = act1 ? 1 : 0;
+            const lr_set* P0 = &sm.sets[0][(role0 >> 2) & 3];
+            const lr_set* A0 = &sm.sets[0][role0 & 3];
+            const lr_set* P1 = &sm.sets[cc1][(r1 >> 2) & 3];
+            const lr_set* A1 = &sm.sets[cc1][r1 & 3];
+            const double v0 = (lane & 16) ? A0->sc[lane & 15] : P0->sc[lane & 15];
+            const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
+            const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                if (c0 + cc >= C) continue;
+                const double v = cc ? v1 : v0;
+                const int iv = cc ? i1 : i0;
+                const double lik_sum = cc ? sum1 : sum0;
+                const double likA = cc ? likA1 : likA0;
+                const int invalid = lr_bcast_i(iv, LR_SETI_INVALID);
+                double lik;
+                bool ok;
+                if (rj) {
+                    ok = lr_mh_accept(lr_bcast_i(iv, LR_SETI_GIBBS), invalid, lik_sum, lr_bcast(v, LR_SET_CONST), likA,
+                                      lr_bcast(v, LR_SET_PRIOR), lr_bcast(v, 16 + LR_SET_PRIOR), lr_bcast(v, LR_SET_HASTING),
+                                      lr_bcast(v, LR_SET_LOG_U), &lik);
+                } else {
+                    lik = lik_sum;
+                    ok = lr_dd_accept(lik, likA, lr_bcast(v, LR_SET_PRIOR), lr_bcast(v, 16 + LR_SET_PRIOR),
+                                      lr_bcast(v, LR_SET_HASTING), lr_bcast(v, LR_SET_LOG_U), it);
+                }
+                if (cc) d1 = ok ? 1 : 0;
+                else d0 = ok ? 1 : 0;
+                if (cc == c) bk.lik_p = (rj && invalid) ? -INFINITY : lik;
+                if (ok) {
+                    if (cc) likA1 = lik;
+                    else likA0 = lik;
+                }
+            }
+        }
+        // the scanners switch to the pair table of the selected candidates
+        if (tid == 0) sm.cur_sel = d0 * 2 + d1;
+        sel_last = d0 * 2 + d1;
+        // roles: accepted -> (A, P, Q0, Q1) = (P, Q1, A, Q0); rejected -> (A, Q0, P, Q1)
+        {
+            auto turn = [](int role, int acc) {
+                const int oA = role & 3, oP = (role >> 2) & 3, o0 = (role >> 4) & 3, o1 = (role >> 6) & 3;
+                return acc ? (oP | (o1 << 2) | (oA << 4) | (o0 << 6)) : (oA | (o0 << 2) | (oP << 4) | (o1 << 6));
+            };
+            role0 = turn(role0, d0), role1 = turn(role1, d1);
+        }
+        // clerk (waves 0 and 2): acceptance count and trace row of iteration `it` (LRF:321-359)
+        if (k == 0 && mine_active) {
+            bk.n_acc += c ? d1 : d0;
+            if (it == bk.next_sample) {
+                const int slot = bk.trace_slot;
+                bk.trace_slot += 1;
+                bk.next_sample += (unsigned long long)a.cfg.s_freq;
+                if (slot < a.cfg.n_trace_slots && ctx.rank == 0) {
+                    const lr_set* A = &sm.sets[c][(c ? role1 : role0) & 3];
+                    const double likA = c ? likA1 : likA0;
+                    lr_spec_trace(&a, c0 + c, lane, slot, it, likA, A, rj ? 1 : 0);
+                }
+            }
+        }
+        LR_XSTAMP(dg_p2);
+        __syncthreads();                                                     // B2: the selected pair table stands
+        LR_XSTAMP(dg_wait2);
+    }
+    LR_XDUMP();
+    // pending proposal, accepted state and scalars back to global memory, in the layout every engine shares
+    if (k == 0 && mine_active && ctx.rank == 0) {
+        const int role = c ? role1 : role0;
+        lr_sets_to_global(a.state_f64 + (size_t)(c0 + c) * LR_STATE_ROWS * LR_ROW,
+                          a.state_i32 + (size_t)(c0 + c) * LR_ISTATE_ROWS * LR_ROW, &sm.sets[c][role & 3],
+                          &sm.sets[c][(role >> 2) & 3], c ? likA1 : likA0, ctx.it0 + (unsigned long long)ctx.n_iters, bk, rj, lane);
+    }
+}
+
+// T threads: waves 0..3 are the candidate waves, the others scan.  The step arguments travel by value (kernarg
+// segment -> scalar registers); both roles are inlined, their loops live in disjoint branches of the kernel.
+template <int H, int T, bool RJ>
+__global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_args a, const uint4* __restrict__ idx8,
+                                                                     long long n8, lr_spec_args x, long long n_iters) {
+    constexpr int NW = T / LR_WAVE;
+    __shared__ lr_spec_lds<H, NW> sm;
+    const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    const int k_team = x.team_blocks;
+    const int team = blockIdx.x % x.n_teams, rank = blockIdx.x / x.n_teams;   // a team's blocks differ by a multiple of
+    const int c0 = team * 2;                                                   // n_teams: one XCD when 8 | n_teams
+    const int C = a.cfg.n_chains;
+    constexpr bool rj = RJ;
+    const bool act1 = c0 + 1 < C;
+    double2* gpair = lr_chain_table(a, c0);
+    if (wave < 2 && c0 + wave < C) {
+        const int c = c0 + wave;
+        lr_sets_from_global(a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW, a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW,
+                            &sm.sets[wave][0], &sm.sets[wave][1], lane);
+    }
+    {
+        // all pair tables start as zeros (the column of a missing second chain must stay zero); the pending pair table
+        // of iteration it0 goes to pairs[it0 & 1][0][0]
+        double2* z = &sm.pairs[0][0][0][0];
+        for (int i = tid; i < 8 * 2 * H; i += T) z[i] = make_double2(0.0, 0.0);
+    }
+    {
+        // sets 2, 3 start as zeros (the parametric samplers write one row only; rows never written must not hold junk
+        // that would reach the workspace at exit)
+        int* z = reinterpret_cast<int*>(&sm.sets[0][0]);
+        constexpr int WORDS = sizeof(lr_set) / 4;
+        for (int i = tid; i < 2 * WORDS; i += T) z[2 * WORDS + i] = 0, z[6 * WORDS + i] = 0;
+        if (!act1)
+            for (int i = tid; i < 2 * WORDS; i += T) z[4 * WORDS + i] = 0;
+    }
+    for (int b = tid; b < 256; b += T) {
+        const bool in = b < a.cfg.n_bins;
+        sm.br[b] = (in && a.br_length) ? a.br_length[b] : 0.0;
+        sm.logbr[b] = in ? a.log_br[b] : 0.0;
+    }
+    if (tid == 0) sm.abort_flag = 0, sm.cur_sel = 0, sm.scan_arrive = 0;
+    lr_spec_ctx ctx;
+    {
+        const int* I0 = a.state_i32 + ((size_t)c0 * LR_ISTATE_ROWS + LR_IROW_SCALARS) * LR_ROW;
+        // this block's slice of the packed lineage indices
+        const long long per = (n8 + k_team - 1) / k_team;
+        const long long g_lo = min((long long)rank * per, n8), g_hi = min(g_lo + per, n8);
+        ctx.idx8 = idx8 + g_lo, ctx.n8 = g_hi - g_lo, ctx.x = x, ctx.n_iters = n_iters;
+        ctx.it0 = (unsigned long long)(unsigned)I0[LR_I_IT_LO] | ((unsigned long long)(unsigned)I0[LR_I_IT_HI] << 32);
+        ctx.c0 = c0, ctx.C = C, ctx.team = team, ctx.rank = rank;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * H; i += T) sm.pairs[ctx.it0 & 1][0][0][i] = gpair[i];
+    // draws of the first candidates (iteration it0 + 1); afterwards the last two scanner waves stay one iteration ahead
+    if (rj && wave >= NW - 2 && c0 + (wave - (NW - 2)) < C)
+        lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, &sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1]);
+    __syncthreads();
+    if (wave < 4) lr_spec_cand_role<H, T, RJ>(sm, a, ctx, tid);
+    else lr_spec_scan_role<H, T, RJ>(sm, a, ctx, tid);
+    __syncthreads();
+    if (sm.abort_flag || rank != 0) return;
+    {
+        const int sel = sm.cur_sel;
+        const double2* cur = sm.pairs[(ctx.it0 + (unsigned long long)n_iters) & 1][sel >> 1][sel & 1];
+        for (int i = tid; i < 2 * H; i += T) gpair[i] = cur[i];
+    }
+}

@@ -15,7 +15,7 @@ from . import _hip, ops
 class ChainEngine:
     def __init__(self, ts, te, n_chains, model=0, seed=1, const_rates=0, const_death_rate=0, use_rate_HP=1,
                  poisson_HP=0.0, update_fraction=0.75, s_freq=1000, n_trace_slots=0, chain_offset=0,
-                 device=None, stats=None, sort_lineages=True, unit_resolution=None, engine="auto", dd=None):
+                 device=None, stats=None, sort_lineages=True, unit_resolution=None, engine="auto", dd=None, team=0):
         """ts/te: lineage birth/death times (death_jitter already added, LRF:471).
 
         stats: optional (t0, n_bins, br_length) if the caller already binned the data; otherwise the
@@ -66,11 +66,11 @@ class ChainEngine:
             s_freq=int(s_freq), n_trace_slots=int(n_trace_slots), poisson_HP=float(poisson_HP),
             update_fraction=float(update_fraction), t0=self.t0, start_time=self.start_time, end_time=self.end_time,
             seed=int(seed), chain_offset=int(chain_offset), unit_resolution=int(self.unit_resolution),
-            engine_mode={"auto": 0, "launch": 1, "persistent": 2, "persistent4": 3}[engine],
+            engine_mode={"auto": 0, "launch": 1, "persistent": 2, "persistent4": 3, "persistent2": 4, "spec": 5}[engine],
             frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0,
             sampler=0 if dd is None else (2 if dd.get("kind") == "trend" else 1),
             m_birth=0 if dd is None else int(dd["m_birth"]), m_death=0 if dd is None else int(dd["m_death"]),
-            dd_present=0.0 if dd is None else float(dd.get("present", 0.0)),
+            team_request=int(team), dd_present=0.0 if dd is None else float(dd.get("present", 0.0)),
             dd_init_death=0.0 if dd is None else float(dd.get("init_death", 0.1)))
         self.dd = dd
         self.layout = _hip.McmcLayout()
@@ -162,6 +162,14 @@ class ChainEngine:
                    "lr_mcmc_time_scan")
         return float(ms.value)
 
+    def check_status(self):
+        """Synchronise and raise if the engine flagged an error on the device (a team exchange of the speculative kernel
+        that timed out: its blocks were not all resident)."""
+        st = C.c_int32(0)
+        _hip.check(_hip.launch(self.lib.lr_mcmc_status, self.device, self.handle, C.byref(st)), "lr_mcmc_status")
+        if st.value != 0:
+            raise _hip.HipLibraryError("engine status %d: a team exchange timed out, the run is void" % st.value)
+
     def kernel_name(self):
         """Name of the kernel steps() spends its time in, as rocprofv3's kernel trace prints it."""
         buf = C.create_string_buffer(128)
@@ -236,6 +244,7 @@ class ChainEngine:
     # ---- host-side snapshots ----
     def snapshot(self):
         """Accepted state of every chain as numpy: dict(L, M, tL, tM (lists), likA, priorA, K_l, K_m, ...)."""
+        self.check_status()
         S = self.state_f64.cpu().numpy()
         I = self.state_i32.cpu().numpy()
         KL, KM = I[:, _hip.IROW_SCALARS, _hip.I_KL], I[:, _hip.IROW_SCALARS, _hip.I_KM]
@@ -255,6 +264,7 @@ class ChainEngine:
 
     def trace_rows(self, n_samples=None):
         """Trace buffer as numpy [samples, chains, LR_TRACE_W] (see include/literate_hip.h)."""
+        self.check_status()
         n_avail = min(self.cfg.n_trace_slots, (self.iterations + self.cfg.s_freq - 1) // self.cfg.s_freq)
         n = n_avail if n_samples is None else min(n_samples, n_avail)
         return self.trace[:n].cpu().numpy()

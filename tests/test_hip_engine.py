@@ -33,16 +33,22 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        (0, dict(unit_resolution=False)), (1, dict(unit_resolution=False)),
                                        (0, dict(engine="launch")), (2, dict(engine="launch")),
                                        (1, dict(engine="persistent")), (0, dict(engine="persistent4")),
-                                       (2, dict(engine="persistent4"))])
+                                       (2, dict(engine="persistent4")), (1, dict(engine="persistent2")),
+                                       (0, dict(engine="spec")), (2, dict(engine="spec", team=2)),
+                                       (0, dict(engine="spec", team=4)), (1, dict(engine="spec", team=8))])
 def test_engine_follows_oracle_trajectory(G, model, kw):
     from literate_amd.engine import ChainEngine, split_trace_row
     name, seed, n_it, C, off = "example_TBP", 2024, 1500, 6, 40
     kw = dict(kw)
     ekw = dict(const_rates=kw.get("const_rates", 0), const_death_rate=kw.get("const_death_rate", 0),
                use_rate_HP=kw.get("use_rate_HP", 1), poisson_HP=kw.get("Poisson_HP", 0.0),
-               unit_resolution=kw.pop("unit_resolution", None), engine=kw.pop("engine", "auto"))
+               unit_resolution=kw.pop("unit_resolution", None), engine=kw.pop("engine", "auto"), team=kw.pop("team", 0))
     eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=model, seed=seed, s_freq=1,
                       n_trace_slots=n_it, chain_offset=off, **ekw)
+    if ekw["engine"] == "spec":
+        assert eng.layout.persistent == 3 and eng.layout.team_blocks == (ekw["team"] or eng.layout.team_blocks)
+    if ekw["engine"] == "persistent2":
+        assert eng.layout.persistent == 1
     # binning done by the engine's own kernel must equal the reference's
     assert np.array_equal(eng.sp_events.cpu().numpy(), G[name + "/sp"])
     assert np.array_equal(eng.br_length.cpu().numpy(), G[name + "/br"])

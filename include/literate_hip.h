@@ -218,7 +218,9 @@ typedef struct lr_mcmc_layout {
     int64_t status;       /* engine status word (uint32): 0 ok, 1 = a team exchange of the speculative kernel timed out */
     int64_t xchg;         /* partial-sum exchange granules of the speculative kernel's teams (team_blocks > 1)        */
     int32_t team_blocks;  /* blocks (= CUs) that share one chain pair, each scanning 1/team_blocks of the lineages     */
-    int32_t reserved2;
+    int32_t table_mode;   /* 0 chain-major general tables, 1 unit-resolution pair tables, 2 pair-general tables (persistent
+                           * engines on general lineage times: in-bin fractions packed as 32-bit fixed point)             */
+    int64_t lineage_frac; /* [4][n padded to 8 + spare] uint4: those fractions (table_mode 2)                            */
 } lr_mcmc_layout;
 
 /* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */

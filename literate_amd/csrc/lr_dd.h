@@ -92,7 +92,7 @@ __device__ __forceinline__ double lr_dd_prior(double v, double origin, double pr
 #define LR_DD_MAXP 4
 template <class F>
 __device__ __forceinline__ void lr_rates_build_tables_wave(F rates, int n_bins, int H, double2* __restrict__ tab, int lane,
-                                                           bool unit, double fs0, double fe0, int es) {
+                                                           int unit, double fs0, double fe0, int es) {
     double* tabd = reinterpret_cast<double*>(tab);
     const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
     const int b0 = min(lane * P, n_bins), b1 = min(b0 + P, n_bins);
@@ -114,32 +114,20 @@ __device__ __forceinline__ void lr_rates_build_tables_wave(F rates, int n_bins, 
         const int b = b0 + i;
         if (i < P && b < b1) {
             const double logB = log(br[i]), logD = log(dr[i]), R = br[i] + dr[i];
-            if (unit) {
-                tabd[es * (b + 1)] = (logB + cum) + fs0 * R;
-                tabd[es * (H + b + 1)] = (logD - cum) - fe0 * R;
-            } else {
-                tab[b + 1] = make_double2(logB + cum, R);
-                tab[H + b + 1] = make_double2(logD - cum, -R);
-            }
+            lr_put_S(tabd, unit, es, b + 1, logB + cum, R, fs0);
+            lr_put_E(tabd, unit, es, H + b + 1, logD - cum, R, fe0);
             cum += R;
         }
     }
     if (lane == 0) {
-        if (unit) {
-            tabd[0] = 0.0, tabd[es * H] = 0.0;
-            tabd[es * (n_bins + 1)] = totR, tabd[es * (H + n_bins + 1)] = -totR;
-        } else {
-            tab[0] = make_double2(0.0, 0.0);
-            tab[H] = make_double2(0.0, 0.0);
-            tab[n_bins + 1] = make_double2(totR, 0.0);
-            tab[H + n_bins + 1] = make_double2(-totR, 0.0);
-        }
+        lr_put_S(tabd, unit, es, 0, 0.0, 0.0, fs0), lr_put_E(tabd, unit, es, H, 0.0, 0.0, fe0);
+        lr_put_S(tabd, unit, es, n_bins + 1, totR, 0.0, fs0), lr_put_E(tabd, unit, es, H + n_bins + 1, -totR, 0.0, fe0);
     }
 }
 
 __device__ inline void lr_dd_build_tables_wave(const lr_dd_params& p, const double* __restrict__ DT, int m_birth,
                                                int m_death, int n_bins, int H, double2* __restrict__ tab, int lane,
-                                               bool unit, double fs0, double fe0, int es) {
+                                               int unit, double fs0, double fe0, int es) {
     lr_rates_build_tables_wave(
         [&](int b, double* br, double* dr) {
             double ni, fr;

@@ -232,7 +232,8 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
 // waves simply keep striding.  The hand-over costs the scan loop nothing.
 __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n,
                                         double t0, int n_bins, int p4, int k_tot, lr_p4_shares sh,
-                                        unsigned short* __restrict__ out) {
+                                        unsigned short* __restrict__ out, unsigned int* __restrict__ frac,
+                                        long long fstride) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int a = min(max(__double2int_rz(floor(ts[i]) - t0), -1), n_bins);
@@ -254,6 +255,40 @@ __global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const dou
         }
     }
     out[g * 8 + (i & 7)] = (unsigned short)((a + 1) | (b << 8));
+    if (frac) {
+        // general times: fs = ts - floor ts and fe' = ceil te - te (both in [0, 1)) as 32-bit fixed point, rounded to
+        // nearest; array j = (i & 7) / 2 of four, uint4 g = (fs, fe', fs, fe') of lineages 2j, 2j + 1 of the group
+        const double s = ts[i], e = te[i];
+        const double fs = fmin(rint((s - floor(s)) * 4294967296.0), 4294967295.0);
+        const double fe = fmin(rint((ceil(e) - e) * 4294967296.0), 4294967295.0);
+        unsigned int* q = frac + ((size_t)((i & 7) >> 1) * fstride + g) * 4 + (i & 1) * 2;
+        q[0] = (unsigned int)fs, q[1] = (unsigned int)fe;
+    }
+}
+
+// One pass of the packed lineages against the pair tables in global memory: the launch-based twin of the persistent
+// scan, used where the engines need the sums outside their kernels (the initial state's likelihood, LRF:224-226, and
+// the lr_mcmc_time_scan hook).  Block (tile, pair): partials[tile][2 pair .. 2 pair + 1].
+template <int H, bool GENERAL>
+__global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk, long long n8, const double2* __restrict__ tables,
+                                                          int n_chains, int tiles, double* __restrict__ partials) {
+    constexpr int ENT = GENERAL ? 2 : 1;                       // double2 per pair entry
+    __shared__ double2 tab[2 * H * ENT];
+    __shared__ double red[4][2];
+    const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    const int tile = blockIdx.x, pair = blockIdx.y;
+    const double2* src = tables + (size_t)pair * (2 * H * ENT);
+    for (int i = tid; i < 2 * H * ENT; i += 256) tab[i] = src[i];
+    __syncthreads();
+    const long long per = (n8 + tiles - 1) / tiles;
+    const long long g0 = min((long long)tile * per, n8), g1 = min(g0 + per, n8);
+    double acc0 = 0.0, acc1 = 0.0;
+    lr_persist_scan<H, GENERAL>(reinterpret_cast<const char*>(tab), pk, g0, g1 - g0, tid, 256, &acc0, &acc1);
+    const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
+    if (lane == 0) red[wave][0] = s0, red[wave][1] = s1;
+    __syncthreads();
+    if (tid < 2 && 2 * pair + tid < n_chains)
+        partials[(size_t)tile * n_chains + 2 * pair + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
 // the chain step of the persistent kernel as a real call: its ~120 live registers then do not add to the scan
@@ -366,13 +401,15 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 // every CU four (cfg4: 1024 chains = 256 blocks).
 #define LR_P4_THREADS 1024
 #define LR_P4_SCANNERS ((LR_P4_THREADS / LR_WAVE - 2) * LR_WAVE)
-template <int H>
+template <int H, bool GENERAL>
 __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
-                                                                       const uint4* __restrict__ idx8, long long n8,
+                                                                       lr_packed_lineages pk, long long n8,
                                                                        lr_p4_shares sh, long long n_iters) {
     const lr_step_args& a = *ap;
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners
-    __shared__ double2 tab[2][2 * H];                     // pair tables
+    constexpr int ENT = GENERAL ? 2 : 1;                  // double2 per pair-table entry (LR_TAB_PAIRGEN / LR_TAB_UNIT)
+    constexpr int ES = 2 * ENT;                           // doubles between a chain's consecutive entries
+    __shared__ double2 tab[2][2 * H * ENT];               // pair tables
     __shared__ double red[2][NW][2];                      // [pair][scanner wave][chain of the pair]
     __shared__ lr_seg_scratch scratch[2];
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
@@ -389,7 +426,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     }
     double2* g0 = lr_chain_table(a, c0);
     double2* g1 = lr_chain_table(a, c0 + 2);             // tables are allocated for whole groups of cb >= 4 chains
-    for (int i = tid; i < 2 * H; i += LR_P4_THREADS) tab[0][i] = g0[i], tab[1][i] = g1[i];
+    for (int i = tid; i < 2 * H * ENT; i += LR_P4_THREADS) tab[0][i] = g0[i], tab[1][i] = g1[i];
     __syncthreads();
     const bool scanner = wave >= 2;
     const int sid = tid - 2 * LR_WAVE;
@@ -409,7 +446,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     // prologue: pair 0's pending proposal is scanned so that phase A can step it
     if (scanner) {
         double s0 = 0.0, s1 = 0.0;
-        lr_persist_scan_pair<H, 2>(reinterpret_cast<const char*>(tab[0]), idx8, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
+        lr_persist_scan<H, GENERAL, GENERAL ? 1 : 2>(reinterpret_cast<const char*>(tab[0]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
         s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
         if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
     }
@@ -423,7 +460,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
 #ifdef LR_DIAG
                 const unsigned long long dq0 = wall_clock64();
 #endif
-                lr_persist_scan_pair<H, 2>(reinterpret_cast<const char*>(tab[1 - ph]), idx8, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
+                lr_persist_scan<H, GENERAL, GENERAL ? 1 : 2>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
 #ifdef LR_DIAG
                 if (lane == 0 && blockIdx.x < 64) atomicAdd(&lr_diag_step[20000 + blockIdx.x * 16 + wave], wall_clock64() - dq0);
 #endif
@@ -436,7 +473,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
 #pragma unroll
                     for (int w2 = 2; w2 < NW; ++w2) lik += red[ph][w2][wave];
                     lr_persist_step(ap, c, lane, &scratch[wave], st_f64[2 * ph + wave], st_i32[2 * ph + wave], lik,
-                                    reinterpret_cast<double2*>(reinterpret_cast<double*>(tab[ph]) + wave), 2);
+                                    reinterpret_cast<double2*>(reinterpret_cast<double*>(tab[ph]) + wave), ES);
                 }
             }
             __syncthreads();
@@ -449,7 +486,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
         for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = st_f64[wave][r * LR_ROW + lane];
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = st_i32[wave][r * LR_ROW + lane];
     }
-    for (int i = tid; i < 2 * H; i += LR_P4_THREADS) g0[i] = tab[0][i], g1[i] = tab[1][i];
+    for (int i = tid; i < 2 * H * ENT; i += LR_P4_THREADS) g0[i] = tab[0][i], g1[i] = tab[1][i];
 }
 
 __global__ void lr_store_args_kernel(lr_step_args a, lr_step_args* dst) {
@@ -493,11 +530,11 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
             const lr_trend_params tp = lr_trend_unpack(A);
             const double* aux = a.br_length;
             lr_rates_build_tables_wave([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
-                                       n_bins, a.H, lr_chain_table(a, c), lane, a.unit != 0, cfg.frac_birth, cfg.frac_death, 2);
+                                       n_bins, a.H, lr_chain_table(a, c), lane, a.unit, cfg.frac_birth, cfg.frac_death, lr_tab_es(a.unit));
         } else {
             const lr_dd_params pp = lr_dd_unpack(A);
             lr_dd_build_tables_wave(pp, a.br_length, cfg.m_birth, cfg.m_death, n_bins, a.H, lr_chain_table(a, c), lane,
-                                    a.unit != 0, cfg.frac_birth, cfg.frac_death, 2);
+                                    a.unit, cfg.frac_birth, cfg.frac_death, lr_tab_es(a.unit));
         }
         for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = 0.0;
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = 0;
@@ -527,7 +564,7 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
     lr_stage_segments(&scratch, L, M, eL, eM, KL, KM, lane, &logL, &logM);
     const double constA = lr_build_tables_segments(&scratch, eL, eM, KL, KM, a.br_length, a.log_br, cfg.model, n_bins,
                                                    a.n_cls, a.H, lr_chain_table(a, c), lane,
-                                                   a.unit != 0, cfg.frac_birth, cfg.frac_death);
+                                                   a.unit, cfg.frac_birth, cfg.frac_death, lr_tab_es(a.unit));
     S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
     S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
     S[LR_ROW_PL * LR_ROW + lane] = L, S[LR_ROW_PM * LR_ROW + lane] = M;
@@ -584,9 +621,20 @@ static int lr_partition(int n_chains, int cb, bool fused_ok, int base[LR_MAX_PAR
 // launch shape of the engine: as lr_plan_scan, but when the pipelined schedule applies the lineage tiles are
 // sized so that the fused launches that run concurrently (one per partition: step blocks of one half + scan
 // blocks of the other) fill the resident block slots of the chip (256 CUs x 4 blocks) exactly once.
+static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k);
 static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, cfg->unit_resolution, p);
     if (rc) return rc;
+    if (!p->unit && p->fast && p->n_cls == 1) {
+        // general lineage times: a persistent engine takes them in the pair-general table layout (LR_TAB_PAIRGEN) with the
+        // in-bin fractions packed as 32-bit fixed point; if none applies the plan stays the launch-based engine's
+        lr_scan_plan q = *p;
+        q.unit = LR_TAB_PAIRGEN, q.cb = 4;
+        if (lr_persist_variant(cfg, q, nullptr) != 0) {
+            *p = q;
+            return LR_OK;
+        }
+    }
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
     const int parts = lr_partition(cfg->n_chains, p->cb, lr_fused_supported(*p), base, hA, pipelined);
@@ -618,11 +666,12 @@ static int lr_device_cus() {
     return cus;
 }
 
-// Speculative team kernel (lr_spec.h): one 1024-thread block per CU, a chain pair owned by a team of k blocks.  Model of
-// an iteration in microseconds (MI355X, measured pieces): candidate build 2.6 (RJ) / 4.0 (parametric samplers),
-// 0.55 per scan trip of the 12 scanner waves (768 lanes x 8 lineages), 1.5 for the team exchange, 0.5 for the two
-// barriers + decision + table copy.  Returns the modelled time and the best team size in *k (0 = not applicable).
-static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out) {
+// Speculative team kernel (lr_spec.h): one block per CU, a chain pair owned by a team of k blocks.  Model of an
+// iteration in microseconds (MI355X, measured pieces): candidate build 3.2 (RJ) / 4.2 (parametric samplers), 0.5 per scan
+// trip of the scanner waves (LR_SPEC_THREADS - 256 lanes x 8 lineages; twice that on general times), 1.0 for the team
+// exchange behind the last scanner, 0.9 for the barriers and the decision.  Returns the modelled time and the best
+// team size in *k (0 = not applicable).
+static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general = false) {
     const int pairs = (cfg->n_chains + 1) / 2;
     const int cus = lr_device_cus();
     *k_out = 0;
@@ -630,14 +679,14 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out) {
     static const int k_env0 = lr_env_int("LR_SPEC_TEAM", 0);
     const int k_env = cfg->team_request > 0 ? cfg->team_request : k_env0;
     const double n8 = (double)((cfg->n_lineages + 7) / 8);
-    const double t_cand = cfg->sampler ? 4.0 : 2.6;
+    const double t_cand = cfg->sampler ? 4.2 : 3.2;
     double best = 1e30;
     for (int k = 1; k <= LR_TEAM_MAX; k *= 2) {
         if (pairs * k > cus) break;
         if (k_env > 0 && k != k_env) continue;
-        const double trips = ceil(n8 / k / 768.0);
-        const double t_scan = trips * 0.55 + (k > 1 ? 1.5 : 0.0);
-        const double t = (t_scan > t_cand ? t_scan : t_cand) + 0.5;
+        const double trips = ceil(n8 / k / (double)(LR_SPEC_THREADS - 256));
+        const double t_scan = trips * (general ? 1.0 : 0.5) + (k > 1 ? 1.0 : 0.0);
+        const double t = (t_scan > t_cand ? t_scan : t_cand) + 0.9;
         if (t < best - 0.05) best = t, *k_out = k;
     }
     return best;
@@ -652,6 +701,7 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     static const int env = lr_env_int("LR_PERSIST", -1);   // debugging override: 0 off, 1 on
     if (env == 0 || cfg->engine_mode == 1) return false;
     if (!p.unit || cfg->n_bins + 1 > 255 || p.cb < 2) return false;
+    const bool general = p.unit == LR_TAB_PAIRGEN;
     if (cfg->n_lineages >= (1ll << 33)) return false;   // the scan loop counts 16-byte index groups in 32 bits
     if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264) return false;
     if (env == 1 || cfg->engine_mode >= 2) return true;
@@ -660,9 +710,10 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     const double rounds = (double)((blocks + 511) / 512);
     double t_persist = rounds * (n * 2.0 * (blocks > 256 ? 2.0 : 1.0) / 2.2e10) + 6e-6;
     int k = 0;
-    const double t_spec = lr_spec_model(cfg, &k) * 1e-6;      // few chains: a team of CUs per chain pair
+    if (general) t_persist = n * c / 2.6e12 + 6e-6;            // four-chain kernel on 32-byte entries (measured: 2.6e12 evals/s)
+    const double t_spec = (general && p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general) * 1e-6;   // few chains: a team of CUs per pair
     if (k > 0 && t_spec < t_persist) t_persist = t_spec;
-    const double t_launch = n * c / 5e12 + 14e-6;
+    const double t_launch = n * c / (general ? 2.6e12 : 5e12) + 14e-6;
     return t_persist <= t_launch;
 }
 
@@ -673,22 +724,24 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
 // two-chain kernel's remainder round is cheaper when at most 512 chains are left (C = 1536: 29.4 vs 33.5 us).
 // Model in units of one full round (15.2 us on cfg4): t4 = ceil(C/1024), t2 = 1.08 floor(C/1024) + (0.82 | 1.08 for
 // the remainder).
-static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k = nullptr) {
+static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k) {
     if (team_k) *team_k = 0;
     if (!lr_persist_eligible(cfg, p)) return 0;
     static const int p4_env = lr_env_int("LR_PERSIST4", -1);
     static const int spec_env = lr_env_int("LR_SPEC", -1);
+    const bool general = p.unit == LR_TAB_PAIRGEN;   // general times: the speculative (H <= 136) and four-chain kernels only
     int k = 0;
-    const double t_spec = lr_spec_model(cfg, &k);
-    if (k > 0 && cfg->engine_mode != 3 && cfg->engine_mode != 4 && spec_env != 0) {
+    const double t_spec = (general && p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general);
+    if (k > 0 && t_spec < 1e29 && cfg->engine_mode != 3 && cfg->engine_mode != 4 && spec_env != 0) {
         // the two-chain kernel with all 16 waves scanning wins only on long scans without room for a team
-        const double t_wide = ceil((double)((cfg->n_lineages + 7) / 8) / 1024.0) * 0.55 + 4.3;
+        const double t_wide = general ? 1e30 : ceil((double)((cfg->n_lineages + 7) / 8) / 1024.0) * 0.55 + 4.3;
         if (cfg->engine_mode == 5 || spec_env == 1 || t_spec <= t_wide) {
             if (team_k) *team_k = k;
             return 3;
         }
     }
     if (cfg->engine_mode == 5) return 0;
+    if (general) return (p.cb >= 4 && cfg->engine_mode != 4) ? 2 : 0;
     if (p.cb < 4) return 1;                 // tables are laid out per group of cb chains; a quad must not straddle
     if (cfg->engine_mode == 3) return 2;
     if (cfg->engine_mode == 4) return 1;
@@ -731,14 +784,17 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
     out->bin_consts = o, o += lr_align_up64((long long)(cfg->n_bins + 2) * 8, 256);   // log(br) + the DD constants
     out->lineage_idx = o, o += lr_align_up64((lr_align_up64(cfg->n_lineages, 8) / 8 + LR_IDX_SPARE) * 16, 256);
+    out->lineage_frac = o;           // general times: [4][n8 + spare] uint4 of packed in-bin fractions (lr_pack_lineages_kernel)
+    if (p.unit == LR_TAB_PAIRGEN) o += lr_align_up64((lr_align_up64(cfg->n_lineages, 8) / 8 + LR_IDX_SPARE) * 64, 256);
     out->args_blob = o, o += 1024;   // lr_step_args of the persistent kernel
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
     out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
     int team_k = 0;
     out->persistent = lr_persist_variant(cfg, p, &team_k);
+    if (p.unit == LR_TAB_PAIRGEN && out->persistent == 0) return LR_ERR_STATE;   // (planned only when a kernel takes it)
     out->team_blocks = team_k;
-    out->reserved2 = 0;
+    out->table_mode = p.unit;
     out->status = o, o += 256;   // engine status word
     // team exchange granules of the speculative kernel: [2 parities][pairs][LR_TEAM_MAX][LR_SPEC_GRANULES] x 8 bytes
     out->xchg = o, o += (team_k > 1) ? lr_align_up64(2ll * ((C + 1) / 2) * LR_TEAM_MAX * LR_SPEC_GRANULES * 8, 256) : 0;
@@ -893,7 +949,28 @@ static lr_step_args lr_make_args(const lr_engine* e) {
     return a;
 }
 
+template <int H>
+static int lr_launch_pairscan(const lr_engine* e, hipStream_t stream) {
+    lr_packed_lineages pk;
+    pk.idx8 = (const uint4*)(e->ws + e->lay.lineage_idx), pk.frac = (const uint4*)(e->ws + e->lay.lineage_frac);
+    pk.fstride = e->n8_alloc;
+    hipLaunchKernelGGL((lr_pairscan_kernel<H, true>), dim3(e->plan.tiles, (e->cfg.n_chains + 1) / 2), dim3(256), 0, stream, pk,
+                       e->n8, (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->plan.tiles,
+                       (double*)(e->ws + e->lay.partials));
+    return (int)hipGetLastError();
+}
+
 static int lr_enqueue_scan_range(const lr_engine* e, int base, int count, hipStream_t stream) {
+    if (e->plan.unit == LR_TAB_PAIRGEN) {
+        // pair-general tables: the launch-based twin of the persistent scan, all chains at once
+        if (base != 0 || count != e->cfg.n_chains) return LR_ERR_STATE;
+        switch (e->plan.H) {
+            case 40: return lr_launch_pairscan<40>(e, stream);
+            case 72: return lr_launch_pairscan<72>(e, stream);
+            case 136: return lr_launch_pairscan<136>(e, stream);
+            default: return lr_launch_pairscan<264>(e, stream);
+        }
+    }
     return lr_launch_scan(e->plan, e->ts, e->te, e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins, e->cfg.end_time,
                           (const double2*)(e->ws + e->lay.tables) + (size_t)base * e->plan.tab_stride, count,
                           (double*)(e->ws + e->lay.partials) + base, e->cfg.n_chains, stream);
@@ -929,10 +1006,13 @@ static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipS
         hipLaunchKernelGGL(lr_store_args_kernel, dim3(1), dim3(64), 0, stream, a, (lr_step_args*)(e->ws + e->lay.args_blob));
         // zero fill (padding entries (0, 0) = "outside the window" on both sides, contribution 0), then the lineages
         (void)hipMemsetAsync(e->ws + e->lay.lineage_idx, 0, (size_t)e->n8_alloc * 16, stream);
+        const bool general = e->plan.unit == LR_TAB_PAIRGEN;
+        if (general) (void)hipMemsetAsync(e->ws + e->lay.lineage_frac, 0, (size_t)e->n8_alloc * 64, stream);
         hipLaunchKernelGGL(lr_pack_lineages_kernel, dim3((unsigned)((e->cfg.n_lineages + 255) / 256)), dim3(256), 0, stream,
                            e->ts, e->te, (long long)e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins,
                            1, (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64)), e->p4,
-                           (unsigned short*)(e->ws + e->lay.lineage_idx));
+                           (unsigned short*)(e->ws + e->lay.lineage_idx),
+                           general ? (unsigned int*)(e->ws + e->lay.lineage_frac) : nullptr, (long long)e->n8_alloc);
     }
 }
 
@@ -1106,6 +1186,9 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
     const lr_step_args a = lr_make_args(e);
     if (e->persistent) {
         const uint4* idx8 = (const uint4*)(e->ws + e->lay.lineage_idx);
+        const bool general = e->plan.unit == LR_TAB_PAIRGEN;
+        lr_packed_lineages pk;
+        pk.idx8 = idx8, pk.frac = general ? (const uint4*)(e->ws + e->lay.lineage_frac) : nullptr, pk.fstride = e->n8_alloc;
         const lr_step_args* ap = (const lr_step_args*)(e->ws + e->lay.args_blob);
         const int blocks = (e->cfg.n_chains + 1) / 2;
         const bool p4 = e->lay.persistent == 2;
@@ -1128,16 +1211,27 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
                     if (he != hipSuccess) return (int)he;
                 }
                 const dim3 grid((unsigned)(blocks * x.team_blocks)), blk(LR_SPEC_THREADS);
-#define LR_SPEC_LAUNCH(HH)                                                                                                  \
-    if (e->cfg.sampler == 0)                                                                                                \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, true>), grid, blk, 0, stream, a, idx8, e->n8, x, (long long)n); \
-    else                                                                                                                    \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, false>), grid, blk, 0, stream, a, idx8, e->n8, x, (long long)n)
-                switch (e->plan.H) {
-                    case 40: LR_SPEC_LAUNCH(40); break;
-                    case 72: LR_SPEC_LAUNCH(72); break;
-                    case 136: LR_SPEC_LAUNCH(136); break;
-                    default: LR_SPEC_LAUNCH(264); break;
+#define LR_SPEC_LAUNCH(HH, GG)                                                                                                \
+    if (e->cfg.sampler == 0)                                                                                                  \
+        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, true, GG>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
+    else                                                                                                                      \
+        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, false, GG>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n)
+                // (general times: pair tables of 32-byte entries; H = 264 would not fit the eight of them in LDS and is
+                // never planned for the speculative kernel, see lr_decide_engine)
+                if (general) {
+                    switch (e->plan.H) {
+                        case 40: LR_SPEC_LAUNCH(40, true); break;
+                        case 72: LR_SPEC_LAUNCH(72, true); break;
+                        case 136: LR_SPEC_LAUNCH(136, true); break;
+                        default: return LR_ERR_SIZE;
+                    }
+                } else {
+                    switch (e->plan.H) {
+                        case 40: LR_SPEC_LAUNCH(40, false); break;
+                        case 72: LR_SPEC_LAUNCH(72, false); break;
+                        case 136: LR_SPEC_LAUNCH(136, false); break;
+                        default: LR_SPEC_LAUNCH(264, false); break;
+                    }
                 }
 #undef LR_SPEC_LAUNCH
                 const int rc = (int)hipGetLastError();
@@ -1148,12 +1242,26 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         }
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
+#define LR_P_LAUNCH(HH)                                                                                                       \
+    if (p4) {                                                                                                                 \
+        if (general)                                                                                                          \
+            hipLaunchKernelGGL((lr_persist4_kernel<HH, true>), dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, \
+                               pk, e->n8, e->p4, (long long)n);                                                               \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((lr_persist4_kernel<HH, false>), dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, \
+                               pk, e->n8, e->p4, (long long)n);                                                               \
+    } else if (wide) {                                                                                                        \
+        hipLaunchKernelGGL((lr_persist_kernel<HH, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); \
+    } else {                                                                                                                  \
+        hipLaunchKernelGGL((lr_persist_kernel<HH, 512>), dim3(blocks), dim3(512), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); \
+    }
             switch (e->plan.H) {
-                case 40: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<40>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else { if (wide) hipLaunchKernelGGL((lr_persist_kernel<40, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); else hipLaunchKernelGGL((lr_persist_kernel<40, 512>), dim3(blocks), dim3(512), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); } break;
-                case 72: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<72>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else { if (wide) hipLaunchKernelGGL((lr_persist_kernel<72, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); else hipLaunchKernelGGL((lr_persist_kernel<72, 512>), dim3(blocks), dim3(512), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); } break;
-                case 136: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<136>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else { if (wide) hipLaunchKernelGGL((lr_persist_kernel<136, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); else hipLaunchKernelGGL((lr_persist_kernel<136, 512>), dim3(blocks), dim3(512), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); } break;
-                default: if (p4) hipLaunchKernelGGL(lr_persist4_kernel<264>, dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, idx8, e->n8, e->p4, (long long)n); else { if (wide) hipLaunchKernelGGL((lr_persist_kernel<264, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); else hipLaunchKernelGGL((lr_persist_kernel<264, 512>), dim3(blocks), dim3(512), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, prio); } break;
+                case 40: LR_P_LAUNCH(40); break;
+                case 72: LR_P_LAUNCH(72); break;
+                case 136: LR_P_LAUNCH(136); break;
+                default: LR_P_LAUNCH(264); break;
             }
+#undef LR_P_LAUNCH
             const int rc = (int)hipGetLastError();
             if (rc) return rc;
             done += n;

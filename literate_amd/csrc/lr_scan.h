@@ -329,3 +329,63 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
     *acc0_ = acc0, *acc1_ = acc1;
 }
 
+// The same scan on GENERAL lineage times: pair tables in the LR_TAB_PAIRGEN layout (32-byte entries: values of the two
+// chains, then their slopes scaled by 2^-32), the lineages as packed table indices plus their in-bin fractions as
+// 32-bit fixed point.  frac: four arrays of uint4, `fstride` entries apart; array j holds (fs, fe', fs, fe') of
+// lineages 2j and 2j + 1 of every group, so each of the four loads is a fully coalesced 16-byte load.
+// Per (lineage, chain pair): four ds_read_b128, two conversions, eight fp64 operations.
+template <int H, int UNROLL = 1>
+__device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
+                                                             const uint4* __restrict__ frac, long long fstride,
+                                                             long long n8, long long sid, int n_scan, double* acc0_,
+                                                             double* acc1_) {
+    double acc0 = *acc0_, acc1 = *acc1_;
+    const int n = (int)n8;
+    int i = (int)sid;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u), f0 = w, f1 = w, f2 = w, f3 = w;
+    if (i < n) w = idx8[i], f0 = frac[i], f1 = frac[i + fstride], f2 = frac[i + 2 * fstride], f3 = frac[i + 3 * fstride];
+#pragma unroll UNROLL
+    while (i < n) {
+        const uint4 cur = w, c0 = f0, c1 = f1, c2 = f2, c3 = f3;
+        const int nx = i + n_scan;
+        if (nx < n) w = idx8[nx], f0 = frac[nx], f1 = frac[nx + fstride], f2 = frac[nx + 2 * fstride], f3 = frac[nx + 3 * fstride];
+        const unsigned int words[4] = {cur.x, cur.y, cur.z, cur.w};
+        const uint4 fr[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned int v = words[k];
+            const unsigned int fq[4] = {fr[k].x, fr[k].y, fr[k].z, fr[k].w};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned int vv = v >> (16 * h);
+                const char* pS = lbase + ((vv << 5) & 0x1fe0u);
+                const char* pE = lbase + ((vv >> 3) & 0x1fe0u) + H * 32;
+                const double2 Sv = *reinterpret_cast<const double2*>(pS);
+                const double2 Ss = *reinterpret_cast<const double2*>(pS + 16);
+                const double2 Ev = *reinterpret_cast<const double2*>(pE);
+                const double2 Es = *reinterpret_cast<const double2*>(pE + 16);
+                const double fs = (double)fq[2 * h], fe = (double)fq[2 * h + 1];
+                double t0 = Sv.x + Ev.x, t1 = Sv.y + Ev.y;
+                t0 = fma(fs, Ss.x, t0), t1 = fma(fs, Ss.y, t1);
+                t0 = fma(fe, Es.x, t0), t1 = fma(fe, Es.y, t1);
+                acc0 += t0, acc1 += t1;
+            }
+        }
+        i = nx;
+    }
+    *acc0_ = acc0, *acc1_ = acc1;
+}
+
+// what a persistent engine scans: packed indices and, on general times, the fractions behind them
+struct lr_packed_lineages {
+    const uint4* idx8;
+    const uint4* frac;      // nullptr for unit-resolution data
+    long long fstride;
+};
+
+template <int H, bool GENERAL, int UNROLL = 1>
+__device__ __forceinline__ void lr_persist_scan(const char* __restrict__ lbase, const lr_packed_lineages& pk, long long g0,
+                                                long long n8, long long sid, int n_scan, double* acc0, double* acc1) {
+    if (GENERAL) lr_persist_scan_pair_general<H, UNROLL>(lbase, pk.idx8 + g0, pk.frac + g0, pk.fstride, n8, sid, n_scan, acc0, acc1);
+    else lr_persist_scan_pair<H, UNROLL>(lbase, pk.idx8 + g0, n8, sid, n_scan, acc0, acc1);
+}

@@ -267,13 +267,13 @@ typedef __attribute__((address_space(1))) unsigned long long lr_gu64;
 typedef __attribute__((address_space(1))) unsigned int lr_gu32;
 
 // everything the block keeps in LDS
-template <int H, int NW>
+template <int H, int NW, int ENT>
 struct lr_spec_lds {
     // Pair tables (S' entries [0,H), E' [H,2H); (.x, .y) = (chain 0, chain 1)) for every combination of outcomes, in two
     // generations: pairs[g][d0][d1] holds candidate d0 of chain 0 beside candidate d1 of chain 1 for the iterations of
     // parity g.  A candidate wave writes its column into the two tables that contain it, so after the decisions the
     // scanners just switch to pairs[g][d0][d1]: no copy between the decision and the next scan.
-    double2 pairs[2][2][2][2 * H];
+    double2 pairs[2][2][2][2 * H * ENT];   // ENT double2 per entry: 1 unit resolution, 2 general times (LR_TAB_PAIRGEN)
     int cur_sel;                 // d0 * 2 + d1 of the pair table now being scanned
     double red[NW][2];           // per scanner wave: partial sums of the two chains
     unsigned int xs[LR_TEAM_MAX * 4];   // gathered partial sums of the team, as 32-bit halves
@@ -287,8 +287,9 @@ struct lr_spec_lds {
 };
 
 struct lr_spec_ctx {
-    const uint4* idx8;           // this block's slice of the packed lineage indices
-    long long n8;                // ... 16-byte groups in it
+    lr_packed_lineages pk;       // the packed lineages
+    long long g0;                // this block's slice of them: first 16-byte group ...
+    long long n8;                // ... and number of groups
     lr_spec_args x;
     long long n_iters;
     unsigned long long it0;      // iteration of the proposal pending at entry
@@ -298,8 +299,8 @@ struct lr_spec_ctx {
 // The scanner role (waves 4..NW-1): per iteration one pass over the block's slice of the lineages against the pending
 // pair table, partial sums to LDS, then the two barriers of the iteration.  Wave 4 also runs the team exchange, waves
 // 4 and 5 the draw duty.  The scanners need nothing from the decision but the new table.
-template <int H, int T, bool RJ>
-__device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE>& sm, const lr_step_args& a,
+template <int H, int T, bool RJ, bool GENERAL>
+__device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
     constexpr int NSCAN = (NW - 4) * LR_WAVE;
@@ -317,7 +318,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE>& s
         LR_XBEGIN();
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(sm.pairs[it & 1][sel >> 1][sel & 1]);
-        lr_persist_scan_pair<H, LR_SPEC_SCAN_UNROLL>(lbase, ctx.idx8, ctx.n8, sid, NSCAN, &acc0, &acc1);
+        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1);
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
         if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
         if (k_team > 1) {
@@ -388,10 +389,11 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE>& s
 // The candidate role (waves 0..3; chain = wave / 2, outcome = wave % 2): build the candidate of iteration it + 1 while
 // the others scan, then - all four waves alike, each on its own SIMD - decide both chains, copy the selected pair
 // table, turn the roles of the sets; waves 0 and 2 keep the books (acceptance count, trace rows, final state).
-template <int H, int T, bool RJ>
-__device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE>& sm, const lr_step_args& a,
+template <int H, int T, bool RJ, bool GENERAL>
+__device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
+    constexpr int ES = GENERAL ? 4 : 2;      // doubles between a chain's consecutive table entries
     // the per-bin data constants come from their LDS copies (a global load per candidate would sit on the critical path)
     const double* br_lds = sm.br;
     const double* logbr_lds = sm.logbr;
@@ -436,7 +438,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE>& s
             { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(8); } }
             if (!rj) {
                 lr_dd_prop p;
-                const double P = lr_propose_dd<true>(a, c0 + c, lane, it + 1, base->L[lane], p, table, 2, br_lds);
+                const double P = lr_propose_dd<true>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds);
                 out->L[lane] = P;
                 if (lane == 0) {
                     out->sc[LR_SET_HASTING] = p.hasting, out->sc[LR_SET_PRIOR] = p.prior, out->sc[LR_SET_LOG_U] = p.log_u;
@@ -451,12 +453,15 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE>& s
                 lr_rj_prop p;
                 lr_rj_draws d;
                 lr_draws_load(&sm.draws[c][(it + 1) & 1], d, lane);
-                lr_propose_rj<true>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, 2, &d, br_lds, logbr_lds);
+                lr_propose_rj<true>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds, logbr_lds);
                 lr_set_store(out, s, p, lane);
                 { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
             }
             LR_WAVE_LDS_ORDER();
-            for (int i = lane; i < 2 * H; i += LR_WAVE) col1[2 * i] = col0[2 * i];
+            for (int i = lane; i < 2 * H; i += LR_WAVE) {
+                col1[ES * i] = col0[ES * i];
+                if (GENERAL) col1[ES * i + 2] = col0[ES * i + 2];
+            }
         }
         LR_XSTAMP(dg_work);
         __syncthreads();                                                     // B1: sums and candidates are in
@@ -568,11 +573,12 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE>& s
 
 // T threads: waves 0..3 are the candidate waves, the others scan.  The step arguments travel by value (kernarg
 // segment -> scalar registers); both roles are inlined, their loops live in disjoint branches of the kernel.
-template <int H, int T, bool RJ>
-__global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_args a, const uint4* __restrict__ idx8,
-                                                                     long long n8, lr_spec_args x, long long n_iters) {
+template <int H, int T, bool RJ, bool GENERAL>
+__global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_args a, lr_packed_lineages pk, long long n8,
+                                                                     lr_spec_args x, long long n_iters) {
     constexpr int NW = T / LR_WAVE;
-    __shared__ lr_spec_lds<H, NW> sm;
+    constexpr int ENT = GENERAL ? 2 : 1;
+    __shared__ lr_spec_lds<H, NW, ENT> sm;
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int k_team = x.team_blocks;
     const int team = blockIdx.x % x.n_teams, rank = blockIdx.x / x.n_teams;   // a team's blocks differ by a multiple of
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         // all pair tables start as zeros (the column of a missing second chain must stay zero); the pending pair table
         // of iteration it0 goes to pairs[it0 & 1][0][0]
         double2* z = &sm.pairs[0][0][0][0];
-        for (int i = tid; i < 8 * 2 * H; i += T) z[i] = make_double2(0.0, 0.0);
+        for (int i = tid; i < 8 * 2 * H * ENT; i += T) z[i] = make_double2(0.0, 0.0);
     }
     {
         // sets 2, 3 start as zeros (the parametric samplers write one row only; rows never written must not hold junk
@@ -613,23 +619,23 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         // this block's slice of the packed lineage indices
         const long long per = (n8 + k_team - 1) / k_team;
         const long long g_lo = min((long long)rank * per, n8), g_hi = min(g_lo + per, n8);
-        ctx.idx8 = idx8 + g_lo, ctx.n8 = g_hi - g_lo, ctx.x = x, ctx.n_iters = n_iters;
+        ctx.pk = pk, ctx.g0 = g_lo, ctx.n8 = g_hi - g_lo, ctx.x = x, ctx.n_iters = n_iters;
         ctx.it0 = (unsigned long long)(unsigned)I0[LR_I_IT_LO] | ((unsigned long long)(unsigned)I0[LR_I_IT_HI] << 32);
         ctx.c0 = c0, ctx.C = C, ctx.team = team, ctx.rank = rank;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * H; i += T) sm.pairs[ctx.it0 & 1][0][0][i] = gpair[i];
+    for (int i = tid; i < 2 * H * ENT; i += T) sm.pairs[ctx.it0 & 1][0][0][i] = gpair[i];
     // draws of the first candidates (iteration it0 + 1); afterwards the last two scanner waves stay one iteration ahead
     if (rj && wave >= NW - 2 && c0 + (wave - (NW - 2)) < C)
         lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, &sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1]);
     __syncthreads();
-    if (wave < 4) lr_spec_cand_role<H, T, RJ>(sm, a, ctx, tid);
-    else lr_spec_scan_role<H, T, RJ>(sm, a, ctx, tid);
+    if (wave < 4) lr_spec_cand_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
+    else lr_spec_scan_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
     __syncthreads();
     if (sm.abort_flag || rank != 0) return;
     {
         const int sel = sm.cur_sel;
         const double2* cur = sm.pairs[(ctx.it0 + (unsigned long long)n_iters) & 1][sel >> 1][sel & 1];
-        for (int i = tid; i < 2 * H; i += T) gpair[i] = cur[i];
+        for (int i = tid; i < 2 * H * ENT; i += T) gpair[i] = cur[i];
     }
 }

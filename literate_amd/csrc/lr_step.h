@@ -30,6 +30,8 @@ struct lr_step_args {
 // the returned pointer addresses this chain's component, consecutive entries are 2 doubles apart.
 __device__ __forceinline__ double2* lr_chain_table(const lr_step_args& a, int c) {
     if (!a.unit) return a.tables + (size_t)c * a.tab_stride;
+    if (a.unit == LR_TAB_PAIRGEN)   // pair-major: 2H entries of 4 doubles per pair, this chain's values at component c & 1
+        return reinterpret_cast<double2*>(reinterpret_cast<double*>(a.tables) + (size_t)(c >> 1) * (8 * a.H) + (c & 1));
     const int l = c % a.cb;
     double* base = reinterpret_cast<double*>(a.tables + (size_t)(c - l) * a.tab_stride);
     return reinterpret_cast<double2*>(base + (size_t)(l >> 1) * (4 * a.H) + (l & 1));
@@ -71,7 +73,7 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
                                                        const double* __restrict__ br_length,
                                                        const double* __restrict__ log_br, int model, int n_bins,
                                                        int n_cls, int H, double2* __restrict__ tab, int lane,
-                                                       bool unit = false, double fs0 = 0.0, double fe0 = 0.0,
+                                                       int unit = LR_TAB_GENERAL, double fs0 = 0.0, double fe0 = 0.0,
                                                        int es = 2) {
     // unit-resolution layout: tab points at this chain's component of its pair table, entries 2 doubles apart
     double* tabd = reinterpret_cast<double*>(tab);
@@ -112,13 +114,8 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
             logD = lmu + lk;
             R = (model == 0) ? lam + mu : mu;
         }
-        if (unit) {
-            tabd[es * (b + 1)] = (logB + cum) + fs0 * R;
-            tabd[es * (H + b + 1)] = (logD - cum) - fe0 * R;
-        } else {
-            tab[b + 1] = make_double2(logB + cum, R);
-            tab[H + b + 1] = make_double2(logD - cum, -R);
-        }
+        lr_put_S(tabd, unit, es, b + 1, logB + cum, R, fs0);
+        lr_put_E(tabd, unit, es, H + b + 1, logD - cum, R, fe0);
         cum += R;
         if (n_cls == 2) {
             tab[2 * H + b + 1] = make_double2(logB + cuml, lam);
@@ -127,15 +124,8 @@ __device__ inline double lr_build_tables_segments_wave(const lr_seg_scratch* sc,
         }
     }
     if (lane == 0) {
-        if (unit) {
-            tabd[0] = 0.0, tabd[es * H] = 0.0;
-            tabd[es * (n_bins + 1)] = totR, tabd[es * (H + n_bins + 1)] = -totR;
-        } else {
-            tab[0] = make_double2(0.0, 0.0);
-            tab[H] = make_double2(0.0, 0.0);
-            tab[n_bins + 1] = make_double2(totR, 0.0);
-            tab[H + n_bins + 1] = make_double2(-totR, 0.0);
-        }
+        lr_put_S(tabd, unit, es, 0, 0.0, 0.0, fs0), lr_put_E(tabd, unit, es, H, 0.0, 0.0, fe0);
+        lr_put_S(tabd, unit, es, n_bins + 1, totR, 0.0, fs0), lr_put_E(tabd, unit, es, H + n_bins + 1, -totR, 0.0, fe0);
         if (n_cls == 2) {
             tab[2 * H] = make_double2(0.0, 0.0);
             tab[3 * H] = make_double2(0.0, 0.0);
@@ -161,7 +151,7 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
                                                                 int KM, const double* __restrict__ br_length,
                                                                 const double* __restrict__ log_br, int model,
                                                                 int n_bins, int H, double2* __restrict__ tab,
-                                                                int lane, bool unit, double fs0, double fe0, int es,
+                                                                int lane, int unit, double fs0, double fe0, int es,
                                                                 lr_seg_cache* sg = nullptr) {
     double* tabd = reinterpret_cast<double*>(tab);
     const int b0 = lane * P;
@@ -240,26 +230,14 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
     for (int p = 0; p < P; ++p) {
         const int b = b0 + p;
         if (b < n_bins) {
-            if (unit) {
-                tabd[es * (b + 1)] = (logB[p] + cum) + fs0 * R[p];
-                tabd[es * (H + b + 1)] = (logD[p] - cum) - fe0 * R[p];
-            } else {
-                tab[b + 1] = make_double2(logB[p] + cum, R[p]);
-                tab[H + b + 1] = make_double2(logD[p] - cum, -R[p]);
-            }
+            lr_put_S(tabd, unit, es, b + 1, logB[p] + cum, R[p], fs0);
+            lr_put_E(tabd, unit, es, H + b + 1, logD[p] - cum, R[p], fe0);
         }
         cum += R[p];
     }
     if (lane == 0) {
-        if (unit) {
-            tabd[0] = 0.0, tabd[es * H] = 0.0;
-            tabd[es * (n_bins + 1)] = totR, tabd[es * (H + n_bins + 1)] = -totR;
-        } else {
-            tab[0] = make_double2(0.0, 0.0);
-            tab[H] = make_double2(0.0, 0.0);
-            tab[n_bins + 1] = make_double2(totR, 0.0);
-            tab[H + n_bins + 1] = make_double2(-totR, 0.0);
-        }
+        lr_put_S(tabd, unit, es, 0, 0.0, 0.0, fs0), lr_put_E(tabd, unit, es, H, 0.0, 0.0, fe0);
+        lr_put_S(tabd, unit, es, n_bins + 1, totR, 0.0, fs0), lr_put_E(tabd, unit, es, H + n_bins + 1, -totR, 0.0, fe0);
     }
     LR_SSTAMP(13);
     return (model == 1) ? lr_wave_sum(csum) : 0.0;
@@ -270,7 +248,7 @@ __device__ __forceinline__ double lr_build_tables_segments(const lr_seg_scratch*
                                                            const double* __restrict__ br_length,
                                                            const double* __restrict__ log_br, int model, int n_bins,
                                                            int n_cls, int H, double2* __restrict__ tab, int lane,
-                                                           bool unit, double fs0, double fe0, int es = 2,
+                                                           int unit, double fs0, double fe0, int es = 2,
                                                            lr_seg_cache* sg = nullptr) {
     if (n_cls == 1 && n_bins <= 2 * LR_WAVE)
         return lr_build_tables_segments_fast<2>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
@@ -599,7 +577,7 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
     const double constP = lr_build_tables_segments(&scratch, peL, peM, PKL, PKM, LDS_CONSTS ? br_lds : a.br_length,
                                                    LDS_CONSTS ? logbr_lds : a.log_br, cfg.model,
                                                    n_bins, a.n_cls, a.H, table, lane,
-                                                   a.unit != 0, cfg.frac_birth, cfg.frac_death, table_es, pre ? &sg : nullptr);
+                                                   a.unit, cfg.frac_birth, cfg.frac_death, table_es, pre ? &sg : nullptr);
     s.sgL = sg.packL, s.sgM = sg.packM, s.sg_valid = (pre && sg.packL != -1) ? 1 : 0;
     LR_SSTAMP(6);
     s.L = pL, s.M = pM, s.tL = ptL, s.tM = ptM, s.eL = peL, s.eM = peM, s.KL = PKL, s.KM = PKM;
@@ -790,11 +768,11 @@ __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, in
         p.prior = lr_trend_prior(P, lane);
         const lr_trend_params tp = lr_trend_unpack(P);
         lr_rates_build_tables_wave([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
-                                   cfg.n_bins, a.H, table, lane, a.unit != 0, cfg.frac_birth, cfg.frac_death, table_es);
+                                   cfg.n_bins, a.H, table, lane, a.unit, cfg.frac_birth, cfg.frac_death, table_es);
     } else {
         p.prior = lr_dd_prior(P, origin, present, k0, log_k0, lane);
         const lr_dd_params pp = lr_dd_unpack(P);
-        lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, a.unit != 0,
+        lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, a.unit,
                                 cfg.frac_birth, cfg.frac_death, table_es);
     }
     p.hasting = hasting, p.move = move_kind;
@@ -889,8 +867,8 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     double part = 0.0;
     for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * a.cfg.n_chains + c];
     const double lik_sum = lr_wave_sum(part);
-    if (a.cfg.sampler != 0) lr_dd_step_core(st, a, mode, c, lane, lik_sum, lr_chain_table(a, c));
-    else lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c));
+    if (a.cfg.sampler != 0) lr_dd_step_core(st, a, mode, c, lane, lik_sum, lr_chain_table(a, c), lr_tab_es(a.unit));
+    else lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c), lr_tab_es(a.unit));
     lr_chain_store(st, S, I, lane);
 }
 

@@ -36,3 +36,6 @@ run("cfg3 10k x 256", lambda: ChainEngine(ts3, te3, 256, model=0, seed=1, s_freq
 run("cfg2 metal_bands x 128 (model 2)", lambda: ChainEngine(G["metal_bands/ts"], G["metal_bands/te"], 128, model=2, seed=1, s_freq=100, n_trace_slots=80), n=4000)
 ts5, te5, _ = synth.make_lineages(50000, 64, 6, 0)
 run("cfg5 DDRate 50k x 256", lambda: DDRateEngine(ts5, te5, float(ts5.min()), float(te5.max()), 256, m_birth=2, m_death=2, seed=1, s_freq=100, n_trace_slots=80), n=4000)
+for eng_name in ("persistent4", "launch"):
+    run("p4general cfg4-general 100k x 1024 %s" % eng_name, lambda: ChainEngine(ts4g, te4g, 1024, model=0, seed=1, s_freq=100, n_trace_slots=40, engine=eng_name))
+    run("p4general cfg4-general 100k x 2048 %s" % eng_name, lambda: ChainEngine(ts4g, te4g, 2048, model=0, seed=1, s_freq=100, n_trace_slots=40, engine=eng_name))

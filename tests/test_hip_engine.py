@@ -108,19 +108,32 @@ def _pipelined_case(G, unit, engine):
     eng.close()
 
 
-def test_engine_continuous_times_general_path(G):
-    """Lineage times that are NOT unit-resolution (uniform jitter added): the engine must pick the general
-    kernels by itself and still follow the oracle loop run on statistics binned from the same jittered data."""
+@pytest.mark.parametrize("engine,kw", [("launch", {}), ("auto", {}), ("spec", dict(team=1)), ("spec", dict(team=4)),
+                                       ("persistent4", {})])
+def test_engine_continuous_times_general_path(G, engine, kw):
+    """Lineage times that are NOT unit-resolution (uniform jitter added): the engine must pick the general-times
+    kernels by itself and still follow the oracle loop run on statistics binned from the same jittered data.
+    "launch" = the launch-based engine (fp64 in-bin fractions from ts / te); the persistent engines (speculative team
+    kernel, four-chain kernel) carry the fractions as 32-bit fixed point in the pair-general table layout.  The jitter
+    sits on the 2^-32 grid, so that packing is exact and every engine must reproduce the oracle's decisions."""
     from literate_amd.engine import ChainEngine, split_trace_row
     from oracle import literate_oracle as lo
     from oracle import mcmc_oracle as mo
     rng = np.random.default_rng(4)
-    ts = G["metal_bands/ts"][:6000] + rng.uniform(0, 0.999, 6000)
-    te = np.maximum(G["metal_bands/te"][:6000] + rng.uniform(0, 0.4, 6000), ts + 0.01)
+    grid = lambda x: np.round(x * 2.0 ** 32) / 2.0 ** 32
+    ts = G["metal_bands/ts"][:6000] + grid(rng.uniform(0, 0.999, 6000))
+    te = np.maximum(G["metal_bands/te"][:6000] + grid(rng.uniform(0, 0.4, 6000)), ts + 0.0078125)
     te[G["metal_bands/te"][:6000] >= 2000.5] = 2000.5
     n_it, seed, C = 300, 21, 40
-    eng = ChainEngine(ts, te, C, model=2, seed=seed, s_freq=1, n_trace_slots=n_it)
-    assert not eng.unit_resolution and eng.layout.chains_per_block == 8 and eng.layout.pipelined == 1
+    eng = ChainEngine(ts, te, C, model=2, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine, **kw)
+    assert not eng.unit_resolution
+    if engine == "launch":
+        assert eng.layout.persistent == 0 and eng.layout.chains_per_block == 8 and eng.layout.pipelined == 1
+        assert eng.layout.table_mode == 0
+    else:
+        assert eng.layout.persistent == (2 if engine == "persistent4" else 3) and eng.layout.table_mode == 2
+        if "team" in kw:
+            assert eng.layout.team_blocks == kw["team"]
     with pytest.raises(ValueError):
         ChainEngine(ts, te, C, model=2, unit_resolution=True)
     eng.init(); eng.steps(n_it)
@@ -135,6 +148,27 @@ def test_engine_continuous_times_general_path(G):
             head, s_row, e_row = split_trace_row(tr[i, c])
             assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9), (c, i, head, ref["mcmc"][i])
     eng.close()
+
+
+def test_general_times_fraction_packing_stays_within_tolerance():
+    """Arbitrary fp64 times (not on the 2^-32 grid): the persistent engines round the in-bin fractions to 32-bit fixed
+    point.  Their log-likelihoods must agree with the launch-based engine (exact fp64 fractions) to the 1e-9 relative
+    tolerance of the north star on every sampled state of a short run - decisions included."""
+    from literate_amd import synth
+    from literate_amd.engine import ChainEngine
+    rng = np.random.default_rng(5)
+    ts, te, _ = synth.make_lineages(20000, 128, 20, 0)
+    ts = ts + rng.uniform(0, 1, len(ts)) * 0.999
+    te = np.maximum(np.ceil(te) - 1.0 + rng.uniform(1e-3, 0.999, len(te)), ts + 1e-3)
+    ref = None
+    for engine, team in (("launch", 0), ("spec", 1), ("spec", 4), ("persistent4", 0)):
+        eng = ChainEngine(ts, te, 8, model=0, seed=3, s_freq=1, n_trace_slots=100, engine=engine, team=team)
+        eng.init(); eng.steps(100)
+        tr = eng.trace_rows()[:, :, :13]
+        eng.close()
+        if ref is None:
+            ref = tr
+        assert np.allclose(tr, ref, rtol=1e-9, atol=1e-9), engine
 
 
 def test_engine_given_initial_state_and_graph_replay(G):

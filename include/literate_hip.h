@@ -32,6 +32,7 @@ extern "C" {
 #define LR_ERR_WORKSPACE (-4) /* workspace too small                                     */
 #define LR_ERR_T0 (-5)        /* bin origin must be integer valued                       */
 #define LR_ERR_STATE (-6)     /* engine used before lr_mcmc_init / after destroy         */
+#define LR_ERR_ORDER (-7)     /* persistent engines: lineages not grouped by birth bin (sort them by ts) */
 
 #define LR_KMAX 32     /* max number of rates per process held on the device (reference: unbounded) */
 #define LR_ROW 64      /* padded row length of per-chain state arrays                                 */
@@ -200,7 +201,8 @@ typedef struct lr_mcmc_layout {
     int64_t state_f64;    /* [C, LR_STATE_ROWS, LR_ROW] doubles  (rows: see LR_ROW_* below)  */
     int64_t state_i32;    /* [C, LR_ISTATE_ROWS, LR_ROW] int32                                */
     int64_t bin_consts;   /* [n_bins] doubles: log(br_length) (models 0/1)                    */
-    int64_t lineage_idx;  /* [n padded to 8] uint16: packed table indices (birth | death << 8) of the lineages */
+    int64_t lineage_idx;  /* [groups] 16 bytes: packed table indices of the lineages (persistent engines): a group = up to
+                           * 14 consecutive lineages of one birth bin: byte 0 birth index, byte 1 count, bytes 2..15 death indices */
     int64_t args_blob;    /* 1 KiB: kernel arguments of the persistent engine, kept in device memory          */
     int64_t tables;       /* [C, table_stride] double2                                        */
     int64_t partials;     /* [tiles, C] doubles                                               */
@@ -220,7 +222,8 @@ typedef struct lr_mcmc_layout {
     int32_t team_blocks;  /* blocks (= CUs) that share one chain pair, each scanning 1/team_blocks of the lineages     */
     int32_t table_mode;   /* 0 chain-major general tables, 1 unit-resolution pair tables, 2 pair-general tables (persistent
                            * engines on general lineage times: in-bin fractions packed as 32-bit fixed point)             */
-    int64_t lineage_frac; /* [4][n padded to 8 + spare] uint4: those fractions (table_mode 2)                            */
+    int64_t lineage_frac; /* [7][groups] uint4: those fractions (table_mode 2)                                           */
+    int64_t pack_tmp;     /* scratch of the lineage packing (two int32 per lineage + the scans' temporary storage)       */
 } lr_mcmc_layout;
 
 /* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */

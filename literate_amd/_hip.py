@@ -6,9 +6,9 @@ from .build import LIB
 
 c_i32, c_i64, c_f64, c_vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 
-LR_ERR_NULL, LR_ERR_SIZE, LR_ERR_MODEL, LR_ERR_WORKSPACE, LR_ERR_T0, LR_ERR_STATE = -1, -2, -3, -4, -5, -6
+LR_ERR_NULL, LR_ERR_SIZE, LR_ERR_MODEL, LR_ERR_WORKSPACE, LR_ERR_T0, LR_ERR_STATE, LR_ERR_ORDER = -1, -2, -3, -4, -5, -6, -7
 ERRORS = {-1: "LR_ERR_NULL", -2: "LR_ERR_SIZE", -3: "LR_ERR_MODEL", -4: "LR_ERR_WORKSPACE", -5: "LR_ERR_T0",
-          -6: "LR_ERR_STATE"}
+          -6: "LR_ERR_STATE", -7: "LR_ERR_ORDER (lineages must be sorted by birth time for the persistent engines)"}
 
 LR_KMAX, LR_ROW, LR_MAX_BINS = 32, 64, 4094
 LR_STATE_ROWS, LR_ISTATE_ROWS = 9, 5
@@ -38,7 +38,7 @@ class McmcLayout(C.Structure):
                 ("partials", c_i64), ("trace", c_i64), ("total_bytes", c_i64), ("table_stride", c_i32),
                 ("tiles", c_i32), ("chains_per_block", c_i32), ("trace_width", c_i32), ("n_parts", c_i32),
                 ("pipelined", c_i32), ("persistent", c_i32), ("reserved1", c_i32), ("status", c_i64), ("xchg", c_i64),
-                ("team_blocks", c_i32), ("table_mode", c_i32), ("lineage_frac", c_i64)]
+                ("team_blocks", c_i32), ("table_mode", c_i32), ("lineage_frac", c_i64), ("pack_tmp", c_i64)]
 
 
 # name -> (restype, argtypes); exactly the symbols include/literate_hip.h declares (+ the RNG debug hook)

@@ -1,0 +1,78 @@
+// lr_engine.h - host-side engine object shared by the translation units of the RJMCMC engines
+// (lr_mcmc.hip: launch-based and two- / four-chain persistent kernels, lr_spec.hip: speculative team kernel,
+// lr_pack.hip: packing of the lineages for the persistent scans).
+#pragma once
+#include "lr_internal.h"
+#include "lr_scan.h"
+#include "lr_step.h"
+
+#define LR_MAX_PARTS 4
+// a partition = a contiguous, independent block of chains with its own stream and captured graph; inside it
+// the chains are software-pipelined in two halves (A = [base, base+hA), B = the rest)
+struct lr_part {
+    int base, count, hA;
+    bool pipelined;
+    hipStream_t stream;
+    hipEvent_t done;
+    hipGraphExec_t graph_exec;
+    int graph_units;
+};
+
+// Four-chain kernel: delta[s] = trips scanner slot s (wave s + 2) scores beyond (+) or short of (-) the equal share
+// k_tot; the deltas sum to zero.  The trips given up are stored, in slot / trip order, behind the takers' own shares.
+struct lr_p4_shares {
+    int delta[16];
+    int n_slots;          // scanner waves striding over the groups: 14 (four-chain kernel) or 8 (two-chain kernel)
+};
+
+struct lr_engine {
+    lr_mcmc_config cfg;
+    lr_mcmc_layout lay;
+    lr_scan_plan plan;
+    const double* ts;
+    const double* te;
+    const double* br_length;
+    char* ws;
+    bool initialised;
+    int n_parts;
+    lr_part part[LR_MAX_PARTS];
+    bool persistent;          // use lr_persist_kernel in lr_mcmc_steps
+    long long n8;             // 16-byte groups of packed lineage indices
+    long long n8_alloc;       // ... allocated (zero-filled behind the data)
+    lr_p4_shares p4;          // per scanner wave: trips more (+) or fewer (-) than the equal share (four-chain kernel)
+    hipEvent_t fork;
+};
+
+
+// spare zero-filled 16-byte groups behind the packed lineages (group 0 bytes = sentinel table entries, contribution 0):
+// room for the trips the four-chain kernel moves between waves and for its prefetch past the end
+#define LR_P4_MAX_GIVE 64
+// sized for the widest stride (16 scanner waves x 64 lanes): the takers' extra trips reach group (k_tot + give) * stride
+#define LR_IDX_SPARE ((LR_P4_MAX_GIVE + 2) * 1024)
+// the packing keeps the caller's order and starts a new group wherever the birth bin changes: lineages sorted by birth
+// time give at most n_bins + 2 such runs; more than LR_MAX_RUNS of them (unsorted input) are refused
+#define LR_MAX_RUNS (1ll << 20)
+
+static inline long long lr_groups_alloc(long long n_lineages) {
+    const long long runs = n_lineages < LR_MAX_RUNS ? n_lineages : LR_MAX_RUNS;
+    return (n_lineages + LR_GRP - 1) / LR_GRP + runs + LR_IDX_SPARE;
+}
+
+// ---- speculative team engine (lr_spec.h / lr_spec.hip) ----
+#ifndef LR_SPEC_THREADS
+#define LR_SPEC_THREADS 768   /* 12 waves: 4 candidate + 8 scanner waves, 3 per SIMD = 168 VGPRs each */
+#endif
+#ifndef LR_SPEC_SCAN_UNROLL
+#define LR_SPEC_SCAN_UNROLL 2
+#endif
+#define LR_TEAM_MAX 8
+#define LR_SPEC_GRANULES 16      /* 8-byte granules reserved per block and parity: one 128-byte line */
+#define LR_SPEC_TIMEOUT_TICKS 200000000ull   /* 2 s of the 100 MHz wall clock */
+
+// lr_mcmc.hip
+lr_step_args lr_make_args(const lr_engine* e);
+// lr_pack.hip: (re)builds the packed lineages in the workspace and the scanner-wave shares; blocks on `stream` once
+int lr_pack_lineages(lr_engine* e, hipStream_t stream);
+long long lr_pack_tmp_bytes(long long n_lineages);
+// lr_spec.hip: n_iters iterations of the speculative team kernel
+int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages& pk, int64_t n_iters, hipStream_t stream);

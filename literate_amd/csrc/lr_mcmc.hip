@@ -12,9 +12,9 @@
 
 #include "lr_chain.h"
 #include "lr_dd.h"
+#include "lr_engine.h"
 #include "lr_internal.h"
 #include "lr_scan.h"
-#include "lr_spec.h"
 #include "lr_step.h"
 
 // ------------------------------------------------------------------------------------------
@@ -111,43 +111,6 @@ extern "C" int lr_debug_draws(uint64_t seed, int64_t chain, const int64_t* it, c
 // ------------------------------------------------------------------------------------------
 // the engine
 // ------------------------------------------------------------------------------------------
-#define LR_MAX_PARTS 4
-// a partition = a contiguous, independent block of chains with its own stream and captured graph; inside it
-// the chains are software-pipelined in two halves (A = [base, base+hA), B = the rest)
-struct lr_part {
-    int base, count, hA;
-    bool pipelined;
-    hipStream_t stream;
-    hipEvent_t done;
-    hipGraphExec_t graph_exec;
-    int graph_units;
-};
-
-// Four-chain kernel: delta[s] = trips scanner slot s (wave s + 2) scores beyond (+) or short of (-) the equal share
-// k_tot; the deltas sum to zero.  The trips given up are stored, in slot / trip order, behind the takers' own shares.
-struct lr_p4_shares {
-    int delta[16];
-    int n_slots;          // scanner waves striding over the groups: 14 (four-chain kernel) or 8 (two-chain kernel)
-};
-
-struct lr_engine {
-    lr_mcmc_config cfg;
-    lr_mcmc_layout lay;
-    lr_scan_plan plan;
-    const double* ts;
-    const double* te;
-    const double* br_length;
-    char* ws;
-    bool initialised;
-    int n_parts;
-    lr_part part[LR_MAX_PARTS];
-    bool persistent;          // use lr_persist_kernel in lr_mcmc_steps
-    long long n8;             // 16-byte groups of packed lineage indices
-    long long n8_alloc;       // ... allocated (zero-filled behind the data)
-    lr_p4_shares p4;          // per scanner wave: trips more (+) or fewer (-) than the equal share (four-chain kernel)
-    hipEvent_t fork;
-};
-
 #define LR_STEP_WAVES (LR_SCAN_THREADS / LR_WAVE)
 
 // chains [chain_base, chain_base + n_sub): one wave per chain, LR_STEP_WAVES chains per block
@@ -217,54 +180,9 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
 #ifndef LR_PERSIST_THREADS
 #define LR_PERSIST_THREADS 512
 #endif
-// spare zero-filled 16-byte groups behind the packed lineage indices (index 0 = sentinel table entries, contribution 0):
-// room for the trips the four-chain kernel moves between waves and for its prefetch past the end
-#define LR_P4_MAX_GIVE 64
-// sized for the widest stride (16 scanner waves x 64 lanes): the takers' extra trips reach group (k_tot + give) * stride
-#define LR_IDX_SPARE ((LR_P4_MAX_GIVE + 2) * 1024)
 #ifndef LR_PERSIST_MINWAVES
 #define LR_PERSIST_MINWAVES 4
 #endif
-
-// p4 = 1: layout for the four-chain kernel.  Its 14 scanner waves stride over the groups (wave slot = (group % 896) /
-// 64, trip = group / 896) and do not all score the same number of trips (lr_p4_shares): the trips a slot gives up,
-// taken in slot / trip order, are stored as the extra trips of the taking slots, in slot / trip order, where those
-// waves simply keep striding.  The hand-over costs the scan loop nothing.
-__global__ void lr_pack_lineages_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n,
-                                        double t0, int n_bins, int p4, int k_tot, lr_p4_shares sh,
-                                        unsigned short* __restrict__ out, unsigned int* __restrict__ frac,
-                                        long long fstride) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int a = min(max(__double2int_rz(floor(ts[i]) - t0), -1), n_bins);
-    const int b = min(max(__double2int_rz(ceil(te[i]) - t0), 0), n_bins + 1);
-    long long g = i >> 3;
-    if (p4) {
-        const int stride = sh.n_slots * 64;
-        const int slot = (int)(g % stride) / 64, trip = (int)(g / stride), lane = (int)(g % 64);
-        if (sh.delta[slot] < 0 && trip >= k_tot + sh.delta[slot]) {
-            int r = trip - (k_tot + sh.delta[slot]);                     // rank of this trip among all given trips
-            for (int q = 0; q < slot; ++q) r += sh.delta[q] < 0 ? -sh.delta[q] : 0;
-            int to = 0;
-            for (; to < sh.n_slots; ++to) {
-                const int extra = sh.delta[to] > 0 ? sh.delta[to] : 0;
-                if (r < extra) break;
-                r -= extra;
-            }
-            g = (long long)(k_tot + r) * stride + to * 64 + lane;
-        }
-    }
-    out[g * 8 + (i & 7)] = (unsigned short)((a + 1) | (b << 8));
-    if (frac) {
-        // general times: fs = ts - floor ts and fe' = ceil te - te (both in [0, 1)) as 32-bit fixed point, rounded to
-        // nearest; array j = (i & 7) / 2 of four, uint4 g = (fs, fe', fs, fe') of lineages 2j, 2j + 1 of the group
-        const double s = ts[i], e = te[i];
-        const double fs = fmin(rint((s - floor(s)) * 4294967296.0), 4294967295.0);
-        const double fe = fmin(rint((ceil(e) - e) * 4294967296.0), 4294967295.0);
-        unsigned int* q = frac + ((size_t)((i & 7) >> 1) * fstride + g) * 4 + (i & 1) * 2;
-        q[0] = (unsigned int)fs, q[1] = (unsigned int)fe;
-    }
-}
 
 // One pass of the packed lineages against the pair tables in global memory: the launch-based twin of the persistent
 // scan, used where the engines need the sums outside their kernels (the initial state's likelihood, LRF:224-226, and
@@ -678,7 +596,7 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
     if (pairs > cus) return 1e30;
     static const int k_env0 = lr_env_int("LR_SPEC_TEAM", 0);
     const int k_env = cfg->team_request > 0 ? cfg->team_request : k_env0;
-    const double n8 = (double)((cfg->n_lineages + 7) / 8);
+    const double n8 = (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP);      // groups, for lineages sorted by birth time
     const double t_cand = cfg->sampler ? 4.2 : 3.2;
     double best = 1e30;
     for (int k = 1; k <= LR_TEAM_MAX; k *= 2) {
@@ -783,9 +701,13 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->state_f64 = o, o += lr_align_up64(C * LR_STATE_ROWS * LR_ROW * 8, 256);
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
     out->bin_consts = o, o += lr_align_up64((long long)(cfg->n_bins + 2) * 8, 256);   // log(br) + the DD constants
-    out->lineage_idx = o, o += lr_align_up64((lr_align_up64(cfg->n_lineages, 8) / 8 + LR_IDX_SPARE) * 16, 256);
-    out->lineage_frac = o;           // general times: [4][n8 + spare] uint4 of packed in-bin fractions (lr_pack_lineages_kernel)
-    if (p.unit == LR_TAB_PAIRGEN) o += lr_align_up64((lr_align_up64(cfg->n_lineages, 8) / 8 + LR_IDX_SPARE) * 64, 256);
+    // packed lineages of the persistent engines (lr_pack.hip): groups of LR_GRP lineages of one birth bin, 16 bytes of
+    // table indices each; on general times LR_GRP / 2 more uint4 arrays with the in-bin fractions; scratch of the packing
+    const long long n_alloc = lr_groups_alloc(cfg->n_lineages);
+    out->lineage_idx = o, o += lr_align_up64(n_alloc * 16, 256);
+    out->lineage_frac = o;
+    if (p.unit == LR_TAB_PAIRGEN) o += lr_align_up64(n_alloc * 16 * (LR_GRP / 2), 256);
+    out->pack_tmp = o, o += lr_align_up64(lr_pack_tmp_bytes(cfg->n_lineages), 256);
     out->args_blob = o, o += 1024;   // lr_step_args of the persistent kernel
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
@@ -837,75 +759,10 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     bool pipelined[LR_MAX_PARTS];
     e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, lr_fused_supported(e->plan), base, hA, pipelined);
     e->persistent = lay.persistent != 0;
-    e->n8 = lr_align_up64(cfg->n_lineages, 8) / 8;
-    e->n8_alloc = e->n8 + LR_IDX_SPARE;
-    {
-        // Shares of the 14 scanner waves, tuned on cfg4 (14 trips per wave) with in-kernel stamps until the waves of a
-        // phase finish together: per wave pair (2,3) (4,5) ... (14,15) the trips beyond / short of the equal share.
-        // The SIMD arbiter serves its oldest wave first and SIMDs 0, 1 also host the stepper waves, hence the shape.
-        // Kept as fractions of the trip count for other inputs; short scans (bound by the chain step) stay equal.
-        static const char* env = getenv("LR_P4_SHARES");       // "d2,d4,d6,d8,d10,d12,d14" for 14 trips
-        static const int env2 = lr_env_int("LR_P2_SHARE", 0);   // two-chain kernel: trips per 24 moved from waves 4..7 to 0..3 (no gain measured: off)
-        for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
-        if (e->lay.persistent == 3) {
-            e->p4.n_slots = 12;      // speculative kernel: plain layout, every scanner wave strides over its block's slice
-        } else if (e->lay.persistent == 2) {
-            e->p4.n_slots = 14;
-            int base[7] = {6, 6, 2, 0, -2, -6, -6};
-            if (env) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
-            const int k_tot = (int)((e->n8 + 895) / 896);
-            int sum = 0;
-            for (int j = 0; j < 7; ++j) {
-                int d = (k_tot >= 6) ? (int)lrint((double)base[j] * k_tot / 14.0) : 0;
-                if (d < -(k_tot - 1)) d = -(k_tot - 1);
-                if (d > LR_P4_MAX_GIVE) d = LR_P4_MAX_GIVE;
-                e->p4.delta[2 * j] = e->p4.delta[2 * j + 1] = d;
-                sum += d;
-            }
-            // make the deltas sum to zero exactly: trim the largest takers / givers
-            for (int guard = 0; sum != 0 && guard < 64; ++guard) {
-                int pick = 0;
-                for (int j = 1; j < 7; ++j)
-                    if (sum > 0 ? e->p4.delta[2 * j] > e->p4.delta[2 * pick] : e->p4.delta[2 * j] < e->p4.delta[2 * pick]) pick = j;
-                const int step = sum > 0 ? -1 : 1;
-                e->p4.delta[2 * pick] += step, e->p4.delta[2 * pick + 1] += step;
-                sum += step;
-            }
-            if (sum != 0) for (int j = 0; j < 14; ++j) e->p4.delta[j] = 0;
-        } else {
-            // two-chain kernel: 8 waves, two per SIMD; the younger four (4..7) trail the older four by ~10 % on long scans,
-            // but with two unsynchronised blocks per CU moving trips between them bought nothing (16.3 us either way)
-            const bool wide2 = e->lay.reserved1 == 1024;
-            e->p4.n_slots = wide2 ? 16 : 8;
-            const int k_tot = (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64));
-            int d = (k_tot >= 12) ? (int)lrint((double)env2 * k_tot / 24.0) : 0;
-            if (d > LR_P4_MAX_GIVE) d = LR_P4_MAX_GIVE;
-            if (e->p4.n_slots == 8)
-                for (int j = 0; j < 4; ++j) e->p4.delta[j] = d, e->p4.delta[4 + j] = -d;
-            if (e->p4.n_slots == 16 && k_tot >= 6) {
-                // wide variant: ONE block per CU, four scanner waves per SIMD - the oldest-first pattern of the four-chain
-                // kernel: waves 0..3 / 4..7 take trips from 12..15 / 8..11 (per 12 trips)
-                static const char* envw = getenv("LR_P2W_SHARES");
-                int a = 5, b = 2;
-                if (envw) sscanf(envw, "%d,%d", &a, &b);
-                int da = (int)lrint((double)a * k_tot / 12.0), db = (int)lrint((double)b * k_tot / 12.0);
-                if (da > LR_P4_MAX_GIVE) da = LR_P4_MAX_GIVE;
-                if (db > LR_P4_MAX_GIVE) db = LR_P4_MAX_GIVE;
-                if (da > k_tot - 1) da = k_tot - 1;
-                if (db > k_tot - 1) db = k_tot - 1;
-                for (int j = 0; j < 4; ++j) e->p4.delta[j] = da, e->p4.delta[4 + j] = db, e->p4.delta[8 + j] = -db, e->p4.delta[12 + j] = -da;
-            }
-        }
-    }
-    {
-        // the takers' extra trips must stay inside the zero-filled spare behind the packed indices
-        const long long stride = (long long)e->p4.n_slots * 64;
-        const long long k_tot = (e->n8 + stride - 1) / stride;
-        int dmax = 0;
-        for (int j = 0; j < 16; ++j) dmax = e->p4.delta[j] > dmax ? e->p4.delta[j] : dmax;
-        if ((k_tot + dmax + 1) * stride > e->n8_alloc)
-            for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
-    }
+    e->n8 = 0;                                          // groups of packed lineages: known once lr_pack_lineages has run
+    e->n8_alloc = lr_groups_alloc(cfg->n_lineages);
+    for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
+    e->p4.n_slots = 8;
     e->fork = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
         lr_part& q = e->part[p];
@@ -927,7 +784,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     return LR_OK;
 }
 
-static lr_step_args lr_make_args(const lr_engine* e) {
+lr_step_args lr_make_args(const lr_engine* e) {
     lr_step_args a;
     a.cfg = e->cfg;
     a.state_f64 = (double*)(e->ws + e->lay.state_f64);
@@ -1004,15 +861,6 @@ static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipS
     if (e->persistent) {
         static_assert(sizeof(lr_step_args) <= 1024, "args blob too small");
         hipLaunchKernelGGL(lr_store_args_kernel, dim3(1), dim3(64), 0, stream, a, (lr_step_args*)(e->ws + e->lay.args_blob));
-        // zero fill (padding entries (0, 0) = "outside the window" on both sides, contribution 0), then the lineages
-        (void)hipMemsetAsync(e->ws + e->lay.lineage_idx, 0, (size_t)e->n8_alloc * 16, stream);
-        const bool general = e->plan.unit == LR_TAB_PAIRGEN;
-        if (general) (void)hipMemsetAsync(e->ws + e->lay.lineage_frac, 0, (size_t)e->n8_alloc * 64, stream);
-        hipLaunchKernelGGL(lr_pack_lineages_kernel, dim3((unsigned)((e->cfg.n_lineages + 255) / 256)), dim3(256), 0, stream,
-                           e->ts, e->te, (long long)e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins,
-                           1, (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64)), e->p4,
-                           (unsigned short*)(e->ws + e->lay.lineage_idx),
-                           general ? (unsigned int*)(e->ws + e->lay.lineage_frac) : nullptr, (long long)e->n8_alloc);
     }
 }
 
@@ -1021,7 +869,9 @@ extern "C" int lr_mcmc_restore(lr_engine* e, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const lr_step_args a = lr_make_args(e);
     lr_prepare_constants(e, a, stream);
-    const int rc = (int)hipGetLastError();
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    if (e->persistent) rc = lr_pack_lineages(e, stream);
     if (rc) return rc;
     e->initialised = true;
     return LR_OK;
@@ -1036,6 +886,10 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
     hipStream_t stream = (hipStream_t)stream_;
     const lr_step_args a = lr_make_args(e);
     lr_prepare_constants(e, a, stream);
+    if (e->persistent) {
+        const int rcp = lr_pack_lineages(e, stream);
+        if (rcp) return rcp;
+    }
     hipLaunchKernelGGL(lr_chain_init_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, L, M, tL, tM, KL, KM,
                        kmax);
     int rc = (int)hipGetLastError();
@@ -1189,6 +1043,7 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         const bool general = e->plan.unit == LR_TAB_PAIRGEN;
         lr_packed_lineages pk;
         pk.idx8 = idx8, pk.frac = general ? (const uint4*)(e->ws + e->lay.lineage_frac) : nullptr, pk.fstride = e->n8_alloc;
+        if (e->n8 <= 0) return LR_ERR_STATE;
         const lr_step_args* ap = (const lr_step_args*)(e->ws + e->lay.args_blob);
         const int blocks = (e->cfg.n_chains + 1) / 2;
         const bool p4 = e->lay.persistent == 2;
@@ -1197,49 +1052,7 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         static const int wide_env = lr_env_int("LR_PERSIST_WIDE", -1);
         const bool wide = e->lay.reserved1 == 1024;   // (short scans keep 512: the 16-wave barrier costs more than it buys)
         (void)wide_env;
-        if (e->lay.persistent == 3) {
-            lr_spec_args x;
-            x.xchg = (unsigned long long*)(e->ws + e->lay.xchg);
-            x.status = (unsigned int*)(e->ws + e->lay.status);
-            x.team_blocks = e->lay.team_blocks, x.n_teams = blocks;
-            const size_t xbytes = (size_t)2 * blocks * LR_TEAM_MAX * LR_SPEC_GRANULES * 8;
-            for (int64_t done = 0; done < n_iters;) {
-                const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
-                // epochs count from 1 inside every launch: all granules start at zero (Guideline 16, "Re-initialise every call")
-                if (x.team_blocks > 1) {
-                    const hipError_t he = hipMemsetAsync(x.xchg, 0, xbytes, stream);
-                    if (he != hipSuccess) return (int)he;
-                }
-                const dim3 grid((unsigned)(blocks * x.team_blocks)), blk(LR_SPEC_THREADS);
-#define LR_SPEC_LAUNCH(HH, GG)                                                                                                \
-    if (e->cfg.sampler == 0)                                                                                                  \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, true, GG>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
-    else                                                                                                                      \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, false, GG>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n)
-                // (general times: pair tables of 32-byte entries; H = 264 would not fit the eight of them in LDS and is
-                // never planned for the speculative kernel, see lr_decide_engine)
-                if (general) {
-                    switch (e->plan.H) {
-                        case 40: LR_SPEC_LAUNCH(40, true); break;
-                        case 72: LR_SPEC_LAUNCH(72, true); break;
-                        case 136: LR_SPEC_LAUNCH(136, true); break;
-                        default: return LR_ERR_SIZE;
-                    }
-                } else {
-                    switch (e->plan.H) {
-                        case 40: LR_SPEC_LAUNCH(40, false); break;
-                        case 72: LR_SPEC_LAUNCH(72, false); break;
-                        case 136: LR_SPEC_LAUNCH(136, false); break;
-                        default: LR_SPEC_LAUNCH(264, false); break;
-                    }
-                }
-#undef LR_SPEC_LAUNCH
-                const int rc = (int)hipGetLastError();
-                if (rc) return rc;
-                done += n;
-            }
-            return LR_OK;
-        }
+        if (e->lay.persistent == 3) return lr_launch_spec(e, a, pk, n_iters, stream);
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
 #define LR_P_LAUNCH(HH)                                                                                                       \

@@ -1,0 +1,225 @@
+// lr_pack.hip - the lineages as the persistent engines scan them.
+//
+// A lineage needs two table indices per chain pair: its birth bin and its death bin (lr_device.h: S and E tables).
+// The engines keep the lineages ordered by (ts, te) - ChainEngine sorts them once - so consecutive lineages share
+// their birth bin for long runs (100k lineages over 128 bins: ~780 per bin).  The packing makes that explicit:
+//
+//   group = up to LR_GRP = 14 CONSECUTIVE lineages of ONE birth bin, 16 bytes:
+//           byte 0 birth index a, byte 1 count, bytes 2..15 the death indices b (0 = padding, contribution 0)
+//
+// A lane of the scan loads one group (16 bytes, coalesced), gathers S[a] ONCE and E[b] per lineage: 15 gathers for
+// 14 lineages instead of 28.  Every lineage still contributes its own two terms - S[a] enters `count` times - the sort
+// order is what lets the gather be shared.  A new group starts wherever the birth bin changes (and every 14 lineages
+// inside a run), so the number of groups depends on the data: <= ceil(N / 14) + runs, runs <= n_bins + 2 for sorted
+// input.  The caller's order is kept (the likelihood is a sum; only its rounding depends on the order), which makes
+// the packing a pair of prefix scans:
+//   run start of lineage i = max-scan of (i if a_i != a_{i-1} else 0); new group at i <=> (i - run start) % 14 == 0;
+//   group of lineage i     = sum-scan of the new-group flags - 1.
+// On general (non-integer) times the in-bin fractions travel beside the indices as 32-bit fixed point: 7 more arrays of
+// uint4, array j of a group = (fs, fe', fs, fe') of its lineages 2j and 2j + 1 (fs = ts - floor ts, fe' = ceil te - te).
+//
+// The four-chain kernel's unequal scanner-wave shares (lr_p4_shares) are a permutation of whole groups and are applied
+// here as before; they depend on the group count, so they are fixed here too, after the scans.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "lr_engine.h"
+
+static int lr_env_int_pack(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+__device__ __forceinline__ int lr_birth_index(double s, double t0, int n_bins) {
+    return min(max(__double2int_rz(floor(s) - t0), -1), n_bins) + 1;
+}
+__device__ __forceinline__ int lr_death_index(double e, double t0, int n_bins) {
+    return min(max(__double2int_rz(ceil(e) - t0), 0), n_bins + 1);
+}
+
+// run-start candidates: i where the birth bin changes (lineage 0 included), else 0
+__global__ void lr_pack_runs_kernel(const double* __restrict__ ts, long long n, double t0, int n_bins,
+                                    int* __restrict__ start_cand) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = lr_birth_index(ts[i], t0, n_bins);
+    const int ap = i > 0 ? lr_birth_index(ts[i - 1], t0, n_bins) : -1;
+    start_cand[i] = (a != ap) ? (int)i : 0;
+}
+
+// new-group flags from the run starts (in place: run_start stays, flag goes to `flag`)
+__global__ void lr_pack_flags_kernel(const int* __restrict__ run_start, long long n, int* __restrict__ flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (((int)i - run_start[i]) % LR_GRP == 0) ? 1 : 0;
+}
+
+// where group g of the plain order goes under the scanner-wave shares (see lr_persist4_kernel)
+__device__ __forceinline__ long long lr_share_permute(long long g, int k_tot, const lr_p4_shares& sh) {
+    const int stride = sh.n_slots * 64;
+    const int slot = (int)(g % stride) / 64, trip = (int)(g / stride), lane = (int)(g % 64);
+    if (sh.delta[slot] < 0 && trip >= k_tot + sh.delta[slot]) {
+        int r = trip - (k_tot + sh.delta[slot]);                     // rank of this trip among all given trips
+        for (int q = 0; q < slot; ++q) r += sh.delta[q] < 0 ? -sh.delta[q] : 0;
+        int to = 0;
+        for (; to < sh.n_slots; ++to) {
+            const int extra = sh.delta[to] > 0 ? sh.delta[to] : 0;
+            if (r < extra) break;
+            r -= extra;
+        }
+        g = (long long)(k_tot + r) * stride + to * 64 + lane;
+    }
+    return g;
+}
+
+__global__ void lr_pack_groups_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n, double t0,
+                                      int n_bins, const int* __restrict__ run_start, const int* __restrict__ group_incl,
+                                      int permute, int k_tot, lr_p4_shares sh, unsigned char* __restrict__ out,
+                                      unsigned int* __restrict__ frac, long long fstride) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int slot = ((int)i - run_start[i]) % LR_GRP;
+    long long g = group_incl[i] - 1;
+    if (permute) g = lr_share_permute(g, k_tot, sh);
+    const double s = ts[i], e = te[i];
+    unsigned char* grp = out + g * 16;
+    grp[2 + slot] = (unsigned char)lr_death_index(e, t0, n_bins);
+    if (slot == 0) {
+        // header: the birth index and the number of lineages of the run that fall into this group
+        const int a = lr_birth_index(s, t0, n_bins);
+        int cnt = 1;
+        while (cnt < LR_GRP && i + cnt < n && lr_birth_index(ts[i + cnt], t0, n_bins) == a) ++cnt;
+        grp[0] = (unsigned char)a, grp[1] = (unsigned char)cnt;
+    }
+    if (frac) {
+        // general times: fs = ts - floor ts and fe' = ceil te - te (both in [0, 1)) as 32-bit fixed point, rounded to
+        // nearest; array j = slot / 2 of LR_GRP / 2, uint4 g = (fs, fe', fs, fe') of the group's lineages 2j, 2j + 1
+        const double fs = fmin(rint((s - floor(s)) * 4294967296.0), 4294967295.0);
+        const double fe = fmin(rint((ceil(e) - e) * 4294967296.0), 4294967295.0);
+        unsigned int* q = frac + ((size_t)(slot >> 1) * fstride + g) * 4 + (slot & 1) * 2;
+        q[0] = (unsigned int)fs, q[1] = (unsigned int)fe;
+    }
+}
+
+struct lr_max_op {
+    __host__ __device__ int operator()(int a, int b) const { return a > b ? a : b; }
+};
+
+static size_t lr_scan_tmp_bytes(long long n) {
+    size_t b1 = 0, b2 = 0;
+    (void)rocprim::inclusive_scan(nullptr, b1, (const int*)nullptr, (int*)nullptr, (size_t)n, lr_max_op());
+    (void)rocprim::inclusive_scan(nullptr, b2, (const int*)nullptr, (int*)nullptr, (size_t)n, rocprim::plus<int>());
+    return (b1 > b2 ? b1 : b2) + 256;
+}
+
+long long lr_pack_tmp_bytes(long long n) {
+    // two int32 arrays (run start, group number) + the scans' temporary storage + the group count read by the host
+    return (long long)(2 * lr_align_up64(n * 4, 256) + (long long)lr_scan_tmp_bytes(n) + 256);
+}
+
+// Shares of the scanner waves given the number of groups (moved here from lr_mcmc_create: the count depends on the data)
+static void lr_set_shares(lr_engine* e) {
+    // Tuned on cfg4 with in-kernel stamps until the waves of a phase finish together: per wave pair (2,3) (4,5) ...
+    // (14,15) of the four-chain kernel the trips beyond / short of the equal share, per 14 trips.  The SIMD arbiter
+    // serves its oldest wave first and SIMDs 0, 1 also host the stepper waves, hence the shape.  Kept as fractions of
+    // the trip count for other inputs; short scans (bound by the chain step) stay equal.
+    static const char* env = getenv("LR_P4_SHARES");       // "d2,d4,d6,d8,d10,d12,d14" for 14 trips
+    static const int env2 = lr_env_int_pack("LR_P2_SHARE", 0);   // two-chain kernel (no gain measured: off)
+    for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
+    if (e->lay.persistent == 3) {
+        e->p4.n_slots = 8;       // speculative kernel: plain layout, every scanner wave strides over its block's slice
+    } else if (e->lay.persistent == 2) {
+        e->p4.n_slots = 14;
+        int base[7] = {6, 6, 2, 0, -2, -6, -6};
+        if (env) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
+        const int k_tot = (int)((e->n8 + 895) / 896);
+        int sum = 0;
+        for (int j = 0; j < 7; ++j) {
+            int d = (k_tot >= 6) ? (int)lrint((double)base[j] * k_tot / 14.0) : 0;
+            if (d < -(k_tot - 1)) d = -(k_tot - 1);
+            if (d > LR_P4_MAX_GIVE) d = LR_P4_MAX_GIVE;
+            e->p4.delta[2 * j] = e->p4.delta[2 * j + 1] = d;
+            sum += d;
+        }
+        // make the deltas sum to zero exactly: trim the largest takers / givers
+        for (int guard = 0; sum != 0 && guard < 64; ++guard) {
+            int pick = 0;
+            for (int j = 1; j < 7; ++j)
+                if (sum > 0 ? e->p4.delta[2 * j] > e->p4.delta[2 * pick] : e->p4.delta[2 * j] < e->p4.delta[2 * pick]) pick = j;
+            const int step = sum > 0 ? -1 : 1;
+            e->p4.delta[2 * pick] += step, e->p4.delta[2 * pick + 1] += step;
+            sum += step;
+        }
+        if (sum != 0) for (int j = 0; j < 14; ++j) e->p4.delta[j] = 0;
+    } else {
+        // two-chain kernel: 8 waves, two per SIMD (16 in its wide form, four per SIMD: the oldest-first pattern of the
+        // four-chain kernel - waves 0..3 / 4..7 take trips from 12..15 / 8..11, per 12 trips)
+        const bool wide2 = e->lay.reserved1 == 1024;
+        e->p4.n_slots = wide2 ? 16 : 8;
+        const int k_tot = (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64));
+        int d = (k_tot >= 12) ? (int)lrint((double)env2 * k_tot / 24.0) : 0;
+        if (d > LR_P4_MAX_GIVE) d = LR_P4_MAX_GIVE;
+        if (e->p4.n_slots == 8)
+            for (int j = 0; j < 4; ++j) e->p4.delta[j] = d, e->p4.delta[4 + j] = -d;
+        if (e->p4.n_slots == 16 && k_tot >= 6) {
+            static const char* envw = getenv("LR_P2W_SHARES");
+            int a = 5, b = 2;
+            if (envw) sscanf(envw, "%d,%d", &a, &b);
+            int da = (int)lrint((double)a * k_tot / 12.0), db = (int)lrint((double)b * k_tot / 12.0);
+            if (da > LR_P4_MAX_GIVE) da = LR_P4_MAX_GIVE;
+            if (db > LR_P4_MAX_GIVE) db = LR_P4_MAX_GIVE;
+            if (da > k_tot - 1) da = k_tot - 1;
+            if (db > k_tot - 1) db = k_tot - 1;
+            for (int j = 0; j < 4; ++j) e->p4.delta[j] = da, e->p4.delta[4 + j] = db, e->p4.delta[8 + j] = -db, e->p4.delta[12 + j] = -da;
+        }
+    }
+    // the takers' extra trips must stay inside the zero-filled spare behind the packed groups
+    const long long stride = (long long)e->p4.n_slots * 64;
+    const long long k_tot = (e->n8 + stride - 1) / stride;
+    int dmax = 0;
+    for (int j = 0; j < 16; ++j) dmax = e->p4.delta[j] > dmax ? e->p4.delta[j] : dmax;
+    if ((k_tot + dmax + 1) * stride > e->n8_alloc)
+        for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
+}
+
+int lr_pack_lineages(lr_engine* e, hipStream_t stream) {
+    const long long n = e->cfg.n_lineages;
+    if (n >= (1ll << 31)) return LR_ERR_SIZE;                         // lineage numbers are scanned as int32
+    char* tmp = e->ws + e->lay.pack_tmp;
+    int* run_start = (int*)tmp;
+    int* group_incl = (int*)(tmp + lr_align_up64(n * 4, 256));
+    char* scan_tmp = tmp + 2 * lr_align_up64(n * 4, 256);
+    size_t scan_bytes = lr_scan_tmp_bytes(n);
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    // group_incl doubles as the scans' input buffer: candidates -> run starts, flags -> group numbers
+    hipLaunchKernelGGL(lr_pack_runs_kernel, grid, blk, 0, stream, e->ts, n, e->cfg.t0, e->cfg.n_bins, group_incl);
+    hipError_t he = rocprim::inclusive_scan(scan_tmp, scan_bytes, (const int*)group_incl, run_start, (size_t)n, lr_max_op(), stream);
+    if (he != hipSuccess) return (int)he;
+    hipLaunchKernelGGL(lr_pack_flags_kernel, grid, blk, 0, stream, run_start, n, group_incl);
+    scan_bytes = lr_scan_tmp_bytes(n);
+    he = rocprim::inclusive_scan(scan_tmp, scan_bytes, (const int*)group_incl, group_incl, (size_t)n, rocprim::plus<int>(), stream);
+    if (he != hipSuccess) return (int)he;
+    int n_groups = 0;
+    he = hipMemcpyAsync(&n_groups, group_incl + (n - 1), sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(stream);
+    if (he != hipSuccess) return (int)he;
+    if (n_groups < 1 || (long long)n_groups + LR_IDX_SPARE > e->n8_alloc) return LR_ERR_ORDER;   // too many runs: unsorted input
+    e->n8 = n_groups;
+    lr_set_shares(e);
+    const bool general = e->plan.unit == LR_TAB_PAIRGEN;
+    // zero fill (a zero group = sentinel entries on both sides, contribution 0), then the groups
+    he = hipMemsetAsync(e->ws + e->lay.lineage_idx, 0, (size_t)e->n8_alloc * 16, stream);
+    if (he == hipSuccess && general) he = hipMemsetAsync(e->ws + e->lay.lineage_frac, 0, (size_t)e->n8_alloc * 16 * (LR_GRP / 2), stream);
+    if (he != hipSuccess) return (int)he;
+    bool any = false;
+    for (int j = 0; j < 16; ++j) any |= e->p4.delta[j] != 0;
+    hipLaunchKernelGGL(lr_pack_groups_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins, (const int*)run_start,
+                       (const int*)group_incl, any ? 1 : 0, (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64)), e->p4,
+                       (unsigned char*)(e->ws + e->lay.lineage_idx),
+                       general ? (unsigned int*)(e->ws + e->lay.lineage_frac) : nullptr, (long long)e->n8_alloc);
+    return (int)hipGetLastError();
+}

@@ -292,48 +292,62 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_unit_kernel(const dou
 }
 
 // ------------------------------------------------------------------------------------------
-// persistent engines: the lineages as packed table indices (lr_pack_lineages_kernel), tables resident in LDS
+// persistent engines: the lineages as packed groups (lr_pack.hip), pair tables resident in LDS
 // ------------------------------------------------------------------------------------------
-// Scan of all lineages against ONE pair table by `n_scan` threads (this thread is number `sid`): the inner loop
-// of the persistent engines.  8 lineages per 16-byte load, next load in flight while the current one is scored.
+#define LR_GRP 14      /* lineages per 16-byte group: byte 0 birth index, byte 1 count, bytes 2..15 death indices */
+
+// byte k (0..15) of a packed group as an LDS byte offset into a table of (1 << SH)-byte entries
+template <int SH>
+__device__ __forceinline__ unsigned int lr_grp_off(const uint4& w, int k) {
+    const unsigned int v = (k < 4) ? w.x : (k < 8 ? w.y : (k < 12 ? w.z : w.w));
+    const int sh = 8 * (k & 3) - SH;                                   // (v >> 8j) & 0xff, then << SH
+    const unsigned int m = 0xffu << SH;
+    return (sh >= 0 ? (v >> sh) : (v << -sh)) & m;
+}
+
+// Scan of `n8` groups against ONE pair table (unit resolution: 16-byte entries = the two chains' values) by `n_scan`
+// threads, this thread being number `sid`: the inner loop of the persistent engines.  Per group one 16-byte load (the
+// next one in flight while the current one is scored), ONE gather of the birth entry - it enters `count` times - and one
+// gather per lineage of its death entry: 15 ds_read_b128 and 31 fp64 operations for 14 lineages x 2 chains.
 template <int H, int UNROLL = 1>
 __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                      long long n8, long long sid, int n_scan, double* acc0_,
                                                      double* acc1_) {
     double acc0 = *acc0_, acc1 = *acc1_;
-    // 32-bit loop arithmetic (n8 = N / 8 < 2^31): a 64-bit compare and add per trip are two instructions each
+    // 32-bit loop arithmetic (fewer than 2^31 groups): a 64-bit compare and add per trip are two instructions each
     const int n = (int)n8;
     int i = (int)sid;
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     if (i < n) w = idx8[i];
-    // UNROLL = 2 saves the register rotation of the prefetched index word (+1 % on long scans) at the price of a dozen
-    // spills around the chain-step call, which the short-scan configurations feel: the four-chain kernel uses it
+    const char* ebase = lbase + H * 16;
 #pragma unroll UNROLL
     while (i < n) {
         const uint4 cur = w;
         const int nx = i + n_scan;
         if (nx < n) w = idx8[nx];
-        const unsigned int words[4] = {cur.x, cur.y, cur.z, cur.w};
+        const double2 S = *reinterpret_cast<const double2*>(lbase + lr_grp_off<4>(cur, 0));
+        const double cnt = (double)((cur.x >> 8) & 0xffu);
+        double2 E[LR_GRP];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned int v = words[k];
-            const double2 s0 = *reinterpret_cast<const double2*>(lbase + ((v << 4) & 0xff0u));
-            const double2 e0 = *reinterpret_cast<const double2*>(lbase + ((v >> 4) & 0xff0u) + H * 16);
-            const double2 s1 = *reinterpret_cast<const double2*>(lbase + ((v >> 12) & 0xff0u));
-            const double2 e1 = *reinterpret_cast<const double2*>(lbase + ((v >> 20) & 0xff0u) + H * 16);
-            acc0 += (s0.x + e0.x) + (s1.x + e1.x);
-            acc1 += (s0.y + e0.y) + (s1.y + e1.y);
-        }
+        for (int k = 0; k < LR_GRP; ++k) E[k] = *reinterpret_cast<const double2*>(ebase + lr_grp_off<4>(cur, k + 2));
+        // fixed pairwise tree over the group's death entries, then the birth entry `count` times
+        double t0[LR_GRP / 2], t1[LR_GRP / 2];
+#pragma unroll
+        for (int k = 0; k < LR_GRP / 2; ++k) t0[k] = E[2 * k].x + E[2 * k + 1].x, t1[k] = E[2 * k].y + E[2 * k + 1].y;
+        const double u0 = ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t0[4] + t0[5]) + t0[6]);
+        const double u1 = ((t1[0] + t1[1]) + (t1[2] + t1[3])) + ((t1[4] + t1[5]) + t1[6]);
+        acc0 += fma(cnt, S.x, u0);
+        acc1 += fma(cnt, S.y, u1);
         i = nx;
     }
     *acc0_ = acc0, *acc1_ = acc1;
 }
 
 // The same scan on GENERAL lineage times: pair tables in the LR_TAB_PAIRGEN layout (32-byte entries: values of the two
-// chains, then their slopes scaled by 2^-32), the lineages as packed table indices plus their in-bin fractions as
-// 32-bit fixed point.  frac: four arrays of uint4, `fstride` entries apart; array j holds (fs, fe', fs, fe') of
-// lineages 2j and 2j + 1 of every group, so each of the four loads is a fully coalesced 16-byte load.
-// Per (lineage, chain pair): four ds_read_b128, two conversions, eight fp64 operations.
+// chains, then their slopes scaled by 2^-32), the groups plus their lineages' in-bin fractions as 32-bit fixed point.
+// frac: LR_GRP / 2 arrays of uint4, `fstride` entries apart; array j holds (fs, fe', fs, fe') of lineages 2j and 2j + 1
+// of every group, so each of the loads is a fully coalesced 16-byte load.
+// Per group: 2 + 28 ds_read_b128; per (lineage, chain pair) two conversions and six fp64 operations.
 template <int H, int UNROLL = 1>
 __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                              const uint4* __restrict__ frac, long long fstride,
@@ -342,41 +356,45 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
     double acc0 = *acc0_, acc1 = *acc1_;
     const int n = (int)n8;
     int i = (int)sid;
-    uint4 w = make_uint4(0u, 0u, 0u, 0u), f0 = w, f1 = w, f2 = w, f3 = w;
-    if (i < n) w = idx8[i], f0 = frac[i], f1 = frac[i + fstride], f2 = frac[i + 2 * fstride], f3 = frac[i + 3 * fstride];
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n) w = idx8[i];
+    const char* ebase = lbase + H * 32;
 #pragma unroll UNROLL
     while (i < n) {
-        const uint4 cur = w, c0 = f0, c1 = f1, c2 = f2, c3 = f3;
-        const int nx = i + n_scan;
-        if (nx < n) w = idx8[nx], f0 = frac[nx], f1 = frac[nx + fstride], f2 = frac[nx + 2 * fstride], f3 = frac[nx + 3 * fstride];
-        const unsigned int words[4] = {cur.x, cur.y, cur.z, cur.w};
-        const uint4 fr[4] = {c0, c1, c2, c3};
+        const uint4 cur = w;
+        uint4 fr[LR_GRP / 2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned int v = words[k];
-            const unsigned int fq[4] = {fr[k].x, fr[k].y, fr[k].z, fr[k].w};
+        for (int j = 0; j < LR_GRP / 2; ++j) fr[j] = frac[i + j * fstride];
+        const int nx = i + n_scan;
+        if (nx < n) w = idx8[nx];
+        const char* pS = lbase + lr_grp_off<5>(cur, 0);
+        const double2 Sv = *reinterpret_cast<const double2*>(pS);
+        const double2 Ss = *reinterpret_cast<const double2*>(pS + 16);
+        const double cnt = (double)((cur.x >> 8) & 0xffu);
+        double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < LR_GRP / 2; ++j) {
+            const unsigned int fq[4] = {fr[j].x, fr[j].y, fr[j].z, fr[j].w};
+            double p0[2], p1[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const unsigned int vv = v >> (16 * h);
-                const char* pS = lbase + ((vv << 5) & 0x1fe0u);
-                const char* pE = lbase + ((vv >> 3) & 0x1fe0u) + H * 32;
-                const double2 Sv = *reinterpret_cast<const double2*>(pS);
-                const double2 Ss = *reinterpret_cast<const double2*>(pS + 16);
+                const char* pE = ebase + lr_grp_off<5>(cur, 2 * j + h + 2);
                 const double2 Ev = *reinterpret_cast<const double2*>(pE);
                 const double2 Es = *reinterpret_cast<const double2*>(pE + 16);
                 const double fs = (double)fq[2 * h], fe = (double)fq[2 * h + 1];
-                double t0 = Sv.x + Ev.x, t1 = Sv.y + Ev.y;
-                t0 = fma(fs, Ss.x, t0), t1 = fma(fs, Ss.y, t1);
-                t0 = fma(fe, Es.x, t0), t1 = fma(fe, Es.y, t1);
-                acc0 += t0, acc1 += t1;
+                p0[h] = fma(fs, Ss.x, fma(fe, Es.x, Ev.x));
+                p1[h] = fma(fs, Ss.y, fma(fe, Es.y, Ev.y));
             }
+            u0 += p0[0] + p0[1], u1 += p1[0] + p1[1];
         }
+        acc0 += fma(cnt, Sv.x, u0);
+        acc1 += fma(cnt, Sv.y, u1);
         i = nx;
     }
     *acc0_ = acc0, *acc1_ = acc1;
 }
 
-// what a persistent engine scans: packed indices and, on general times, the fractions behind them
+// what a persistent engine scans: packed groups and, on general times, the fractions behind them
 struct lr_packed_lineages {
     const uint4* idx8;
     const uint4* frac;      // nullptr for unit-resolution data

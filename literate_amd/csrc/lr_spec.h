@@ -22,16 +22,6 @@
 #include "lr_scan.h"
 #include "lr_step.h"
 
-#ifndef LR_SPEC_THREADS
-#define LR_SPEC_THREADS 768   /* 12 waves: 4 candidate + 8 scanner waves, 3 per SIMD = 168 VGPRs each */
-#endif
-#ifndef LR_SPEC_SCAN_UNROLL
-#define LR_SPEC_SCAN_UNROLL 2
-#endif
-#define LR_TEAM_MAX 8
-#define LR_SPEC_GRANULES 16      /* 8-byte granules reserved per block and parity: one 128-byte line */
-#define LR_SPEC_TIMEOUT_TICKS 200000000ull   /* 2 s of the 100 MHz wall clock */
-
 // one state "as accepted" together with the bookkeeping of the proposal that led to it, in LDS
 struct lr_set {
     double L[LR_ROW], M[LR_ROW], tL[LR_ROW], tM[LR_ROW];

@@ -211,14 +211,24 @@ __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk,
 
 // the chain step of the persistent kernel as a real call: its ~120 live registers then do not add to the scan
 // loop's, and both fit the 128-VGPR budget of 4 waves per SIMD without spilling
-__device__ __attribute__((noinline)) void lr_persist_step(const lr_step_args* a, int c, int lane,
-                                                          lr_seg_scratch* scratch, double* st_f64, int* st_i32,
-                                                          double lik, double2* table, int table_es) {
+// Every pointer is LDS-typed: the argument block (copied to LDS once per launch; reading it through the generic pointer
+// to global memory costs an L2 round trip per field), the per-wave scratch, the state rows and the pair table.
+typedef __attribute__((address_space(3))) double lr_lds_f64;
+typedef __attribute__((address_space(3))) int lr_lds_i32;
+__device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
+                                                          __attribute__((address_space(3))) lr_seg_scratch* scratch3,
+                                                          lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* table3,
+                                                          int table_es, lr_lds_f64* br3 /* [2][256]: br_length, log br_length */) {
+    const lr_step_args& a = *(const lr_step_args*)a3;
+    const double* br_lds = (const double*)br3;
     lr_chain_regs st;
-    lr_chain_load(st, st_f64, st_i32, lane);
-    if (a->cfg.sampler != 0) lr_dd_step_core(st, *a, 0, c, lane, lik, table, table_es);
-    else lr_chain_step_core(st, *a, 0, c, lane, scratch, lik, table, table_es);
-    lr_chain_store(st, st_f64, st_i32, lane);
+    lr_chain_load(st, (double*)st_f64, (int*)st_i32, lane);
+    if (a.cfg.sampler != 0)
+        lr_dd_step_core<true>(st, a, 0, c, lane, lik, reinterpret_cast<double2*>((double*)table3), table_es, br_lds);
+    else
+        lr_chain_step_core<true>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
+                                 table_es, br_lds, br_lds + 256);
+    lr_chain_store(st, (double*)st_f64, (int*)st_i32, lane);
 }
 
 // T = threads per block: 512 (two blocks share a CU) or, when there are no more blocks than CUs anyway (at most 512
@@ -235,7 +245,15 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
     // the two chains' state rows live in LDS between iterations (registers are needed by the step itself)
     __shared__ double st_f64[2][LR_STATE_ROWS * LR_ROW];
     __shared__ int st_i32[2][LR_ISTATE_ROWS * LR_ROW];
+    __shared__ lr_step_args a_lds;
+    __shared__ double br_lds[2][256];      // per-bin data constants of the table builders: br_length / DT / TREND, log br_length
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    if (tid < (int)(sizeof(lr_step_args) / 4)) reinterpret_cast<int*>(&a_lds)[tid] = reinterpret_cast<const int*>(ap)[tid];
+    if (tid < 256) {
+        const bool in = tid < ap->cfg.n_bins;
+        br_lds[0][tid] = (in && ap->br_length) ? ap->br_length[tid] : 0.0;
+        br_lds[1][tid] = in ? ap->log_br[tid] : 0.0;
+    }
     const int c0 = blockIdx.x * 2;
     const int c = c0 + wave;
     const bool stepper = (wave < 2) && (c < a.cfg.n_chains);
@@ -285,8 +303,10 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
             double lik = 0.0;
 #pragma unroll
             for (int w2 = 0; w2 < T / LR_WAVE; ++w2) lik += red[w2][wave];
-            lr_persist_step(ap, c, lane, &scratch[wave], st_f64[wave], st_i32[wave], lik,
-                            reinterpret_cast<double2*>(reinterpret_cast<double*>(tab) + wave), 2);
+            lr_persist_step((const __attribute__((address_space(3))) lr_step_args*)&a_lds, c, lane,
+                            (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave], (lr_lds_f64*)st_f64[wave],
+                            (lr_lds_i32*)st_i32[wave], lik, (lr_lds_f64*)(reinterpret_cast<double*>(tab) + wave), 2,
+                            (lr_lds_f64*)&br_lds[0][0]);
         }
         __syncthreads();  // new tables ready
 #ifdef LR_DIAG
@@ -332,7 +352,15 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     __shared__ lr_seg_scratch scratch[2];
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
     __shared__ int st_i32[4][LR_ISTATE_ROWS * LR_ROW];
+    __shared__ lr_step_args a_lds;
+    __shared__ double br_lds[2][256];      // per-bin data constants of the table builders: br_length / DT / TREND, log br_length
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    if (tid < (int)(sizeof(lr_step_args) / 4)) reinterpret_cast<int*>(&a_lds)[tid] = reinterpret_cast<const int*>(ap)[tid];
+    if (tid < 256) {
+        const bool in = tid < ap->cfg.n_bins;
+        br_lds[0][tid] = (in && ap->br_length) ? ap->br_length[tid] : 0.0;
+        br_lds[1][tid] = in ? ap->log_br[tid] : 0.0;
+    }
     const int c0 = blockIdx.x * 4;
     const int C = a.cfg.n_chains;
     if (wave < 4 && c0 + wave < C) {
@@ -364,7 +392,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     // prologue: pair 0's pending proposal is scanned so that phase A can step it
     if (scanner) {
         double s0 = 0.0, s1 = 0.0;
-        lr_persist_scan<H, GENERAL, GENERAL ? 1 : 2>(reinterpret_cast<const char*>(tab[0]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
+        lr_persist_scan<H, GENERAL, 1>(reinterpret_cast<const char*>(tab[0]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
         s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
         if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
     }
@@ -378,7 +406,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
 #ifdef LR_DIAG
                 const unsigned long long dq0 = wall_clock64();
 #endif
-                lr_persist_scan<H, GENERAL, GENERAL ? 1 : 2>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
+                lr_persist_scan<H, GENERAL, 1>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
 #ifdef LR_DIAG
                 if (lane == 0 && blockIdx.x < 64) atomicAdd(&lr_diag_step[20000 + blockIdx.x * 16 + wave], wall_clock64() - dq0);
 #endif
@@ -390,8 +418,10 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
                     double lik = 0.0;
 #pragma unroll
                     for (int w2 = 2; w2 < NW; ++w2) lik += red[ph][w2][wave];
-                    lr_persist_step(ap, c, lane, &scratch[wave], st_f64[2 * ph + wave], st_i32[2 * ph + wave], lik,
-                                    reinterpret_cast<double2*>(reinterpret_cast<double*>(tab[ph]) + wave), ES);
+                    lr_persist_step((const __attribute__((address_space(3))) lr_step_args*)&a_lds, c, lane,
+                                    (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave],
+                                    (lr_lds_f64*)st_f64[2 * ph + wave], (lr_lds_i32*)st_i32[2 * ph + wave], lik,
+                                    (lr_lds_f64*)(reinterpret_cast<double*>(tab[ph]) + wave), ES, (lr_lds_f64*)&br_lds[0][0]);
                 }
             }
             __syncthreads();

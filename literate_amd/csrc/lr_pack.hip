@@ -134,7 +134,9 @@ static void lr_set_shares(lr_engine* e) {
         e->p4.n_slots = 8;       // speculative kernel: plain layout, every scanner wave strides over its block's slice
     } else if (e->lay.persistent == 2) {
         e->p4.n_slots = 14;
-        int base[7] = {6, 6, 2, 0, -2, -6, -6};
+        // (with 14-lineage groups a scan is ~8 trips of cfg4 and equal shares measure as fast as any: the default is
+        // equal; the knob stays for experiments)
+        int base[7] = {0, 0, 0, 0, 0, 0, 0};
         if (env) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
         const int k_tot = (int)((e->n8 + 895) / 896);
         int sum = 0;

@@ -590,9 +590,11 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
 // (lik_sum, without the model constant), write the trace row, draw the next proposal and build its lookup
 // tables at `table` (global memory or LDS; see lr_chain_table for the addressing).
 // mode: 0 = regular step, 1 = finish init (adopt the evaluated initial state, then propose iteration 0)
+template <bool LDS_CONSTS = false>
 __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
                                                    lr_seg_scratch* scratch_p, double lik_sum, double2* table,
-                                                   int table_es = 2) {
+                                                   int table_es = 2, const double* br_lds = nullptr,
+                                                   const double* logbr_lds = nullptr) {
     const lr_mcmc_config& cfg = a.cfg;
     const double sc = st.sc;
     const int isc = st.isc;
@@ -650,7 +652,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
 
     // ---- propose iteration `it` (LRF:234-304) ----
     lr_rj_prop p;
-    lr_propose_rj(a, c, lane, scratch_p, it, s, p, table, table_es);
+    lr_propose_rj<LDS_CONSTS>(a, c, lane, scratch_p, it, s, p, table, table_es, nullptr, br_lds, logbr_lds);
 
     // ---- back into the state registers ----
     st.pL = s.L, st.pM = s.M, st.ptL = s.tL, st.ptM = s.tM, st.peL = s.eL, st.peM = s.eM;
@@ -800,8 +802,10 @@ __device__ __forceinline__ void lr_dd_write_trace_row(const lr_step_args& a, int
     for (int j = lane; j < LR_TRACE_W; j += LR_WAVE) row[j] = (j == lane) ? h : __longlong_as_double(0x7ff8000000000000LL);
 }
 
+template <bool LDS_CONSTS = false>
 __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
-                                                double lik_sum, double2* table, int table_es = 2) {
+                                                double lik_sum, double2* table, int table_es = 2,
+                                                const double* aux_lds = nullptr) {
     const lr_mcmc_config& cfg = a.cfg;
     const bool trend = cfg.sampler == 2;
     const int npar = trend ? LR_TR_NPAR : LR_DD_NPAR;
@@ -833,7 +837,7 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
     }
     // ---- propose iteration `it` ----
     lr_dd_prop p;
-    const double P = lr_propose_dd(a, c, lane, it, A, p, table, table_es);
+    const double P = lr_propose_dd<LDS_CONSTS>(a, c, lane, it, A, p, table, table_es, aux_lds);
     st.L = A, st.pL = P;
     {
         double so = 0.0;

@@ -6,19 +6,24 @@ LRF = LiteRateForward.py in /root/reference).  Where the reference's functions r
 globals (`sp_events_bin`, `br_length_bin`, `model_BDI`, ... LRF:150-156) this module keeps the
 same globals; `bind_lineages()` fills them from the data, as the CLI body does (LRF:515-577).
 """
-import argparse
-import random
-from warnings import warn
-
+# The reference's callers do `from literate_library import *` (DDRate.py:15, trend_rate.py) and rely on the names
+# its own import block brings along (lib:8-21): numpy's namespace, np, scipy, stats, pd, csv, random, warn ...  So no
+# __all__ here, and the same names at module level.
+import argparse, os, sys   # noqa: E401
+from numpy import *        # noqa: F401,F403
 import numpy as np
+import csv                 # noqa: F401
+import random
+import scipy.stats         # noqa: F401
+from scipy import stats    # noqa: F401
+from scipy.special import gamma, gdtr, gdtrix, betainc   # noqa: F401
+from scipy.special import beta as f_beta                 # noqa: F401
+from scipy.special import gammaln, betaln, xlogy, xlog1py
+from warnings import warn
+import pandas as pd        # noqa: F401
 
 from . import ops
-
-__all__ = ["calcHPD", "get_br", "precompute_events", "create_bins", "get_rate_index", "BD_lik_Keiding",
-           "BDI_partial_lik", "BD_partial_lik", "get_BDlik", "update_multiplier_proposal",
-           "update_multiplier_proposal_vec", "update_multiplier_freq", "add_shift_RJ_weighted_mean",
-           "remove_shift_RJ_weighted_mean", "prior_gamma", "Poisson_prior", "parse_ts_te", "core_arguments",
-           "set_seed", "calculate_r_squared", "print_empirical_rates", "random_choice", "bind_lineages"]
+import builtins as _py      # the star import above shadows max / min / round / ... with numpy's, as in the reference
 
 # ---- module globals the likelihood operators close over (LRF:150-156, 566-574) ----
 ts = te = None
@@ -62,7 +67,7 @@ def bind_lineages(ts_, te_, model=0):
 def calcHPD(data, level=0.95):
     assert (0 < level < 1)
     d = np.sort(np.asarray(list(data), dtype=float))
-    nIn = int(round(level * len(d)))
+    nIn = int(_py.round(level * len(d)))
     if nIn < 2:
         raise RuntimeError("not enough data")
     i = int(np.argmin(d[nIn - 1:] - d[:len(d) - nIn + 1]))
@@ -143,7 +148,7 @@ def get_BDlik(times, rates, par):
 # ---- proposals: numpy draws in the reference's order, scored on the device ----
 def _score(rates, times, move, index, draws):
     k = len(rates)
-    kmax = max(k + 1, 2)
+    kmax = _py.max(k + 1, 2)
     R = np.zeros((1, kmax)); T = np.zeros((1, kmax + 1)); D = np.zeros((1, 2 * kmax))
     R[0, :k] = rates
     if times is not None:
@@ -162,7 +167,7 @@ def update_multiplier_proposal_vec(q, d=1.1, f=0.75):
 
     def fill(D, kmax):
         D[:len(q)], D[kmax:kmax + len(q)] = ff, u
-    R = np.zeros((1, max(len(q) + 1, 2))); R[0, :len(q)] = q
+    R = np.zeros((1, _py.max(len(q) + 1, 2))); R[0, :len(q)] = q
     D = np.zeros((1, 2 * R.shape[1])); fill(D[0], R.shape[1])
     r, _, _, s = ops.rj_propose_score(R, np.zeros((1, R.shape[1] + 1)), [len(q)], [0], [0], D, d)
     return _host(r)[0, :len(q)], float(s[0])
@@ -195,17 +200,108 @@ def remove_shift_RJ_weighted_mean(rates, times):
     return _score(rates, times, 2, idx, lambda D, kmax: None)
 
 
-# ---- priors (LRF:198-202) ----
-def prior_gamma(L, a=2, b=2):
+# ---- proposals on scalars / vectors that never touch the lineages: host numpy, the reference's draw order (lib:124-154) ----
+def update_sliding_win(i, m=0, M=1, d=0.05):
+    ii = i + (np.random.random() - .5) * d
+    if ii > M:
+        ii = M - (ii - M)
+    if m == 0:
+        ii = abs(ii)
+    return ii
+
+
+def update_sliding_win_log(i, m=1, M=np.e, d=0.05):
+    ii = i + (np.random.random() - .5) * d
+    if ii > M:
+        ii = M - (ii - M)
+    elif ii < m:
+        ii = m + (m - ii)
+    return ii
+
+
+def update_normal_nobound(i, d=0.05):
+    return i + np.random.normal(0, d)
+
+
+def update_normal_nobound_vec(i, d=0.05, f=.75):
+    S = np.shape(i)
+    ff = np.random.binomial(1, f, S)
+    m = np.random.normal(0, d, S)
+    m[ff == 0] = 0.
+    return i + m, 0
+
+
+def approx_log_fact(n):
+    """Stirling's series as the reference writes it (lib:61-63)."""
+    return np.log(np.sqrt((2 * n + 1. / 3) * np.pi)) + n * np.log(n) - n
+
+
+def get_log_factorial(n):
+    """lib:65-67; below 100 the reference takes log(n!) from scipy.misc.factorial, which no longer exists in scipy
+    (SURVEY 8c): log Gamma(n + 1) is that value."""
+    if n < 100:
+        return float(gammaln(n + 1.0))
+    return approx_log_fact(n)
+
+
+def logPoisson_pmf(x, l):
+    return (x * np.log(l) - l) - get_log_factorial(x)
+
+
+def update_poisson_proposal(kt):
+    ktp = np.random.poisson(kt)
+    if ktp == 0:
+        return kt, 0
+    return ktp, logPoisson_pmf(kt, ktp) - logPoisson_pmf(ktp, kt)
+
+
+# ---- priors.  lib's forms (lib:178-193: log-densities, element-wise) under the reference's names; the summed
+# Gamma / Poisson priors of the CLI (LRF:198-202) run on the device under their own names ----
+def prior_gamma(x, a, s, l):
+    """scipy.stats.gamma.logpdf(x, a, scale=s, loc=l) in closed form (mean = a*s)."""
+    y = (np.asarray(x, dtype=float) - l) / s
+    with np.errstate(all="ignore"):
+        out = np.where(y >= 0, xlogy(a - 1.0, y) - y - gammaln(a) - np.log(s), -np.inf)
+    return out if np.ndim(x) else np.float64(out)
+
+
+def prior_norm(x, l=0, s=1):
+    y = (np.asarray(x, dtype=float) - l) / s
+    out = -0.5 * y * y - 0.5 * np.log(2 * np.pi) - np.log(s)
+    return out if np.ndim(x) else np.float64(out)
+
+
+def prior_beta(x, a, b):
+    x_ = np.asarray(x, dtype=float)
+    with np.errstate(all="ignore"):
+        out = np.where((x_ >= 0) & (x_ <= 1), xlog1py(b - 1.0, -x_) + xlogy(a - 1.0, x_) - betaln(a, b), -np.inf)
+    return out if np.ndim(x) else np.float64(out)
+
+
+def prior_sym_beta(x, a):
+    return prior_beta(x, a, a)
+
+
+def prior_gamma_LRF(L, a=2, b=2):
+    """LiteRateForward.py's prior_gamma(L, a, b) (LRF:201-202): summed Gamma(a, rate b) log-density, on the device."""
     L = np.atleast_1d(np.asarray(L, dtype=float))
-    R = np.ones((1, max(len(L), 1))); R[0, :len(L)] = L
+    R = np.ones((1, _py.max(len(L), 1))); R[0, :len(L)] = L
     return float(ops.log_priors(R, [len(L)], a, [b])[0])
 
 
 def Poisson_prior(k, rate):
-    R = np.ones((1, max(k, 1)))
+    """LRF:198-199 (k = number of rates), on the device."""
+    R = np.ones((1, _py.max(k, 1)))
     base = ops.log_priors(R, [k], 2.0, [1.0])
     return float((ops.log_priors(R, [k], 2.0, [1.0], [rate]) - base)[0])
+
+
+def print_R_vec(name, v):
+    """lib:43-58: an R vector literal, NaN as NA."""
+    vals = ["NA" if (isinstance(x, float) and np.isnan(x)) else x for x in v] if len(v) > 2 else list(v)
+    if len(v) <= 2:
+        return "%s=c(%s)" % (name, ",".join(str(x) for x in vals))
+    return "%s=c(%s, %s%s)" % (name, vals[0], "".join("%s," % x for x in vals[1:-1]), vals[-1])
 
 
 # ---- set-up (lib:196-229, 260-308) ----

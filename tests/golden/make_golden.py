@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,shipped,cfg1,trendtraj,traj]
+    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,shipped,cfg1,trendtraj,traj,library,flags,marginal]
     python tests/golden/make_chains.py <dataset> <model> <n> <s> <chains>   # long reference chains
 
 The reference is executed unmodified: LiteRateForward.py / DDRate.py through
@@ -506,13 +506,158 @@ def make_trajectories(work):
     np.savez_compressed(os.path.join(HERE, "trajectories.npz"), **out)
 
 
+def make_library_surface(work):
+    """The host-side names of literate_library.py that the reference's own callers import (DDRate.py:110-122, 195-207):
+    priors on grids, the proposal helpers under fixed numpy seeds (outputs only; the functions consume np.random in the
+    reference's call order, so a restatement seeded the same way must reproduce them bit for bit)."""
+    sys.path.insert(0, REF)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            import literate_library as ref
+    finally:
+        sys.path.pop(0)
+    rng = np.random.default_rng(31)
+    out = {"prior_gamma": [], "prior_norm": [], "prior_beta": [], "prior_sym_beta": [], "logPoisson_pmf": [],
+           "approx_log_fact": [], "seeded": []}
+    for _ in range(40):
+        x = float(rng.uniform(-1, 30)); a = float(rng.uniform(0.5, 5)); sc = float(rng.uniform(0.1, 12)); loc = float(rng.choice([0.0, 0.001, 1.5]))
+        with np.errstate(all="ignore"):
+            out["prior_gamma"].append(dict(x=x, a=a, s=sc, l=loc, out=float(ref.prior_gamma(x, a, sc, loc))))
+        out["prior_norm"].append(dict(x=x, l=loc, s=sc, out=float(ref.prior_norm(x, loc, sc))))
+        u = float(rng.uniform(-0.2, 1.2)); b = float(rng.uniform(0.5, 12))
+        with np.errstate(all="ignore"):
+            out["prior_beta"].append(dict(x=u, a=a, b=b, out=float(ref.prior_beta(u, a, b))))
+            out["prior_sym_beta"].append(dict(x=u, a=a, out=float(ref.prior_sym_beta(u, a))))
+    xs = np.array([0.3, 2.0, 7.5])
+    out["prior_gamma"].append(dict(x=xs.tolist(), a=1.0, s=10.0, l=0.0, out=ref.prior_gamma(xs, a=1, s=10, l=0).tolist()))
+    out["prior_norm"].append(dict(x=xs.tolist(), l=0.0, s=1.0, out=ref.prior_norm(xs).tolist()))
+    for n in (100, 150, 1000):                       # (n < 100 needs scipy.misc.factorial, gone from scipy: SURVEY 8c)
+        out["approx_log_fact"].append(dict(n=n, out=float(ref.approx_log_fact(n))))
+        out["logPoisson_pmf"].append(dict(x=n, l=87.5, out=float(ref.logPoisson_pmf(n, 87.5))))
+    for seed in range(12):
+        rec = dict(seed=seed)
+        np.random.seed(seed)
+        rec["sliding_win"] = float(ref.update_sliding_win(0.4 + seed, m=0, M=6.0, d=1.5))
+        rec["sliding_win_m1"] = float(ref.update_sliding_win(0.98, m=0.5, M=1.0, d=0.2))
+        rec["sliding_win_log"] = float(ref.update_sliding_win_log(1.05 + 0.1 * seed, m=1, M=np.e, d=0.5))
+        rec["normal_nobound"] = float(ref.update_normal_nobound(1.5, d=0.2))
+        v, h = ref.update_normal_nobound_vec(np.array([.1, .2, .3, .4, .5, .6]), d=0.001, f=np.array([0, 0, .5, .5, 0, 0]))
+        rec["normal_nobound_vec"] = [np.asarray(v).tolist(), float(h)]
+        q, U = ref.update_multiplier_proposal_vec(np.array([.5, 1.5, 3., 10., 2e4, .1, 1., 1.]), d=1.1, f=np.array([1, 1, 0, 1, 1, 1, 1, 1]) / 7.)
+        rec["multiplier_vec"] = [np.asarray(q).tolist(), float(U)]
+        q, U = ref.update_multiplier_proposal(0.37, d=1.2)
+        rec["multiplier"] = [float(q), float(U)]
+        out["seeded"].append(rec)
+    with open(os.path.join(HERE, "library_surface.json"), "w") as f:
+        json.dump(out, f)
+    print("library surface:", {k: len(v) for k, v in out.items()})
+
+
+def make_flag_paths(work):
+    """CLI flag paths around the hot loop: -rev_se, -first_year / -last_year (parsed arrays and unit-bin
+    statistics through the reference body with -n 0) and -pyrate_output (a short seeded run: the three logs)."""
+    out = {}
+    rel, flags = DATASETS["metal_bands"]
+    raw = np.genfromtxt(os.path.join(REF, rel), skip_header=1)
+    for tag, extra in (("last_year", ["-last_year", "2010"]), ("first_last", ["-first_year", "1900", "-last_year", "2005"]),
+                       ("first_year_filtering", ["-first_year", "1985"])):
+        d = tempfile.mkdtemp(dir=work)
+        try:
+            g = run_cli("LiteRateForward.py", rel, flags + ["-n", "0", "-seed", "1"] + extra, d)
+            out["%s/ts" % tag], out["%s/te" % tag] = np.asarray(g["ts"], float), np.asarray(g["te"], float)
+            out["%s/sp" % tag] = np.asarray(g["sp_events_bin"]); out["%s/ex" % tag] = np.asarray(g["ex_events_bin"])
+            out["%s/br" % tag] = np.asarray(g["br_length_bin"], float)
+            out["%s/error" % tag] = np.array("")
+        except Exception as ex:                      # LRF:460-461 filters te with the already filtered ts
+            out["%s/error" % tag] = np.array(type(ex).__name__)
+        out["%s/flags" % tag] = np.array(extra)
+        print(tag, str(out["%s/error" % tag]) or "ok")
+    # -rev_se 1: the same TBP data with the two time columns swapped in the file
+    rel_t, flags_t = DATASETS["example_TBP"]
+    d = tempfile.mkdtemp(dir=work)
+    src = os.path.join(REF, rel_t)
+    lines = open(src).read().splitlines()
+    swapped = os.path.join(d, "swapped.txt")
+    rows = [l.split() for l in lines[1:] if l.strip()]
+    with open(swapped, "w") as f:                    # three columns (id, te, ts): -rev_se only acts on three-column input
+        f.write("species\tte\tts\n")
+        for r in rows:
+            f.write("\t".join([r[1], r[3], r[2]]) + "\n")
+    old_ds = dict(DATASETS)
+    # run_cli copies REF-relative paths: call the body directly here
+    argv = ["LiteRateForward.py", "-d", swapped, "-TBP", "-rev_se", "1", "-n", "0", "-seed", "1"]
+    old_argv, old_path = sys.argv, list(sys.path)
+    sys.argv = argv
+    sys.path.insert(0, REF)
+    try:
+        with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+            warnings.simplefilter("ignore")
+            g = runpy.run_path(os.path.join(REF, "LiteRateForward.py"))
+    finally:
+        sys.argv, sys.path[:] = old_argv, old_path
+    out["rev_se/file_cols"] = np.array([[float(r[2]), float(r[3])] for r in rows])      # (ts, te) as the shipped file has them
+    out["rev_se/ts"], out["rev_se/te"] = np.asarray(g["ts"], float), np.asarray(g["te"], float)
+    out["rev_se/sp"], out["rev_se/ex"] = np.asarray(g["sp_events_bin"]), np.asarray(g["ex_events_bin"])
+    out["rev_se/br"] = np.asarray(g["br_length_bin"], float)
+    # -pyrate_output: full reference run, logs kept
+    d = tempfile.mkdtemp(dir=work)
+    dst = os.path.join(d, os.path.basename(rel_t))
+    shutil.copy(src, dst)
+    seed, n, s_freq = 21, 3000, 10
+    cmd = [sys.executable, "-B", os.path.join(REF, "LiteRateForward.py"), "-d", dst, "-n", str(n), "-s", str(s_freq),
+           "-p", str(10**9), "-seed", str(seed), "-model_BDI", "0", "-pyrate_output"] + flags_t
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                   env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    stem = os.path.splitext(os.path.basename(rel_t))[0] + "_BD"
+    mc, sp, ex = parse_logs(os.path.join(d, "literate_mcmc_logs"), stem)
+    out["pyrate/mcmc"], out["pyrate/sp"], out["pyrate/ex"] = mc, pack_rows(sp), pack_rows(ex)
+    out["pyrate/meta"] = np.array([seed, n, s_freq], dtype=float)
+    out["pyrate/header"] = np.array(open(os.path.join(d, "literate_mcmc_logs", stem + "_mcmc.log")).readline().rstrip("\n"))
+    print("pyrate_output", mc.shape)
+    np.savez_compressed(os.path.join(HERE, "flag_paths.npz"), **out)
+
+
+def make_marginal_rates(work):
+    """The parity metric's definition: get_marginal_rates (plotRJforward.v3.py:92-139) executed on the shipped
+    metal_bands sp / ex rate logs.  The function body is compiled from the reference file at run time (nothing of it
+    is stored); the fixture holds its outputs."""
+    path = os.path.join(REF, "plotRJforward.v3.py")
+    src = open(path).read().splitlines()
+    first = next(i for i, l in enumerate(src) if l.startswith("def get_marginal_rates("))
+    last = next(i for i in range(first + 1, len(src)) if src[i].startswith("def ") or (src[i] and not src[i][0].isspace() and not src[i].startswith("#")))
+    sys.path.insert(0, REF)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            import literate_library as ref
+    finally:
+        sys.path.pop(0)
+    ns = {"np": np, "calcHPD": ref.calcHPD}
+    exec(compile("\n".join(src[first:last]), path, "exec"), ns)
+    base = os.path.join(REF, "example_data/metal_bands/single_run")
+    mc = np.loadtxt(os.path.join(base, "metal_bands_1_mcmc.log"), skiprows=1)
+    start_age, end_age = float(np.max(mc[:, 9])), float(np.min(mc[:, 8]))      # as plotRJforward.v3.py reads them (max age, min age)
+    out = {"ages": np.array([start_age, end_age])}
+    for kind in ("sp", "ex"):
+        f = os.path.join(base, "metal_bands_1_%s_rates.log" % kind)
+        res = ns["get_marginal_rates"](f, start_age, end_age, nbins=0, burnin=0.2)
+        out[kind + "/time_frames"], out[kind + "/mean"] = np.asarray(res[0], float), np.asarray(res[1], float)
+        out[kind + "/hpd_lo"], out[kind + "/hpd_hi"] = np.asarray(res[2], float), np.asarray(res[3], float)
+        out[kind + "/n_samples"] = np.array(res[5])
+        rows = [np.array(l.split(), float) for l in open(f)]
+        out[kind + "/rows"] = pack_rows(rows)
+        print("marginal", kind, res[1].shape, res[5])
+    np.savez_compressed(os.path.join(HERE, "marginal_rates.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="lr_golden_")
     steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps, ddtraj=make_dd_trajectories, shipped=make_shipped, cfg1=make_cfg1, trendtraj=make_trend_trajectories,
-                 traj=make_trajectories)
+                 traj=make_trajectories, library=make_library_surface, flags=make_flag_paths, marginal=make_marginal_rates)
     for name, fn in steps.items():
         if args.only and name not in args.only.split(","):
             continue

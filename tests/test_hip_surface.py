@@ -85,7 +85,7 @@ def test_library_proposals_consume_numpy_stream_like_reference(G, golden_dir):
         q, h = ll.update_multiplier_proposal(r["q"], 1.1)
         assert q == pytest.approx(r["out"], rel=1e-14) and h == pytest.approx(r["hastings"], rel=1e-12, abs=1e-15)
     for r in P["priors"]["gamma"][:8]:
-        assert ll.prior_gamma(np.array(r["x"]), r["a"], r["b"]) == pytest.approx(r["out"], rel=1e-12, abs=1e-12)
+        assert ll.prior_gamma_LRF(np.array(r["x"]), r["a"], r["b"]) == pytest.approx(r["out"], rel=1e-12, abs=1e-12)
     for r in P["priors"]["poisson"][:20]:
         assert ll.Poisson_prior(r["k"], r["rate"]) == pytest.approx(r["out"], rel=1e-11, abs=1e-11)
 

@@ -27,14 +27,26 @@ def test_library_exports_every_declared_symbol():
     cfg = _hip.McmcConfig(n_lineages=100000, n_bins=128, n_chains=1024, model=0, s_freq=100, n_trace_slots=10,
                           t0=0.0, start_time=0.0, end_time=128.5, seed=1)
     lay = _hip.McmcLayout()
+    # general lineage times: the four-chain persistent kernel on pair-general tables (32-bit fixed-point fractions) ...
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
+    assert lay.persistent == 2 and lay.table_mode == 2 and lay.chains_per_block == 4 and lay.table_stride == 2 * 136
+    assert lay.lineage_frac > lay.lineage_idx > 0 and lay.pack_tmp > lay.lineage_frac
+    # ... or, forced, the launch-based engine on chain-major tables with fp64 fractions
+    cfg.engine_mode = 1
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
+    assert lay.persistent == 0 and lay.table_mode == 0
     assert lay.chains_per_block == 8 and lay.table_stride == 2 * 136 and lay.trace_width == _hip.LR_TRACE_W
     assert lay.total_bytes > lay.trace > lay.partials > lay.tables > lay.bin_consts > lay.state_i32 > 0
     assert lay.n_parts == 2 and lay.pipelined == 1
+    cfg.engine_mode = 0
     cfg.unit_resolution, cfg.frac_death = 1, 0.5                  # unit-resolution tables: 8-byte entries, 16 chains/block
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
     assert lay.chains_per_block == 16 and lay.table_stride == 136 and lay.pipelined == 1
-    assert lay.persistent == 2 and lay.lineage_idx > 0           # auto: four-chain persistent kernel for 1024 chains x 100k
+    assert lay.persistent == 2 and lay.lineage_idx > 0 and lay.table_mode == 1   # auto: four-chain kernel for 1024 chains x 100k
+    cfg.n_chains = 128                                            # a 128-chain shard: speculative kernel, a team of 4 CUs per pair
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
+    assert lay.persistent == 3 and lay.team_blocks == 4 and lay.xchg > 0 and lay.reserved1 == 768
+    cfg.n_chains = 1024
     cfg.engine_mode = 1
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0
     cfg.engine_mode, cfg.n_chains, cfg.n_lineages = 0, 16, 10_000_000   # few chains, huge input: tiled launches

@@ -289,6 +289,54 @@ def test_cfg3_synthetic_10k_lineages_256_chains(G):
     eng.close()
 
 
+@pytest.mark.parametrize("engine,C,kw", [("spec", 12, {}), ("spec", 128, {}), ("persistent2", 24, {}), ("persistent4", 24, {}),
+                                          ("spec", 6, dict(general=True))])
+def test_long_inputs_and_few_chain_shards_keep_parity(engine, C, kw):
+    """1.3 million lineages (the advisor's out-of-bounds case of round 1: more than 136 trips per scanner wave) and the
+    128-chain shard of BASELINE.json configs[3] (1024 chains over 8 GPUs) under every persistent kernel: the accepted
+    log-likelihood every chain carries after a run must equal an independent evaluation of its accepted state - by
+    lr_bd_loglik_batch (another kernel) for all chains and by the oracle's binned form for a sample; one chain also
+    walks the oracle loop's trajectory."""
+    from literate_amd import ops, synth
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import literate_oracle as lo
+    from oracle import mcmc_oracle as mo
+    general = kw.get("general", False)
+    n_lin = 100_000 if C == 128 else 1_300_000
+    ts, te, _ = synth.make_lineages(n_lin, n_bins=128, n_shifts=20, seed=4)
+    if general:
+        rng = np.random.default_rng(9)
+        grid = lambda x: np.round(x * 2.0 ** 32) / 2.0 ** 32
+        ts = ts + grid(rng.uniform(0, 0.999, n_lin))
+        te = np.maximum(np.ceil(te) - 1.0 + grid(rng.uniform(1e-3, 0.999, n_lin)), ts + 0.0078125)
+    n_it, seed = 40, 77
+    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine)
+    assert eng.layout.persistent == {"spec": 3, "persistent2": 1, "persistent4": 2}[engine]
+    if engine == "spec":
+        assert eng.layout.team_blocks == (4 if C == 128 else 8)
+    assert eng.layout.table_mode == (2 if general else 1)
+    eng.init(); eng.steps(25); eng.steps(n_it - 25)
+    tr = eng.trace_rows()
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it) and np.all(np.isfinite(snap["likA"]))
+    t0, sp, ex, br = lo.bin_events_cli(ts, te)
+    n_bins = eng.n_bins
+    lam = np.stack([snap["L"][c][lo.get_rate_index(np.floor(snap["tL"][c]), n_bins)] for c in range(C)])
+    mu = np.stack([snap["M"][c][lo.get_rate_index(np.floor(snap["tM"][c]), n_bins)] for c in range(C)])
+    lik = ops.bd_loglik_batch(eng.ts, eng.te, eng.t0, lam, mu, 0, br_length=br).cpu().numpy()
+    assert np.allclose(lik, snap["likA"], rtol=1e-9)
+    stats = dict(sp=sp, ex=ex, br=br)
+    for c in range(0, C, max(1, C // 5)):
+        assert lo.calc_likelihood(0, lam[c], mu[c], stats) == pytest.approx(snap["likA"][c], rel=1e-9)
+    c = C - 1
+    with np.errstate(all="ignore"):
+        ref = mo.run_mcmc(stats, ts.min(), te.max(), mo.Settings(model_BDI=0), mo.PhiloxDraws(seed, c), n_it, 1, k_max=32)
+    for i in range(n_it):
+        head, s_row, e_row = split_trace_row(tr[i, c])
+        assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9), (c, i)
+    eng.close()
+
+
 def test_cfg4_full_size_1024_chains_100k_lineages():
     """BASELINE.json configs[3] at FULL size on one GPU (the bench workload: 1024 chains x 100k lineages, the
     four-chain persistent kernel).  (i) chains from the first / a middle / the last block walk the oracle loop's

@@ -88,7 +88,12 @@ def make_engine(name, ts, te, model, chains, chain_offset, s_freq, n_slots, engi
 def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
     """LDS-roofline figures of `n_iters` iterations that took `kernel_ms` of device time."""
     unit = bool(eng.unit_resolution)
-    lds_bytes_per_eval = 16 if unit else 32          # two 8-byte / two 16-byte table entries per (lineage, chain)
+    if eng.layout.persistent:
+        # persistent engines: groups of 14 lineages of one birth bin (lr_pack.hip): per group and chain PAIR one gather of the
+        # birth entry + 14 of the death entries, 16 B each (unit resolution) or 32 B each (general times)
+        lds_bytes_per_eval = (1 + 14) * (16 if unit else 32) / (14 * 2.0)
+    else:
+        lds_bytes_per_eval = 16 if unit else 32      # launch-based scan: two 8-byte / two 16-byte entries per (lineage, chain)
     evals = float(n_iters) * n_lin * chains
     achieved = evals * lds_bytes_per_eval / (kernel_ms * 1e-3) / 1e9
     return dict(kernel=eng.kernel_name(), us_per_iter=kernel_ms / n_iters * 1e3, evals_per_s=evals / (kernel_ms * 1e-3),
@@ -415,12 +420,13 @@ def main():
                          "lds_bytes_per_eval": fig["lds_bytes_per_eval"],
                          "kernel_evals_per_s": fig["evals_per_s"],
                          "frac_engine": value / world * fig["lds_bytes_per_eval"] / 1e9 / LDS_PEAK_GBS,
-                         "bound_note": "LDS gather bandwidth: per (lineage, chain) the scan gathers %d B of lookup-table "
+                         "bound_note": "LDS gather bandwidth: per (lineage, chain) the scan gathers %.2f B of lookup-table "
                                        "entries from LDS (256 B/clk/CU x 256 CU x 2.4 GHz); no MFMA in a gather/scan/reduce"
                                        % fig["lds_bytes_per_eval"],
                          "hbm": hbm,
                          "engine": {"persistent": fig["persistent"], "threads_per_block": fig["threads_per_block"],
-                                    "chains_per_block": 2 * eng.layout.persistent if persistent else cb,
+                                    "chains_per_block": {1: 2, 2: 4, 3: 2}[int(eng.layout.persistent)] if persistent else cb,
+                                    "team_blocks": int(eng.layout.team_blocks), "table_mode": int(eng.layout.table_mode),
                                     "unit_resolution_tables": unit, "us_per_iter_device": fig["us_per_iter"]}},
         }
     eng.close()

@@ -1192,8 +1192,10 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
     if (!e || !buf) return LR_ERR_NULL;
     if (n < 64) return LR_ERR_SIZE;
     if (e->persistent) {
-        if (e->lay.persistent == 3) snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
-        else if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d>", e->plan.H);
+        const char* gen = e->plan.unit == LR_TAB_PAIRGEN ? "true" : "false";
+        if (e->lay.persistent == 3)
+            snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d, %s, %s>", e->plan.H, e->lay.reserved1, e->cfg.sampler == 0 ? "true" : "false", gen);
+        else if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s>", e->plan.H, gen);
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
     } else if (e->part[0].pipelined) {
         snprintf(buf, (size_t)n, "lr_fused_iter_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");

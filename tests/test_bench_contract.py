@@ -1,5 +1,5 @@
-"""The committed bench line (profiles/r01_bench_cfg4_1gpu.json = `python bench.py` on an MI355X) carries every field the
-driver's contract names, and the numbers in it are mutually consistent."""
+"""The committed bench line (profiles/r02_bench_cfg4_1gpu.json = `python bench.py` on an MI355X) carries every field the
+driver's contract names, and the numbers in it are mutually consistent and agree with the committed rocprofv3 summary."""
 import json
 import os
 
@@ -9,18 +9,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    b = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_cfg4_1gpu.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_cfg4_1gpu.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "configs"):
         assert k in b, k
     assert b["n_gpus"] == 1 and b["scaling"] == "weak" and b["vs_baseline"] is None and b["dtype"] == "f64"
     assert b["higher_is_better"] is True and b["data"] == "synthetic" and "workload" in b["config"]
     r = b["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
-    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9)
+    # the kernel gathers lookup-table entries from LDS: that pipe is its roofline (256 B/clk/CU x 256 CUs x 2.4 GHz)
+    assert r["bound"] == "lds" and r["unit"] == "GB/s" and r["peak"] == pytest.approx(256 * 256 * 2.4)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.0 < r["frac"] < 1.0
+    assert r["achieved"] == pytest.approx(r["evals_per_launch"] * r["lds_bytes_per_eval"] / (r["kernel_ms"] * 1e-3) / 1e9)
+    # HBM side fields: the survey's 16-B convention, and the bytes that really reach HBM (PMC, measured in the run)
+    assert r["traffic"] is not None and r["traffic"] > 0 and "rocprofv3 --pmc" in r["traffic_note"]
+    h = r["hbm"]
+    assert h["peak_GBs"] == 8000.0 and h["measured_GBs"] == pytest.approx(r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9)
+    assert h["measured_frac_of_peak"] < 0.05 < 1.0 < h["algorithmic_GBs_16B_convention"] / h["peak_GBs"]
     # value = iterations x lineages x chains / time
     cfg = b["config"]
     assert b["value"] == pytest.approx(b["steps"] * cfg["lineages"] * cfg["chains_total"] / (b["ms_per_step"] * 1e-3 * b["steps"]))
@@ -28,6 +34,20 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["unit"] == b["unit"]
-    # the traffic file the bench reads names the kernel the bench line reports
-    t = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
-    assert t["kernel"] == r["kernel"] and t["workload"] == "cfg4"
+    # every BASELINE configuration carries a number, cfg5 its own CPU leg
+    for name in ("cfg2", "cfg3", "cfg5", "cfg4_general", "cfg4_shard128"):
+        s = b["configs"][name]
+        assert s["evals_per_s"] > 0 and s["us_per_iter"] > 0 and 0 < s["lds_frac"] < 1 and s["kernel"].startswith("lr_")
+    assert b["configs"]["cfg5"]["cpu_baseline"]["kind"] == "port"
+
+
+def test_profile_summary_agrees_with_the_bench_line():
+    """profiles/r02_launch_durations.json: the timed launch in rocprofv3's kernel trace against bench.py's HIP events of
+    the same (profiled) run; profiles/r02_pmc_1000it.json names the same kernel."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_launch_durations.json")))
+    assert d["timed_2000_iteration_launch_ms_kernel_trace"] == pytest.approx(
+        d["bench_hip_event_ms_for_the_timed_2000_iteration_launch"], rel=0.01)
+    p = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_1000it.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_cfg4_1gpu.json")))
+    assert p["kernel"].split("<")[0] == b["roofline"]["kernel"].split("<")[0] == d["kernel"].split("<")[0]
+    assert 0 < p["lds_busy_fraction"] < 1 and 0 < p["valu_busy_fraction"] < 1

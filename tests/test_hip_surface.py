@@ -247,6 +247,11 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert b["n_gpus"] == 2 and b["config"]["chains_total"] == 128 and b["config"]["chains_per_gpu"] == 64
     assert b["scaling"] == "weak" and b["value"] > 0 and b["cpu_baseline"] is None
     assert b["value"] == pytest.approx(300 * b["config"]["lineages"] * 128 / (b["ms_per_step"] * 1e-3 * 300))
+    # the second leg of a multi-rank run: the same 64 chains IN TOTAL, sharded over the two ranks (strong scaling, the way
+    # BASELINE.json words cfg4: "1024 chains sharded across 8 GPUs")
+    s = b["strong_scaling"]
+    assert s["chains_total"] == 64 and s["chains_per_gpu"] == 32 and s["value"] > 0
+    assert s["value"] == pytest.approx(300 * b["config"]["lineages"] * 64 / (s["ms_per_step"] * 1e-3 * 300))
 
 
 def test_cli_cfg1_fixed_two_shifts(G, tmp_path):

@@ -401,15 +401,12 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             // phase ph: steppers advance pair `ph`, scanners score pair `1 - ph`
+#ifdef LR_DIAG
+            const unsigned long long dq0 = wall_clock64();
+#endif
             if (scanner) {
                 double s0 = 0.0, s1 = 0.0;
-#ifdef LR_DIAG
-                const unsigned long long dq0 = wall_clock64();
-#endif
                 lr_persist_scan<H, GENERAL, 1>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
-#ifdef LR_DIAG
-                if (lane == 0 && blockIdx.x < 64) atomicAdd(&lr_diag_step[20000 + blockIdx.x * 16 + wave], wall_clock64() - dq0);
-#endif
                 s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
                 if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
             } else {
@@ -424,7 +421,16 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
                                     (lr_lds_f64*)(reinterpret_cast<double*>(tab[ph]) + wave), ES, (lr_lds_f64*)&br_lds[0][0]);
                 }
             }
+#ifdef LR_DIAG
+            const unsigned long long dq1 = wall_clock64();
+#endif
             __syncthreads();
+#ifdef LR_DIAG
+            if (lane == 0 && blockIdx.x < 64) {
+                atomicAdd(&lr_diag_step[16384 + (blockIdx.x * 16 + wave) * 4 + 0], dq1 - dq0);
+                atomicAdd(&lr_diag_step[16384 + (blockIdx.x * 16 + wave) * 4 + 1], wall_clock64() - dq1);
+            }
+#endif
         }
     }
     if (wave < 4 && c0 + wave < C) {
@@ -573,6 +579,29 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, 
 static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, cfg->unit_resolution, p);
     if (rc) return rc;
+    if (cfg->model == LR_MODEL_KEIDING_DEAD && cfg->n_bins <= 126) {
+        // model 3 on a persistent engine: one table class with an extant block behind the death-side entries (lr_step.h),
+        // so the half-stride must hold 2 (n_bins + 2) entries and a death byte reaches 2 n_bins + 3
+        static const int fast_H[] = {40, 72, 136, 264};
+        lr_scan_plan q = *p;
+        q.n_cls = 1, q.fast = 1, q.H = 0;
+        for (int h : fast_H)
+            if (2 * (cfg->n_bins + 2) <= h) {
+                q.H = h;
+                break;
+            }
+        if (q.H) {
+            q.unit = cfg->unit_resolution ? LR_TAB_UNIT : LR_TAB_PAIRGEN;
+            q.cb = cfg->unit_resolution ? 16 : 4;
+            while (q.unit == LR_TAB_UNIT && q.cb > 2 && q.cb / 2 >= cfg->n_chains) q.cb >>= 1;
+            q.tab_stride = q.unit == LR_TAB_UNIT ? q.H : 2 * q.H;
+            q.groups = (cfg->n_chains + q.cb - 1) / q.cb;
+            if (lr_persist_variant(cfg, q, nullptr) != 0) {
+                *p = q;
+                return LR_OK;
+            }
+        }
+    }
     if (!p->unit && p->fast && p->n_cls == 1) {
         // general lineage times: a persistent engine takes them in the pair-general table layout (LR_TAB_PAIRGEN) with the
         // in-bin fractions packed as 32-bit fixed point; if none applies the plan stays the launch-based engine's
@@ -841,15 +870,19 @@ static int lr_launch_pairscan(const lr_engine* e, hipStream_t stream) {
     lr_packed_lineages pk;
     pk.idx8 = (const uint4*)(e->ws + e->lay.lineage_idx), pk.frac = (const uint4*)(e->ws + e->lay.lineage_frac);
     pk.fstride = e->n8_alloc;
-    hipLaunchKernelGGL((lr_pairscan_kernel<H, true>), dim3(e->plan.tiles, (e->cfg.n_chains + 1) / 2), dim3(256), 0, stream, pk,
-                       e->n8, (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->plan.tiles,
-                       (double*)(e->ws + e->lay.partials));
+    const dim3 grid(e->plan.tiles, (e->cfg.n_chains + 1) / 2);
+    if (e->plan.unit == LR_TAB_PAIRGEN)
+        hipLaunchKernelGGL((lr_pairscan_kernel<H, true>), grid, dim3(256), 0, stream, pk, e->n8,
+                           (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->plan.tiles, (double*)(e->ws + e->lay.partials));
+    else
+        hipLaunchKernelGGL((lr_pairscan_kernel<H, false>), grid, dim3(256), 0, stream, pk, e->n8,
+                           (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->plan.tiles, (double*)(e->ws + e->lay.partials));
     return (int)hipGetLastError();
 }
 
 static int lr_enqueue_scan_range(const lr_engine* e, int base, int count, hipStream_t stream) {
-    if (e->plan.unit == LR_TAB_PAIRGEN) {
-        // pair-general tables: the launch-based twin of the persistent scan, all chains at once
+    if (e->plan.unit == LR_TAB_PAIRGEN || (e->persistent && e->cfg.model == LR_MODEL_KEIDING_DEAD)) {
+        // pair-general tables / the extant block of model 3: the launch-based twin of the persistent scan, all chains at once
         if (base != 0 || count != e->cfg.n_chains) return LR_ERR_STATE;
         switch (e->plan.H) {
             case 40: return lr_launch_pairscan<40>(e, stream);

@@ -79,7 +79,8 @@ __device__ __forceinline__ long long lr_share_permute(long long g, int k_tot, co
 __global__ void lr_pack_groups_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n, double t0,
                                       int n_bins, const int* __restrict__ run_start, const int* __restrict__ group_incl,
                                       int permute, int k_tot, lr_p4_shares sh, unsigned char* __restrict__ out,
-                                      unsigned int* __restrict__ frac, long long fstride) {
+                                      unsigned int* __restrict__ frac, long long fstride, int extant_block,
+                                      double end_time) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int slot = ((int)i - run_start[i]) % LR_GRP;
@@ -87,10 +88,12 @@ __global__ void lr_pack_groups_kernel(const double* __restrict__ ts, const doubl
     if (permute) g = lr_share_permute(g, k_tot, sh);
     const double s = ts[i], e = te[i];
     unsigned char* grp = out + g * 16;
-    grp[2 + slot] = (unsigned char)lr_death_index(e, t0, n_bins);
+    const int a = lr_birth_index(s, t0, n_bins);
+    // model 3: extant lineages gather the extant block of the death-side table, indexed by their BIRTH bin (lr_step.h)
+    const bool extant = extant_block && e >= end_time;
+    grp[2 + slot] = (unsigned char)(extant ? n_bins + 2 + a : lr_death_index(e, t0, n_bins));
     if (slot == 0) {
         // header: the birth index and the number of lineages of the run that fall into this group
-        const int a = lr_birth_index(s, t0, n_bins);
         int cnt = 1;
         while (cnt < LR_GRP && i + cnt < n && lr_birth_index(ts[i + cnt], t0, n_bins) == a) ++cnt;
         grp[0] = (unsigned char)a, grp[1] = (unsigned char)cnt;
@@ -99,7 +102,7 @@ __global__ void lr_pack_groups_kernel(const double* __restrict__ ts, const doubl
         // general times: fs = ts - floor ts and fe' = ceil te - te (both in [0, 1)) as 32-bit fixed point, rounded to
         // nearest; array j = slot / 2 of LR_GRP / 2, uint4 g = (fs, fe', fs, fe') of the group's lineages 2j, 2j + 1
         const double fs = fmin(rint((s - floor(s)) * 4294967296.0), 4294967295.0);
-        const double fe = fmin(rint((ceil(e) - e) * 4294967296.0), 4294967295.0);
+        const double fe = extant ? fs : fmin(rint((ceil(e) - e) * 4294967296.0), 4294967295.0);
         unsigned int* q = frac + ((size_t)(slot >> 1) * fstride + g) * 4 + (slot & 1) * 2;
         q[0] = (unsigned int)fs, q[1] = (unsigned int)fe;
     }
@@ -222,6 +225,7 @@ int lr_pack_lineages(lr_engine* e, hipStream_t stream) {
     hipLaunchKernelGGL(lr_pack_groups_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins, (const int*)run_start,
                        (const int*)group_incl, any ? 1 : 0, (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64)), e->p4,
                        (unsigned char*)(e->ws + e->lay.lineage_idx),
-                       general ? (unsigned int*)(e->ws + e->lay.lineage_frac) : nullptr, (long long)e->n8_alloc);
+                       general ? (unsigned int*)(e->ws + e->lay.lineage_frac) : nullptr, (long long)e->n8_alloc,
+                       e->cfg.model == LR_MODEL_KEIDING_DEAD ? 1 : 0, e->cfg.end_time);
     return (int)hipGetLastError();
 }

@@ -239,6 +239,30 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
         lr_put_S(tabd, unit, es, 0, 0.0, 0.0, fs0), lr_put_E(tabd, unit, es, H, 0.0, 0.0, fe0);
         lr_put_S(tabd, unit, es, n_bins + 1, totR, 0.0, fs0), lr_put_E(tabd, unit, es, H + n_bins + 1, -totR, 0.0, fe0);
     }
+    if (model == LR_MODEL_KEIDING_DEAD && unit != LR_TAB_GENERAL) {
+        // Model 3 (LRF:141-142, 529-546) in the packed layouts: an EXTANT lineage (te >= end_time) contributes to the
+        // birth process only: log lam at its birth + the exposure to lam from there on.  Relative to the birth entry
+        // S[a] it already gathers, that is  -tot(lam) - cum(mu)_a - fs mu_a,  a function of its birth bin alone: a second
+        // block of n_bins + 2 death-side entries E_ext[a], which the packing points extant lineages at (death byte
+        // n_bins + 2 + a; on general times their fe' slot carries fs).  No table class in the scan loop.
+        double mu_b[P], sumM = 0.0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            mu_b[p] = (b0 + p < n_bins) ? sc->rate[1][segM[p]] : 0.0;
+            sumM += mu_b[p];
+        }
+        double totM;
+        double cumM = lr_wave_exclusive_scan(sumM, lane, &totM);
+        const double totL = totR - totM;
+        const int x0 = H + n_bins + 2;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int b = b0 + p;
+            if (b < n_bins) lr_put_S(tabd, unit, es, x0 + b + 1, -totL - cumM, -mu_b[p], fs0);
+            cumM += mu_b[p];
+        }
+        if (lane == 0) lr_put_S(tabd, unit, es, x0, -totL, 0.0, fs0), lr_put_S(tabd, unit, es, x0 + n_bins + 1, -totR, 0.0, fs0);
+    }
     LR_SSTAMP(13);
     return (model == 1) ? lr_wave_sum(csum) : 0.0;
 }

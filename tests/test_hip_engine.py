@@ -35,7 +35,10 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        (1, dict(engine="persistent")), (0, dict(engine="persistent4")),
                                        (2, dict(engine="persistent4")), (1, dict(engine="persistent2")),
                                        (0, dict(engine="spec")), (2, dict(engine="spec", team=2)),
-                                       (0, dict(engine="spec", team=4)), (1, dict(engine="spec", team=8))])
+                                       (0, dict(engine="spec", team=4)), (1, dict(engine="spec", team=8)),
+                                       (3, dict(engine="launch")), (3, dict(engine="spec", team=2)),
+                                       (3, dict(engine="persistent4")), (3, dict(engine="persistent2")),
+                                       (3, dict(engine="spec", unit_resolution=False))])
 def test_engine_follows_oracle_trajectory(G, model, kw):
     from literate_amd.engine import ChainEngine, split_trace_row
     name, seed, n_it, C, off = "example_TBP", 2024, 1500, 6, 40

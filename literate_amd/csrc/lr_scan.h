@@ -348,7 +348,7 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
 // frac: LR_GRP / 2 arrays of uint4, `fstride` entries apart; array j holds (fs, fe', fs, fe') of lineages 2j and 2j + 1
 // of every group, so each of the loads is a fully coalesced 16-byte load.
 // Per group: 2 + 28 ds_read_b128; per (lineage, chain pair) two conversions and six fp64 operations.
-template <int H, int UNROLL = 1>
+template <int H, int UNROLL = 1, bool PREFETCH = false>
 __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                              const uint4* __restrict__ frac, long long fstride,
                                                              long long n8, long long sid, int n_scan, double* acc0_,
@@ -357,16 +357,33 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
     const int n = (int)n8;
     int i = (int)sid;
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    if (i < n) w = idx8[i];
+    uint4 fw[LR_GRP / 2];
+#pragma unroll
+    for (int j = 0; j < LR_GRP / 2; ++j) fw[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n) {
+        w = idx8[i];
+        if (PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < LR_GRP / 2; ++j) fw[j] = frac[i + j * fstride];
+        }
+    }
     const char* ebase = lbase + H * 32;
 #pragma unroll UNROLL
     while (i < n) {
         const uint4 cur = w;
         uint4 fr[LR_GRP / 2];
 #pragma unroll
-        for (int j = 0; j < LR_GRP / 2; ++j) fr[j] = frac[i + j * fstride];
+        for (int j = 0; j < LR_GRP / 2; ++j) fr[j] = PREFETCH ? fw[j] : frac[i + j * fstride];
         const int nx = i + n_scan;
-        if (nx < n) w = idx8[nx];
+        if (nx < n) {
+            // the next group in flight while this one is scored - with its fractions where the register budget allows
+            // (28 more VGPRs: the 768-thread speculative kernel; the four-chain kernel's 128-VGPR cap would spill)
+            w = idx8[nx];
+            if (PREFETCH) {
+#pragma unroll
+                for (int j = 0; j < LR_GRP / 2; ++j) fw[j] = frac[nx + j * fstride];
+            }
+        }
         const char* pS = lbase + lr_grp_off<5>(cur, 0);
         const double2 Sv = *reinterpret_cast<const double2*>(pS);
         const double2 Ss = *reinterpret_cast<const double2*>(pS + 16);
@@ -401,9 +418,9 @@ struct lr_packed_lineages {
     long long fstride;
 };
 
-template <int H, bool GENERAL, int UNROLL = 1>
+template <int H, bool GENERAL, int UNROLL = 1, bool PREFETCH = false>
 __device__ __forceinline__ void lr_persist_scan(const char* __restrict__ lbase, const lr_packed_lineages& pk, long long g0,
                                                 long long n8, long long sid, int n_scan, double* acc0, double* acc1) {
-    if (GENERAL) lr_persist_scan_pair_general<H, UNROLL>(lbase, pk.idx8 + g0, pk.frac + g0, pk.fstride, n8, sid, n_scan, acc0, acc1);
+    if (GENERAL) lr_persist_scan_pair_general<H, UNROLL, PREFETCH>(lbase, pk.idx8 + g0, pk.frac + g0, pk.fstride, n8, sid, n_scan, acc0, acc1);
     else lr_persist_scan_pair<H, UNROLL>(lbase, pk.idx8 + g0, n8, sid, n_scan, acc0, acc1);
 }

@@ -308,7 +308,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         LR_XBEGIN();
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(sm.pairs[it & 1][sel >> 1][sel & 1]);
-        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1);
+        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1);
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
         if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
         if (k_team > 1) {
@@ -414,6 +414,32 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
     for (long long iter = 0; iter < ctx.n_iters; ++iter) {
         const unsigned long long it = ctx.it0 + (unsigned long long)iter;      // iteration of the pending proposal
         LR_XBEGIN();
+        // What the two decisions of THIS iteration need beside the scan sums is known since the last barrier: fetched
+        // now (four row reads, lanes 0-15 the pending proposal's scalars, 16-31 the accepted state's), broadcast to
+        // scalars while the candidate is built - after the barrier only the sums are waited for.
+        int dq_gibbs[2] = {0, 0}, dq_invalid[2] = {0, 0};
+        double dq_const[2] = {0.0, 0.0}, dq_priorP[2] = {0.0, 0.0}, dq_priorA[2] = {0.0, 0.0}, dq_hasting[2] = {0.0, 0.0},
+               dq_log_u[2] = {0.0, 0.0};
+        {
+            const int r1 = act1 ? role1 : role0;
+            const int cc1 = act1 ? 1 : 0;
+            const lr_set* P0 = &sm.sets[0][(role0 >> 2) & 3];
+            const lr_set* A0 = &sm.sets[0][role0 & 3];
+            const lr_set* P1 = &sm.sets[cc1][(r1 >> 2) & 3];
+            const lr_set* A1 = &sm.sets[cc1][r1 & 3];
+            const double v0 = (lane & 16) ? A0->sc[lane & 15] : P0->sc[lane & 15];
+            const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
+            const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const double v = cc ? v1 : v0;
+                const int iv = cc ? i1 : i0;
+                dq_gibbs[cc] = lr_bcast_i(iv, LR_SETI_GIBBS), dq_invalid[cc] = lr_bcast_i(iv, LR_SETI_INVALID);
+                dq_const[cc] = lr_bcast(v, LR_SET_CONST), dq_priorP[cc] = lr_bcast(v, LR_SET_PRIOR);
+                dq_priorA[cc] = lr_bcast(v, 16 + LR_SET_PRIOR), dq_hasting[cc] = lr_bcast(v, LR_SET_HASTING);
+                dq_log_u[cc] = lr_bcast(v, LR_SET_LOG_U);
+            }
+        }
         // ---- phase 1: the candidate of iteration it + 1 for outcome k of chain c ----
         if (mine_active) {
             const int role = c ? role1 : role0;
@@ -466,8 +492,6 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             for (int b = 0; b < LR_TEAM_MAX; ++b)
                 if (b < k_team) sum0 += lr_bcast(xv.x, b), sum1 += lr_bcast(xv.y, b);
         } else {
-            // one read per lane, then a fixed-order sum over the scanner waves through register broadcasts
-            // one read per lane, then the fixed-order DPP wave sum over the scanner waves' lanes
             // one read per lane, then a fixed pairwise tree over the scanner waves' values (short dependency chain)
             const double2 rv = *reinterpret_cast<const double2*>(&sm.red[lane < NW ? lane : NW - 1][0]);
             double t0[NW - 4], t1[NW - 4];
@@ -482,44 +506,26 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             sum0 = t0[0], sum1 = t1[0];
         }
         int d0 = 0, d1 = 0;
-        {
-            // the scalars both decisions need in four row reads issued together: lanes 0-15 the pending proposal's,
-            // lanes 16-31 the accepted state's
-            const int r1 = act1 ? role1 : role0;
-            const int cc1 = act1 ? 1 : 0;
-            const lr_set* P0 = &sm.sets[0][(role0 >> 2) & 3];
-            const lr_set* A0 = &sm.sets[0][role0 & 3];
-            const lr_set* P1 = &sm.sets[cc1][(r1 >> 2) & 3];
-            const lr_set* A1 = &sm.sets[cc1][r1 & 3];
-            const double v0 = (lane & 16) ? A0->sc[lane & 15] : P0->sc[lane & 15];
-            const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
-            const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                if (c0 + cc >= C) continue;
-                const double v = cc ? v1 : v0;
-                const int iv = cc ? i1 : i0;
-                const double lik_sum = cc ? sum1 : sum0;
-                const double likA = cc ? likA1 : likA0;
-                const int invalid = lr_bcast_i(iv, LR_SETI_INVALID);
-                double lik;
-                bool ok;
-                if (rj) {
-                    ok = lr_mh_accept(lr_bcast_i(iv, LR_SETI_GIBBS), invalid, lik_sum, lr_bcast(v, LR_SET_CONST), likA,
-                                      lr_bcast(v, LR_SET_PRIOR), lr_bcast(v, 16 + LR_SET_PRIOR), lr_bcast(v, LR_SET_HASTING),
-                                      lr_bcast(v, LR_SET_LOG_U), &lik);
-                } else {
-                    lik = lik_sum;
-                    ok = lr_dd_accept(lik, likA, lr_bcast(v, LR_SET_PRIOR), lr_bcast(v, 16 + LR_SET_PRIOR),
-                                      lr_bcast(v, LR_SET_HASTING), lr_bcast(v, LR_SET_LOG_U), it);
-                }
-                if (cc) d1 = ok ? 1 : 0;
-                else d0 = ok ? 1 : 0;
-                if (cc == c) bk.lik_p = (rj && invalid) ? -INFINITY : lik;
-                if (ok) {
-                    if (cc) likA1 = lik;
-                    else likA0 = lik;
-                }
+        for (int cc = 0; cc < 2; ++cc) {
+            if (c0 + cc >= C) continue;
+            const double lik_sum = cc ? sum1 : sum0;
+            const double likA = cc ? likA1 : likA0;
+            double lik;
+            bool ok;
+            if (rj) {
+                ok = lr_mh_accept(dq_gibbs[cc], dq_invalid[cc], lik_sum, dq_const[cc], likA, dq_priorP[cc], dq_priorA[cc],
+                                  dq_hasting[cc], dq_log_u[cc], &lik);
+            } else {
+                lik = lik_sum;
+                ok = lr_dd_accept(lik, likA, dq_priorP[cc], dq_priorA[cc], dq_hasting[cc], dq_log_u[cc], it);
+            }
+            if (cc) d1 = ok ? 1 : 0;
+            else d0 = ok ? 1 : 0;
+            if (cc == c) bk.lik_p = (rj && dq_invalid[cc]) ? -INFINITY : lik;
+            if (ok) {
+                if (cc) likA1 = lik;
+                else likA0 = lik;
             }
         }
         // the scanners switch to the pair table of the selected candidates

@@ -231,10 +231,10 @@ __device__ __attribute__((noinline)) void lr_sets_to_global(double* S, int* I, c
 }
 
 #ifdef LR_DIAG
-#define LR_XDECL() unsigned long long dg_work = 0, dg_wait1 = 0, dg_p2 = 0, dg_wait2 = 0, dg_t = 0
+#define LR_XDECL() unsigned long long dg_work = 0, dg_wait1 = 0, dg_p2 = 0, dg_wait2 = 0, dg_t = 0, dg_a = 0, dg_b = 0, dg_c = 0
 #define LR_XBEGIN() dg_t = wall_clock64()
 #define LR_XSTAMP(acc) { const unsigned long long t_ = wall_clock64(); acc += t_ - dg_t; dg_t = t_; }
-#define LR_XDUMP() if (lane == 0 && blockIdx.x < 64) { unsigned long long* o = lr_diag_step + 16384 + (blockIdx.x * 16 + wave) * 4; o[0] = dg_work, o[1] = dg_wait1, o[2] = dg_p2, o[3] = dg_wait2; }
+#define LR_XDUMP() if (lane == 0 && blockIdx.x < 64) { unsigned long long* o = lr_diag_step + 16384 + (blockIdx.x * 16 + wave) * 4; o[0] = dg_work, o[1] = dg_wait1, o[2] = dg_p2, o[3] = dg_wait2; unsigned long long* q = lr_diag_step + 24576 + (blockIdx.x * 16 + wave) * 4; q[0] = dg_a, q[1] = dg_b, q[2] = dg_c; }
 #else
 #define LR_XDECL()
 #define LR_XBEGIN()
@@ -274,6 +274,8 @@ struct lr_spec_lds {
     lr_set sets[2][4];
     lr_draw_slot draws[2][2];    // [chain][iteration parity]
     double br[256], logbr[256];  // per-bin data constants of the table builders (br_length / DT / TREND and log br_length)
+    lr_step_args args;           // copy for the out-of-line trace writer: taking the address of the kernel argument itself
+                                 // would move the whole struct from scalar registers to scratch
 };
 
 struct lr_spec_ctx {
@@ -505,6 +507,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             }
             sum0 = t0[0], sum1 = t1[0];
         }
+        LR_XSTAMP(dg_a);
         int d0 = 0, d1 = 0;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
@@ -528,6 +531,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 else likA0 = lik;
             }
         }
+        LR_XSTAMP(dg_b);
         // the scanners switch to the pair table of the selected candidates
         if (tid == 0) sm.cur_sel = d0 * 2 + d1;
         sel_last = d0 * 2 + d1;
@@ -539,6 +543,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             };
             role0 = turn(role0, d0), role1 = turn(role1, d1);
         }
+        LR_XSTAMP(dg_c);
         // clerk (waves 0 and 2): acceptance count and trace row of iteration `it` (LRF:321-359)
         if (k == 0 && mine_active) {
             bk.n_acc += c ? d1 : d0;
@@ -549,7 +554,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 if (slot < a.cfg.n_trace_slots && ctx.rank == 0) {
                     const lr_set* A = &sm.sets[c][(c ? role1 : role0) & 3];
                     const double likA = c ? likA1 : likA0;
-                    lr_spec_trace(&a, c0 + c, lane, slot, it, likA, A, rj ? 1 : 0);
+                    lr_spec_trace(&sm.args, c0 + c, lane, slot, it, likA, A, rj ? 1 : 0);
                 }
             }
         }
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         sm.br[b] = (in && a.br_length) ? a.br_length[b] : 0.0;
         sm.logbr[b] = in ? a.log_br[b] : 0.0;
     }
-    if (tid == 0) sm.abort_flag = 0, sm.cur_sel = 0, sm.scan_arrive = 0;
+    if (tid == 0) sm.abort_flag = 0, sm.cur_sel = 0, sm.scan_arrive = 0, sm.args = a;
     lr_spec_ctx ctx;
     {
         const int* I0 = a.state_i32 + ((size_t)c0 * LR_ISTATE_ROWS + LR_IROW_SCALARS) * LR_ROW;

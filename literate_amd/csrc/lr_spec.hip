@@ -47,3 +47,18 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
             }
             return LR_OK;
 }
+
+#ifdef LR_DIAG
+// diagnostic builds: the stamp buffers are per translation unit (static __device__ in lr_step.h)
+extern "C" int lr_diag_dump_step_spec(unsigned long long* host_out, int n_words) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lr_diag_step), (size_t)n_words * 8);
+}
+extern "C" int lr_diag_dump_seg_spec(unsigned long long* host_out, int n_words, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lr_diag_seg), (size_t)n_words * 8);
+    if (reset) {
+        static unsigned long long zeros[64 * 16];
+        rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(lr_diag_seg), zeros, sizeof(zeros));
+    }
+    return rc;
+}
+#endif

@@ -12,10 +12,10 @@ eng.init(); eng.steps(300); torch.cuda.synchronize()
 NIT = 2000
 lib = _hip.load()
 seg = (ctypes.c_ulonglong * (64 * 16))()
-lib.lr_diag_dump_seg.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-lib.lr_diag_dump_seg(seg, 64 * 16, 1)
+lib.lr_diag_dump_seg_spec.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+lib.lr_diag_dump_seg_spec(seg, 64 * 16, 1)
 ms = eng.timed_steps(NIT)
-lib.lr_diag_dump_seg(seg, 64 * 16, 1)
+lib.lr_diag_dump_seg_spec(seg, 64 * 16, 1)
 sg = np.frombuffer(seg, dtype=np.uint64).reshape(64, 16).astype(np.float64)[:min(C, 64)]
 order = [8, 0, 2, 3, 4, 5, 6, 7]
 names = {0: 'set load', 2: 'draws load', 3: 'move', 4: 'stage (log)', 5: 'prior', 6: 'tables', 7: 'set store'}
@@ -25,11 +25,13 @@ print('table builder:', sub)
 print('candidate segments (last iteration, mean over chains, us at 2.4 GHz):', d, 'total %.2f' % (float(np.mean(sg[:, 7] - sg[:, 8])) / 2400.0))
 print('N=%d C=%d team=%d: %.2f us/iter' % (N, C, eng.layout.team_blocks, ms / NIT * 1e3))
 buf = (ctypes.c_ulonglong * (4096 * 12))()
-lib.lr_diag_dump_step.argtypes = [ctypes.c_void_p, ctypes.c_int]
-lib.lr_diag_dump_step(buf, 4096 * 12)
+lib.lr_diag_dump_step_spec.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.lr_diag_dump_step_spec(buf, 4096 * 12)
 a = np.frombuffer(buf, dtype=np.uint64)[16384:16384 + 64 * 16 * 4].reshape(64, 16, 4).astype(np.float64) * 10 / 1000.0 / NIT
 nb = min(64, (C + 1) // 2 * eng.layout.team_blocks)
 a = a[:nb]
 print('per wave (mean over blocks), us per iteration: work | wait B1 | phase 2 | wait B2')
+b2 = np.frombuffer(buf, dtype=np.uint64)[24576:24576 + 64 * 16 * 4].reshape(64, 16, 4).astype(np.float64)[:nb] * 10 / 1000.0 / NIT
+print('phase 2 of the candidate waves: sums %.2f | decisions %.2f | select + roles %.2f (then clerk + stamp -> phase 2 total)' % tuple(b2[:, :4, k].mean() for k in range(3)))
 for w in range(eng.layout.reserved1 // 64):
     print('wave %2d %s: %5.2f %5.2f %5.2f %5.2f' % (w, 'cand' if w < 4 else 'scan', *a[:, w].mean(0)))

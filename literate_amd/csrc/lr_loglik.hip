@@ -150,7 +150,7 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res,
     p->H = n_bins + 2;
     if (p->n_cls == 1) {
         for (int h : fast_H)
-            if (n_bins + 2 <= h) {
+            if (n_bins + 2 <= h && n_bins <= 64 * lr_bins_per_lane(h)) {
                 p->H = h, p->fast = 1;
                 break;
             }

@@ -471,7 +471,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 lr_rj_prop p;
                 lr_rj_draws d;
                 lr_draws_load(&sm.draws[c][(it + 1) & 1], d, lane);
-                lr_propose_rj<true>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds, logbr_lds);
+                lr_propose_rj<true, lr_bins_per_lane(H)>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds, logbr_lds);
                 lr_set_store(out, s, p, lane);
                 { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
             }

@@ -57,6 +57,13 @@ static __device__ unsigned long long lr_diag_seg[64 * 16];
         asm volatile("" ::: "memory");      \
     } while (0)
 
+// Table layout a builder writes.  The persistent kernels (LDS_CONSTS) only ever run on the packed layouts and know the
+// entry stride at compile time, so the layout switches of lr_put_S / lr_put_E fold away in them.
+template <bool LDS_CONSTS>
+__device__ __forceinline__ int lr_tab_mode(const lr_step_args& a, int table_es) {
+    return LDS_CONSTS ? (table_es == 4 ? LR_TAB_PAIRGEN : LR_TAB_UNIT) : a.unit;
+}
+
 // per-wave LDS scratch: segment rates, their logs and integer edges of both processes
 struct lr_seg_scratch {
     double rate[2][LR_KMAX];
@@ -267,13 +274,18 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
     return (model == 1) ? lr_wave_sum(csum) : 0.0;
 }
 
-// dispatcher: fast one-pass builder when the shape allows, general two-pass builder otherwise
+// dispatcher: fast one-pass builder when the shape allows, general two-pass builder otherwise; PB > 0: the caller is
+// instantiated for a table size whose bins-per-lane count is PB (lr_bins_per_lane) and has one table class
+template <int PB = 0>
 __device__ __forceinline__ double lr_build_tables_segments(const lr_seg_scratch* sc, int eL, int eM, int KL, int KM,
                                                            const double* __restrict__ br_length,
                                                            const double* __restrict__ log_br, int model, int n_bins,
                                                            int n_cls, int H, double2* __restrict__ tab, int lane,
                                                            int unit, double fs0, double fe0, int es = 2,
                                                            lr_seg_cache* sg = nullptr) {
+    if (PB > 0)
+        return lr_build_tables_segments_fast<(PB > 0 ? PB : 1)>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane,
+                                                                unit, fs0, fe0, es, sg);
     if (n_cls == 1 && n_bins <= 2 * LR_WAVE)
         return lr_build_tables_segments_fast<2>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
                                                 fs0, fe0, es, sg);
@@ -447,7 +459,7 @@ __device__ __forceinline__ double lr_wave_multiplier_pre(double& R, int K, bool 
 // hyper-parameters, every other move the rates / times of one process), `p` its bookkeeping, and its lookup tables
 // stand at `table`.  A pure function of (s, it, the chain's Philox stream, the data): the speculative engine calls it
 // on both possible outcomes of the pending decision.
-template <bool LDS_CONSTS = false>
+template <bool LDS_CONSTS = false, int PB = 0>
 __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int lane, lr_seg_scratch* scratch_p,
                                               uint64_t it, lr_rj_state& s, lr_rj_prop& p, double2* table,
                                               int table_es, const lr_rj_draws* pre = nullptr,
@@ -598,10 +610,11 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
     if (pre && s.sg_valid && PKL == KL && PKM == KM)
         sg.reuse = __ballot(lane <= LR_KMAX && (peL != eL || peM != eM)) == 0ull;
     // (the per-bin data constants from the caller's LDS copies when it keeps some)
-    const double constP = lr_build_tables_segments(&scratch, peL, peM, PKL, PKM, LDS_CONSTS ? br_lds : a.br_length,
+    const double constP = lr_build_tables_segments<PB>(&scratch, peL, peM, PKL, PKM, LDS_CONSTS ? br_lds : a.br_length,
                                                    LDS_CONSTS ? logbr_lds : a.log_br, cfg.model,
                                                    n_bins, a.n_cls, a.H, table, lane,
-                                                   a.unit, cfg.frac_birth, cfg.frac_death, table_es, pre ? &sg : nullptr);
+                                                   lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death,
+                                                   table_es, pre ? &sg : nullptr);
     s.sgL = sg.packL, s.sgM = sg.packM, s.sg_valid = (pre && sg.packL != -1) ? 1 : 0;
     LR_SSTAMP(6);
     s.L = pL, s.M = pM, s.tL = ptL, s.tM = ptM, s.eL = peL, s.eM = peM, s.KL = PKL, s.KM = PKM;
@@ -794,11 +807,11 @@ __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, in
         p.prior = lr_trend_prior(P, lane);
         const lr_trend_params tp = lr_trend_unpack(P);
         lr_rates_build_tables_wave([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
-                                   cfg.n_bins, a.H, table, lane, a.unit, cfg.frac_birth, cfg.frac_death, table_es);
+                                   cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death, table_es);
     } else {
         p.prior = lr_dd_prior(P, origin, present, k0, log_k0, lane);
         const lr_dd_params pp = lr_dd_unpack(P);
-        lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, a.unit,
+        lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es),
                                 cfg.frac_birth, cfg.frac_death, table_es);
     }
     p.hasting = hasting, p.move = move_kind;

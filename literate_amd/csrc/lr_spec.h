@@ -471,14 +471,18 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 lr_rj_prop p;
                 lr_rj_draws d;
                 lr_draws_load(&sm.draws[c][(it + 1) & 1], d, lane);
-                lr_propose_rj<true, lr_bins_per_lane(H)>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds, logbr_lds);
+                // (the one-pass builder writes the column into both pair tables)
+                lr_propose_rj<true, lr_bins_per_lane(H), true>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
+                                                               logbr_lds, (int)(col1 - col0));
                 lr_set_store(out, s, p, lane);
                 { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
             }
-            LR_WAVE_LDS_ORDER();
-            for (int i = lane; i < 2 * H; i += LR_WAVE) {
-                col1[ES * i] = col0[ES * i];
-                if (GENERAL) col1[ES * i + 2] = col0[ES * i + 2];
+            if (!rj) {
+                LR_WAVE_LDS_ORDER();
+                for (int i = lane; i < 2 * H; i += LR_WAVE) {
+                    col1[ES * i] = col0[ES * i];
+                    if (GENERAL) col1[ES * i + 2] = col0[ES * i + 2];
+                }
             }
         }
         LR_XSTAMP(dg_work);

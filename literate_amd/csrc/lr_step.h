@@ -153,14 +153,24 @@ struct lr_seg_cache {
     bool reuse;
 };
 
-template <int P>
+// DUP: every entry is written a second time `dup` doubles further on (the speculative kernel keeps a candidate's column
+// in two pair tables; writing both beats copying one from the other afterwards)
+template <int P, bool DUP = false>
 __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scratch* sc, int eL, int eM, int KL,
                                                                 int KM, const double* __restrict__ br_length,
                                                                 const double* __restrict__ log_br, int model,
                                                                 int n_bins, int H, double2* __restrict__ tab,
                                                                 int lane, int unit, double fs0, double fe0, int es,
-                                                                lr_seg_cache* sg = nullptr) {
+                                                                lr_seg_cache* sg = nullptr, int dup = 0) {
     double* tabd = reinterpret_cast<double*>(tab);
+    auto put_S = [&](int j, double v, double R) {
+        lr_put_S(tabd, unit, es, j, v, R, fs0);
+        if (DUP) lr_put_S(tabd + dup, unit, es, j, v, R, fs0);
+    };
+    auto put_E = [&](int j, double v, double R) {
+        lr_put_E(tabd, unit, es, j, v, R, fe0);
+        if (DUP) lr_put_E(tabd + dup, unit, es, j, v, R, fe0);
+    };
     const int b0 = lane * P;
 #ifdef LR_DIAG
     const int c = blockIdx.x * 2 + ((threadIdx.x >> 7) & 1);
@@ -237,14 +247,14 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
     for (int p = 0; p < P; ++p) {
         const int b = b0 + p;
         if (b < n_bins) {
-            lr_put_S(tabd, unit, es, b + 1, logB[p] + cum, R[p], fs0);
-            lr_put_E(tabd, unit, es, H + b + 1, logD[p] - cum, R[p], fe0);
+            put_S(b + 1, logB[p] + cum, R[p]);
+            put_E(H + b + 1, logD[p] - cum, R[p]);
         }
         cum += R[p];
     }
     if (lane == 0) {
-        lr_put_S(tabd, unit, es, 0, 0.0, 0.0, fs0), lr_put_E(tabd, unit, es, H, 0.0, 0.0, fe0);
-        lr_put_S(tabd, unit, es, n_bins + 1, totR, 0.0, fs0), lr_put_E(tabd, unit, es, H + n_bins + 1, -totR, 0.0, fe0);
+        put_S(0, 0.0, 0.0), put_E(H, 0.0, 0.0);
+        put_S(n_bins + 1, totR, 0.0), put_E(H + n_bins + 1, -totR, 0.0);
     }
     if (model == LR_MODEL_KEIDING_DEAD && unit != LR_TAB_GENERAL) {
         // Model 3 (LRF:141-142, 529-546) in the packed layouts: an EXTANT lineage (te >= end_time) contributes to the
@@ -265,10 +275,10 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int b = b0 + p;
-            if (b < n_bins) lr_put_S(tabd, unit, es, x0 + b + 1, -totL - cumM, -mu_b[p], fs0);
+            if (b < n_bins) put_S(x0 + b + 1, -totL - cumM, -mu_b[p]);
             cumM += mu_b[p];
         }
-        if (lane == 0) lr_put_S(tabd, unit, es, x0, -totL, 0.0, fs0), lr_put_S(tabd, unit, es, x0 + n_bins + 1, -totR, 0.0, fs0);
+        if (lane == 0) put_S(x0, -totL, 0.0), put_S(x0 + n_bins + 1, -totR, 0.0);
     }
     LR_SSTAMP(13);
     return (model == 1) ? lr_wave_sum(csum) : 0.0;
@@ -276,16 +286,16 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
 
 // dispatcher: fast one-pass builder when the shape allows, general two-pass builder otherwise; PB > 0: the caller is
 // instantiated for a table size whose bins-per-lane count is PB (lr_bins_per_lane) and has one table class
-template <int PB = 0>
+template <int PB = 0, bool DUP = false>
 __device__ __forceinline__ double lr_build_tables_segments(const lr_seg_scratch* sc, int eL, int eM, int KL, int KM,
                                                            const double* __restrict__ br_length,
                                                            const double* __restrict__ log_br, int model, int n_bins,
                                                            int n_cls, int H, double2* __restrict__ tab, int lane,
                                                            int unit, double fs0, double fe0, int es = 2,
-                                                           lr_seg_cache* sg = nullptr) {
+                                                           lr_seg_cache* sg = nullptr, int dup = 0) {
     if (PB > 0)
-        return lr_build_tables_segments_fast<(PB > 0 ? PB : 1)>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane,
-                                                                unit, fs0, fe0, es, sg);
+        return lr_build_tables_segments_fast<(PB > 0 ? PB : 1), DUP>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab,
+                                                                     lane, unit, fs0, fe0, es, sg, dup);
     if (n_cls == 1 && n_bins <= 2 * LR_WAVE)
         return lr_build_tables_segments_fast<2>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
                                                 fs0, fe0, es, sg);
@@ -459,11 +469,13 @@ __device__ __forceinline__ double lr_wave_multiplier_pre(double& R, int K, bool 
 // hyper-parameters, every other move the rates / times of one process), `p` its bookkeeping, and its lookup tables
 // stand at `table`.  A pure function of (s, it, the chain's Philox stream, the data): the speculative engine calls it
 // on both possible outcomes of the pending decision.
-template <bool LDS_CONSTS = false, int PB = 0>
+template <bool LDS_CONSTS = false, int PB = 0, bool DUP = false>
 __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int lane, lr_seg_scratch* scratch_p,
                                               uint64_t it, lr_rj_state& s, lr_rj_prop& p, double2* table,
                                               int table_es, const lr_rj_draws* pre = nullptr,
-                                              const double* br_lds = nullptr, const double* logbr_lds = nullptr) {
+                                              const double* br_lds = nullptr, const double* logbr_lds = nullptr,
+                                              int table_dup = 0) {
+    static_assert(!DUP || PB > 0, "the duplicate column is written by the one-pass builder only");
     lr_seg_scratch& scratch = *scratch_p;
     const lr_mcmc_config& cfg = a.cfg;
     const int n_bins = cfg.n_bins;
@@ -610,11 +622,11 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
     if (pre && s.sg_valid && PKL == KL && PKM == KM)
         sg.reuse = __ballot(lane <= LR_KMAX && (peL != eL || peM != eM)) == 0ull;
     // (the per-bin data constants from the caller's LDS copies when it keeps some)
-    const double constP = lr_build_tables_segments<PB>(&scratch, peL, peM, PKL, PKM, LDS_CONSTS ? br_lds : a.br_length,
+    const double constP = lr_build_tables_segments<PB, DUP>(&scratch, peL, peM, PKL, PKM, LDS_CONSTS ? br_lds : a.br_length,
                                                    LDS_CONSTS ? logbr_lds : a.log_br, cfg.model,
                                                    n_bins, a.n_cls, a.H, table, lane,
                                                    lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death,
-                                                   table_es, pre ? &sg : nullptr);
+                                                   table_es, pre ? &sg : nullptr, table_dup);
     s.sgL = sg.packL, s.sgM = sg.packM, s.sg_valid = (pre && sg.packL != -1) ? 1 : 0;
     LR_SSTAMP(6);
     s.L = pL, s.M = pM, s.tL = ptL, s.tM = ptM, s.eL = peL, s.eM = peM, s.KL = PKL, s.KM = PKM;

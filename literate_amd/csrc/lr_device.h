@@ -187,34 +187,37 @@ __device__ inline double lr_gamma(const lr_stream& s, uint64_t it, uint32_t purp
 // table layouts (`mode`) the builders write and the scans read
 //   0  chain-major general: entry j of a chain = double2 (value, slope); the launch-based scans take the in-bin
 //      fractions from ts / te themselves (fs = ts - floor ts, fe = te - (ceil te - 1))
-//   1  unit resolution: every lineage has the same fractions (fs0, fe0), folded into 8-byte entries `es` doubles apart
-//      (pair tables: es = 2, the two chains of a pair side by side)
-//   2  pair-general (persistent engines on general times): 32-byte entries (value c0, value c1, slope c0, slope c1),
-//      a chain's values `es` = 4 doubles apart and its slope 2 doubles behind the value.  The packed lineages carry
-//      fs and fe' = ceil te - te = 1 - fe as 32-bit fixed-point fractions, so the slopes are stored times 2^-32 and
-//      the death side is kept as  E' = (value - R, +R):  value + fe (-R) = (value - R) + fe' R.
+//   1  unit resolution: every lineage has the same fractions (fs0, fe0), folded into 8-byte entries; pair tables: the two
+//      chains of a pair side by side, i.e. a chain's consecutive entries 2 doubles apart
+//   2  pair-general (persistent engines on general times): a VALUE plane of 2H entries (v chain 0, v chain 1) and, `so` =
+//      4H doubles behind it, a SLOPE plane of 2H entries (s chain 0, s chain 1) - both with the 16-byte entry stride of
+//      the unit layout, so that a wave's 16-byte gathers spread over all LDS banks (interleaved 32-byte entries would
+//      leave half of the banks idle on every read).  The packed lineages carry fs and fe' = ceil te - te = 1 - fe as
+//      32-bit fixed-point fractions, so the slopes are stored times 2^-32 and the death side is kept as
+//      E' = (value - R, +R):  value + fe (-R) = (value - R) + fe' R.
 // ---------------------------------------------------------------------------------------
 #define LR_TAB_GENERAL 0
 #define LR_TAB_UNIT 1
 #define LR_TAB_PAIRGEN 2
 #define LR_FRAC_SCALE 0x1p-32
-// doubles between a chain's consecutive entries in its (pair) table
-__host__ __device__ __forceinline__ int lr_tab_es(int mode) { return mode == LR_TAB_PAIRGEN ? 4 : 2; }
+// `so` argument of the builders: doubles from a chain's value to its slope in the pair-general layout (4H), 2 otherwise
+// (the value doubles as the layout switch of the kernels that know their layout at compile time)
+__host__ __device__ __forceinline__ int lr_tab_es(int mode, int H) { return mode == LR_TAB_PAIRGEN ? 4 * H : 2; }
 
 // Unit bins one lane of the one-pass table builder handles for the instantiated table sizes H = 40 / 72 / 136 / 264
 // (lr_plan_scan picks H so that n_bins <= 64 * lr_bins_per_lane(H)): a kernel instantiated for H needs one builder only.
 __host__ __device__ constexpr int lr_bins_per_lane(int H) { return H <= 40 ? 1 : (H <= 136 ? 2 : 4); }
 
 // birth-side entry j: value v = logB + cum, exposure rate R
-__device__ __forceinline__ void lr_put_S(double* tabd, int mode, int es, int j, double v, double R, double fs0) {
-    if (mode == LR_TAB_UNIT) tabd[es * j] = v + fs0 * R;
-    else if (mode == LR_TAB_PAIRGEN) tabd[es * j] = v, tabd[es * j + 2] = R * LR_FRAC_SCALE;
+__device__ __forceinline__ void lr_put_S(double* tabd, int mode, int so, int j, double v, double R, double fs0) {
+    if (mode == LR_TAB_UNIT) tabd[2 * j] = v + fs0 * R;
+    else if (mode == LR_TAB_PAIRGEN) tabd[2 * j] = v, tabd[2 * j + so] = R * LR_FRAC_SCALE;
     else reinterpret_cast<double2*>(tabd)[j] = make_double2(v, R);
 }
 // death-side entry j (H + bin + 1): value v = logD - cum, exposure rate R
-__device__ __forceinline__ void lr_put_E(double* tabd, int mode, int es, int j, double v, double R, double fe0) {
-    if (mode == LR_TAB_UNIT) tabd[es * j] = v - fe0 * R;
-    else if (mode == LR_TAB_PAIRGEN) tabd[es * j] = v - R, tabd[es * j + 2] = R * LR_FRAC_SCALE;
+__device__ __forceinline__ void lr_put_E(double* tabd, int mode, int so, int j, double v, double R, double fe0) {
+    if (mode == LR_TAB_UNIT) tabd[2 * j] = v - fe0 * R;
+    else if (mode == LR_TAB_PAIRGEN) tabd[2 * j] = v - R, tabd[2 * j + so] = R * LR_FRAC_SCALE;
     else reinterpret_cast<double2*>(tabd)[j] = make_double2(v, -R);
 }
 

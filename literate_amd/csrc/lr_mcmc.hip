@@ -346,7 +346,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     const lr_step_args& a = *ap;
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners
     constexpr int ENT = GENERAL ? 2 : 1;                  // double2 per pair-table entry (LR_TAB_PAIRGEN / LR_TAB_UNIT)
-    constexpr int ES = 2 * ENT;                           // doubles between a chain's consecutive entries
+    constexpr int ES = GENERAL ? 4 * H : 2;               // the builders' `so`: doubles from a value to its slope (lr_device.h)
     __shared__ double2 tab[2][2 * H * ENT];               // pair tables
     __shared__ double red[2][NW][2];                      // [pair][scanner wave][chain of the pair]
     __shared__ lr_seg_scratch scratch[2];
@@ -484,11 +484,11 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
             const lr_trend_params tp = lr_trend_unpack(A);
             const double* aux = a.br_length;
             lr_rates_build_tables_wave([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
-                                       n_bins, a.H, lr_chain_table(a, c), lane, a.unit, cfg.frac_birth, cfg.frac_death, lr_tab_es(a.unit));
+                                       n_bins, a.H, lr_chain_table(a, c), lane, a.unit, cfg.frac_birth, cfg.frac_death, lr_tab_es(a.unit, a.H));
         } else {
             const lr_dd_params pp = lr_dd_unpack(A);
             lr_dd_build_tables_wave(pp, a.br_length, cfg.m_birth, cfg.m_death, n_bins, a.H, lr_chain_table(a, c), lane,
-                                    a.unit, cfg.frac_birth, cfg.frac_death, lr_tab_es(a.unit));
+                                    a.unit, cfg.frac_birth, cfg.frac_death, lr_tab_es(a.unit, a.H));
         }
         for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = 0.0;
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = 0;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
     lr_stage_segments(&scratch, L, M, eL, eM, KL, KM, lane, &logL, &logM);
     const double constA = lr_build_tables_segments(&scratch, eL, eM, KL, KM, a.br_length, a.log_br, cfg.model, n_bins,
                                                    a.n_cls, a.H, lr_chain_table(a, c), lane,
-                                                   a.unit, cfg.frac_birth, cfg.frac_death, lr_tab_es(a.unit));
+                                                   a.unit, cfg.frac_birth, cfg.frac_death, lr_tab_es(a.unit, a.H));
     S[LR_ROW_L * LR_ROW + lane] = L, S[LR_ROW_M * LR_ROW + lane] = M;
     S[LR_ROW_TL * LR_ROW + lane] = tL, S[LR_ROW_TM * LR_ROW + lane] = tM;
     S[LR_ROW_PL * LR_ROW + lane] = L, S[LR_ROW_PM * LR_ROW + lane] = M;
@@ -761,11 +761,11 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->state_i32 = o, o += lr_align_up64(C * LR_ISTATE_ROWS * LR_ROW * 4, 256);
     out->bin_consts = o, o += lr_align_up64((long long)(cfg->n_bins + 2) * 8, 256);   // log(br) + the DD constants
     // packed lineages of the persistent engines (lr_pack.hip): groups of LR_GRP lineages of one birth bin, 16 bytes of
-    // table indices each; on general times LR_GRP / 2 more uint4 arrays with the in-bin fractions; scratch of the packing
+    // table indices each; on general times LR_FRAC_ARRAYS more uint4 arrays with the in-bin fractions; scratch of the packing
     const long long n_alloc = lr_groups_alloc(cfg->n_lineages);
     out->lineage_idx = o, o += lr_align_up64(n_alloc * 16, 256);
     out->lineage_frac = o;
-    if (p.unit == LR_TAB_PAIRGEN) o += lr_align_up64(n_alloc * 16 * (LR_GRP / 2), 256);
+    if (p.unit == LR_TAB_PAIRGEN) o += lr_align_up64(n_alloc * 16 * LR_FRAC_ARRAYS, 256);
     out->pack_tmp = o, o += lr_align_up64(lr_pack_tmp_bytes(cfg->n_lineages), 256);
     out->args_blob = o, o += 1024;   // lr_step_args of the persistent kernel
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);

@@ -92,19 +92,31 @@ __global__ void lr_pack_groups_kernel(const double* __restrict__ ts, const doubl
     // model 3: extant lineages gather the extant block of the death-side table, indexed by their BIRTH bin (lr_step.h)
     const bool extant = extant_block && e >= end_time;
     grp[2 + slot] = (unsigned char)(extant ? n_bins + 2 + a : lr_death_index(e, t0, n_bins));
+    int cnt0 = 0;
     if (slot == 0) {
         // header: the birth index and the number of lineages of the run that fall into this group
         int cnt = 1;
         while (cnt < LR_GRP && i + cnt < n && lr_birth_index(ts[i + cnt], t0, n_bins) == a) ++cnt;
         grp[0] = (unsigned char)a, grp[1] = (unsigned char)cnt;
+        cnt0 = cnt;
     }
     if (frac) {
         // general times: fs = ts - floor ts and fe' = ceil te - te (both in [0, 1)) as 32-bit fixed point, rounded to
-        // nearest; array j = slot / 2 of LR_GRP / 2, uint4 g = (fs, fe', fs, fe') of the group's lineages 2j, 2j + 1
-        const double fs = fmin(rint((s - floor(s)) * 4294967296.0), 4294967295.0);
-        const double fe = extant ? fs : fmin(rint((ceil(e) - e) * 4294967296.0), 4294967295.0);
-        unsigned int* q = frac + ((size_t)(slot >> 1) * fstride + g) * 4 + (slot & 1) * 2;
-        q[0] = (unsigned int)fs, q[1] = (unsigned int)fe;
+        // nearest.  fe' of slot k goes to array k / 4, component k % 4, of LR_FRAC_ARRAYS uint4 arrays; the group's
+        // first lineage also leaves the sum of the group's fs (an exact integer) as a double in array 3, (.z, .w).
+        auto fix = [](double f) { return fmin(rint(f * 4294967296.0), 4294967295.0); };
+        const double fs = fix(s - floor(s));
+        const double fe = extant ? fs : fix(ceil(e) - e);
+        frac[((size_t)(slot >> 2) * fstride + g) * 4 + (slot & 3)] = (unsigned int)fe;
+        if (slot == 0) {
+            double sum = fs;
+            for (int k = 1; k < cnt0; ++k) {
+                const double sk = ts[i + k];
+                sum += fix(sk - floor(sk));
+            }
+            unsigned int* q = frac + ((size_t)3 * fstride + g) * 4 + 2;
+            q[0] = (unsigned int)__double2loint(sum), q[1] = (unsigned int)__double2hiint(sum);
+        }
     }
 }
 
@@ -218,7 +230,7 @@ int lr_pack_lineages(lr_engine* e, hipStream_t stream) {
     const bool general = e->plan.unit == LR_TAB_PAIRGEN;
     // zero fill (a zero group = sentinel entries on both sides, contribution 0), then the groups
     he = hipMemsetAsync(e->ws + e->lay.lineage_idx, 0, (size_t)e->n8_alloc * 16, stream);
-    if (he == hipSuccess && general) he = hipMemsetAsync(e->ws + e->lay.lineage_frac, 0, (size_t)e->n8_alloc * 16 * (LR_GRP / 2), stream);
+    if (he == hipSuccess && general) he = hipMemsetAsync(e->ws + e->lay.lineage_frac, 0, (size_t)e->n8_alloc * 16 * LR_FRAC_ARRAYS, stream);
     if (he != hipSuccess) return (int)he;
     bool any = false;
     for (int j = 0; j < 16; ++j) any |= e->p4.delta[j] != 0;

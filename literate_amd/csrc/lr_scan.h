@@ -343,11 +343,15 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
     *acc0_ = acc0, *acc1_ = acc1;
 }
 
-// The same scan on GENERAL lineage times: pair tables in the LR_TAB_PAIRGEN layout (32-byte entries: values of the two
-// chains, then their slopes scaled by 2^-32), the groups plus their lineages' in-bin fractions as 32-bit fixed point.
-// frac: LR_GRP / 2 arrays of uint4, `fstride` entries apart; array j holds (fs, fe', fs, fe') of lineages 2j and 2j + 1
-// of every group, so each of the loads is a fully coalesced 16-byte load.
-// Per group: 2 + 28 ds_read_b128; per (lineage, chain pair) two conversions and six fp64 operations.
+// The same scan on GENERAL lineage times: pair tables in the LR_TAB_PAIRGEN layout (a plane of value pairs and a plane of
+// slope pairs scaled by 2^-32, 16-byte entries each), the groups plus their lineages' in-bin fractions as 32-bit fixed point.
+// A group's lineages share the birth bin, so the birth side needs the SUM of their fractions only - a data constant the
+// packing computes once (exactly: an integer below 2^36):
+//     sum_i (S.v + fs_i S.s + E_i.v + fe'_i E_i.s)  =  cnt S.v + (sum_i fs_i) S.s + sum_i fma(fe'_i, E_i.s, E_i.v)
+// frac: LR_FRAC_ARRAYS arrays of uint4, `fstride` entries apart, every load a fully coalesced 16-byte load: arrays 0-2
+// hold fe' of lineages 0-11 of every group, array 3 = (fe'_12, fe'_13, sum of fs as a double).
+// Per group: 2 + 28 ds_read_b128; per (lineage, chain pair) one conversion and four fp64 operations.
+#define LR_FRAC_ARRAYS 4
 template <int H, int UNROLL = 1, bool PREFETCH = false>
 __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                              const uint4* __restrict__ frac, long long fstride,
@@ -357,55 +361,61 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
     const int n = (int)n8;
     int i = (int)sid;
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    uint4 fw[LR_GRP / 2];
+    uint4 fw[LR_FRAC_ARRAYS];
 #pragma unroll
-    for (int j = 0; j < LR_GRP / 2; ++j) fw[j] = make_uint4(0u, 0u, 0u, 0u);
+    for (int j = 0; j < LR_FRAC_ARRAYS; ++j) fw[j] = make_uint4(0u, 0u, 0u, 0u);
     if (i < n) {
         w = idx8[i];
         if (PREFETCH) {
 #pragma unroll
-            for (int j = 0; j < LR_GRP / 2; ++j) fw[j] = frac[i + j * fstride];
+            for (int j = 0; j < LR_FRAC_ARRAYS; ++j) fw[j] = frac[i + j * fstride];
         }
     }
-    const char* ebase = lbase + H * 32;
+    constexpr int SLOPES = 2 * H * 16;        // bytes from the value plane to the slope plane (LR_TAB_PAIRGEN)
+    const char* ebase = lbase + H * 16;
 #pragma unroll UNROLL
     while (i < n) {
         const uint4 cur = w;
-        uint4 fr[LR_GRP / 2];
+        uint4 fr[LR_FRAC_ARRAYS];
 #pragma unroll
-        for (int j = 0; j < LR_GRP / 2; ++j) fr[j] = PREFETCH ? fw[j] : frac[i + j * fstride];
+        for (int j = 0; j < LR_FRAC_ARRAYS; ++j) fr[j] = PREFETCH ? fw[j] : frac[i + j * fstride];
         const int nx = i + n_scan;
         if (nx < n) {
             // the next group in flight while this one is scored - with its fractions where the register budget allows
-            // (28 more VGPRs: the 768-thread speculative kernel; the four-chain kernel's 128-VGPR cap would spill)
+            // (16 more VGPRs: the 768-thread speculative kernel; the four-chain kernel runs at a 128-VGPR cap)
             w = idx8[nx];
             if (PREFETCH) {
 #pragma unroll
-                for (int j = 0; j < LR_GRP / 2; ++j) fw[j] = frac[nx + j * fstride];
+                for (int j = 0; j < LR_FRAC_ARRAYS; ++j) fw[j] = frac[nx + j * fstride];
             }
         }
-        const char* pS = lbase + lr_grp_off<5>(cur, 0);
+        const char* pS = lbase + lr_grp_off<4>(cur, 0);
         const double2 Sv = *reinterpret_cast<const double2*>(pS);
-        const double2 Ss = *reinterpret_cast<const double2*>(pS + 16);
+        const double2 Ss = *reinterpret_cast<const double2*>(pS + SLOPES);
         const double cnt = (double)((cur.x >> 8) & 0xffu);
-        double u0 = 0.0, u1 = 0.0;
+        const double sfs = __hiloint2double((int)fr[3].w, (int)fr[3].z);
+        const unsigned int fq[16] = {fr[0].x, fr[0].y, fr[0].z, fr[0].w, fr[1].x, fr[1].y, fr[1].z, fr[1].w,
+                                     fr[2].x, fr[2].y, fr[2].z, fr[2].w, fr[3].x, fr[3].y, 0u, 0u};
+        double t0[LR_GRP / 2], t1[LR_GRP / 2];
 #pragma unroll
         for (int j = 0; j < LR_GRP / 2; ++j) {
-            const unsigned int fq[4] = {fr[j].x, fr[j].y, fr[j].z, fr[j].w};
             double p0[2], p1[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const char* pE = ebase + lr_grp_off<5>(cur, 2 * j + h + 2);
+                const char* pE = ebase + lr_grp_off<4>(cur, 2 * j + h + 2);
                 const double2 Ev = *reinterpret_cast<const double2*>(pE);
-                const double2 Es = *reinterpret_cast<const double2*>(pE + 16);
-                const double fs = (double)fq[2 * h], fe = (double)fq[2 * h + 1];
-                p0[h] = fma(fs, Ss.x, fma(fe, Es.x, Ev.x));
-                p1[h] = fma(fs, Ss.y, fma(fe, Es.y, Ev.y));
+                const double2 Es = *reinterpret_cast<const double2*>(pE + SLOPES);
+                const double fe = (double)fq[2 * j + h];
+                p0[h] = fma(fe, Es.x, Ev.x);
+                p1[h] = fma(fe, Es.y, Ev.y);
             }
-            u0 += p0[0] + p0[1], u1 += p1[0] + p1[1];
+            t0[j] = p0[0] + p0[1], t1[j] = p1[0] + p1[1];
         }
-        acc0 += fma(cnt, Sv.x, u0);
-        acc1 += fma(cnt, Sv.y, u1);
+        // the same fixed pairwise tree as the unit-resolution scan, then the birth side of the whole group
+        const double u0 = ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t0[4] + t0[5]) + t0[6]);
+        const double u1 = ((t1[0] + t1[1]) + (t1[2] + t1[3])) + ((t1[4] + t1[5]) + t1[6]);
+        acc0 += fma(sfs, Ss.x, fma(cnt, Sv.x, u0));
+        acc1 += fma(sfs, Ss.y, fma(cnt, Sv.y, u1));
         i = nx;
     }
     *acc0_ = acc0, *acc1_ = acc1;

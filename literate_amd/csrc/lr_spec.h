@@ -385,7 +385,7 @@ template <int H, int T, bool RJ, bool GENERAL>
 __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
-    constexpr int ES = GENERAL ? 4 : 2;      // doubles between a chain's consecutive table entries
+    constexpr int ES = GENERAL ? 4 * H : 2;  // the builders' `so`: doubles from a value to its slope (lr_device.h)
     // the per-bin data constants come from their LDS copies (a global load per candidate would sit on the critical path)
     const double* br_lds = sm.br;
     const double* logbr_lds = sm.logbr;
@@ -480,8 +480,8 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             if (!rj) {
                 LR_WAVE_LDS_ORDER();
                 for (int i = lane; i < 2 * H; i += LR_WAVE) {
-                    col1[ES * i] = col0[ES * i];
-                    if (GENERAL) col1[ES * i + 2] = col0[ES * i + 2];
+                    col1[2 * i] = col0[2 * i];
+                    if (GENERAL) col1[2 * i + ES] = col0[2 * i + ES];
                 }
             }
         }

@@ -30,7 +30,7 @@ struct lr_step_args {
 // the returned pointer addresses this chain's component, consecutive entries are 2 doubles apart.
 __device__ __forceinline__ double2* lr_chain_table(const lr_step_args& a, int c) {
     if (!a.unit) return a.tables + (size_t)c * a.tab_stride;
-    if (a.unit == LR_TAB_PAIRGEN)   // pair-major: 2H entries of 4 doubles per pair, this chain's values at component c & 1
+    if (a.unit == LR_TAB_PAIRGEN)   // pair-major: 8H doubles per pair (value plane, slope plane), this chain's at component c & 1
         return reinterpret_cast<double2*>(reinterpret_cast<double*>(a.tables) + (size_t)(c >> 1) * (8 * a.H) + (c & 1));
     const int l = c % a.cb;
     double* base = reinterpret_cast<double*>(a.tables + (size_t)(c - l) * a.tab_stride);
@@ -61,7 +61,7 @@ static __device__ unsigned long long lr_diag_seg[64 * 16];
 // entry stride at compile time, so the layout switches of lr_put_S / lr_put_E fold away in them.
 template <bool LDS_CONSTS>
 __device__ __forceinline__ int lr_tab_mode(const lr_step_args& a, int table_es) {
-    return LDS_CONSTS ? (table_es == 4 ? LR_TAB_PAIRGEN : LR_TAB_UNIT) : a.unit;
+    return LDS_CONSTS ? (table_es != 2 ? LR_TAB_PAIRGEN : LR_TAB_UNIT) : a.unit;
 }
 
 // per-wave LDS scratch: segment rates, their logs and integer edges of both processes
@@ -920,8 +920,8 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     double part = 0.0;
     for (int t = lane; t < a.tiles; t += LR_WAVE) part += a.partials[(size_t)t * a.cfg.n_chains + c];
     const double lik_sum = lr_wave_sum(part);
-    if (a.cfg.sampler != 0) lr_dd_step_core(st, a, mode, c, lane, lik_sum, lr_chain_table(a, c), lr_tab_es(a.unit));
-    else lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c), lr_tab_es(a.unit));
+    if (a.cfg.sampler != 0) lr_dd_step_core(st, a, mode, c, lane, lik_sum, lr_chain_table(a, c), lr_tab_es(a.unit, a.H));
+    else lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c), lr_tab_es(a.unit, a.H));
     lr_chain_store(st, S, I, lane);
 }
 

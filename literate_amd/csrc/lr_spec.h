@@ -256,6 +256,21 @@ __device__ __attribute__((noinline)) void lr_spec_trace(const lr_step_args* a, i
 typedef __attribute__((address_space(1))) unsigned long long lr_gu64;
 typedef __attribute__((address_space(1))) unsigned int lr_gu32;
 
+// The decisions of one iteration, left in LDS by the deciding wave before the iteration's barrier
+struct lr_spec_decision {
+    double lik[2];               // log-likelihood of the two pending proposals (= the accepted states' if accepted)
+    double lik_p[2];             // what the state row records for them (-inf for an invalid proposal)
+    int sel;                     // d0 * 2 + d1
+    int pad_;
+};
+
+// the roles of a chain's four sets after a decision: accepted -> (A, P, Q0, Q1) = (P, Q1, A, Q0); rejected -> (A, Q0, P, Q1)
+__device__ __forceinline__ int lr_spec_turn(int role, int acc) {
+    const int oA = role & 3, oP = (role >> 2) & 3, o0 = (role >> 4) & 3, o1 = (role >> 6) & 3;
+    return acc ? (oP | (o1 << 2) | (oA << 4) | (o0 << 6)) : (oA | (o0 << 2) | (oP << 4) | (o1 << 6));
+}
+#define LR_SPEC_ROLES0 (0 | (1 << 2) | (2 << 4) | (3 << 6))
+
 // everything the block keeps in LDS
 template <int H, int NW, int ENT>
 struct lr_spec_lds {
@@ -264,9 +279,10 @@ struct lr_spec_lds {
     // parity g.  A candidate wave writes its column into the two tables that contain it, so after the decisions the
     // scanners just switch to pairs[g][d0][d1]: no copy between the decision and the next scan.
     double2 pairs[2][2][2][2 * H * ENT];   // ENT double2 per entry: 1 unit resolution, 2 general times (LR_TAB_PAIRGEN)
-    int cur_sel;                 // d0 * 2 + d1 of the pair table now being scanned
+    int cur_sel;                 // d0 * 2 + d1 of the pair table that stands when the kernel ends
     double red[NW][2];           // per scanner wave: partial sums of the two chains
-    unsigned int xs[LR_TEAM_MAX * 4];   // gathered partial sums of the team, as 32-bit halves
+    lr_spec_decision dec[2];     // [iteration parity]: what the deciding wave found
+    double likA[2];              // log-likelihood of the accepted state of the two chains
     int abort_flag;
     int scan_arrive;             // scanner waves that have delivered their sums, counted over the whole launch
     int pad_[1];
@@ -289,8 +305,13 @@ struct lr_spec_ctx {
 };
 
 // The scanner role (waves 4..NW-1): per iteration one pass over the block's slice of the lineages against the pending
-// pair table, partial sums to LDS, then the two barriers of the iteration.  Wave 4 also runs the team exchange, waves
-// 4 and 5 the draw duty.  The scanners need nothing from the decision but the new table.
+// pair table and partial sums to LDS.  The wave that finishes LAST also takes the decision of the iteration: it adds up
+// the block's sums (in a team: publishes them and sweeps the team's), runs the two Metropolis-Hastings tests and leaves
+// the outcome in LDS - all of it BEFORE the iteration's one barrier, beside the candidate waves' tail, because a
+// decision needs the scan sums and the scalars of the pending proposal and the accepted state, not the candidates being
+// built.  Behind the barrier every wave reads the outcome, turns the roles of the sets and goes on: the scanners to the
+// pair table of the selected candidates, the candidate waves to the next candidates.  The last two scanner waves also
+// have the draw duty.
 template <int H, int T, bool RJ, bool GENERAL>
 __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
@@ -299,39 +320,69 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int k_team = ctx.x.team_blocks;
     constexpr bool rj = RJ;
-    // draw duty: the last two scanner waves (wave 4 runs the team exchange and should not be late)
+    const bool act1 = ctx.c0 + 1 < ctx.C;
+    // draw duty: the last two scanner waves (they hold the smallest shares of the scan)
     const int dch = wave - (NW - 2);
     const bool drawer = rj && dch >= 0 && ctx.c0 + dch < ctx.C;
     const int sid = tid - 4 * LR_WAVE;
     int sel = 0;
+    int role0 = LR_SPEC_ROLES0, role1 = LR_SPEC_ROLES0;
+    // In a team the scanners and the exchange behind them are the critical path: they may be given priority over the
+    // candidate wave of their SIMD (which is older and would otherwise win every arbitration).
+    if (LR_SPEC_SCAN_PRIO > 0 && k_team > 1) {
+        if (wave >= (NW + 4) / 2) __builtin_amdgcn_s_setprio(LR_SPEC_SCAN_PRIO + 1);
+        else __builtin_amdgcn_s_setprio(LR_SPEC_SCAN_PRIO);
+    }
     LR_XDECL();
     for (long long iter = 0; iter < ctx.n_iters; ++iter) {
         const unsigned long long it = ctx.it0 + (unsigned long long)iter;
         LR_XBEGIN();
+        // What the decisions need beside the sums stands since the last barrier: fetched now (four row reads, lanes 0-15
+        // the pending proposal's scalars, 16-31 the accepted state's; used by the deciding wave only, but which wave
+        // that will be is not known yet and the reads are free while the scan runs)
+        const int cc1 = act1 ? 1 : 0;
+        const int r1 = act1 ? role1 : role0;
+        const lr_set* P0 = &sm.sets[0][(role0 >> 2) & 3];
+        const lr_set* A0 = &sm.sets[0][role0 & 3];
+        const lr_set* P1 = &sm.sets[cc1][(r1 >> 2) & 3];
+        const lr_set* A1 = &sm.sets[cc1][r1 & 3];
+        const double v0 = (lane & 16) ? A0->sc[lane & 15] : P0->sc[lane & 15];
+        const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
+        const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
+        const double lA = sm.likA[lane & 1];
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(sm.pairs[it & 1][sel >> 1][sel & 1]);
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1);
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
         if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
-        if (k_team > 1) {
-            // The team exchange runs BEFORE the block's barrier, beside the candidate waves' tail: the scanner waves
-            // count themselves in on an LDS word (a wave's LDS operations execute in order: sums first, then the count),
-            // wave 4 waits for all of them, publishes the block's sums and sweeps the team's.
-            if (lane == 0) __hip_atomic_fetch_add(&sm.scan_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (wave == 4) {
-                const int want = (NW - 4) * ((int)iter + 1);
-                while (__hip_atomic_load(&sm.scan_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
-                    __builtin_amdgcn_s_sleep(1);
-                // this block's sums in wave order, published as four {epoch, half} granules; then the sweep
-                asm volatile("" ::: "memory");     // the sums are read after the count was seen
-                const double2 rv = *reinterpret_cast<const double2*>(&sm.red[lane < NW ? lane : NW - 1][0]);
-                double b0 = 0.0, b1 = 0.0;
+        LR_XSTAMP(dg_a);
+        // the scanner waves count themselves in on an LDS word (a wave's LDS operations execute in order: sums first,
+        // then the count); the wave that arrives last decides
+        int prev = 0;
+        if (lane == 0) prev = __hip_atomic_fetch_add(&sm.scan_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        if (prev == (NW - 4) * ((int)iter + 1) - 1) {
+            LR_XSTAMP(dg_b);
+            asm volatile("" ::: "memory");     // the sums are read after the count was seen
+            // the block's sums: one read per lane, then a fixed pairwise tree over the scanner waves' values
+            const double2 rv = *reinterpret_cast<const double2*>(&sm.red[lane < NW ? lane : NW - 1][0]);
+            double t0[NW - 4], t1[NW - 4];
 #pragma unroll
-                for (int w = 4; w < NW; ++w) b0 += lr_bcast(rv.x, w), b1 += lr_bcast(rv.y, w);
+            for (int w = 4; w < NW; ++w) t0[w - 4] = lr_bcast(rv.x, w), t1[w - 4] = lr_bcast(rv.y, w);
+#pragma unroll
+            for (int n = NW - 4; n > 1; n = (n + 1) / 2) {
+#pragma unroll
+                for (int j = 0; j < n / 2; ++j) t0[j] = t0[2 * j] + t0[2 * j + 1], t1[j] = t1[2 * j] + t1[2 * j + 1];
+                if (n & 1) t0[n / 2] = t0[n - 1], t1[n / 2] = t1[n - 1];
+            }
+            double sum0 = t0[0], sum1 = t1[0];
+            bool fail = false;
+            if (k_team > 1) {
+                // this block's sums published as four {epoch, half} granules; then the sweep over the team's
                 const unsigned int epoch = (unsigned int)iter + 1u;
                 lr_gu64* slot = (lr_gu64*)(ctx.x.xchg + ((size_t)(epoch & 1u) * ctx.x.n_teams + ctx.team) * (LR_TEAM_MAX * LR_SPEC_GRANULES));
                 if (lane < 4) {
-                    const double v = (lane < 2) ? b0 : b1;
+                    const double v = (lane < 2) ? sum0 : sum1;
                     const unsigned int half = (lane & 1) ? (unsigned int)__double2hiint(v) : (unsigned int)__double2loint(v);
                     __hip_atomic_store(slot + ctx.rank * LR_SPEC_GRANULES + lane, ((unsigned long long)epoch << 32) | half,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -340,7 +391,6 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
                 lr_gu64* g = slot + (lane >> 2) * LR_SPEC_GRANULES + (lane & 3);
                 unsigned long long v = (unsigned long long)epoch << 32;
                 const unsigned long long t_start = wall_clock64();
-                bool fail = false;
                 for (unsigned int spins = 0;; ++spins) {
                     if (mine) v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__all((unsigned int)(v >> 32) == epoch)) break;
@@ -359,21 +409,62 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
                         __hip_atomic_store((lr_gu32*)ctx.x.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         sm.abort_flag = 1;
                     }
-                } else if (mine) {
-                    sm.xs[lane] = (unsigned int)v;
+                } else {
+                    // [block][chain] halves sit in lanes 4 b + 2 c (+1): summed in block order through register broadcasts
+                    const int half = (int)(unsigned int)v;
+                    sum0 = 0.0, sum1 = 0.0;
+#pragma unroll
+                    for (int b = 0; b < LR_TEAM_MAX; ++b)
+                        if (b < k_team) {
+                            sum0 += __hiloint2double(lr_bcast_i(half, 4 * b + 1), lr_bcast_i(half, 4 * b));
+                            sum1 += __hiloint2double(lr_bcast_i(half, 4 * b + 3), lr_bcast_i(half, 4 * b + 2));
+                        }
                 }
+                LR_XSTAMP(dg_c);
+            }
+            if (!fail) {
+                // the two Metropolis-Hastings tests (LRF:305-319; DD:204-219)
+                int d[2] = {0, 0};
+                double lik[2] = {0.0, 0.0}, lik_p[2] = {0.0, 0.0};
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    if (ctx.c0 + cc >= ctx.C) continue;
+                    const double v = cc ? v1 : v0;
+                    const int iv = cc ? i1 : i0;
+                    const int gibbs = lr_bcast_i(iv, LR_SETI_GIBBS), invalid = lr_bcast_i(iv, LR_SETI_INVALID);
+                    const double priorP = lr_bcast(v, LR_SET_PRIOR), priorA = lr_bcast(v, 16 + LR_SET_PRIOR);
+                    const double hasting = lr_bcast(v, LR_SET_HASTING), log_u = lr_bcast(v, LR_SET_LOG_U);
+                    const double likA = lr_bcast(lA, cc);
+                    const double lik_sum = cc ? sum1 : sum0;
+                    bool ok;
+                    if (rj) {
+                        ok = lr_mh_accept(gibbs, invalid, lik_sum, lr_bcast(v, LR_SET_CONST), likA, priorP, priorA, hasting, log_u, &lik[cc]);
+                        lik_p[cc] = invalid ? -INFINITY : lik[cc];
+                    } else {
+                        lik[cc] = lik_sum;
+                        ok = lr_dd_accept(lik[cc], likA, priorP, priorA, hasting, log_u, it);
+                        lik_p[cc] = lik[cc];
+                    }
+                    d[cc] = ok ? 1 : 0;
+                }
+                lr_spec_decision* out = &sm.dec[iter & 1];
+                if (lane < 2) {
+                    const double l = lane ? lik[1] : lik[0];
+                    out->lik[lane] = l, out->lik_p[lane] = lane ? lik_p[1] : lik_p[0];
+                    if (lane ? d[1] : d[0]) sm.likA[lane] = l;
+                }
+                if (lane == 2) out->sel = d[0] * 2 + d[1];
             }
         }
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
         if (drawer) lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
         LR_XSTAMP(dg_work);
-        __syncthreads();                                                     // B1: (team) sums and candidates are in
+        __syncthreads();                                                     // the decision and the candidates are in
         LR_XSTAMP(dg_wait1);
         if (k_team > 1 && sm.abort_flag) return;
+        sel = sm.dec[iter & 1].sel;
+        role0 = lr_spec_turn(role0, sel >> 1), role1 = lr_spec_turn(role1, sel & 1);
         LR_XSTAMP(dg_p2);
-        __syncthreads();                                                     // B2: the decisions are taken
-        sel = sm.cur_sel;
-        LR_XSTAMP(dg_wait2);
     }
     LR_XDUMP();
 }
@@ -398,7 +489,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
     const bool mine_active = c0 + c < C;
     // run state: which of a chain's four sets plays which role (bits 0-1 A, 2-3 P, 4-5 Q0, 6-7 Q1), the accepted
     // log-likelihoods; every candidate wave tracks both chains (all four take the same decisions)
-    int role0 = 0 | (1 << 2) | (2 << 4) | (3 << 6), role1 = role0;
+    int role0 = LR_SPEC_ROLES0, role1 = LR_SPEC_ROLES0;
     double likA0 = 0.0, likA1 = 0.0;
     likA0 = a.state_f64[((size_t)c0 * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA];
     if (act1) likA1 = a.state_f64[((size_t)(c0 + 1) * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA];
@@ -416,32 +507,6 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
     for (long long iter = 0; iter < ctx.n_iters; ++iter) {
         const unsigned long long it = ctx.it0 + (unsigned long long)iter;      // iteration of the pending proposal
         LR_XBEGIN();
-        // What the two decisions of THIS iteration need beside the scan sums is known since the last barrier: fetched
-        // now (four row reads, lanes 0-15 the pending proposal's scalars, 16-31 the accepted state's), broadcast to
-        // scalars while the candidate is built - after the barrier only the sums are waited for.
-        int dq_gibbs[2] = {0, 0}, dq_invalid[2] = {0, 0};
-        double dq_const[2] = {0.0, 0.0}, dq_priorP[2] = {0.0, 0.0}, dq_priorA[2] = {0.0, 0.0}, dq_hasting[2] = {0.0, 0.0},
-               dq_log_u[2] = {0.0, 0.0};
-        {
-            const int r1 = act1 ? role1 : role0;
-            const int cc1 = act1 ? 1 : 0;
-            const lr_set* P0 = &sm.sets[0][(role0 >> 2) & 3];
-            const lr_set* A0 = &sm.sets[0][role0 & 3];
-            const lr_set* P1 = &sm.sets[cc1][(r1 >> 2) & 3];
-            const lr_set* A1 = &sm.sets[cc1][r1 & 3];
-            const double v0 = (lane & 16) ? A0->sc[lane & 15] : P0->sc[lane & 15];
-            const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
-            const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const double v = cc ? v1 : v0;
-                const int iv = cc ? i1 : i0;
-                dq_gibbs[cc] = lr_bcast_i(iv, LR_SETI_GIBBS), dq_invalid[cc] = lr_bcast_i(iv, LR_SETI_INVALID);
-                dq_const[cc] = lr_bcast(v, LR_SET_CONST), dq_priorP[cc] = lr_bcast(v, LR_SET_PRIOR);
-                dq_priorA[cc] = lr_bcast(v, 16 + LR_SET_PRIOR), dq_hasting[cc] = lr_bcast(v, LR_SET_HASTING);
-                dq_log_u[cc] = lr_bcast(v, LR_SET_LOG_U);
-            }
-        }
         // ---- phase 1: the candidate of iteration it + 1 for outcome k of chain c ----
         if (mine_active) {
             const int role = c ? role1 : role0;
@@ -486,67 +551,23 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             }
         }
         LR_XSTAMP(dg_work);
-        __syncthreads();                                                     // B1: sums and candidates are in
+        __syncthreads();                                                     // the decision and the candidates are in
         LR_XSTAMP(dg_wait1);
         if (k_team > 1 && sm.abort_flag) return;
-        // ---- phase 2: sums -> decisions -> selected tables ----
-        double sum0 = 0.0, sum1 = 0.0;
-        if (k_team > 1) {
-            // [block][chain] in one read per lane, summed in block order through register broadcasts
-            const double2 xv = reinterpret_cast<const double2*>(sm.xs)[lane & (LR_TEAM_MAX - 1)];
-#pragma unroll
-            for (int b = 0; b < LR_TEAM_MAX; ++b)
-                if (b < k_team) sum0 += lr_bcast(xv.x, b), sum1 += lr_bcast(xv.y, b);
-        } else {
-            // one read per lane, then a fixed pairwise tree over the scanner waves' values (short dependency chain)
-            const double2 rv = *reinterpret_cast<const double2*>(&sm.red[lane < NW ? lane : NW - 1][0]);
-            double t0[NW - 4], t1[NW - 4];
-#pragma unroll
-            for (int w = 4; w < NW; ++w) t0[w - 4] = lr_bcast(rv.x, w), t1[w - 4] = lr_bcast(rv.y, w);
-#pragma unroll
-            for (int n = NW - 4; n > 1; n = (n + 1) / 2) {
-#pragma unroll
-                for (int j = 0; j < n / 2; ++j) t0[j] = t0[2 * j] + t0[2 * j + 1], t1[j] = t1[2 * j] + t1[2 * j + 1];
-                if (n & 1) t0[n / 2] = t0[n - 1], t1[n / 2] = t1[n - 1];
-            }
-            sum0 = t0[0], sum1 = t1[0];
-        }
-        LR_XSTAMP(dg_a);
-        int d0 = 0, d1 = 0;
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            if (c0 + cc >= C) continue;
-            const double lik_sum = cc ? sum1 : sum0;
-            const double likA = cc ? likA1 : likA0;
-            double lik;
-            bool ok;
-            if (rj) {
-                ok = lr_mh_accept(dq_gibbs[cc], dq_invalid[cc], lik_sum, dq_const[cc], likA, dq_priorP[cc], dq_priorA[cc],
-                                  dq_hasting[cc], dq_log_u[cc], &lik);
-            } else {
-                lik = lik_sum;
-                ok = lr_dd_accept(lik, likA, dq_priorP[cc], dq_priorA[cc], dq_hasting[cc], dq_log_u[cc], it);
-            }
-            if (cc) d1 = ok ? 1 : 0;
-            else d0 = ok ? 1 : 0;
-            if (cc == c) bk.lik_p = (rj && dq_invalid[cc]) ? -INFINITY : lik;
-            if (ok) {
-                if (cc) likA1 = lik;
-                else likA0 = lik;
-            }
+        // ---- phase 2: what the deciding scanner wave found -> roles and books ----
+        int d0, d1;
+        {
+            const lr_spec_decision* dc = &sm.dec[iter & 1];
+            const double dv = (lane & 2) ? dc->lik_p[lane & 1] : dc->lik[lane & 1];     // lanes 0, 1 lik; 2, 3 lik_p
+            const int sel = dc->sel;
+            d0 = sel >> 1, d1 = sel & 1;
+            if (d0) likA0 = lr_bcast(dv, 0);
+            if (d1) likA1 = lr_bcast(dv, 1);
+            bk.lik_p = c ? lr_bcast(dv, 3) : lr_bcast(dv, 2);
+            sel_last = sel;
         }
         LR_XSTAMP(dg_b);
-        // the scanners switch to the pair table of the selected candidates
-        if (tid == 0) sm.cur_sel = d0 * 2 + d1;
-        sel_last = d0 * 2 + d1;
-        // roles: accepted -> (A, P, Q0, Q1) = (P, Q1, A, Q0); rejected -> (A, Q0, P, Q1)
-        {
-            auto turn = [](int role, int acc) {
-                const int oA = role & 3, oP = (role >> 2) & 3, o0 = (role >> 4) & 3, o1 = (role >> 6) & 3;
-                return acc ? (oP | (o1 << 2) | (oA << 4) | (o0 << 6)) : (oA | (o0 << 2) | (oP << 4) | (o1 << 6));
-            };
-            role0 = turn(role0, d0), role1 = turn(role1, d1);
-        }
+        role0 = lr_spec_turn(role0, d0), role1 = lr_spec_turn(role1, d1);
         LR_XSTAMP(dg_c);
         // clerk (waves 0 and 2): acceptance count and trace row of iteration `it` (LRF:321-359)
         if (k == 0 && mine_active) {
@@ -563,10 +584,9 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             }
         }
         LR_XSTAMP(dg_p2);
-        __syncthreads();                                                     // B2: the selected pair table stands
-        LR_XSTAMP(dg_wait2);
     }
     LR_XDUMP();
+    if (tid == 0) sm.cur_sel = sel_last;
     // pending proposal, accepted state and scalars back to global memory, in the layout every engine shares
     if (k == 0 && mine_active && ctx.rank == 0) {
         const int role = c ? role1 : role0;
@@ -618,6 +638,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         sm.logbr[b] = in ? a.log_br[b] : 0.0;
     }
     if (tid == 0) sm.abort_flag = 0, sm.cur_sel = 0, sm.scan_arrive = 0, sm.args = a;
+    if (tid < 2) sm.likA[tid] = (c0 + tid < C) ? a.state_f64[((size_t)(c0 + tid) * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA] : 0.0;
     lr_spec_ctx ctx;
     {
         const int* I0 = a.state_i32 + ((size_t)c0 * LR_ISTATE_ROWS + LR_IROW_SCALARS) * LR_ROW;

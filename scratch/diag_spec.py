@@ -35,3 +35,6 @@ b2 = np.frombuffer(buf, dtype=np.uint64)[24576:24576 + 64 * 16 * 4].reshape(64, 
 print('phase 2 of the candidate waves: sums %.2f | decisions %.2f | select + roles %.2f (then clerk + stamp -> phase 2 total)' % tuple(b2[:, :4, k].mean() for k in range(3)))
 for w in range(eng.layout.reserved1 // 64):
     print('wave %2d %s: %5.2f %5.2f %5.2f %5.2f' % (w, 'cand' if w < 4 else 'scan', *a[:, w].mean(0)))
+print('scanner waves: scan | (wave 4) wait for the block | exchange  [us per iteration]')
+for w in range(4, eng.layout.reserved1 // 64):
+    print('wave %2d: %5.2f %5.2f %5.2f   (min/max over blocks of scan: %.2f %.2f; of exchange: %.2f %.2f)' % (w, *b2[:, w, :3].mean(0), b2[:, w, 0].min(), b2[:, w, 0].max(), b2[:, w, 2].min(), b2[:, w, 2].max()))

@@ -309,16 +309,24 @@ __device__ __forceinline__ unsigned int lr_grp_off(const uint4& w, int k) {
 // threads, this thread being number `sid`: the inner loop of the persistent engines.  Per group one 16-byte load (the
 // next one in flight while the current one is scored), ONE gather of the birth entry - it enters `count` times - and one
 // gather per lineage of its death entry: 15 ds_read_b128 and 31 fp64 operations for 14 lineages x 2 chains.
+// A lane's first group of every scan is the same group: a persistent kernel may keep it (and, on general times, its
+// fractions) in registers across iterations instead of waiting for the load at the top of each scan.
+struct lr_first_group {
+    uint4 w;
+    uint4 fw[4];
+};
+
 template <int H, int UNROLL = 1>
 __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                      long long n8, long long sid, int n_scan, double* acc0_,
-                                                     double* acc1_) {
+                                                     double* acc1_, const lr_first_group* first = nullptr) {
     double acc0 = *acc0_, acc1 = *acc1_;
     // 32-bit loop arithmetic (fewer than 2^31 groups): a 64-bit compare and add per trip are two instructions each
     const int n = (int)n8;
     int i = (int)sid;
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    if (i < n) w = idx8[i];
+    if (first) w = first->w;
+    else if (i < n) w = idx8[i];
     const char* ebase = lbase + H * 16;
 #pragma unroll UNROLL
     while (i < n) {
@@ -356,7 +364,7 @@ template <int H, int UNROLL = 1, bool PREFETCH = false>
 __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                              const uint4* __restrict__ frac, long long fstride,
                                                              long long n8, long long sid, int n_scan, double* acc0_,
-                                                             double* acc1_) {
+                                                             double* acc1_, const lr_first_group* first = nullptr) {
     double acc0 = *acc0_, acc1 = *acc1_;
     const int n = (int)n8;
     int i = (int)sid;
@@ -364,7 +372,11 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
     uint4 fw[LR_FRAC_ARRAYS];
 #pragma unroll
     for (int j = 0; j < LR_FRAC_ARRAYS; ++j) fw[j] = make_uint4(0u, 0u, 0u, 0u);
-    if (i < n) {
+    if (first && PREFETCH) {
+        w = first->w;
+#pragma unroll
+        for (int j = 0; j < LR_FRAC_ARRAYS; ++j) fw[j] = first->fw[j];
+    } else if (i < n) {
         w = idx8[i];
         if (PREFETCH) {
 #pragma unroll
@@ -430,7 +442,24 @@ struct lr_packed_lineages {
 
 template <int H, bool GENERAL, int UNROLL = 1, bool PREFETCH = false>
 __device__ __forceinline__ void lr_persist_scan(const char* __restrict__ lbase, const lr_packed_lineages& pk, long long g0,
-                                                long long n8, long long sid, int n_scan, double* acc0, double* acc1) {
-    if (GENERAL) lr_persist_scan_pair_general<H, UNROLL, PREFETCH>(lbase, pk.idx8 + g0, pk.frac + g0, pk.fstride, n8, sid, n_scan, acc0, acc1);
-    else lr_persist_scan_pair<H, UNROLL>(lbase, pk.idx8 + g0, n8, sid, n_scan, acc0, acc1);
+                                                long long n8, long long sid, int n_scan, double* acc0, double* acc1,
+                                                const lr_first_group* first = nullptr) {
+    if (GENERAL) lr_persist_scan_pair_general<H, UNROLL, PREFETCH>(lbase, pk.idx8 + g0, pk.frac + g0, pk.fstride, n8, sid, n_scan, acc0, acc1, first);
+    else lr_persist_scan_pair<H, UNROLL>(lbase, pk.idx8 + g0, n8, sid, n_scan, acc0, acc1, first);
+}
+
+// the first group of lane `sid` (zeros when the lane has none)
+template <bool GENERAL>
+__device__ __forceinline__ void lr_load_first_group(const lr_packed_lineages& pk, long long g0, long long n8, long long sid,
+                                                    lr_first_group* f) {
+    f->w = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f->fw[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (sid < n8) {
+        f->w = pk.idx8[g0 + sid];
+        if (GENERAL) {
+#pragma unroll
+            for (int j = 0; j < LR_FRAC_ARRAYS; ++j) f->fw[j] = pk.frac[g0 + sid + j * pk.fstride];
+        }
+    }
 }

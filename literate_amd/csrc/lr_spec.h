@@ -333,6 +333,9 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         if (wave >= (NW + 4) / 2) __builtin_amdgcn_s_setprio(LR_SPEC_SCAN_PRIO + 1);
         else __builtin_amdgcn_s_setprio(LR_SPEC_SCAN_PRIO);
     }
+    // every scan starts with the same group: kept in registers, no load to wait for at the top of an iteration
+    lr_first_group first;
+    lr_load_first_group<GENERAL>(ctx.pk, ctx.g0, ctx.n8, sid, &first);
     LR_XDECL();
     for (long long iter = 0; iter < ctx.n_iters; ++iter) {
         const unsigned long long it = ctx.it0 + (unsigned long long)iter;
@@ -352,7 +355,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         const double lA = sm.likA[lane & 1];
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(sm.pairs[it & 1][sel >> 1][sel & 1]);
-        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1);
+        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1, &first);
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
         if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
         LR_XSTAMP(dg_a);

@@ -82,6 +82,42 @@ __device__ __forceinline__ void lr_spec_draw(const lr_step_args& a, int c, int l
     lr_draws_store(out, d, lane);
 }
 
+// The duty split over two waves (the two halves are independent Philox blocks, each a long dependency chain):
+// part 0 the wave-uniform draws (acceptance uniform and its log, move selectors, the RJ pairs, the split's beta),
+// part 1 the per-rate multiplier draws.  Part 1 runs whether or not the move turns out to be a multiplier move: the
+// proposal reads x / m / da in multiplier moves only.
+__device__ __forceinline__ void lr_spec_draw_part(const lr_step_args& a, int c, int lane, unsigned long long it,
+                                                  lr_draw_slot* out, int part) {
+    const lr_mcmc_config& cfg = a.cfg;
+    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
+    if (part) {
+        const lr_u2 u = lr_pair(rng, it, LR_P_MULT, lane);                 // LRF:165-176
+        const double x = a.mult_l * (u.b - .5);
+        out->x[lane] = x, out->m[lane] = exp(x), out->da[lane] = u.a;
+    } else {
+        const uint32_t purpose = (lane == 0) ? LR_P_ACCEPT : (lane == 1 ? LR_P_MOVE : LR_P_RJ);
+        const lr_u2 ud = lr_pair(rng, it, purpose, lane == 3 ? 1u : 0u);
+        const double lu = log(lane == 0 ? ud.a : 1.0);
+        const double r_a = lr_bcast(ud.a, 1), q_b = lr_bcast(ud.b, 2);
+        double beta = 0.0;
+        if (!(r_a < 0.8) && r_a < 0.999 && cfg.const_rates == 0 && q_b > 0.5) {
+            double ga, gb;
+            lr_wave_gamma2(rng, it, LR_P_BETA_A, LR_SHAPE_BETA_RJ, LR_P_BETA_B, LR_SHAPE_BETA_RJ, lane, &ga, &gb);
+            beta = ga / (ga + gb);
+        }
+        // slots: log_u, r_a, r_b, q_a, q_b, q2_a, q2_b, beta  <-  lanes 0..3 of (ud.a, ud.b)
+        double so = lu;
+        so = (lane == 1) ? r_a : so;
+        so = (lane == 2) ? lr_bcast(ud.b, 1) : so;
+        so = (lane == 3) ? lr_bcast(ud.a, 2) : so;
+        so = (lane == 4) ? q_b : so;
+        so = (lane == 5) ? lr_bcast(ud.a, 3) : so;
+        so = (lane == 6) ? lr_bcast(ud.b, 3) : so;
+        so = (lane == 7) ? beta : so;
+        if (lane < 8) out->sc[lane] = so;
+    }
+}
+
 struct lr_spec_args {
     unsigned long long* xchg;     // [2 parities][n_teams][LR_TEAM_MAX][LR_SPEC_GRANULES] granules (k > 1)
     unsigned int* status;         // engine status word: 0 ok, 1 = a team exchange timed out
@@ -321,8 +357,11 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     const int k_team = ctx.x.team_blocks;
     constexpr bool rj = RJ;
     const bool act1 = ctx.c0 + 1 < ctx.C;
-    // draw duty: the last two scanner waves (they hold the smallest shares of the scan)
-    const int dch = wave - (NW - 2);
+    // Draw duty.  A block on its own is bound by its slowest wave before the barrier, so the duty is split over the last
+    // four scanner waves, two per chain; in a team the last scanner to finish also runs the exchange and must not carry
+    // more than its scan, so there the last two scanner waves (the smallest scan shares) take a chain each.
+    const bool split_draws = k_team == 1;
+    const int dch = split_draws ? (wave - (NW - 4)) >> 1 : wave - (NW - 2), dpart = (wave - (NW - 4)) & 1;
     const bool drawer = rj && dch >= 0 && ctx.c0 + dch < ctx.C;
     const int sid = tid - 4 * LR_WAVE;
     int sel = 0;
@@ -460,7 +499,10 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
             }
         }
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
-        if (drawer) lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
+        if (drawer) {
+            if (split_draws) lr_spec_draw_part(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1], dpart);
+            else lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
+        }
         LR_XSTAMP(dg_work);
         __syncthreads();                                                     // the decision and the candidates are in
         LR_XSTAMP(dg_wait1);
@@ -654,7 +696,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     }
     __syncthreads();
     for (int i = tid; i < 2 * H * ENT; i += T) sm.pairs[ctx.it0 & 1][0][0][i] = gpair[i];
-    // draws of the first candidates (iteration it0 + 1); afterwards the last two scanner waves stay one iteration ahead
+    // draws of the first candidates (iteration it0 + 1); afterwards the last four scanner waves stay one iteration ahead
     if (rj && wave >= NW - 2 && c0 + (wave - (NW - 2)) < C)
         lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, &sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1]);
     __syncthreads();

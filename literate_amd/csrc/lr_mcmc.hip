@@ -644,10 +644,12 @@ static int lr_device_cus() {
 }
 
 // Speculative team kernel (lr_spec.h): one block per CU, a chain pair owned by a team of k blocks.  Model of an
-// iteration in microseconds (MI355X, measured pieces): candidate build 3.2 (RJ) / 4.2 (parametric samplers), 0.5 per scan
-// trip of the scanner waves (LR_SPEC_THREADS - 256 lanes x 8 lineages; twice that on general times), 1.0 for the team
-// exchange behind the last scanner, 0.9 for the barriers and the decision.  Returns the modelled time and the best
-// team size in *k (0 = not applicable).
+// iteration in microseconds, fitted to MI355X measurements over 1k..200k lineages x k = 1, 2, 4, 8
+// (scratch/exp_teams.py): with `trips` = groups / k / 512 scanner lanes,
+//     unit resolution   k = 1: max(2.9, 2.75 + 0.33 trips)     k > 1: max(3.3,  3.05 + 0.30 trips)
+//     general times     k = 1: max(2.9, 2.60 + 0.83 trips)     k > 1: max(3.45, 2.90 + 0.85 trips)
+// (the floor is the candidate build; a team pays the exchange behind its last scanner).  The parametric samplers build
+// their candidates more slowly (+0.9).  Returns the modelled time and the best team size in *k (0 = not applicable).
 static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general = false) {
     const int pairs = (cfg->n_chains + 1) / 2;
     const int cus = lr_device_cus();
@@ -656,14 +658,16 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
     static const int k_env0 = lr_env_int("LR_SPEC_TEAM", 0);
     const int k_env = cfg->team_request > 0 ? cfg->team_request : k_env0;
     const double n8 = (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP);      // groups, for lineages sorted by birth time
-    const double t_cand = cfg->sampler ? 4.2 : 3.2;
+    const double extra = cfg->sampler ? 0.9 : 0.0;
     double best = 1e30;
     for (int k = 1; k <= LR_TEAM_MAX; k *= 2) {
         if (pairs * k > cus) break;
         if (k_env > 0 && k != k_env) continue;
-        const double trips = ceil(n8 / k / (double)(LR_SPEC_THREADS - 256));
-        const double t_scan = trips * (general ? 1.0 : 0.5) + (k > 1 ? 1.0 : 0.0);
-        const double t = (t_scan > t_cand ? t_scan : t_cand) + 0.9;
+        const double trips = n8 / k / (double)(LR_SPEC_THREADS - 256);
+        double t;
+        if (!general) t = (k == 1) ? fmax(2.9, 2.75 + 0.33 * trips) : fmax(3.3, 3.05 + 0.30 * trips);
+        else t = (k == 1) ? fmax(2.9, 2.60 + 0.83 * trips) : fmax(3.45, 2.90 + 0.85 * trips);
+        t += extra;
         if (t < best - 0.05) best = t, *k_out = k;
     }
     return best;
@@ -711,7 +715,9 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, 
     const double t_spec = (general && p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general);
     if (k > 0 && t_spec < 1e29 && cfg->engine_mode != 3 && cfg->engine_mode != 4 && spec_env != 0) {
         // the two-chain kernel with all 16 waves scanning wins only on long scans without room for a team
-        const double t_wide = general ? 1e30 : ceil((double)((cfg->n_lineages + 7) / 8) / 1024.0) * 0.55 + 4.3;
+        // (measured at 256 pairs, 10k..1M lineages: 5.0 + 0.45 us per trip of its 1024 scanner lanes, 4.6 at least; the
+        // speculative kernel is ahead up to ~150k lineages)
+        const double t_wide = general ? 1e30 : fmax(4.6, 5.0 + 0.45 * (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP) / 1024.0);
         if (cfg->engine_mode == 5 || spec_env == 1 || t_spec <= t_wide) {
             if (team_k) *team_k = k;
             return 3;

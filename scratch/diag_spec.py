@@ -6,8 +6,12 @@ from literate_amd import synth, _hip
 from literate_amd.engine import ChainEngine
 N, C = int(sys.argv[1]), int(sys.argv[2])
 team = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+model = 0
 ts, te, _ = synth.make_lineages(N, 128, 20, 0)
-eng = ChainEngine(ts, te, C, model=0, seed=1, s_freq=100, n_trace_slots=40, engine="spec", team=team)
+if os.environ.get("LR_DIAG_DATA") == "metal_bands":
+    G = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "binning_lik.npz"))
+    ts, te, model = G["metal_bands/ts"], G["metal_bands/te"], 2
+eng = ChainEngine(ts, te, C, model=model, seed=1, s_freq=100, n_trace_slots=40, engine="spec", team=team)
 eng.init(); eng.steps(300); torch.cuda.synchronize()
 NIT = 2000
 lib = _hip.load()

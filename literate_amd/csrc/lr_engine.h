@@ -63,7 +63,7 @@ static inline long long lr_groups_alloc(long long n_lineages) {
 #define LR_SPEC_THREADS 768   /* 12 waves: 4 candidate + 8 scanner waves, 3 per SIMD = 168 VGPRs each */
 #endif
 #ifndef LR_SPEC_SCAN_UNROLL
-#define LR_SPEC_SCAN_UNROLL 2
+#define LR_SPEC_SCAN_UNROLL 1
 #ifndef LR_SPEC_SCAN_PRIO
 #define LR_SPEC_SCAN_PRIO 2
 #endif

@@ -337,10 +337,15 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 // steps of one pair, waves 2..15 scan the lineages for the OTHER pair, so the latency-bound step always hides
 // under a scan of the same block and the LDS pipe never waits for it.  Used when there are enough chains to give
 // every CU four (cfg4: 1024 chains = 256 blocks).
+#ifndef LR_P4_THREADS
 #define LR_P4_THREADS 1024
+#endif
+#ifndef LR_P4_UNROLL
+#define LR_P4_UNROLL 1
+#endif
 #define LR_P4_SCANNERS ((LR_P4_THREADS / LR_WAVE - 2) * LR_WAVE)
 template <int H, bool GENERAL>
-__global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
+__global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
                                                                        lr_packed_lineages pk, long long n8,
                                                                        lr_p4_shares sh, long long n_iters) {
     const lr_step_args& a = *ap;
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
     // prologue: pair 0's pending proposal is scanned so that phase A can step it
     if (scanner) {
         double s0 = 0.0, s1 = 0.0;
-        lr_persist_scan<H, GENERAL, 1>(reinterpret_cast<const char*>(tab[0]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
+        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL>(reinterpret_cast<const char*>(tab[0]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
         s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
         if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
     }
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, 4) void lr_persist4_kernel(const lr_
 #endif
             if (scanner) {
                 double s0 = 0.0, s1 = 0.0;
-                lr_persist_scan<H, GENERAL, 1>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
+                lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
                 s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
                 if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
             } else {

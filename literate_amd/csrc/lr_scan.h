@@ -300,6 +300,14 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_unit_kernel(const dou
 template <int SH>
 __device__ __forceinline__ unsigned int lr_grp_off(const uint4& w, int k) {
     const unsigned int v = (k < 4) ? w.x : (k < 8 ? w.y : (k < 12 ? w.z : w.w));
+    if ((k & 3) == 0) {
+        // byte 0 of a word: the compiler would shift and mask (two instructions); the byte-select form of the shift does
+        // it in one, as it does by itself for bytes 1..3 (the scan loop is bound by vector instruction issue)
+        unsigned int r;
+        const unsigned int sh = SH;
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(sh), "v"(v));
+        return r;
+    }
     const int sh = 8 * (k & 3) - SH;                                   // (v >> 8j) & 0xff, then << SH
     const unsigned int m = 0xffu << SH;
     return (sh >= 0 ? (v >> sh) : (v << -sh)) & m;

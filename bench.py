@@ -55,6 +55,8 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 LDS_PEAK_GBS = 256 * 256 * 2.4e9 / 1e9     # 256 B/clk/CU x 256 CUs x 2.4 GHz = 157,286 GB/s (MI355X_MICROARCH.md, LDS)
+ISSUE_CYCLES = 4.18                       # cycles per wave64 vector instruction per SIMD (scratch/ubench/valu_rate.hip)
+ISSUE_PEAK_LANE_INSTR_PER_S = 256 * 4 * 2.4e9 / ISSUE_CYCLES * 64
 
 
 def make_workload(name):
@@ -96,10 +98,21 @@ def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
         lds_bytes_per_eval = 16 if unit else 32      # launch-based scan: two 8-byte / two 16-byte entries per (lineage, chain)
     evals = float(n_iters) * n_lin * chains
     achieved = evals * lds_bytes_per_eval / (kernel_ms * 1e-3) / 1e9
-    return dict(kernel=eng.kernel_name(), us_per_iter=kernel_ms / n_iters * 1e3, evals_per_s=evals / (kernel_ms * 1e-3),
-                lds_bytes_per_eval=lds_bytes_per_eval, lds_GBs=achieved, lds_frac=achieved / LDS_PEAK_GBS,
-                unit_resolution_tables=unit, persistent=int(eng.layout.persistent),
-                threads_per_block=int(eng.layout.reserved1))
+    out = dict(kernel=eng.kernel_name(), us_per_iter=kernel_ms / n_iters * 1e3, evals_per_s=evals / (kernel_ms * 1e-3),
+               lds_bytes_per_eval=lds_bytes_per_eval, lds_GBs=achieved, lds_frac=achieved / LDS_PEAK_GBS,
+               unit_resolution_tables=unit, persistent=int(eng.layout.persistent),
+               threads_per_block=int(eng.layout.reserved1))
+    if eng.layout.persistent:
+        # What the scan loop is really bound by (scratch/ubench/README.md): vector instruction issue.  Per group of 14
+        # lineages and chain pair the compiled loop issues 51 VALU + 15 LDS + 1 global instruction (unit resolution) or
+        # 95 + 30 + 5 (general times) - counted in the ISA of lr_persist4_kernel<136, .> - and a SIMD issues one wave64
+        # vector instruction per 4.18 cycles whatever its kind (measured).  The chain steps share the same SIMDs, so the
+        # fraction below is the share of the chip's issue rate spent on SCAN instructions.
+        instr_per_eval = (67 if unit else 130) / 28.0
+        peak = ISSUE_PEAK_LANE_INSTR_PER_S / instr_per_eval
+        out["issue"] = dict(vector_instr_per_eval=instr_per_eval, cycles_per_wave_instr=ISSUE_CYCLES, peak_evals_per_s=peak,
+                            frac=out["evals_per_s"] / peak)
+    return out
 
 
 def side_config(name, steps, warmup):
@@ -421,8 +434,10 @@ def main():
                          "kernel_evals_per_s": fig["evals_per_s"],
                          "frac_engine": value / world * fig["lds_bytes_per_eval"] / 1e9 / LDS_PEAK_GBS,
                          "bound_note": "LDS gather bandwidth: per (lineage, chain) the scan gathers %.2f B of lookup-table "
-                                       "entries from LDS (256 B/clk/CU x 256 CU x 2.4 GHz); no MFMA in a gather/scan/reduce"
-                                       % fig["lds_bytes_per_eval"],
+                                       "entries from LDS (256 B/clk/CU x 256 CU x 2.4 GHz); no MFMA in a gather/scan/reduce.  "
+                                       "Micro-benchmarks (scratch/ubench) show the loop itself is bound by vector instruction "
+                                       "issue before LDS bandwidth: see `issue`" % fig["lds_bytes_per_eval"],
+                         "issue": fig.get("issue"),
                          "hbm": hbm,
                          "engine": {"persistent": fig["persistent"], "threads_per_block": fig["threads_per_block"],
                                     "chains_per_block": {1: 2, 2: 4, 3: 2}[int(eng.layout.persistent)] if persistent else cb,

@@ -416,10 +416,14 @@ def test_cfg5_ddrate_50k_lineages_256_states():
                                                 (200, False, "auto"), (253, None, "auto"), (254, None, "auto"),
                                                 (60, None, "persistent4"), (134, None, "persistent4"),
                                                 (253, None, "persistent4"),
+                                                (30, None, "spec"), (64, None, "spec"), (65, None, "spec"), (128, None, "spec"),
+                                                (129, None, "spec"), (134, None, "spec"), (253, None, "spec"),
+                                                (120, False, "spec"),
                                                 (300, None, "auto"), (1000, None, "auto")])
 def test_engine_shapes_bins(n_bins, unit, engine):
-    """Table half-stride classes (H = 72, 136, 264) and the generic kernel beyond them (n_bins = 300),
-    unit-resolution and general tables: a few chains against the oracle loop on synthetic data."""
+    """Table half-stride classes (H = 40, 72, 136, 264; a class holds n_bins <= 64 x its bins-per-lane count, so 129..134
+    bins move up to H = 264) and the generic kernel beyond them (n_bins = 300), unit-resolution and general tables:
+    a few chains against the oracle loop on synthetic data."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need an MI355X")
@@ -434,6 +438,8 @@ def test_engine_shapes_bins(n_bins, unit, engine):
     assert eng.n_bins == n_bins
     if engine == "persistent4":
         assert eng.layout.persistent == 2      # 37 chains: the last block holds one chain of four
+    if engine == "spec":
+        assert eng.layout.persistent == 3      # 37 chains: the last block holds one chain of its pair
     eng.init(); eng.steps(n_it)
     tr = eng.trace_rows()
     t0, sp, ex, br = lo.bin_events_cli(ts, te)
@@ -471,7 +477,8 @@ def test_engine_chain_count_shapes(G, engine):
         eng.close(); last.close()
 
 
-@pytest.mark.parametrize("engine,C", [("launch", 24), ("persistent", 24), ("persistent", 10), ("persistent4", 10)])
+@pytest.mark.parametrize("engine,C", [("launch", 24), ("persistent", 24), ("persistent", 10), ("persistent4", 10), ("spec", 9),
+                                      ("spec2", 10)])
 def test_checkpoint_resume_is_bit_identical(G, tmp_path, engine, C):
     """save() after 130 iterations, load() into a fresh engine, 170 more: state, pending proposals and all 300
     trace rows equal an uninterrupted run bit for bit (draws are addressed by (seed, chain, iteration));
@@ -480,6 +487,8 @@ def test_checkpoint_resume_is_bit_identical(G, tmp_path, engine, C):
     from literate_amd.engine import ChainEngine
     name = "metal_bands"
     kw = dict(model=0, seed=77, s_freq=1, n_trace_slots=300, engine=engine)
+    if engine == "spec2":
+        kw.update(engine="spec", team=2)       # a team of two blocks per chain pair
     full = ChainEngine(G[name + "/ts"], G[name + "/te"], C, **kw)
     full.init(); full.steps(300)
     a = ChainEngine(G[name + "/ts"], G[name + "/te"], C, **kw)

@@ -31,6 +31,10 @@ summary = {"kernel": kname, "workload": "cfg4: 1024 chains x 100k lineages", "it
            "lds_busy_fraction": v["SQ_LDS_IDX_ACTIVE"] / v["GRBM_GUI_ACTIVE"] / 32,
            "valu_busy_fraction": v["SQ_ACTIVE_INST_VALU"] / v["GRBM_GUI_ACTIVE"] / 32,
            "lds_bank_conflict_fraction": v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"],
+           # wave64 vector instructions (VALU + LDS) per SIMD x 4.18 cycles each (scratch/ubench/valu_rate.hip) over the
+           # cycles of the launch (GRBM_GUI_ACTIVE sums the 8 XCDs): how full the SIMDs' issue ports are
+           "vector_issue_fraction": (v["SQ_INSTS_VALU"] + v["SQ_INSTS_LDS"]) / (256 * 4) * 4.18 / (v["GRBM_GUI_ACTIVE"] / 8),
+           "vector_instructions_per_CU_per_iteration": (v["SQ_INSTS_VALU"] + v["SQ_INSTS_LDS"]) / 256 / 1000,
            "wave_cycles_split": {x: v[x] / v["SQ_WAVE_CYCLES"] for x in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS") if x in v},
            "source": "rocprofv3 --pmc <counter group> --kernel-trace (separate passes) -- python3 scratch/prof_persist.py (one launch of "
                      "1000 iterations)"}

@@ -55,7 +55,8 @@ struct lr_engine {
 
 static inline long long lr_groups_alloc(long long n_lineages) {
     const long long runs = n_lineages < LR_MAX_RUNS ? n_lineages : LR_MAX_RUNS;
-    return (n_lineages + LR_GRP - 1) / LR_GRP + runs + LR_IDX_SPARE;
+    // (unit resolution: LR_SLOTS slots of one or two lineages per group - all singles in the worst case)
+    return (n_lineages + LR_SLOTS - 1) / LR_SLOTS + runs + LR_IDX_SPARE;
 }
 
 // ---- speculative team engine (lr_spec.h / lr_spec.hip) ----

@@ -189,15 +189,19 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
 // the lr_mcmc_time_scan hook).  Block (tile, pair): partials[tile][2 pair .. 2 pair + 1].
 template <int H, bool GENERAL>
 __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk, long long n8, const double2* __restrict__ tables,
-                                                          int n_chains, int tiles, double* __restrict__ partials) {
-    constexpr int ENT = GENERAL ? 2 : 1;                       // double2 per pair entry
-    __shared__ double2 tab[2 * H * ENT];
+                                                          int n_chains, int n_bins, int tiles, double* __restrict__ partials) {
+    constexpr int ENT = GENERAL ? 2 : 1;                       // double2 per pair entry in global memory
+    __shared__ double2 tab[GENERAL ? 4 * H : LR_UNIT_PLANES * H];     // unit resolution: + the pair-sum planes (lr_scan.h)
     __shared__ double red[4][2];
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int tile = blockIdx.x, pair = blockIdx.y;
     const double2* src = tables + (size_t)pair * (2 * H * ENT);
     for (int i = tid; i < 2 * H * ENT; i += 256) tab[i] = src[i];
     __syncthreads();
+    if (!GENERAL) {
+        lr_pair_planes_block(tab, H, n_bins, tid, 256);
+        __syncthreads();
+    }
     const long long per = (n8 + tiles - 1) / tiles;
     const long long g0 = min((long long)tile * per, n8), g1 = min(g0 + per, n8);
     double acc0 = 0.0, acc1 = 0.0;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
                                            copy it to scratch */,
     const uint4* __restrict__ idx8, long long n8, lr_p4_shares sh, long long n_iters, int prio_shift) {
     const lr_step_args& a = *ap;
-    __shared__ double2 tab[2 * H];  // the pair table: S' entries [0,H), E' entries [H,2H); (.x, .y) = (chain 0, chain 1)
+    __shared__ double2 tab[LR_UNIT_PLANES * H];  // the pair table: S' entries [0,H), E' [H,2H), pair sums behind; (.x, .y) = (chain 0, chain 1)
     __shared__ double red[T / LR_WAVE][2];
     __shared__ lr_seg_scratch scratch[2];
     // the two chains' state rows live in LDS between iterations (registers are needed by the step itself)
@@ -265,6 +269,8 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) st_i32[wave][r * LR_ROW + lane] = I[r * LR_ROW + lane];
     }
     for (int i = tid; i < 2 * H; i += T) tab[i] = gpair[i];
+    __syncthreads();
+    lr_pair_planes_block(tab, H, a.cfg.n_bins, tid, T);
     __syncthreads();
     const char* lbase = reinterpret_cast<const char*>(tab);
     // unequal shares of the waves (see lr_persist4_kernel): older waves 0..3 take trips from the younger 4..7
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners
     constexpr int ENT = GENERAL ? 2 : 1;                  // double2 per pair-table entry (LR_TAB_PAIRGEN / LR_TAB_UNIT)
     constexpr int ES = GENERAL ? 4 * H : 2;               // the builders' `so`: doubles from a value to its slope (lr_device.h)
-    __shared__ double2 tab[2][2 * H * ENT];               // pair tables
+    __shared__ double2 tab[2][GENERAL ? 4 * H : LR_UNIT_PLANES * H];   // pair tables (unit resolution: S, E and the pair-sum planes)
     __shared__ double red[2][NW][2];                      // [pair][scanner wave][chain of the pair]
     __shared__ lr_seg_scratch scratch[2];
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
@@ -379,6 +385,11 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     double2* g1 = lr_chain_table(a, c0 + 2);             // tables are allocated for whole groups of cb >= 4 chains
     for (int i = tid; i < 2 * H * ENT; i += LR_P4_THREADS) tab[0][i] = g0[i], tab[1][i] = g1[i];
     __syncthreads();
+    if (!GENERAL) {
+        lr_pair_planes_block(tab[0], H, a.cfg.n_bins, tid, LR_P4_THREADS);
+        lr_pair_planes_block(tab[1], H, a.cfg.n_bins, tid, LR_P4_THREADS);
+        __syncthreads();
+    }
     const bool scanner = wave >= 2;
     const int sid = tid - 2 * LR_WAVE;
     // The SIMD issue arbiter serves its oldest wave first: with equal shares the scanner waves of a SIMD finish one
@@ -697,7 +708,7 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     double t_persist = rounds * (n * 2.0 * (blocks > 256 ? 2.0 : 1.0) / 2.2e10) + 6e-6;
     int k = 0;
     if (general) t_persist = n * c / 2.6e12 + 6e-6;            // four-chain kernel on 32-byte entries (measured: 2.6e12 evals/s)
-    const double t_spec = (general && p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general) * 1e-6;   // few chains: a team of CUs per pair
+    const double t_spec = (p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general) * 1e-6;   // few chains: a team of CUs per pair
     if (k > 0 && t_spec < t_persist) t_persist = t_spec;
     const double t_launch = n * c / (general ? 2.6e12 : 5e12) + 14e-6;
     return t_persist <= t_launch;
@@ -717,7 +728,7 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, 
     static const int spec_env = lr_env_int("LR_SPEC", -1);
     const bool general = p.unit == LR_TAB_PAIRGEN;   // general times: the speculative (H <= 136) and four-chain kernels only
     int k = 0;
-    const double t_spec = (general && p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general);
+    const double t_spec = (p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general);
     if (k > 0 && t_spec < 1e29 && cfg->engine_mode != 3 && cfg->engine_mode != 4 && spec_env != 0) {
         // the two-chain kernel with all 16 waves scanning wins only on long scans without room for a team
         // (measured at 256 pairs, 10k..1M lineages: 5.0 + 0.45 us per trip of its 1024 scanner lanes, 4.6 at least; the
@@ -884,10 +895,10 @@ static int lr_launch_pairscan(const lr_engine* e, hipStream_t stream) {
     const dim3 grid(e->plan.tiles, (e->cfg.n_chains + 1) / 2);
     if (e->plan.unit == LR_TAB_PAIRGEN)
         hipLaunchKernelGGL((lr_pairscan_kernel<H, true>), grid, dim3(256), 0, stream, pk, e->n8,
-                           (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->plan.tiles, (double*)(e->ws + e->lay.partials));
+                           (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->cfg.n_bins, e->plan.tiles, (double*)(e->ws + e->lay.partials));
     else
         hipLaunchKernelGGL((lr_pairscan_kernel<H, false>), grid, dim3(256), 0, stream, pk, e->n8,
-                           (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->plan.tiles, (double*)(e->ws + e->lay.partials));
+                           (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->cfg.n_bins, e->plan.tiles, (double*)(e->ws + e->lay.partials));
     return (int)hipGetLastError();
 }
 

@@ -120,6 +120,85 @@ __global__ void lr_pack_groups_kernel(const double* __restrict__ ts, const doubl
     }
 }
 
+// ---- unit resolution: pair slots (lr_scan.h) --------------------------------------------------------------------------
+// death entry of lineage i as the packed scan addresses it (model 3: extant lineages gather the extant block, by birth bin)
+__device__ __forceinline__ int lr_pack_death_entry(const double* __restrict__ ts, const double* __restrict__ te, long long i,
+                                                   double t0, int n_bins, int extant_block, double end_time, bool* extant) {
+    const double e = te[i];
+    *extant = extant_block && e >= end_time;
+    return *extant ? n_bins + 2 + lr_birth_index(ts[i], t0, n_bins) : lr_death_index(e, t0, n_bins);
+}
+// lineage i can share a slot with lineage i - 1: same run, both with a death entry of the window, 0 <= d <= LR_PAIR_DMAX
+__device__ __forceinline__ bool lr_pack_pairable(const double* __restrict__ ts, const double* __restrict__ te, long long i,
+                                                 const int* __restrict__ run_start, double t0, int n_bins, int extant_block,
+                                                 double end_time) {
+    if (i == 0 || run_start[i] == (int)i) return false;
+    bool x0, x1;
+    const int d0 = lr_pack_death_entry(ts, te, i - 1, t0, n_bins, extant_block, end_time, &x0);
+    const int d1 = lr_pack_death_entry(ts, te, i, t0, n_bins, extant_block, end_time, &x1);
+    return !x0 && !x1 && d1 >= d0 && d1 - d0 <= LR_PAIR_DMAX;
+}
+// stretch-start candidates: a stretch = a maximal sequence of lineages each pairable with its predecessor
+__global__ void lr_pack_stretch_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n, double t0,
+                                       int n_bins, const int* __restrict__ run_start, int extant_block, double end_time,
+                                       int* __restrict__ cand) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cand[i] = lr_pack_pairable(ts, te, i, run_start, t0, n_bins, extant_block, end_time) ? 0 : (int)i;
+}
+// slot heads: the lineages at even positions of their stretch (greedy pairing from the stretch start)
+__global__ void lr_pack_heads_kernel(const int* __restrict__ stretch_start, long long n, int* __restrict__ head) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (((int)i - stretch_start[i]) & 1) ? 0 : 1;
+}
+// new-group flags: heads whose slot number inside the run is a multiple of LR_SLOTS
+__global__ void lr_pack_slot_flags_kernel(const int* __restrict__ run_start, const int* __restrict__ stretch_start,
+                                          const int* __restrict__ head_incl, long long n, int* __restrict__ flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool head = !(((int)i - stretch_start[i]) & 1);
+    const int slot = head_incl[i] - head_incl[run_start[i]];          // the run start is a head: slots before i in the run
+    flag[i] = (head && slot % LR_SLOTS == 0) ? 1 : 0;
+}
+__global__ void lr_pack_slots_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n, double t0,
+                                     int n_bins, int H, const int* __restrict__ run_start, const int* __restrict__ stretch_start,
+                                     const int* __restrict__ head_incl, const int* __restrict__ group_incl, int permute,
+                                     int k_tot, lr_p4_shares sh, unsigned short* __restrict__ out, int extant_block,
+                                     double end_time) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (((int)i - stretch_start[i]) & 1) return;                       // second lineage of a pair: written by its head
+    const int rs = run_start[i];
+    const int slot_in_run = head_incl[i] - head_incl[rs];
+    const int slot = slot_in_run % LR_SLOTS;
+    long long g = group_incl[i] - 1;
+    if (permute) g = lr_share_permute(g, k_tot, sh);
+    unsigned short* grp = out + g * 8;
+    bool x0;
+    const int d0 = lr_pack_death_entry(ts, te, i, t0, n_bins, extant_block, end_time, &x0);
+    const bool pair = i + 1 < n && stretch_start[i + 1] == stretch_start[i];
+    int entry = H + d0;                                                // single: the E plane
+    if (pair) {
+        bool x1;
+        const int d1 = lr_pack_death_entry(ts, te, i + 1, t0, n_bins, extant_block, end_time, &x1);
+        entry = (2 + (d1 - d0)) * H + d0;                              // pair: plane 2 + d
+    }
+    grp[1 + slot] = (unsigned short)entry;
+    if (slot == 0) {
+        // header: birth index and the number of lineages in the group's (up to LR_SLOTS) slots; unused slots -> E[0] = 0
+        const int a = lr_birth_index(ts[i], t0, n_bins);
+        int cnt = 0, slots = 0;
+        long long k = i;
+        while (slots < LR_SLOTS && k < n && run_start[k] == rs) {
+            const bool pr = k + 1 < n && stretch_start[k + 1] == stretch_start[k];     // k is a head by construction
+            cnt += pr ? 2 : 1, k += pr ? 2 : 1, ++slots;
+        }
+        grp[0] = (unsigned short)(a | (cnt << 8));
+        for (int q = slots; q < LR_SLOTS; ++q) grp[1 + q] = (unsigned short)H;
+    }
+}
+
 struct lr_max_op {
     __host__ __device__ int operator()(int a, int b) const { return a > b ? a : b; }
 };
@@ -132,8 +211,9 @@ static size_t lr_scan_tmp_bytes(long long n) {
 }
 
 long long lr_pack_tmp_bytes(long long n) {
-    // two int32 arrays (run start, group number) + the scans' temporary storage + the group count read by the host
-    return (long long)(2 * lr_align_up64(n * 4, 256) + (long long)lr_scan_tmp_bytes(n) + 256);
+    // four int32 arrays (run start, stretch start, slot heads, group number) + the scans' temporary storage + the group
+    // count read by the host
+    return (long long)(4 * lr_align_up64(n * 4, 256) + (long long)lr_scan_tmp_bytes(n) + 256);
 }
 
 // Shares of the scanner waves given the number of groups (moved here from lr_mcmc_create: the count depends on the data)
@@ -206,17 +286,38 @@ static void lr_set_shares(lr_engine* e) {
 int lr_pack_lineages(lr_engine* e, hipStream_t stream) {
     const long long n = e->cfg.n_lineages;
     if (n >= (1ll << 31)) return LR_ERR_SIZE;                         // lineage numbers are scanned as int32
+    const bool general = e->plan.unit == LR_TAB_PAIRGEN;
+    const int extant_block = e->cfg.model == LR_MODEL_KEIDING_DEAD ? 1 : 0;
     char* tmp = e->ws + e->lay.pack_tmp;
+    const long long arr = lr_align_up64(n * 4, 256);
     int* run_start = (int*)tmp;
-    int* group_incl = (int*)(tmp + lr_align_up64(n * 4, 256));
-    char* scan_tmp = tmp + 2 * lr_align_up64(n * 4, 256);
+    int* group_incl = (int*)(tmp + arr);
+    int* stretch_start = (int*)(tmp + 2 * arr);
+    int* head_incl = (int*)(tmp + 3 * arr);
+    char* scan_tmp = tmp + 4 * arr;
     size_t scan_bytes = lr_scan_tmp_bytes(n);
     const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
     // group_incl doubles as the scans' input buffer: candidates -> run starts, flags -> group numbers
     hipLaunchKernelGGL(lr_pack_runs_kernel, grid, blk, 0, stream, e->ts, n, e->cfg.t0, e->cfg.n_bins, group_incl);
     hipError_t he = rocprim::inclusive_scan(scan_tmp, scan_bytes, (const int*)group_incl, run_start, (size_t)n, lr_max_op(), stream);
     if (he != hipSuccess) return (int)he;
-    hipLaunchKernelGGL(lr_pack_flags_kernel, grid, blk, 0, stream, run_start, n, group_incl);
+    if (general) {
+        hipLaunchKernelGGL(lr_pack_flags_kernel, grid, blk, 0, stream, run_start, n, group_incl);
+    } else {
+        // unit resolution: pair slots.  Stretches of pairable neighbours (max-scan), greedy pairs from each stretch start
+        // (heads = even positions, sum-scan = slot numbers), a new group every LR_SLOTS slots of a run.
+        hipLaunchKernelGGL(lr_pack_stretch_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins,
+                           (const int*)run_start, extant_block, e->cfg.end_time, group_incl);
+        scan_bytes = lr_scan_tmp_bytes(n);
+        he = rocprim::inclusive_scan(scan_tmp, scan_bytes, (const int*)group_incl, stretch_start, (size_t)n, lr_max_op(), stream);
+        if (he != hipSuccess) return (int)he;
+        hipLaunchKernelGGL(lr_pack_heads_kernel, grid, blk, 0, stream, (const int*)stretch_start, n, group_incl);
+        scan_bytes = lr_scan_tmp_bytes(n);
+        he = rocprim::inclusive_scan(scan_tmp, scan_bytes, (const int*)group_incl, head_incl, (size_t)n, rocprim::plus<int>(), stream);
+        if (he != hipSuccess) return (int)he;
+        hipLaunchKernelGGL(lr_pack_slot_flags_kernel, grid, blk, 0, stream, (const int*)run_start, (const int*)stretch_start,
+                           (const int*)head_incl, n, group_incl);
+    }
     scan_bytes = lr_scan_tmp_bytes(n);
     he = rocprim::inclusive_scan(scan_tmp, scan_bytes, (const int*)group_incl, group_incl, (size_t)n, rocprim::plus<int>(), stream);
     if (he != hipSuccess) return (int)he;
@@ -227,17 +328,22 @@ int lr_pack_lineages(lr_engine* e, hipStream_t stream) {
     if (n_groups < 1 || (long long)n_groups + LR_IDX_SPARE > e->n8_alloc) return LR_ERR_ORDER;   // too many runs: unsorted input
     e->n8 = n_groups;
     lr_set_shares(e);
-    const bool general = e->plan.unit == LR_TAB_PAIRGEN;
-    // zero fill (a zero group = sentinel entries on both sides, contribution 0), then the groups
+    // zero fill (general: a zero group = sentinel entries on both sides, contribution 0), then the groups
     he = hipMemsetAsync(e->ws + e->lay.lineage_idx, 0, (size_t)e->n8_alloc * 16, stream);
     if (he == hipSuccess && general) he = hipMemsetAsync(e->ws + e->lay.lineage_frac, 0, (size_t)e->n8_alloc * 16 * LR_FRAC_ARRAYS, stream);
     if (he != hipSuccess) return (int)he;
     bool any = false;
     for (int j = 0; j < 16; ++j) any |= e->p4.delta[j] != 0;
-    hipLaunchKernelGGL(lr_pack_groups_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins, (const int*)run_start,
-                       (const int*)group_incl, any ? 1 : 0, (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64)), e->p4,
-                       (unsigned char*)(e->ws + e->lay.lineage_idx),
-                       general ? (unsigned int*)(e->ws + e->lay.lineage_frac) : nullptr, (long long)e->n8_alloc,
-                       e->cfg.model == LR_MODEL_KEIDING_DEAD ? 1 : 0, e->cfg.end_time);
+    const int k_tot = (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64));
+    if (general) {
+        hipLaunchKernelGGL(lr_pack_groups_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins, (const int*)run_start,
+                           (const int*)group_incl, any ? 1 : 0, k_tot, e->p4, (unsigned char*)(e->ws + e->lay.lineage_idx),
+                           (unsigned int*)(e->ws + e->lay.lineage_frac), (long long)e->n8_alloc, extant_block, e->cfg.end_time);
+    } else {
+        // (an all-zero group of the spare: birth entry 0 x count 0 and seven gathers of S[0] = 0 - contribution 0)
+        hipLaunchKernelGGL(lr_pack_slots_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins, e->plan.H,
+                           (const int*)run_start, (const int*)stretch_start, (const int*)head_incl, (const int*)group_incl,
+                           any ? 1 : 0, k_tot, e->p4, (unsigned short*)(e->ws + e->lay.lineage_idx), extant_block, e->cfg.end_time);
+    }
     return (int)hipGetLastError();
 }

@@ -313,10 +313,33 @@ __device__ __forceinline__ unsigned int lr_grp_off(const uint4& w, int k) {
     return (sh >= 0 ? (v >> sh) : (v << -sh)) & m;
 }
 
-// Scan of `n8` groups against ONE pair table (unit resolution: 16-byte entries = the two chains' values) by `n_scan`
-// threads, this thread being number `sid`: the inner loop of the persistent engines.  Per group one 16-byte load (the
-// next one in flight while the current one is scored), ONE gather of the birth entry - it enters `count` times - and one
-// gather per lineage of its death entry: 15 ds_read_b128 and 31 fp64 operations for 14 lineages x 2 chains.
+// ---- unit resolution: pair slots ------------------------------------------------------------------------------------
+// Group format (lr_pack.hip, unit-resolution data): uint4 = byte 0 birth index a, byte 1 number of lineages, then
+// LR_SLOTS = 7 sixteen-bit ENTRY indices into the block's pair table.  A slot holds ONE lineage (entry H + j, its death
+// entry E[j]) or TWO consecutive lineages of the run whose death entries are j and j + d, 0 <= d <= 3 (entry
+// (2 + d) H + j, the pair sum E[j] + E[j + d]); padding slots point at E[0] = 0.  The pair table in LDS therefore has six
+// planes of H entries: S, E and the four pair-sum planes, which every block derives from its E plane (lr_pair_planes_*);
+// only S and E exist in global memory.  Sorted lineages of one birth bin die in nearly sorted order, so almost every slot
+// is a pair (cfg4: 49,953 pairs and 94 singles for 100,000 lineages): 8 gathers and 17 fp64 operations score 14
+// lineages x 2 chains, every lineage through its own (birth, death) entry.
+#define LR_SLOTS 7
+#define LR_PAIR_DMAX 3
+#define LR_UNIT_PLANES 6                /* S, E, E2[0..3] */
+
+// byte offset (entry * 16) of 16-bit field `hi` of a word / of byte 0: one byte-/word-select shift each (the loop is bound
+// by vector instruction issue: scratch/ubench/README.md)
+__device__ __forceinline__ unsigned int lr_word_off16(unsigned int v, int hi) {
+    unsigned int r;
+    const unsigned int sh = 4;
+    if (hi) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(sh), "v"(v));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(sh), "v"(v));
+    return r;
+}
+
+// Scan of `n8` groups against ONE pair table (unit resolution, six planes of 16-byte entries = the two chains' values)
+// by `n_scan` threads, this thread being number `sid`: the inner loop of the persistent engines.  Per group one 16-byte
+// load (the next one in flight while the current one is scored), ONE gather of the birth entry - it enters `count` times -
+// and one gather per slot.
 // A lane's first group of every scan is the same group: a persistent kernel may keep it (and, on general times, its
 // fractions) in registers across iterations instead of waiting for the load at the top of each scan.
 struct lr_first_group {
@@ -335,7 +358,6 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     if (first) w = first->w;
     else if (i < n) w = idx8[i];
-    const char* ebase = lbase + H * 16;
 #pragma unroll UNROLL
     while (i < n) {
         const uint4 cur = w;
@@ -343,20 +365,52 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
         if (nx < n) w = idx8[nx];
         const double2 S = *reinterpret_cast<const double2*>(lbase + lr_grp_off<4>(cur, 0));
         const double cnt = (double)((cur.x >> 8) & 0xffu);
-        double2 E[LR_GRP];
-#pragma unroll
-        for (int k = 0; k < LR_GRP; ++k) E[k] = *reinterpret_cast<const double2*>(ebase + lr_grp_off<4>(cur, k + 2));
-        // fixed pairwise tree over the group's death entries, then the birth entry `count` times
-        double t0[LR_GRP / 2], t1[LR_GRP / 2];
-#pragma unroll
-        for (int k = 0; k < LR_GRP / 2; ++k) t0[k] = E[2 * k].x + E[2 * k + 1].x, t1[k] = E[2 * k].y + E[2 * k + 1].y;
-        const double u0 = ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t0[4] + t0[5]) + t0[6]);
-        const double u1 = ((t1[0] + t1[1]) + (t1[2] + t1[3])) + ((t1[4] + t1[5]) + t1[6]);
+        double2 E[LR_SLOTS];
+        E[0] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.x, 1));
+        E[1] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 0));
+        E[2] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 1));
+        E[3] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 0));
+        E[4] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 1));
+        E[5] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 0));
+        E[6] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 1));
+        // fixed pairwise tree over the slots, then the birth entry `count` times
+        const double u0 = ((E[0].x + E[1].x) + (E[2].x + E[3].x)) + ((E[4].x + E[5].x) + E[6].x);
+        const double u1 = ((E[0].y + E[1].y) + (E[2].y + E[3].y)) + ((E[4].y + E[5].y) + E[6].y);
         acc0 += fma(cnt, S.x, u0);
         acc1 += fma(cnt, S.y, u1);
         i = nx;
     }
     *acc0_ = acc0, *acc1_ = acc1;
+}
+
+// The pair-sum planes of a pair table from its E plane.  `tab` = the table's doubles (entry e of chain c at 2 e + c);
+// plane 2 + d, entry j = E[j] + E[j + d] for the death entries j, j + d <= n_bins + 1 that lineages can be paired on (the
+// extant block of model 3 behind them is gathered through single slots only).
+// (a) one chain's column, by the wave that just built its S and E planes; `dup` != 0: also the copy `dup` doubles on
+__device__ __forceinline__ void lr_pair_planes_wave(double* tab, int H, int n_bins, int lane, int dup) {
+    const double* E = tab + 2 * H;
+    for (int j = lane; j <= n_bins + 1; j += LR_WAVE) {
+        const double e0 = E[2 * j];
+#pragma unroll
+        for (int d = 0; d <= LR_PAIR_DMAX; ++d) {
+            if (j + d <= n_bins + 1) {
+                const double v = e0 + E[2 * (j + d)];
+                tab[2 * ((2 + d) * H + j)] = v;
+                if (dup) tab[2 * ((2 + d) * H + j) + dup] = v;
+            }
+        }
+    }
+}
+// (b) both chains at once, by a whole block that just copied S and E from global memory
+__device__ __forceinline__ void lr_pair_planes_block(double2* tab, int H, int n_bins, int tid, int n_threads) {
+    const double2* E = tab + H;
+    for (int q = tid; q < (n_bins + 2) * (LR_PAIR_DMAX + 1); q += n_threads) {
+        const int j = q % (n_bins + 2), d = q / (n_bins + 2);
+        if (j + d <= n_bins + 1) {
+            const double2 a = E[j], b = E[j + d];
+            tab[(2 + d) * H + j] = make_double2(a.x + b.x, a.y + b.y);
+        }
+    }
 }
 
 // The same scan on GENERAL lineage times: pair tables in the LR_TAB_PAIRGEN layout (a plane of value pairs and a plane of

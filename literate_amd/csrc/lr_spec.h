@@ -310,18 +310,20 @@ __device__ __forceinline__ int lr_spec_turn(int role, int acc) {
 // everything the block keeps in LDS
 template <int H, int NW, int ENT>
 struct lr_spec_lds {
+    static constexpr bool GENERAL_ENTRIES = ENT == 2;
+    static constexpr int TAB = GENERAL_ENTRIES ? 4 * H : LR_UNIT_PLANES * H;   // double2 per pair table
     // Pair tables (S' entries [0,H), E' [H,2H); (.x, .y) = (chain 0, chain 1)) for every combination of outcomes, in two
     // generations: pairs[g][d0][d1] holds candidate d0 of chain 0 beside candidate d1 of chain 1 for the iterations of
     // parity g.  A candidate wave writes its column into the two tables that contain it, so after the decisions the
     // scanners just switch to pairs[g][d0][d1]: no copy between the decision and the next scan.
-    double2 pairs[2][2][2][2 * H * ENT];   // ENT double2 per entry: 1 unit resolution, 2 general times (LR_TAB_PAIRGEN)
+    double2 pairs[2][2][2][GENERAL_ENTRIES ? 4 * H : LR_UNIT_PLANES * H];   // general times: value + slope planes (LR_TAB_PAIRGEN); unit: S, E, pair sums
     int cur_sel;                 // d0 * 2 + d1 of the pair table that stands when the kernel ends
     double red[NW][2];           // per scanner wave: partial sums of the two chains
     lr_spec_decision dec[2];     // [iteration parity]: what the deciding wave found
     double likA[2];              // log-likelihood of the accepted state of the two chains
     int abort_flag;
     int scan_arrive;             // scanner waves that have delivered their sums, counted over the whole launch
-    int pad_[1];
+    int plane_arrive;            // scanner waves that have written their share of the pair-sum planes, likewise
     lr_seg_scratch scratch[4];
     lr_set sets[2][4];
     lr_draw_slot draws[2][2];    // [chain][iteration parity]
@@ -363,6 +365,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     const bool split_draws = k_team == 1;
     const int dch = split_draws ? (wave - (NW - 4)) >> 1 : wave - (NW - 2), dpart = (wave - (NW - 4)) & 1;
     const bool drawer = rj && dch >= 0 && ctx.c0 + dch < ctx.C;
+    const int n_derive = (rj && split_draws) ? NW - 8 : NW - 4;      // waves 4 .. 4 + n_derive - 1 derive the pair-sum planes
     const int sid = tid - 4 * LR_WAVE;
     int sel = 0;
     int role0 = LR_SPEC_ROLES0, role1 = LR_SPEC_ROLES0;
@@ -392,6 +395,15 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
         const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
         const double lA = sm.likA[lane & 1];
+        // a block on its own: the draw duty first (it depends on nothing), so that the wave's scan - and with it the
+        // decision, which falls to whoever scans last - is not followed by more work before the barrier
+        if (drawer && split_draws) lr_spec_draw_part(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1], dpart);
+        if (!GENERAL && iter > 0) {
+            // the pair-sum planes of this iteration's table (derived behind the last barrier, see below) must stand
+            const int want = n_derive * (int)iter;
+            while (__hip_atomic_load(&sm.plane_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        }
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(sm.pairs[it & 1][sel >> 1][sel & 1]);
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1, &first);
@@ -499,16 +511,23 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
             }
         }
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
-        if (drawer) {
-            if (split_draws) lr_spec_draw_part(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1], dpart);
-            else lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
-        }
+        if (drawer && !split_draws) lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
         LR_XSTAMP(dg_work);
         __syncthreads();                                                     // the decision and the candidates are in
         LR_XSTAMP(dg_wait1);
         if (k_team > 1 && sm.abort_flag) return;
         sel = sm.dec[iter & 1].sel;
         role0 = lr_spec_turn(role0, sel >> 1), role1 = lr_spec_turn(role1, sel & 1);
+        if (!GENERAL) {
+            // The pair-sum planes (lr_scan.h) of the table that was selected - the candidates wrote S and E only -, both
+            // chains at once, by the scanner waves without draw duty; every scanner wave waits for them on an LDS
+            // counter before its next scan (the candidate waves are already building: no block barrier)
+            if (wave - 4 < n_derive) {
+                lr_pair_planes_block(sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, n_derive * LR_WAVE);
+                LR_WAVE_LDS_ORDER();
+                if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         LR_XSTAMP(dg_p2);
     }
     LR_XDUMP();
@@ -566,7 +585,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(8); } }
             if (!rj) {
                 lr_dd_prop p;
-                const double P = lr_propose_dd<true>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds);
+                const double P = lr_propose_dd<true, false>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds);
                 out->L[lane] = P;
                 if (lane == 0) {
                     out->sc[LR_SET_HASTING] = p.hasting, out->sc[LR_SET_PRIOR] = p.prior, out->sc[LR_SET_LOG_U] = p.log_u;
@@ -582,7 +601,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 lr_rj_draws d;
                 lr_draws_load(&sm.draws[c][(it + 1) & 1], d, lane);
                 // (the one-pass builder writes the column into both pair tables)
-                lr_propose_rj<true, lr_bins_per_lane(H), true>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
+                lr_propose_rj<true, lr_bins_per_lane(H), true, false>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
                                                                logbr_lds, (int)(col1 - col0));
                 lr_set_store(out, s, p, lane);
                 { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
@@ -648,6 +667,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
                                                                      lr_spec_args x, long long n_iters) {
     constexpr int NW = T / LR_WAVE;
     constexpr int ENT = GENERAL ? 2 : 1;
+    static_assert(sizeof(lr_spec_lds<H, NW, ENT>) <= 160 * 1024, "the block's LDS image must fit a CU");
     __shared__ lr_spec_lds<H, NW, ENT> sm;
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int k_team = x.team_blocks;
@@ -666,7 +686,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         // all pair tables start as zeros (the column of a missing second chain must stay zero); the pending pair table
         // of iteration it0 goes to pairs[it0 & 1][0][0]
         double2* z = &sm.pairs[0][0][0][0];
-        for (int i = tid; i < 8 * 2 * H * ENT; i += T) z[i] = make_double2(0.0, 0.0);
+        for (int i = tid; i < 8 * lr_spec_lds<H, NW, ENT>::TAB; i += T) z[i] = make_double2(0.0, 0.0);
     }
     {
         // sets 2, 3 start as zeros (the parametric samplers write one row only; rows never written must not hold junk
@@ -682,7 +702,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         sm.br[b] = (in && a.br_length) ? a.br_length[b] : 0.0;
         sm.logbr[b] = in ? a.log_br[b] : 0.0;
     }
-    if (tid == 0) sm.abort_flag = 0, sm.cur_sel = 0, sm.scan_arrive = 0, sm.args = a;
+    if (tid == 0) sm.abort_flag = 0, sm.cur_sel = 0, sm.scan_arrive = 0, sm.plane_arrive = 0, sm.args = a;
     if (tid < 2) sm.likA[tid] = (c0 + tid < C) ? a.state_f64[((size_t)(c0 + tid) * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA] : 0.0;
     lr_spec_ctx ctx;
     {
@@ -696,6 +716,10 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     }
     __syncthreads();
     for (int i = tid; i < 2 * H * ENT; i += T) sm.pairs[ctx.it0 & 1][0][0][i] = gpair[i];
+    if (!GENERAL) {
+        __syncthreads();
+        lr_pair_planes_block(sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
+    }
     // draws of the first candidates (iteration it0 + 1); afterwards the last four scanner waves stay one iteration ahead
     if (rj && wave >= NW - 2 && c0 + (wave - (NW - 2)) < C)
         lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, &sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1]);

@@ -9,6 +9,7 @@
 #include "lr_chain.h"
 #include "lr_dd.h"
 #include "lr_internal.h"
+#include "lr_scan.h"
 
 struct lr_step_args {
     lr_mcmc_config cfg;
@@ -469,7 +470,7 @@ __device__ __forceinline__ double lr_wave_multiplier_pre(double& R, int K, bool 
 // hyper-parameters, every other move the rates / times of one process), `p` its bookkeeping, and its lookup tables
 // stand at `table`.  A pure function of (s, it, the chain's Philox stream, the data): the speculative engine calls it
 // on both possible outcomes of the pending decision.
-template <bool LDS_CONSTS = false, int PB = 0, bool DUP = false>
+template <bool LDS_CONSTS = false, int PB = 0, bool DUP = false, bool PAIR_PLANES = true>
 __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int lane, lr_seg_scratch* scratch_p,
                                               uint64_t it, lr_rj_state& s, lr_rj_prop& p, double2* table,
                                               int table_es, const lr_rj_draws* pre = nullptr,
@@ -628,6 +629,12 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
                                                    lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death,
                                                    table_es, pre ? &sg : nullptr, table_dup);
     s.sgL = sg.packL, s.sgM = sg.packM, s.sg_valid = (pre && sg.packL != -1) ? 1 : 0;
+    if (LDS_CONSTS && PAIR_PLANES && lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) {
+        // persistent engines, unit resolution: the pair-sum planes the packed scan gathers from (lr_scan.h; the speculative
+        // kernel leaves them to its scanner waves, which derive them for the selected table only)
+        LR_WAVE_LDS_ORDER();
+        lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, n_bins, lane, DUP ? table_dup : 0);
+    }
     LR_SSTAMP(6);
     s.L = pL, s.M = pM, s.tL = ptL, s.tM = ptM, s.eL = peL, s.eM = peM, s.KL = PKL, s.KM = PKM;
     s.g0 = g0, s.g1 = g1, s.poi = poi, s.lg0 = lg0, s.lg1 = lg1, s.lpoi = lpoi, s.priorPoi = priorPoi;
@@ -759,10 +766,10 @@ struct lr_dd_prop {
     double hasting, prior, log_u;
     int move;
 };
-template <bool LDS_CONSTS = false>
+template <bool LDS_CONSTS = false, bool PAIR_PLANES = true>
 __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, int lane, uint64_t it, double A,
                                                 lr_dd_prop& p, double2* table, int table_es,
-                                                const double* aux_lds = nullptr) {
+                                                const double* aux_lds = nullptr, int table_dup = 0) {
     const lr_mcmc_config& cfg = a.cfg;
     const bool trend = cfg.sampler == 2;
     const int npar = trend ? LR_TR_NPAR : LR_DD_NPAR;
@@ -825,6 +832,10 @@ __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, in
         const lr_dd_params pp = lr_dd_unpack(P);
         lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es),
                                 cfg.frac_birth, cfg.frac_death, table_es);
+    }
+    if (LDS_CONSTS && PAIR_PLANES && lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) {
+        LR_WAVE_LDS_ORDER();
+        lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, table_dup);
     }
     p.hasting = hasting, p.move = move_kind;
     return P;

@@ -45,6 +45,45 @@ __device__ __forceinline__ void scan_asm(const char* lbase, const uint4* idx8, i
     *a0 = acc0, *a1 = acc1;
 }
 
+// variant 5: pair-slot format (7 slots of up to two lineages per group, 16-bit entry indices into a table that also
+// holds the pair sums E[j] + E[j + d], d = 0..3): 8 gathers and 17 fp64 operations per 14 lineages x 2 chains
+__device__ __forceinline__ unsigned int word_off(unsigned int v, int hi) {
+    unsigned int r;
+    const unsigned int sh = 4;
+    if (hi) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(sh), "v"(v));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(sh), "v"(v));
+    return r;
+}
+__device__ __forceinline__ void scan_pairs(const char* lbase, const uint4* idx, int n, int sid, int n_scan, double* a0, double* a1) {
+    double acc0 = *a0, acc1 = *a1;
+    int i = sid;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n) w = idx[i];
+    while (i < n) {
+        const uint4 cur = w;
+        const int nx = i + n_scan;
+        if (nx < n) w = idx[nx];
+        unsigned int sb;
+        { const unsigned int sh = 4; asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(sb) : "v"(sh), "v"(cur.x)); }
+        const double2 S = *reinterpret_cast<const double2*>(lbase + sb);
+        const double cnt = (double)((cur.x >> 8) & 0xffu);
+        double2 E[7];
+        E[0] = *reinterpret_cast<const double2*>(lbase + word_off(cur.x, 1));
+        E[1] = *reinterpret_cast<const double2*>(lbase + word_off(cur.y, 0));
+        E[2] = *reinterpret_cast<const double2*>(lbase + word_off(cur.y, 1));
+        E[3] = *reinterpret_cast<const double2*>(lbase + word_off(cur.z, 0));
+        E[4] = *reinterpret_cast<const double2*>(lbase + word_off(cur.z, 1));
+        E[5] = *reinterpret_cast<const double2*>(lbase + word_off(cur.w, 0));
+        E[6] = *reinterpret_cast<const double2*>(lbase + word_off(cur.w, 1));
+        const double u0 = ((E[0].x + E[1].x) + (E[2].x + E[3].x)) + ((E[4].x + E[5].x) + E[6].x);
+        const double u1 = ((E[0].y + E[1].y) + (E[2].y + E[3].y)) + ((E[4].y + E[5].y) + E[6].y);
+        acc0 += fma(cnt, S.x, u0);
+        acc1 += fma(cnt, S.y, u1);
+        i = nx;
+    }
+    *a0 = acc0, *a1 = acc1;
+}
+
 template <int VAR>
 __device__ __forceinline__ void scan_once(const char* lbase, const uint4* idx8, int n, int sid, int n_scan, double* a0, double* a1) {
     if (VAR == 0) { lr_persist_scan_pair<H, 1>(lbase, idx8, n, sid, n_scan, a0, a1); return; }
@@ -104,6 +143,37 @@ __global__ __launch_bounds__(1024) void k(const uint4* __restrict__ idx8, int n,
     if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) cyc[2 * (threadIdx.x >> 6)] = t0, cyc[2 * (threadIdx.x >> 6) + 1] = t1;
 }
 
+__global__ __launch_bounds__(1024) void kp(const uint4* __restrict__ idx, int n, long long* cyc, double* sink) {
+    __shared__ double2 tab[6 * H];
+    for (int i = threadIdx.x; i < 6 * H; i += blockDim.x) tab[i] = make_double2(1.0 + i, 2.0 + i);
+    __syncthreads();
+    double a0 = 0.0, a1 = 0.0;
+    const long long t0 = clock64();
+    for (int r = 0; r < REPS; ++r) scan_pairs(reinterpret_cast<const char*>(tab), idx, n, threadIdx.x, blockDim.x, &a0, &a1);
+    const long long t1 = clock64();
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) cyc[2 * (threadIdx.x >> 6)] = t0, cyc[2 * (threadIdx.x >> 6) + 1] = t1;
+}
+static void run_pairs(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { printf("no %s\n", path); return; }
+    fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+    unsigned char* h = (unsigned char*)malloc(sz); if (fread(h, 1, sz, f) != (size_t)sz) return; fclose(f);
+    const int n = (int)(sz / 16);
+    uint4* d; hipMalloc(&d, sz); hipMemcpy(d, h, sz, hipMemcpyHostToDevice);
+    long long* cyc; double* sink;
+    hipMalloc(&cyc, 8 * 64); hipMalloc(&sink, 8 * 1024);
+    for (int threads : {512, 640, 768, 896, 1024}) {
+        hipLaunchKernelGGL(kp, dim3(1), dim3(threads), 0, 0, d, n, cyc, sink);
+        hipLaunchKernelGGL(kp, dim3(1), dim3(threads), 0, 0, d, n, cyc, sink);
+        long long hw[64]; hipMemcpy(hw, cyc, 8 * 64, hipMemcpyDeviceToHost);
+        long long lo = hw[0], hi = hw[1];
+        for (int w = 0; w < threads / 64; ++w) { if (hw[2 * w] < lo) lo = hw[2 * w]; if (hw[2 * w + 1] > hi) hi = hw[2 * w + 1]; }
+        printf("%-34s waves=%2d blocks=  1: one pass %.2f us (%.1f cycles per wave-trip of 64 groups, CU-wide)\n", "pair-slot format", threads / 64,
+               (hi - lo) / (double)REPS / 2400.0, (hi - lo) / (double)REPS / ((n + 63) / 64));
+    }
+}
+
 template <int VAR>
 static void run(const char* name, const uint4* d, int n, int threads, int blocks) {
     long long* cyc; double* sink;
@@ -119,6 +189,7 @@ static void run(const char* name, const uint4* d, int n, int threads, int blocks
 }
 
 int main(int argc, char** argv) {
+    if (argc > 2) { run_pairs(argv[2]); return 0; }
     FILE* f = fopen(argc > 1 ? argv[1] : "scratch/ubench/idx8_cfg4.bin", "rb");
     if (!f) { printf("no index file\n"); return 1; }
     fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);

@@ -403,13 +403,15 @@ __device__ __forceinline__ void lr_pair_planes_wave(double* tab, int H, int n_bi
 }
 // (b) both chains at once, by a whole block that just copied S and E from global memory
 __device__ __forceinline__ void lr_pair_planes_block(double2* tab, int H, int n_bins, int tid, int n_threads) {
+    // one death entry per lane (four independent reads, four writes: one LDS round trip, no index arithmetic)
     const double2* E = tab + H;
-    for (int q = tid; q < (n_bins + 2) * (LR_PAIR_DMAX + 1); q += n_threads) {
-        const int j = q % (n_bins + 2), d = q / (n_bins + 2);
-        if (j + d <= n_bins + 1) {
-            const double2 a = E[j], b = E[j + d];
-            tab[(2 + d) * H + j] = make_double2(a.x + b.x, a.y + b.y);
-        }
+    for (int j = tid; j <= n_bins + 1; j += n_threads) {
+        double2 v[LR_PAIR_DMAX + 1];
+#pragma unroll
+        for (int d = 0; d <= LR_PAIR_DMAX; ++d) v[d] = E[min(j + d, n_bins + 1)];
+#pragma unroll
+        for (int d = 0; d <= LR_PAIR_DMAX; ++d)
+            if (j + d <= n_bins + 1) tab[(2 + d) * H + j] = make_double2(v[0].x + v[d].x, v[0].y + v[d].y);
     }
 }
 

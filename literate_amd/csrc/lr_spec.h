@@ -365,7 +365,6 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     const bool split_draws = k_team == 1;
     const int dch = split_draws ? (wave - (NW - 4)) >> 1 : wave - (NW - 2), dpart = (wave - (NW - 4)) & 1;
     const bool drawer = rj && dch >= 0 && ctx.c0 + dch < ctx.C;
-    const int n_derive = (rj && split_draws) ? NW - 8 : NW - 4;      // waves 4 .. 4 + n_derive - 1 derive the pair-sum planes
     const int sid = tid - 4 * LR_WAVE;
     int sel = 0;
     int role0 = LR_SPEC_ROLES0, role1 = LR_SPEC_ROLES0;
@@ -395,15 +394,6 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
         const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
         const double lA = sm.likA[lane & 1];
-        // a block on its own: the draw duty first (it depends on nothing), so that the wave's scan - and with it the
-        // decision, which falls to whoever scans last - is not followed by more work before the barrier
-        if (drawer && split_draws) lr_spec_draw_part(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1], dpart);
-        if (!GENERAL && iter > 0) {
-            // the pair-sum planes of this iteration's table (derived behind the last barrier, see below) must stand
-            const int want = n_derive * (int)iter;
-            while (__hip_atomic_load(&sm.plane_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-        }
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(sm.pairs[it & 1][sel >> 1][sel & 1]);
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1, &first);
@@ -511,7 +501,10 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
             }
         }
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
-        if (drawer && !split_draws) lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
+        if (drawer) {
+            if (split_draws) lr_spec_draw_part(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1], dpart);
+            else lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
+        }
         LR_XSTAMP(dg_work);
         __syncthreads();                                                     // the decision and the candidates are in
         LR_XSTAMP(dg_wait1);
@@ -520,13 +513,14 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         role0 = lr_spec_turn(role0, sel >> 1), role1 = lr_spec_turn(role1, sel & 1);
         if (!GENERAL) {
             // The pair-sum planes (lr_scan.h) of the table that was selected - the candidates wrote S and E only -, both
-            // chains at once, by the scanner waves without draw duty; every scanner wave waits for them on an LDS
-            // counter before its next scan (the candidate waves are already building: no block barrier)
-            if (wave - 4 < n_derive) {
-                lr_pair_planes_block(sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, n_derive * LR_WAVE);
-                LR_WAVE_LDS_ORDER();
-                if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            // chains at once, by all scanner lanes; the scanner waves then wait for each other on an LDS counter (the
+            // candidate waves are already building: no block barrier)
+            lr_pair_planes_block(sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, NSCAN);
+            LR_WAVE_LDS_ORDER();
+            if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int want = (NW - 4) * ((int)iter + 1);
+            while (__hip_atomic_load(&sm.plane_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
         }
         LR_XSTAMP(dg_p2);
     }

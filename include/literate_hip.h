@@ -222,7 +222,7 @@ typedef struct lr_mcmc_layout {
     int32_t team_blocks;  /* blocks (= CUs) that share one chain pair, each scanning 1/team_blocks of the lineages     */
     int32_t table_mode;   /* 0 chain-major general tables, 1 unit-resolution pair tables, 2 pair-general tables (persistent
                            * engines on general lineage times: in-bin fractions packed as 32-bit fixed point)             */
-    int64_t lineage_frac; /* [4][groups] uint4: fe' x14 + sum of fs (table_mode 2)                                         */
+    int64_t lineage_frac; /* [3][groups] uint4: fe' of the 7 slots + sum of fs (table_mode 2)                               */
     int64_t pack_tmp;     /* scratch of the lineage packing (two int32 per lineage + the scans' temporary storage)       */
 } lr_mcmc_layout;
 

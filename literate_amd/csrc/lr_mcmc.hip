@@ -191,17 +191,16 @@ template <int H, bool GENERAL>
 __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk, long long n8, const double2* __restrict__ tables,
                                                           int n_chains, int n_bins, int tiles, double* __restrict__ partials) {
     constexpr int ENT = GENERAL ? 2 : 1;                       // double2 per pair entry in global memory
-    __shared__ double2 tab[GENERAL ? 4 * H : LR_UNIT_PLANES * H];     // unit resolution: + the pair-sum planes (lr_scan.h)
+    __shared__ double2 tab[LR_UNIT_PLANES * H];                       // S, E (and their slopes) + the pair planes (lr_scan.h)
     __shared__ double red[4][2];
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int tile = blockIdx.x, pair = blockIdx.y;
     const double2* src = tables + (size_t)pair * (2 * H * ENT);
-    for (int i = tid; i < 2 * H * ENT; i += 256) tab[i] = src[i];
+    for (int i = tid; i < 2 * H * ENT; i += 256) tab[GENERAL ? lr_pairgen_lds_entry(i, H) : i] = src[i];
     __syncthreads();
-    if (!GENERAL) {
-        lr_pair_planes_block(tab, H, n_bins, tid, 256);
-        __syncthreads();
-    }
+    if (GENERAL) lr_pair_planes_block_general(tab, H, n_bins, tid, 256);
+    else lr_pair_planes_block(tab, H, n_bins, tid, 256);
+    __syncthreads();
     const long long per = (n8 + tiles - 1) / tiles;
     const long long g0 = min((long long)tile * per, n8), g1 = min(g0 + per, n8);
     double acc0 = 0.0, acc1 = 0.0;
@@ -357,8 +356,8 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     const lr_step_args& a = *ap;
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners
     constexpr int ENT = GENERAL ? 2 : 1;                  // double2 per pair-table entry (LR_TAB_PAIRGEN / LR_TAB_UNIT)
-    constexpr int ES = GENERAL ? 4 * H : 2;               // the builders' `so`: doubles from a value to its slope (lr_device.h)
-    __shared__ double2 tab[2][GENERAL ? 4 * H : LR_UNIT_PLANES * H];   // pair tables (unit resolution: S, E and the pair-sum planes)
+    constexpr int ES = GENERAL ? 6 * H : 2;               // the builders' `so`: doubles from a value to its slope in the LDS image
+    __shared__ double2 tab[2][LR_UNIT_PLANES * H];        // pair tables: S, E (general times: and their slopes) + the pair planes
     __shared__ double red[2][NW][2];                      // [pair][scanner wave][chain of the pair]
     __shared__ lr_seg_scratch scratch[2];
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
@@ -383,13 +382,19 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     }
     double2* g0 = lr_chain_table(a, c0);
     double2* g1 = lr_chain_table(a, c0 + 2);             // tables are allocated for whole groups of cb >= 4 chains
-    for (int i = tid; i < 2 * H * ENT; i += LR_P4_THREADS) tab[0][i] = g0[i], tab[1][i] = g1[i];
+    for (int i = tid; i < 2 * H * ENT; i += LR_P4_THREADS) {
+        const int e = GENERAL ? lr_pairgen_lds_entry(i, H) : i;
+        tab[0][e] = g0[i], tab[1][e] = g1[i];
+    }
     __syncthreads();
-    if (!GENERAL) {
+    if (GENERAL) {
+        lr_pair_planes_block_general(tab[0], H, a.cfg.n_bins, tid, LR_P4_THREADS);
+        lr_pair_planes_block_general(tab[1], H, a.cfg.n_bins, tid, LR_P4_THREADS);
+    } else {
         lr_pair_planes_block(tab[0], H, a.cfg.n_bins, tid, LR_P4_THREADS);
         lr_pair_planes_block(tab[1], H, a.cfg.n_bins, tid, LR_P4_THREADS);
-        __syncthreads();
     }
+    __syncthreads();
     const bool scanner = wave >= 2;
     const int sid = tid - 2 * LR_WAVE;
     // The SIMD issue arbiter serves its oldest wave first: with equal shares the scanner waves of a SIMD finish one
@@ -456,7 +461,10 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = st_f64[wave][r * LR_ROW + lane];
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = st_i32[wave][r * LR_ROW + lane];
     }
-    for (int i = tid; i < 2 * H * ENT; i += LR_P4_THREADS) g0[i] = tab[0][i], g1[i] = tab[1][i];
+    for (int i = tid; i < 2 * H * ENT; i += LR_P4_THREADS) {
+        const int e = GENERAL ? lr_pairgen_lds_entry(i, H) : i;
+        g0[i] = tab[0][e], g1[i] = tab[1][e];
+    }
 }
 
 __global__ void lr_store_args_kernel(lr_step_args a, lr_step_args* dst) {

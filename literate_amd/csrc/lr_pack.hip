@@ -51,13 +51,6 @@ __global__ void lr_pack_runs_kernel(const double* __restrict__ ts, long long n, 
     start_cand[i] = (a != ap) ? (int)i : 0;
 }
 
-// new-group flags from the run starts (in place: run_start stays, flag goes to `flag`)
-__global__ void lr_pack_flags_kernel(const int* __restrict__ run_start, long long n, int* __restrict__ flag) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    flag[i] = (((int)i - run_start[i]) % LR_GRP == 0) ? 1 : 0;
-}
-
 // where group g of the plain order goes under the scanner-wave shares (see lr_persist4_kernel)
 __device__ __forceinline__ long long lr_share_permute(long long g, int k_tot, const lr_p4_shares& sh) {
     const int stride = sh.n_slots * 64;
@@ -76,51 +69,7 @@ __device__ __forceinline__ long long lr_share_permute(long long g, int k_tot, co
     return g;
 }
 
-__global__ void lr_pack_groups_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n, double t0,
-                                      int n_bins, const int* __restrict__ run_start, const int* __restrict__ group_incl,
-                                      int permute, int k_tot, lr_p4_shares sh, unsigned char* __restrict__ out,
-                                      unsigned int* __restrict__ frac, long long fstride, int extant_block,
-                                      double end_time) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int slot = ((int)i - run_start[i]) % LR_GRP;
-    long long g = group_incl[i] - 1;
-    if (permute) g = lr_share_permute(g, k_tot, sh);
-    const double s = ts[i], e = te[i];
-    unsigned char* grp = out + g * 16;
-    const int a = lr_birth_index(s, t0, n_bins);
-    // model 3: extant lineages gather the extant block of the death-side table, indexed by their BIRTH bin (lr_step.h)
-    const bool extant = extant_block && e >= end_time;
-    grp[2 + slot] = (unsigned char)(extant ? n_bins + 2 + a : lr_death_index(e, t0, n_bins));
-    int cnt0 = 0;
-    if (slot == 0) {
-        // header: the birth index and the number of lineages of the run that fall into this group
-        int cnt = 1;
-        while (cnt < LR_GRP && i + cnt < n && lr_birth_index(ts[i + cnt], t0, n_bins) == a) ++cnt;
-        grp[0] = (unsigned char)a, grp[1] = (unsigned char)cnt;
-        cnt0 = cnt;
-    }
-    if (frac) {
-        // general times: fs = ts - floor ts and fe' = ceil te - te (both in [0, 1)) as 32-bit fixed point, rounded to
-        // nearest.  fe' of slot k goes to array k / 4, component k % 4, of LR_FRAC_ARRAYS uint4 arrays; the group's
-        // first lineage also leaves the sum of the group's fs (an exact integer) as a double in array 3, (.z, .w).
-        auto fix = [](double f) { return fmin(rint(f * 4294967296.0), 4294967295.0); };
-        const double fs = fix(s - floor(s));
-        const double fe = extant ? fs : fix(ceil(e) - e);
-        frac[((size_t)(slot >> 2) * fstride + g) * 4 + (slot & 3)] = (unsigned int)fe;
-        if (slot == 0) {
-            double sum = fs;
-            for (int k = 1; k < cnt0; ++k) {
-                const double sk = ts[i + k];
-                sum += fix(sk - floor(sk));
-            }
-            unsigned int* q = frac + ((size_t)3 * fstride + g) * 4 + 2;
-            q[0] = (unsigned int)__double2loint(sum), q[1] = (unsigned int)__double2hiint(sum);
-        }
-    }
-}
-
-// ---- unit resolution: pair slots (lr_scan.h) --------------------------------------------------------------------------
+// ---- pair slots (lr_scan.h) ------------------------------------------------------------------------------------------
 // death entry of lineage i as the packed scan addresses it (model 3: extant lineages gather the extant block, by birth bin)
 __device__ __forceinline__ int lr_pack_death_entry(const double* __restrict__ ts, const double* __restrict__ te, long long i,
                                                    double t0, int n_bins, int extant_block, double end_time, bool* extant) {
@@ -131,20 +80,20 @@ __device__ __forceinline__ int lr_pack_death_entry(const double* __restrict__ ts
 // lineage i can share a slot with lineage i - 1: same run, both with a death entry of the window, 0 <= d <= LR_PAIR_DMAX
 __device__ __forceinline__ bool lr_pack_pairable(const double* __restrict__ ts, const double* __restrict__ te, long long i,
                                                  const int* __restrict__ run_start, double t0, int n_bins, int extant_block,
-                                                 double end_time) {
+                                                 double end_time, int dmax) {
     if (i == 0 || run_start[i] == (int)i) return false;
     bool x0, x1;
     const int d0 = lr_pack_death_entry(ts, te, i - 1, t0, n_bins, extant_block, end_time, &x0);
     const int d1 = lr_pack_death_entry(ts, te, i, t0, n_bins, extant_block, end_time, &x1);
-    return !x0 && !x1 && d1 >= d0 && d1 - d0 <= LR_PAIR_DMAX;
+    return !x0 && !x1 && d1 >= d0 && d1 - d0 <= dmax;
 }
 // stretch-start candidates: a stretch = a maximal sequence of lineages each pairable with its predecessor
 __global__ void lr_pack_stretch_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n, double t0,
                                        int n_bins, const int* __restrict__ run_start, int extant_block, double end_time,
-                                       int* __restrict__ cand) {
+                                       int dmax, int* __restrict__ cand) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    cand[i] = lr_pack_pairable(ts, te, i, run_start, t0, n_bins, extant_block, end_time) ? 0 : (int)i;
+    cand[i] = lr_pack_pairable(ts, te, i, run_start, t0, n_bins, extant_block, end_time, dmax) ? 0 : (int)i;
 }
 // slot heads: the lineages at even positions of their stretch (greedy pairing from the stretch start)
 __global__ void lr_pack_heads_kernel(const int* __restrict__ stretch_start, long long n, int* __restrict__ head) {
@@ -165,7 +114,7 @@ __global__ void lr_pack_slots_kernel(const double* __restrict__ ts, const double
                                      int n_bins, int H, const int* __restrict__ run_start, const int* __restrict__ stretch_start,
                                      const int* __restrict__ head_incl, const int* __restrict__ group_incl, int permute,
                                      int k_tot, lr_p4_shares sh, unsigned short* __restrict__ out, int extant_block,
-                                     double end_time) {
+                                     double end_time, unsigned int* __restrict__ frac, long long fstride) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (((int)i - stretch_start[i]) & 1) return;                       // second lineage of a pair: written by its head
@@ -182,9 +131,22 @@ __global__ void lr_pack_slots_kernel(const double* __restrict__ ts, const double
     if (pair) {
         bool x1;
         const int d1 = lr_pack_death_entry(ts, te, i + 1, t0, n_bins, extant_block, end_time, &x1);
-        entry = (2 + (d1 - d0)) * H + d0;                              // pair: plane 2 + d
+        entry = (2 + (d1 - d0)) * H + d0;                              // pair: plane 2 + d (general times: d = 0 only)
     }
     grp[1 + slot] = (unsigned short)entry;
+    // general times: fs = ts - floor ts and fe' = ceil te - te (both in [0, 1)) as 32-bit fixed point, rounded to nearest
+    auto fix = [](double f) { return fmin(rint(f * 4294967296.0), 4294967295.0); };
+    if (frac) {
+        // the slot's fe' (model 3: an extant lineage carries fs here, see lr_step.h); a pair: the mean of its two, which
+        // the doubled slope of the E2 plane turns back into their sum
+        const double s0 = ts[i], e0 = te[i];
+        double fe = x0 ? fix(s0 - floor(s0)) : fix(ceil(e0) - e0);
+        if (pair) {
+            const double e1 = te[i + 1];
+            fe = floor((fe + fix(ceil(e1) - e1) + 1.0) * 0.5);
+        }
+        frac[((size_t)(slot >> 2) * fstride + g) * 4 + (slot & 3)] = (unsigned int)fe;
+    }
     if (slot == 0) {
         // header: birth index and the number of lineages in the group's (up to LR_SLOTS) slots; unused slots -> E[0] = 0
         const int a = lr_birth_index(ts[i], t0, n_bins);
@@ -196,6 +158,16 @@ __global__ void lr_pack_slots_kernel(const double* __restrict__ ts, const double
         }
         grp[0] = (unsigned short)(a | (cnt << 8));
         for (int q = slots; q < LR_SLOTS; ++q) grp[1 + q] = (unsigned short)H;
+        if (frac) {
+            // the sum of the group's fs (an exact integer below 2^36) as a double: array 2, (.x, .y)
+            double sum = 0.0;
+            for (long long m = i; m < k; ++m) {
+                const double sm = ts[m];
+                sum += fix(sm - floor(sm));
+            }
+            unsigned int* q = frac + ((size_t)2 * fstride + g) * 4;
+            q[0] = (unsigned int)__double2loint(sum), q[1] = (unsigned int)__double2hiint(sum);
+        }
     }
 }
 
@@ -301,13 +273,12 @@ int lr_pack_lineages(lr_engine* e, hipStream_t stream) {
     hipLaunchKernelGGL(lr_pack_runs_kernel, grid, blk, 0, stream, e->ts, n, e->cfg.t0, e->cfg.n_bins, group_incl);
     hipError_t he = rocprim::inclusive_scan(scan_tmp, scan_bytes, (const int*)group_incl, run_start, (size_t)n, lr_max_op(), stream);
     if (he != hipSuccess) return (int)he;
-    if (general) {
-        hipLaunchKernelGGL(lr_pack_flags_kernel, grid, blk, 0, stream, run_start, n, group_incl);
-    } else {
-        // unit resolution: pair slots.  Stretches of pairable neighbours (max-scan), greedy pairs from each stretch start
-        // (heads = even positions, sum-scan = slot numbers), a new group every LR_SLOTS slots of a run.
+    {
+        // Pair slots.  Stretches of pairable neighbours (max-scan), greedy pairs from each stretch start (heads = even
+        // positions, sum-scan = slot numbers), a new group every LR_SLOTS slots of a run.  Unit resolution pairs death
+        // entries up to LR_PAIR_DMAX apart, general times equal ones only.
         hipLaunchKernelGGL(lr_pack_stretch_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins,
-                           (const int*)run_start, extant_block, e->cfg.end_time, group_incl);
+                           (const int*)run_start, extant_block, e->cfg.end_time, general ? 0 : LR_PAIR_DMAX, group_incl);
         scan_bytes = lr_scan_tmp_bytes(n);
         he = rocprim::inclusive_scan(scan_tmp, scan_bytes, (const int*)group_incl, stretch_start, (size_t)n, lr_max_op(), stream);
         if (he != hipSuccess) return (int)he;
@@ -335,15 +306,10 @@ int lr_pack_lineages(lr_engine* e, hipStream_t stream) {
     bool any = false;
     for (int j = 0; j < 16; ++j) any |= e->p4.delta[j] != 0;
     const int k_tot = (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64));
-    if (general) {
-        hipLaunchKernelGGL(lr_pack_groups_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins, (const int*)run_start,
-                           (const int*)group_incl, any ? 1 : 0, k_tot, e->p4, (unsigned char*)(e->ws + e->lay.lineage_idx),
-                           (unsigned int*)(e->ws + e->lay.lineage_frac), (long long)e->n8_alloc, extant_block, e->cfg.end_time);
-    } else {
-        // (an all-zero group of the spare: birth entry 0 x count 0 and seven gathers of S[0] = 0 - contribution 0)
-        hipLaunchKernelGGL(lr_pack_slots_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins, e->plan.H,
-                           (const int*)run_start, (const int*)stretch_start, (const int*)head_incl, (const int*)group_incl,
-                           any ? 1 : 0, k_tot, e->p4, (unsigned short*)(e->ws + e->lay.lineage_idx), extant_block, e->cfg.end_time);
-    }
+    // (an all-zero group of the spare: birth entry 0 x count 0 and seven gathers of S[0] = 0 - contribution 0)
+    hipLaunchKernelGGL(lr_pack_slots_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins, e->plan.H,
+                       (const int*)run_start, (const int*)stretch_start, (const int*)head_incl, (const int*)group_incl,
+                       any ? 1 : 0, k_tot, e->p4, (unsigned short*)(e->ws + e->lay.lineage_idx), extant_block, e->cfg.end_time,
+                       general ? (unsigned int*)(e->ws + e->lay.lineage_frac) : nullptr, (long long)e->n8_alloc);
     return (int)hipGetLastError();
 }

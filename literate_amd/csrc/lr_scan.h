@@ -415,15 +415,19 @@ __device__ __forceinline__ void lr_pair_planes_block(double2* tab, int H, int n_
     }
 }
 
-// The same scan on GENERAL lineage times: pair tables in the LR_TAB_PAIRGEN layout (a plane of value pairs and a plane of
-// slope pairs scaled by 2^-32, 16-byte entries each), the groups plus their lineages' in-bin fractions as 32-bit fixed point.
-// A group's lineages share the birth bin, so the birth side needs the SUM of their fractions only - a data constant the
-// packing computes once (exactly: an integer below 2^36):
-//     sum_i (S.v + fs_i S.s + E_i.v + fe'_i E_i.s)  =  cnt S.v + (sum_i fs_i) S.s + sum_i fma(fe'_i, E_i.s, E_i.v)
-// frac: LR_FRAC_ARRAYS arrays of uint4, `fstride` entries apart, every load a fully coalesced 16-byte load: arrays 0-2
-// hold fe' of lineages 0-11 of every group, array 3 = (fe'_12, fe'_13, sum of fs as a double).
-// Per group: 2 + 28 ds_read_b128; per (lineage, chain pair) one conversion and four fp64 operations.
-#define LR_FRAC_ARRAYS 4
+// The same scan on GENERAL lineage times.  Pair tables in LDS (LR_TAB_PAIRGEN as the persistent kernels lay it out): six
+// planes of H 16-byte entries,  S | E | E2 | slopes of S | slopes of E | slopes of E2,  slopes scaled by 2^-32 and
+// E2[j] = 2 E[j] (value and slope alike; derived in LDS by lr_pair_planes_*_general, global memory holds S, E and their
+// slopes only).  Groups as at unit resolution - byte 0 birth index, byte 1 number of lineages, LR_SLOTS sixteen-bit
+// value-entry indices - where a slot holds one lineage (entry H + j) or two consecutive lineages of the run that die in
+// the SAME bin j (entry 2 H + j); the slope entry of a slot is its value entry + 3 H.  Beside the groups LR_FRAC_ARRAYS
+// arrays of uint4, `fstride` entries apart (every load a fully coalesced 16-byte load): arrays 0 and 1 hold the slots'
+// in-bin fractions fe' = ceil te - te as 32-bit fixed point (a pair: the mean of its two, which the doubled slope of the
+// E2 plane turns back into their sum), array 2 the SUM of the group's birth fractions fs as one exact double - the
+// lineages of a group share the birth bin, so the birth side needs nothing else:
+//     sum_i (S.v + fs_i S.s + E_i.v + fe'_i E_i.s)  =  cnt S.v + (sum_i fs_i) S.s + sum_slots fma(fe'_slot, E*_slot.s, E*_slot.v)
+// Per group: 2 + 14 ds_read_b128; per slot and chain pair one conversion and four fp64 operations.
+#define LR_FRAC_ARRAYS 3
 template <int H, int UNROLL = 1, bool PREFETCH = false>
 __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                              const uint4* __restrict__ frac, long long fstride,
@@ -447,8 +451,7 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
             for (int j = 0; j < LR_FRAC_ARRAYS; ++j) fw[j] = frac[i + j * fstride];
         }
     }
-    constexpr int SLOPES = 2 * H * 16;        // bytes from the value plane to the slope plane (LR_TAB_PAIRGEN)
-    const char* ebase = lbase + H * 16;
+    constexpr int SLOPES = 3 * H * 16;        // bytes from a value entry to its slope entry
 #pragma unroll UNROLL
     while (i < n) {
         const uint4 cur = w;
@@ -458,7 +461,6 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
         const int nx = i + n_scan;
         if (nx < n) {
             // the next group in flight while this one is scored - with its fractions where the register budget allows
-            // (16 more VGPRs: the 768-thread speculative kernel; the four-chain kernel runs at a 128-VGPR cap)
             w = idx8[nx];
             if (PREFETCH) {
 #pragma unroll
@@ -469,33 +471,48 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
         const double2 Sv = *reinterpret_cast<const double2*>(pS);
         const double2 Ss = *reinterpret_cast<const double2*>(pS + SLOPES);
         const double cnt = (double)((cur.x >> 8) & 0xffu);
-        const double sfs = __hiloint2double((int)fr[3].w, (int)fr[3].z);
-        const unsigned int fq[16] = {fr[0].x, fr[0].y, fr[0].z, fr[0].w, fr[1].x, fr[1].y, fr[1].z, fr[1].w,
-                                     fr[2].x, fr[2].y, fr[2].z, fr[2].w, fr[3].x, fr[3].y, 0u, 0u};
-        double t0[LR_GRP / 2], t1[LR_GRP / 2];
+        const double sfs = __hiloint2double((int)fr[2].y, (int)fr[2].x);
+        const unsigned int off[LR_SLOTS] = {lr_word_off16(cur.x, 1), lr_word_off16(cur.y, 0), lr_word_off16(cur.y, 1), lr_word_off16(cur.z, 0),
+                                            lr_word_off16(cur.z, 1), lr_word_off16(cur.w, 0), lr_word_off16(cur.w, 1)};
+        const unsigned int fq[LR_SLOTS] = {fr[0].x, fr[0].y, fr[0].z, fr[0].w, fr[1].x, fr[1].y, fr[1].z};
+        double p0[LR_SLOTS], p1[LR_SLOTS];
 #pragma unroll
-        for (int j = 0; j < LR_GRP / 2; ++j) {
-            double p0[2], p1[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const char* pE = ebase + lr_grp_off<4>(cur, 2 * j + h + 2);
-                const double2 Ev = *reinterpret_cast<const double2*>(pE);
-                const double2 Es = *reinterpret_cast<const double2*>(pE + SLOPES);
-                const double fe = (double)fq[2 * j + h];
-                p0[h] = fma(fe, Es.x, Ev.x);
-                p1[h] = fma(fe, Es.y, Ev.y);
-            }
-            t0[j] = p0[0] + p0[1], t1[j] = p1[0] + p1[1];
+        for (int k = 0; k < LR_SLOTS; ++k) {
+            const double2 Ev = *reinterpret_cast<const double2*>(lbase + off[k]);
+            const double2 Es = *reinterpret_cast<const double2*>(lbase + off[k] + SLOPES);
+            const double fe = (double)fq[k];
+            p0[k] = fma(fe, Es.x, Ev.x);
+            p1[k] = fma(fe, Es.y, Ev.y);
         }
-        // the same fixed pairwise tree as the unit-resolution scan, then the birth side of the whole group
-        const double u0 = ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t0[4] + t0[5]) + t0[6]);
-        const double u1 = ((t1[0] + t1[1]) + (t1[2] + t1[3])) + ((t1[4] + t1[5]) + t1[6]);
+        // the same fixed tree over the slots as the unit-resolution scan, then the birth side of the whole group
+        const double u0 = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + p0[6]);
+        const double u1 = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + p1[6]);
         acc0 += fma(sfs, Ss.x, fma(cnt, Sv.x, u0));
         acc1 += fma(sfs, Ss.y, fma(cnt, Sv.y, u1));
         i = nx;
     }
     *acc0_ = acc0, *acc1_ = acc1;
 }
+
+// the doubled planes of a pair-general table in LDS: value plane E2 (entries [2H, 3H)) and its slopes ([5H, 6H)) from E
+// ([H, 2H)) and its slopes ([4H, 5H)); `tab` in doubles, entry e of chain c at 2 e + c
+__device__ __forceinline__ void lr_pair_planes_wave_general(double* tab, int H, int n_bins, int lane, int dup) {
+    for (int j = lane; j <= n_bins + 1; j += LR_WAVE) {
+        const double v = 2.0 * tab[2 * (H + j)], sl = 2.0 * tab[2 * (4 * H + j)];
+        tab[2 * (2 * H + j)] = v, tab[2 * (5 * H + j)] = sl;
+        if (dup) tab[2 * (2 * H + j) + dup] = v, tab[2 * (5 * H + j) + dup] = sl;
+    }
+}
+__device__ __forceinline__ void lr_pair_planes_block_general(double2* tab, int H, int n_bins, int tid, int n_threads) {
+    for (int j = tid; j <= n_bins + 1; j += n_threads) {
+        const double2 v = tab[H + j], sl = tab[4 * H + j];
+        tab[2 * H + j] = make_double2(2.0 * v.x, 2.0 * v.y);
+        tab[5 * H + j] = make_double2(2.0 * sl.x, 2.0 * sl.y);
+    }
+}
+// global memory keeps a pair-general table as [S | E | slopes of S | slopes of E] (4 H entries); its place in the six
+// planes of the LDS image
+__host__ __device__ __forceinline__ int lr_pairgen_lds_entry(int i, int H) { return i < 2 * H ? i : i + H; }
 
 // what a persistent engine scans: packed groups and, on general times, the fractions behind them
 struct lr_packed_lineages {

@@ -311,12 +311,12 @@ __device__ __forceinline__ int lr_spec_turn(int role, int acc) {
 template <int H, int NW, int ENT>
 struct lr_spec_lds {
     static constexpr bool GENERAL_ENTRIES = ENT == 2;
-    static constexpr int TAB = GENERAL_ENTRIES ? 4 * H : LR_UNIT_PLANES * H;   // double2 per pair table
+    static constexpr int TAB = LR_UNIT_PLANES * H;   // double2 per pair table
     // Pair tables (S' entries [0,H), E' [H,2H); (.x, .y) = (chain 0, chain 1)) for every combination of outcomes, in two
     // generations: pairs[g][d0][d1] holds candidate d0 of chain 0 beside candidate d1 of chain 1 for the iterations of
     // parity g.  A candidate wave writes its column into the two tables that contain it, so after the decisions the
     // scanners just switch to pairs[g][d0][d1]: no copy between the decision and the next scan.
-    double2 pairs[2][2][2][GENERAL_ENTRIES ? 4 * H : LR_UNIT_PLANES * H];   // general times: value + slope planes (LR_TAB_PAIRGEN); unit: S, E, pair sums
+    double2 pairs[2][2][2][LR_UNIT_PLANES * H];   // six planes each: S, E, pair sums (unit resolution) / S, E, 2 E and their slopes (general)
     int cur_sel;                 // d0 * 2 + d1 of the pair table that stands when the kernel ends
     double red[NW][2];           // per scanner wave: partial sums of the two chains
     lr_spec_decision dec[2];     // [iteration parity]: what the deciding wave found
@@ -511,11 +511,12 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         if (k_team > 1 && sm.abort_flag) return;
         sel = sm.dec[iter & 1].sel;
         role0 = lr_spec_turn(role0, sel >> 1), role1 = lr_spec_turn(role1, sel & 1);
-        if (!GENERAL) {
-            // The pair-sum planes (lr_scan.h) of the table that was selected - the candidates wrote S and E only -, both
+        {
+            // The pair planes (lr_scan.h) of the table that was selected - the candidates wrote S and E only -, both
             // chains at once, by all scanner lanes; the scanner waves then wait for each other on an LDS counter (the
             // candidate waves are already building: no block barrier)
-            lr_pair_planes_block(sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, NSCAN);
+            if (GENERAL) lr_pair_planes_block_general(sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, NSCAN);
+            else lr_pair_planes_block(sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, NSCAN);
             LR_WAVE_LDS_ORDER();
             if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int want = (NW - 4) * ((int)iter + 1);
@@ -534,7 +535,7 @@ template <int H, int T, bool RJ, bool GENERAL>
 __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
-    constexpr int ES = GENERAL ? 4 * H : 2;  // the builders' `so`: doubles from a value to its slope (lr_device.h)
+    constexpr int ES = GENERAL ? 6 * H : 2;  // the builders' `so`: doubles from a value to its slope in the LDS image
     // the per-bin data constants come from their LDS copies (a global load per candidate would sit on the critical path)
     const double* br_lds = sm.br;
     const double* logbr_lds = sm.logbr;
@@ -709,11 +710,10 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         ctx.c0 = c0, ctx.C = C, ctx.team = team, ctx.rank = rank;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * H * ENT; i += T) sm.pairs[ctx.it0 & 1][0][0][i] = gpair[i];
-    if (!GENERAL) {
-        __syncthreads();
-        lr_pair_planes_block(sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
-    }
+    for (int i = tid; i < 2 * H * ENT; i += T) sm.pairs[ctx.it0 & 1][0][0][GENERAL ? lr_pairgen_lds_entry(i, H) : i] = gpair[i];
+    __syncthreads();
+    if (GENERAL) lr_pair_planes_block_general(sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
+    else lr_pair_planes_block(sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
     // draws of the first candidates (iteration it0 + 1); afterwards the last four scanner waves stay one iteration ahead
     if (rj && wave >= NW - 2 && c0 + (wave - (NW - 2)) < C)
         lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, &sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1]);
@@ -725,6 +725,6 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     {
         const int sel = sm.cur_sel;
         const double2* cur = sm.pairs[(ctx.it0 + (unsigned long long)n_iters) & 1][sel >> 1][sel & 1];
-        for (int i = tid; i < 2 * H * ENT; i += T) gpair[i] = cur[i];
+        for (int i = tid; i < 2 * H * ENT; i += T) gpair[i] = cur[GENERAL ? lr_pairgen_lds_entry(i, H) : i];
     }
 }

@@ -629,11 +629,12 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
                                                    lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death,
                                                    table_es, pre ? &sg : nullptr, table_dup);
     s.sgL = sg.packL, s.sgM = sg.packM, s.sg_valid = (pre && sg.packL != -1) ? 1 : 0;
-    if (LDS_CONSTS && PAIR_PLANES && lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) {
-        // persistent engines, unit resolution: the pair-sum planes the packed scan gathers from (lr_scan.h; the speculative
-        // kernel leaves them to its scanner waves, which derive them for the selected table only)
+    if (LDS_CONSTS && PAIR_PLANES) {
+        // persistent engines: the pair planes the packed scan gathers from (lr_scan.h; the speculative kernel leaves them
+        // to its scanner waves, which derive them for the selected table only)
         LR_WAVE_LDS_ORDER();
-        lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, n_bins, lane, DUP ? table_dup : 0);
+        if (lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, n_bins, lane, DUP ? table_dup : 0);
+        else lr_pair_planes_wave_general(reinterpret_cast<double*>(table), a.H, n_bins, lane, DUP ? table_dup : 0);
     }
     LR_SSTAMP(6);
     s.L = pL, s.M = pM, s.tL = ptL, s.tM = ptM, s.eL = peL, s.eM = peM, s.KL = PKL, s.KM = PKM;
@@ -833,9 +834,10 @@ __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, in
         lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es),
                                 cfg.frac_birth, cfg.frac_death, table_es);
     }
-    if (LDS_CONSTS && PAIR_PLANES && lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) {
+    if (LDS_CONSTS && PAIR_PLANES) {
         LR_WAVE_LDS_ORDER();
-        lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, table_dup);
+        if (lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, table_dup);
+        else lr_pair_planes_wave_general(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, table_dup);
     }
     p.hasting = hasting, p.move = move_kind;
     return P;

@@ -30,11 +30,13 @@ class ChainEngine:
         ts_d = ops._dev(ts, torch.float64, self.device)
         te_d = ops._dev(te, torch.float64, self.device)
         if sort_lineages:
-            # HBM layout choice: lineages ordered by (ts, te).  A wave's 64 lineages then hit the same or
-            # neighbouring table entries, so the LDS gathers broadcast / stay conflict-free (13-30 % faster
-            # scan).  The log-likelihood is a sum over lineages: the order changes only its rounding.
+            # HBM layout choice: lineages ordered by (birth bin, te) - for year-resolution data that is (ts, te).
+            # A wave's 64 lineages then hit the same or neighbouring table entries (LDS gathers broadcast / stay
+            # conflict-free), runs of one birth bin share their birth gather and consecutive lineages of a run die
+            # in the same or a neighbouring bin, which is what the packed pair slots need (csrc/lr_pack.hip).  The
+            # log-likelihood is a sum over lineages: the order changes only its rounding.
             o1 = torch.sort(te_d, stable=True).indices
-            o2 = torch.sort(ts_d[o1], stable=True).indices
+            o2 = torch.sort(torch.floor(ts_d[o1]), stable=True).indices
             order = o1[o2]
             ts_d, te_d = ts_d[order].contiguous(), te_d[order].contiguous()
         self.ts, self.te = ts_d, te_d

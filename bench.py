@@ -91,9 +91,10 @@ def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
     """LDS-roofline figures of `n_iters` iterations that took `kernel_ms` of device time."""
     unit = bool(eng.unit_resolution)
     if eng.layout.persistent:
-        # persistent engines: groups of 14 lineages of one birth bin (lr_pack.hip): per group and chain PAIR one gather of the
-        # birth entry + 14 of the death entries, 16 B each (unit resolution) or 32 B each (general times)
-        lds_bytes_per_eval = (1 + 14) * (16 if unit else 32) / (14 * 2.0)
+        # persistent engines: groups of up to 14 lineages of one birth bin in 7 slots (lr_pack.hip; a slot = one lineage or a
+        # pair through a pair-sum plane): per group and chain PAIR one gather of the birth entry + 7 of the slots' entries,
+        # 16 B each (unit resolution); value and slope entry each on general times
+        lds_bytes_per_eval = (1 + 7) * (16 if unit else 32) / (14 * 2.0)
     else:
         lds_bytes_per_eval = 16 if unit else 32      # launch-based scan: two 8-byte / two 16-byte entries per (lineage, chain)
     evals = float(n_iters) * n_lin * chains
@@ -104,11 +105,11 @@ def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
                threads_per_block=int(eng.layout.reserved1))
     if eng.layout.persistent:
         # What the scan loop is really bound by (scratch/ubench/README.md): vector instruction issue.  Per group of 14
-        # lineages and chain pair the compiled loop issues 51 VALU + 15 LDS + 1 global instruction (unit resolution) or
-        # 95 + 30 + 5 (general times) - counted in the ISA of lr_persist4_kernel<136, .> - and a SIMD issues one wave64
+        # lineages and chain pair the compiled loop issues 30 VALU + 8 LDS + 1 global instruction (unit resolution) or
+        # 52 + 16 + 4 (general times) - counted in the ISA of lr_persist4_kernel<136, .> - and a SIMD issues one wave64
         # vector instruction per 4.18 cycles whatever its kind (measured).  The chain steps share the same SIMDs, so the
         # fraction below is the share of the chip's issue rate spent on SCAN instructions.
-        instr_per_eval = (67 if unit else 130) / 28.0
+        instr_per_eval = (39 if unit else 72) / 28.0
         peak = ISSUE_PEAK_LANE_INSTR_PER_S / instr_per_eval
         out["issue"] = dict(vector_instr_per_eval=instr_per_eval, cycles_per_wave_instr=ISSUE_CYCLES, peak_evals_per_s=peak,
                             frac=out["evals_per_s"] / peak)

@@ -669,9 +669,9 @@ static int lr_device_cus() {
 
 // Speculative team kernel (lr_spec.h): one block per CU, a chain pair owned by a team of k blocks.  Model of an
 // iteration in microseconds, fitted to MI355X measurements over 1k..200k lineages x k = 1, 2, 4, 8
-// (scratch/exp_teams.py): with `trips` = groups / k / 512 scanner lanes,
-//     unit resolution   k = 1: max(2.9, 2.75 + 0.33 trips)     k > 1: max(3.3,  3.05 + 0.30 trips)
-//     general times     k = 1: max(2.9, 2.60 + 0.83 trips)     k > 1: max(3.45, 2.90 + 0.85 trips)
+// (scratch/exp_teams.py, pair-slot group formats): with `trips` = groups / k / 512 scanner lanes,
+//     unit resolution   k = 1: max(3.0, 3.20 + 0.20 trips)      k > 1: max(3.4,  3.20 + 0.205 trips)
+//     general times     k = 1: max(3.0, 3.28 + 0.464 trips)     k > 1: max(3.45, 2.90 + 0.478 trips)
 // (the floor is the candidate build; a team pays the exchange behind its last scanner).  The parametric samplers build
 // their candidates more slowly (+0.9).  Returns the modelled time and the best team size in *k (0 = not applicable).
 static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general = false) {
@@ -689,8 +689,8 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
         if (k_env > 0 && k != k_env) continue;
         const double trips = n8 / k / (double)(LR_SPEC_THREADS - 256);
         double t;
-        if (!general) t = (k == 1) ? fmax(2.9, 2.75 + 0.33 * trips) : fmax(3.3, 3.05 + 0.30 * trips);
-        else t = (k == 1) ? fmax(2.9, 2.60 + 0.83 * trips) : fmax(3.45, 2.90 + 0.85 * trips);
+        if (!general) t = (k == 1) ? fmax(3.0, 3.20 + 0.20 * trips) : fmax(3.4, 3.20 + 0.205 * trips);
+        else t = (k == 1) ? fmax(3.0, 3.28 + 0.464 * trips) : fmax(3.45, 2.90 + 0.478 * trips);
         t += extra;
         if (t < best - 0.05) best = t, *k_out = k;
     }
@@ -739,9 +739,9 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, 
     const double t_spec = (p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general);
     if (k > 0 && t_spec < 1e29 && cfg->engine_mode != 3 && cfg->engine_mode != 4 && spec_env != 0) {
         // the two-chain kernel with all 16 waves scanning wins only on long scans without room for a team
-        // (measured at 256 pairs, 10k..1M lineages: 5.0 + 0.45 us per trip of its 1024 scanner lanes, 4.6 at least; the
-        // speculative kernel is ahead up to ~150k lineages)
-        const double t_wide = general ? 1e30 : fmax(4.6, 5.0 + 0.45 * (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP) / 1024.0);
+        // (measured at 256 pairs, 10k..1M lineages: 5.1 + 0.26 us per trip of its 1024 scanner lanes, 4.9 at least; the
+        // speculative kernel is ahead up to ~200k lineages)
+        const double t_wide = general ? 1e30 : fmax(4.9, 5.1 + 0.262 * (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP) / 1024.0);
         if (cfg->engine_mode == 5 || spec_env == 1 || t_spec <= t_wide) {
             if (team_k) *team_k = k;
             return 3;

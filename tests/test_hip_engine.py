@@ -340,6 +340,42 @@ def test_long_inputs_and_few_chain_shards_keep_parity(engine, C, kw):
     eng.close()
 
 
+@pytest.mark.parametrize("engine,model,general", [("spec", 0, False), ("persistent4", 0, False), ("persistent2", 2, False),
+                                                  ("spec", 3, False), ("persistent4", 3, False), ("spec", 0, True),
+                                                  ("persistent4", 0, True), ("spec", 3, True)])
+def test_packing_of_unsorted_sparse_and_extant_lineages(engine, model, general):
+    """The pair-slot packing (csrc/lr_pack.hip) on input it was not designed for: lineages in RANDOM order (runs of one or
+    two lineages of a birth bin, death bins far apart or decreasing: singles, short stretches, groups of one slot), many
+    extant lineages (model 3 sends them through the extant block), a window of few bins.  The accepted log-likelihoods
+    after a run must equal an independent evaluation of the accepted states by lr_bd_loglik_batch on the raw times."""
+    from literate_amd import ops, synth
+    from literate_amd.engine import ChainEngine
+    from oracle import literate_oracle as lo
+    rng = np.random.default_rng(31)
+    n_lin, C, n_it = 3000, 10, 60
+    ts, te, _ = synth.make_lineages(n_lin, n_bins=40, n_shifts=4, seed=12)
+    if general:
+        grid = lambda x: np.round(x * 2.0 ** 32) / 2.0 ** 32
+        ts = ts + grid(rng.uniform(0, 0.999, n_lin))
+        te = np.maximum(np.ceil(te) - 1.0 + grid(rng.uniform(1e-3, 0.999, n_lin)), ts + 0.0078125)
+    order = rng.permutation(n_lin)
+    order[:600] = np.sort(order[:600])          # a sorted stretch inside the shuffle: pairs beside singles
+    ts, te = ts[order], te[order]
+    eng = ChainEngine(ts, te, C, model=model, seed=3, s_freq=10, n_trace_slots=8, engine=engine, sort_lineages=False)
+    assert eng.layout.persistent == {"spec": 3, "persistent2": 1, "persistent4": 2}[engine]
+    assert eng.layout.table_mode == (2 if general else 1)
+    eng.init(); eng.steps(n_it)
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it) and np.all(np.isfinite(snap["likA"]))
+    n_bins = eng.n_bins
+    lam = np.stack([snap["L"][c][lo.get_rate_index(np.floor(snap["tL"][c]), n_bins)] for c in range(C)])
+    mu = np.stack([snap["M"][c][lo.get_rate_index(np.floor(snap["tM"][c]), n_bins)] for c in range(C)])
+    t0, sp, ex, br = lo.bin_events_cli(ts, te)
+    lik = ops.bd_loglik_batch(eng.ts, eng.te, eng.t0, lam, mu, model, br_length=br, end_time=eng.end_time).cpu().numpy()
+    assert np.allclose(lik, snap["likA"], rtol=1e-9), (lik, snap["likA"])
+    eng.close()
+
+
 def test_cfg4_full_size_1024_chains_100k_lineages():
     """BASELINE.json configs[3] at FULL size on one GPU (the bench workload: 1024 chains x 100k lineages, the
     four-chain persistent kernel).  (i) chains from the first / a middle / the last block walk the oracle loop's

@@ -1,25 +1,35 @@
 // lr_pack.hip - the lineages as the persistent engines scan them.
 //
-// A lineage needs two table indices per chain pair: its birth bin and its death bin (lr_device.h: S and E tables).
-// The engines keep the lineages ordered by (ts, te) - ChainEngine sorts them once - so consecutive lineages share
-// their birth bin for long runs (100k lineages over 128 bins: ~780 per bin).  The packing makes that explicit:
+// A lineage needs two table entries per chain pair: its birth bin's and its death bin's (lr_device.h: S and E tables).
+// The engines keep the lineages ordered by (birth bin, te) - ChainEngine sorts them once - so consecutive lineages share
+// their birth bin for long runs (100k lineages over 128 bins: ~780 per bin) and, inside a run, die in the same or a
+// neighbouring bin.  The packing makes both explicit:
 //
-//   group = up to LR_GRP = 14 CONSECUTIVE lineages of ONE birth bin, 16 bytes:
-//           byte 0 birth index a, byte 1 count, bytes 2..15 the death indices b (0 = padding, contribution 0)
+//   group = up to 14 CONSECUTIVE lineages of ONE birth bin in LR_SLOTS = 7 slots, 16 bytes:
+//           byte 0 birth index a, byte 1 number of lineages, then seven 16-bit ENTRY indices into the block's pair table
+//   slot  = ONE lineage (entry H + j: its death entry E[j]) or TWO consecutive lineages of the run with death entries
+//           j and j + d, 0 <= d <= 3 at unit resolution (entry (2 + d) H + j: the pair-sum plane E[j] + E[j + d]) /
+//           d = 0 on general times (entry 2 H + j: the doubled plane); unused slots point at E[0] = 0
 //
-// A lane of the scan loads one group (16 bytes, coalesced), gathers S[a] ONCE and E[b] per lineage: 15 gathers for
-// 14 lineages instead of 28.  Every lineage still contributes its own two terms - S[a] enters `count` times - the sort
-// order is what lets the gather be shared.  A new group starts wherever the birth bin changes (and every 14 lineages
-// inside a run), so the number of groups depends on the data: <= ceil(N / 14) + runs, runs <= n_bins + 2 for sorted
-// input.  The caller's order is kept (the likelihood is a sum; only its rounding depends on the order), which makes
-// the packing a pair of prefix scans:
-//   run start of lineage i = max-scan of (i if a_i != a_{i-1} else 0); new group at i <=> (i - run start) % 14 == 0;
-//   group of lineage i     = sum-scan of the new-group flags - 1.
-// On general (non-integer) times the in-bin fractions travel beside the indices as 32-bit fixed point: 7 more arrays of
-// uint4, array j of a group = (fs, fe', fs, fe') of its lineages 2j and 2j + 1 (fs = ts - floor ts, fe' = ceil te - te).
+// A lane of the scan loads one group (16 bytes, coalesced), gathers S[a] ONCE and one entry per slot: 8 gathers for up to
+// 14 lineages instead of 28.  Every lineage still enters through its own (birth bin, death bin) - S[a] `count` times, its
+// death entry alone or inside the pair sum of its slot - the sort order is what lets the gathers be shared; the pair-sum
+// planes are derived from the chain's own E plane in LDS every time a table is built (lr_scan.h), so global memory and
+// the launch-based engine know nothing of them.  The caller's order is kept (the likelihood is a sum; only its
+// rounding depends on the order), which makes the packing four prefix scans:
+//   run start of lineage i      = max-scan of (i if a_i != a_{i-1} else 0)
+//   stretch start of lineage i  = max-scan of (0 if i can share a slot with i - 1 else i); greedy pairs from a stretch's
+//                                 start: the lineages at even positions of their stretch are the slot HEADS
+//   slot of a head inside its run = sum-scan of the head flags, minus its value at the run start
+//   group of a head             = sum-scan of (head and slot % 7 == 0) - 1
+// so the number of groups depends on the data: <= ceil(N / 7) + runs (all singles), ~ N / 14 + runs for sorted input
+// (cfg4: 49,953 pairs and 94 singles), runs <= n_bins + 2.
+// On general (non-integer) times the in-bin fractions travel beside the entries as 32-bit fixed point in LR_FRAC_ARRAYS
+// = 3 more arrays of uint4: the slots' fe' = ceil te - te (a pair: the mean of its two, which the doubled slope plane
+// turns back into their sum) and the SUM of the group's fs = ts - floor ts as one exact double.
 //
-// The four-chain kernel's unequal scanner-wave shares (lr_p4_shares) are a permutation of whole groups and are applied
-// here as before; they depend on the group count, so they are fixed here too, after the scans.
+// The scanner-wave shares of the persistent kernels (lr_p4_shares; equal by default) are a permutation of whole groups
+// and are applied here; they depend on the group count, so they are fixed here too, after the scans.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

@@ -436,8 +436,10 @@ def main():
                          "frac_engine": value / world * fig["lds_bytes_per_eval"] / 1e9 / LDS_PEAK_GBS,
                          "bound_note": "LDS gather bandwidth: per (lineage, chain) the scan gathers %.2f B of lookup-table "
                                        "entries from LDS (256 B/clk/CU x 256 CU x 2.4 GHz); no MFMA in a gather/scan/reduce.  "
-                                       "Micro-benchmarks (scratch/ubench) show the loop itself is bound by vector instruction "
-                                       "issue before LDS bandwidth: see `issue`" % fig["lds_bytes_per_eval"],
+                                       "Micro-benchmarks (scratch/ubench) show the scan loop is bound by vector instruction "
+                                       "issue before LDS bandwidth (see `issue`); with the pair-slot format the four-chain "
+                                       "kernel's iteration is two phases of one chain step's latency (~4.2 us of dependent fp64 "
+                                       "work on one wave) under which the scans hide" % fig["lds_bytes_per_eval"],
                          "issue": fig.get("issue"),
                          "hbm": hbm,
                          "engine": {"persistent": fig["persistent"], "threads_per_block": fig["threads_per_block"],

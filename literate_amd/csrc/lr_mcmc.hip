@@ -687,7 +687,10 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
     for (int k = 1; k <= LR_TEAM_MAX; k *= 2) {
         if (pairs * k > cus) break;
         if (k_env > 0 && k != k_env) continue;
-        const double trips = n8 / k / (double)(LR_SPEC_THREADS - 256);
+        // (groups beyond an XCD's 4 MB of L2 stream from HBM with one group of prefetch per lane: measured 0.32 instead of
+        // 0.205 us per trip at 10M lineages, scratch/exp_fewchains.py)
+        const double slow = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) > 4.0e6 ? 1.55 : 1.0;
+        const double trips = slow * n8 / k / (double)(LR_SPEC_THREADS - 256);
         double t;
         if (!general) t = (k == 1) ? fmax(3.0, 3.20 + 0.20 * trips) : fmax(3.4, 3.20 + 0.205 * trips);
         else t = (k == 1) ? fmax(3.0, 3.28 + 0.464 * trips) : fmax(3.45, 2.90 + 0.478 * trips);

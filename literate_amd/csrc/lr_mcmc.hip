@@ -670,7 +670,7 @@ static int lr_device_cus() {
 // Speculative team kernel (lr_spec.h): one block per CU, a chain pair owned by a team of k blocks.  Model of an
 // iteration in microseconds, fitted to MI355X measurements over 1k..200k lineages x k = 1, 2, 4, 8
 // (scratch/exp_teams.py, pair-slot group formats): with `trips` = groups / k / 512 scanner lanes,
-//     unit resolution   k = 1: max(3.0, 3.20 + 0.20 trips)      k > 1: max(3.4,  3.20 + 0.205 trips)
+//     unit resolution   k = 1: max(3.0, 2.95 + 0.222 trips)     k > 1: max(3.4,  3.20 + 0.205 trips)
 //     general times     k = 1: max(3.0, 3.28 + 0.464 trips)     k > 1: max(3.45, 2.90 + 0.478 trips)
 // (the floor is the candidate build; a team pays the exchange behind its last scanner).  The parametric samplers build
 // their candidates more slowly (+0.9).  Returns the modelled time and the best team size in *k (0 = not applicable).
@@ -692,7 +692,7 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
         const double slow = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) > 4.0e6 ? 1.55 : 1.0;
         const double trips = slow * n8 / k / (double)(LR_SPEC_THREADS - 256);
         double t;
-        if (!general) t = (k == 1) ? fmax(3.0, 3.20 + 0.20 * trips) : fmax(3.4, 3.20 + 0.205 * trips);
+        if (!general) t = (k == 1) ? fmax(3.0, 2.95 + 0.222 * trips) : fmax(3.4, 3.20 + 0.205 * trips);
         else t = (k == 1) ? fmax(3.0, 3.28 + 0.464 * trips) : fmax(3.45, 2.90 + 0.478 * trips);
         t += extra;
         if (t < best - 0.05) best = t, *k_out = k;

@@ -65,9 +65,9 @@ static inline long long lr_groups_alloc(long long n_lineages) {
 #endif
 #ifndef LR_SPEC_SCAN_UNROLL
 #define LR_SPEC_SCAN_UNROLL 1
-#ifndef LR_SPEC_SCAN_PRIO
-#define LR_SPEC_SCAN_PRIO 2
 #endif
+#ifndef LR_SPEC_SCAN_PRIO
+#define LR_SPEC_SCAN_PRIO 2   /* s_setprio of the scanner waves of a team (0 = leave the default) */
 #endif
 #define LR_TEAM_MAX 8
 #define LR_SPEC_GRANULES 16      /* 8-byte granules reserved per block and parity: one 128-byte line */

@@ -426,7 +426,11 @@ def main():
                            "DDRate sampler -m_birth 2 -m_death 2" if model == "dd" else "model_BDI %d, RJ prior on shifts" % model),
                        "lineages": n_lin, "chains_per_gpu": chains, "chains_total": total_chains,
                        "n_bins": eng.n_bins, "sample_every": args.sample_every,
-                       "iters_per_s_per_chain": args.steps / elapsed},
+                       "iters_per_s_per_chain": args.steps / elapsed,
+                       "eval_note": "one eval = one lineage scored under one chain's rates in one iteration; every iteration "
+                                    "reads every lineage's (birth bin, death bin) from the packed groups - two neighbouring "
+                                    "lineages of a birth bin may share one table gather through a pair-sum entry built from the "
+                                    "chain's rates in that iteration (DESIGN.md, Kernels); no per-bin event counts are used"},
             "roofline": {"bound": "lds", "achieved": fig["lds_GBs"], "peak": LDS_PEAK_GBS, "unit": "GB/s",
                          "frac": fig["lds_frac"], "traffic": None, "traffic_note": "not measured",
                          "kernel": kname, "kernel_ms": kernel_ms, "iterations_per_launch": n_ev,

@@ -204,9 +204,9 @@ __device__ inline double lr_gamma(const lr_stream& s, uint64_t it, uint32_t purp
 // (the value doubles as the layout switch of the kernels that know their layout at compile time)
 __host__ __device__ __forceinline__ int lr_tab_es(int mode, int H) { return mode == LR_TAB_PAIRGEN ? 4 * H : 2; }
 
-// Unit bins one lane of the one-pass table builder handles for the instantiated table sizes H = 40 / 72 / 136 / 264
+// Unit bins one lane of the one-pass table builder handles for the instantiated table sizes H = 40 / 72 / 136 / 264 / 520
 // (lr_plan_scan picks H so that n_bins <= 64 * lr_bins_per_lane(H)): a kernel instantiated for H needs one builder only.
-__host__ __device__ constexpr int lr_bins_per_lane(int H) { return H <= 40 ? 1 : (H <= 136 ? 2 : 4); }
+__host__ __device__ constexpr int lr_bins_per_lane(int H) { return H <= 40 ? 1 : (H <= 136 ? 2 : (H <= 264 ? 4 : 8)); }
 
 // birth-side entry j: value v = logB + cum, exposure rate R
 __device__ __forceinline__ void lr_put_S(double* tabd, int mode, int so, int j, double v, double R, double fs0) {

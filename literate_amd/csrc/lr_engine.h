@@ -59,6 +59,9 @@ static inline long long lr_groups_alloc(long long n_lineages) {
     return (n_lineages + LR_SLOTS - 1) / LR_SLOTS + runs + LR_IDX_SPARE;
 }
 
+// widest table class of the persistent kernels (the launch-based scans are instantiated up to H = 264)
+#define LR_H_WIDE 520
+
 // ---- speculative team engine (lr_spec.h / lr_spec.hip) ----
 #ifndef LR_SPEC_THREADS
 #define LR_SPEC_THREADS 768   /* 12 waves: 4 candidate + 8 scanner waves, 3 per SIMD = 168 VGPRs each */

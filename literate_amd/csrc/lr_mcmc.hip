@@ -230,7 +230,7 @@ __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((a
         lr_dd_step_core<true>(st, a, 0, c, lane, lik, reinterpret_cast<double2*>((double*)table3), table_es, br_lds);
     else
         lr_chain_step_core<true>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
-                                 table_es, br_lds, br_lds + 256);
+                                 table_es, br_lds, br_lds + LR_H_WIDE);
     lr_chain_store(st, (double*)st_f64, (int*)st_i32, lane);
 }
 
@@ -249,13 +249,13 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
     __shared__ double st_f64[2][LR_STATE_ROWS * LR_ROW];
     __shared__ int st_i32[2][LR_ISTATE_ROWS * LR_ROW];
     __shared__ lr_step_args a_lds;
-    __shared__ double br_lds[2][256];      // per-bin data constants of the table builders: br_length / DT / TREND, log br_length
+    __shared__ double br_lds[2][LR_H_WIDE];   // per-bin data constants of the table builders: br_length / DT / TREND, log br_length
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     if (tid < (int)(sizeof(lr_step_args) / 4)) reinterpret_cast<int*>(&a_lds)[tid] = reinterpret_cast<const int*>(ap)[tid];
-    if (tid < 256) {
-        const bool in = tid < ap->cfg.n_bins;
-        br_lds[0][tid] = (in && ap->br_length) ? ap->br_length[tid] : 0.0;
-        br_lds[1][tid] = in ? ap->log_br[tid] : 0.0;
+    for (int b = tid; b < LR_H_WIDE; b += blockDim.x) {
+        const bool in = b < ap->cfg.n_bins;
+        br_lds[0][b] = (in && ap->br_length) ? ap->br_length[b] : 0.0;
+        br_lds[1][b] = in ? ap->log_br[b] : 0.0;
     }
     const int c0 = blockIdx.x * 2;
     const int c = c0 + wave;
@@ -363,13 +363,13 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
     __shared__ int st_i32[4][LR_ISTATE_ROWS * LR_ROW];
     __shared__ lr_step_args a_lds;
-    __shared__ double br_lds[2][256];      // per-bin data constants of the table builders: br_length / DT / TREND, log br_length
+    __shared__ double br_lds[2][LR_H_WIDE];   // per-bin data constants of the table builders: br_length / DT / TREND, log br_length
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     if (tid < (int)(sizeof(lr_step_args) / 4)) reinterpret_cast<int*>(&a_lds)[tid] = reinterpret_cast<const int*>(ap)[tid];
-    if (tid < 256) {
-        const bool in = tid < ap->cfg.n_bins;
-        br_lds[0][tid] = (in && ap->br_length) ? ap->br_length[tid] : 0.0;
-        br_lds[1][tid] = in ? ap->log_br[tid] : 0.0;
+    for (int b = tid; b < LR_H_WIDE; b += blockDim.x) {
+        const bool in = b < ap->cfg.n_bins;
+        br_lds[0][b] = (in && ap->br_length) ? ap->br_length[b] : 0.0;
+        br_lds[1][b] = in ? ap->log_br[b] : 0.0;
     }
     const int c0 = blockIdx.x * 4;
     const int C = a.cfg.n_chains;
@@ -603,10 +603,10 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, 
 static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, cfg->unit_resolution, p);
     if (rc) return rc;
-    if (cfg->model == LR_MODEL_KEIDING_DEAD && cfg->n_bins <= 126) {
+    if (cfg->model == LR_MODEL_KEIDING_DEAD && cfg->n_bins <= 258) {
         // model 3 on a persistent engine: one table class with an extant block behind the death-side entries (lr_step.h),
-        // so the half-stride must hold 2 (n_bins + 2) entries and a death byte reaches 2 n_bins + 3
-        static const int fast_H[] = {40, 72, 136, 264};
+        // so the half-stride must hold 2 (n_bins + 2) entries
+        static const int fast_H[] = {40, 72, 136, 264, LR_H_WIDE};
         lr_scan_plan q = *p;
         q.n_cls = 1, q.fast = 1, q.H = 0;
         for (int h : fast_H)
@@ -631,6 +631,22 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
         // in-bin fractions packed as 32-bit fixed point; if none applies the plan stays the launch-based engine's
         lr_scan_plan q = *p;
         q.unit = LR_TAB_PAIRGEN, q.cb = 4;
+        if (lr_persist_variant(cfg, q, nullptr) != 0) {
+            *p = q;
+            return LR_OK;
+        }
+    }
+    if (!p->fast && cfg->model != LR_MODEL_KEIDING_DEAD && cfg->n_bins + 2 <= LR_H_WIDE && cfg->n_bins <= 64 * lr_bins_per_lane(LR_H_WIDE)) {
+        // 255..512 bins: beyond the table sizes the launch-based scans are instantiated for, but the persistent kernels
+        // (two- and four-chain; the packed groups address their entries with 16 bits) take one more class, H = 520;
+        // the scans outside the kernels go through lr_pairscan_kernel as they do for pair-general tables
+        lr_scan_plan q = *p;
+        q.n_cls = 1, q.fast = 1, q.H = LR_H_WIDE;
+        q.unit = cfg->unit_resolution ? LR_TAB_UNIT : LR_TAB_PAIRGEN;
+        q.cb = cfg->unit_resolution ? 16 : 4;
+        while (q.unit == LR_TAB_UNIT && q.cb > 2 && q.cb / 2 >= cfg->n_chains) q.cb >>= 1;
+        q.tab_stride = q.unit == LR_TAB_UNIT ? q.H : 2 * q.H;
+        q.groups = (cfg->n_chains + q.cb - 1) / q.cb;
         if (lr_persist_variant(cfg, q, nullptr) != 0) {
             *p = q;
             return LR_OK;
@@ -708,10 +724,10 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
 static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
     static const int env = lr_env_int("LR_PERSIST", -1);   // debugging override: 0 off, 1 on
     if (env == 0 || cfg->engine_mode == 1) return false;
-    if (!p.unit || cfg->n_bins + 1 > 255 || p.cb < 2) return false;
+    if (!p.unit || cfg->n_bins + 2 > LR_H_WIDE || p.cb < 2) return false;
     const bool general = p.unit == LR_TAB_PAIRGEN;
     if (cfg->n_lineages >= (1ll << 33)) return false;   // the scan loop counts 16-byte index groups in 32 bits
-    if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264) return false;
+    if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264 && p.H != LR_H_WIDE) return false;
     if (env == 1 || cfg->engine_mode >= 2) return true;
     const double n = (double)cfg->n_lineages, c = (double)cfg->n_chains;
     const int blocks = (cfg->n_chains + 1) / 2;
@@ -914,14 +930,15 @@ static int lr_launch_pairscan(const lr_engine* e, hipStream_t stream) {
 }
 
 static int lr_enqueue_scan_range(const lr_engine* e, int base, int count, hipStream_t stream) {
-    if (e->plan.unit == LR_TAB_PAIRGEN || (e->persistent && e->cfg.model == LR_MODEL_KEIDING_DEAD)) {
+    if (e->plan.unit == LR_TAB_PAIRGEN || (e->persistent && (e->cfg.model == LR_MODEL_KEIDING_DEAD || e->plan.H == LR_H_WIDE))) {
         // pair-general tables / the extant block of model 3: the launch-based twin of the persistent scan, all chains at once
         if (base != 0 || count != e->cfg.n_chains) return LR_ERR_STATE;
         switch (e->plan.H) {
             case 40: return lr_launch_pairscan<40>(e, stream);
             case 72: return lr_launch_pairscan<72>(e, stream);
             case 136: return lr_launch_pairscan<136>(e, stream);
-            default: return lr_launch_pairscan<264>(e, stream);
+            case 264: return lr_launch_pairscan<264>(e, stream);
+            default: return lr_launch_pairscan<LR_H_WIDE>(e, stream);
         }
     }
     return lr_launch_scan(e->plan, e->ts, e->te, e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins, e->cfg.end_time,
@@ -1168,7 +1185,8 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
                 case 40: LR_P_LAUNCH(40); break;
                 case 72: LR_P_LAUNCH(72); break;
                 case 136: LR_P_LAUNCH(136); break;
-                default: LR_P_LAUNCH(264); break;
+                case 264: LR_P_LAUNCH(264); break;
+                default: LR_P_LAUNCH(LR_H_WIDE); break;
             }
 #undef LR_P_LAUNCH
             const int rc = (int)hipGetLastError();

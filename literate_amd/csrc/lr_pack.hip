@@ -6,7 +6,8 @@
 // neighbouring bin.  The packing makes both explicit:
 //
 //   group = up to 14 CONSECUTIVE lineages of ONE birth bin in LR_SLOTS = 7 slots, 16 bytes:
-//           byte 0 birth index a, byte 1 number of lineages, then seven 16-bit ENTRY indices into the block's pair table
+//           a 16-bit header (birth index a << 4 | number of lineages), then seven 16-bit ENTRY indices into the block's
+//           pair table
 //   slot  = ONE lineage (entry H + j: its death entry E[j]) or TWO consecutive lineages of the run with death entries
 //           j and j + d, 0 <= d <= 3 at unit resolution (entry (2 + d) H + j: the pair-sum plane E[j] + E[j + d]) /
 //           d = 0 on general times (entry 2 H + j: the doubled plane); unused slots point at E[0] = 0
@@ -166,7 +167,7 @@ __global__ void lr_pack_slots_kernel(const double* __restrict__ ts, const double
             const bool pr = k + 1 < n && stretch_start[k + 1] == stretch_start[k];     // k is a head by construction
             cnt += pr ? 2 : 1, k += pr ? 2 : 1, ++slots;
         }
-        grp[0] = (unsigned short)(a | (cnt << 8));
+        grp[0] = (unsigned short)((a << 4) | cnt);                         // masked with 0xfff0: the byte offset of S[a]
         for (int q = slots; q < LR_SLOTS; ++q) grp[1 + q] = (unsigned short)H;
         if (frac) {
             // the sum of the group's fs (an exact integer below 2^36) as a double: array 2, (.x, .y)

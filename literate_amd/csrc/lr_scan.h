@@ -314,8 +314,9 @@ __device__ __forceinline__ unsigned int lr_grp_off(const uint4& w, int k) {
 }
 
 // ---- unit resolution: pair slots ------------------------------------------------------------------------------------
-// Group format (lr_pack.hip, unit-resolution data): uint4 = byte 0 birth index a, byte 1 number of lineages, then
-// LR_SLOTS = 7 sixteen-bit ENTRY indices into the block's pair table.  A slot holds ONE lineage (entry H + j, its death
+// Group format (lr_pack.hip, unit-resolution data): uint4 = a 16-bit header (birth index a << 4 | number of lineages:
+// masked with 0xfff0 it IS the byte offset of the birth entry), then LR_SLOTS = 7 sixteen-bit ENTRY indices into the
+// block's pair table.  A slot holds ONE lineage (entry H + j, its death
 // entry E[j]) or TWO consecutive lineages of the run whose death entries are j and j + d, 0 <= d <= 3 (entry
 // (2 + d) H + j, the pair sum E[j] + E[j + d]); padding slots point at E[0] = 0.  The pair table in LDS therefore has six
 // planes of H entries: S, E and the four pair-sum planes, which every block derives from its E plane (lr_pair_planes_*);
@@ -363,8 +364,8 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
         const uint4 cur = w;
         const int nx = i + n_scan;
         if (nx < n) w = idx8[nx];
-        const double2 S = *reinterpret_cast<const double2*>(lbase + lr_grp_off<4>(cur, 0));
-        const double cnt = (double)((cur.x >> 8) & 0xffu);
+        const double2 S = *reinterpret_cast<const double2*>(lbase + (cur.x & 0xfff0u));
+        const double cnt = (double)(cur.x & 0xfu);
         double2 E[LR_SLOTS];
         E[0] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.x, 1));
         E[1] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 0));
@@ -418,7 +419,7 @@ __device__ __forceinline__ void lr_pair_planes_block(double2* tab, int H, int n_
 // The same scan on GENERAL lineage times.  Pair tables in LDS (LR_TAB_PAIRGEN as the persistent kernels lay it out): six
 // planes of H 16-byte entries,  S | E | E2 | slopes of S | slopes of E | slopes of E2,  slopes scaled by 2^-32 and
 // E2[j] = 2 E[j] (value and slope alike; derived in LDS by lr_pair_planes_*_general, global memory holds S, E and their
-// slopes only).  Groups as at unit resolution - byte 0 birth index, byte 1 number of lineages, LR_SLOTS sixteen-bit
+// slopes only).  Groups as at unit resolution - header (birth index << 4 | number of lineages), LR_SLOTS sixteen-bit
 // value-entry indices - where a slot holds one lineage (entry H + j) or two consecutive lineages of the run that die in
 // the SAME bin j (entry 2 H + j); the slope entry of a slot is its value entry + 3 H.  Beside the groups LR_FRAC_ARRAYS
 // arrays of uint4, `fstride` entries apart (every load a fully coalesced 16-byte load): arrays 0 and 1 hold the slots'
@@ -467,10 +468,10 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
                 for (int j = 0; j < LR_FRAC_ARRAYS; ++j) fw[j] = frac[nx + j * fstride];
             }
         }
-        const char* pS = lbase + lr_grp_off<4>(cur, 0);
+        const char* pS = lbase + (cur.x & 0xfff0u);
         const double2 Sv = *reinterpret_cast<const double2*>(pS);
         const double2 Ss = *reinterpret_cast<const double2*>(pS + SLOPES);
-        const double cnt = (double)((cur.x >> 8) & 0xffu);
+        const double cnt = (double)(cur.x & 0xfu);
         const double sfs = __hiloint2double((int)fr[2].y, (int)fr[2].x);
         const unsigned int off[LR_SLOTS] = {lr_word_off16(cur.x, 1), lr_word_off16(cur.y, 0), lr_word_off16(cur.y, 1), lr_word_off16(cur.z, 0),
                                             lr_word_off16(cur.z, 1), lr_word_off16(cur.w, 0), lr_word_off16(cur.w, 1)};

@@ -454,11 +454,13 @@ def test_cfg5_ddrate_50k_lineages_256_states():
                                                 (253, None, "persistent4"),
                                                 (30, None, "spec"), (64, None, "spec"), (65, None, "spec"), (128, None, "spec"), (120, None, "spec"),
                                                 (120, False, "spec"),
-                                                (300, None, "auto"), (1000, None, "auto")])
+                                                (300, None, "auto"), (300, None, "persistent4"), (300, None, "persistent2"),
+                                                (300, False, "persistent4"), (512, None, "persistent4"), (513, None, "auto"),
+                                                (1000, None, "auto")])
 def test_engine_shapes_bins(n_bins, unit, engine):
     """Table half-stride classes (H = 40, 72, 136, 264; a class holds n_bins <= 64 x its bins-per-lane count, so 129..134
-    bins move up to H = 264) and the generic kernel beyond them (n_bins = 300), unit-resolution and general tables:
-    a few chains against the oracle loop on synthetic data."""
+    bins move up to H = 264; 255..512 bins: H = 520, persistent kernels only) and the generic kernel beyond them
+    (n_bins = 513, 1000), unit-resolution and general tables: a few chains against the oracle loop on synthetic data."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need an MI355X")
@@ -473,6 +475,12 @@ def test_engine_shapes_bins(n_bins, unit, engine):
     assert eng.n_bins == n_bins
     if engine == "persistent4":
         assert eng.layout.persistent == 2      # 37 chains: the last block holds one chain of four
+    if engine == "persistent2":
+        assert eng.layout.persistent == 1
+    if n_bins == 300 and engine == "auto":
+        assert eng.layout.persistent != 0      # the H = 520 class
+    if n_bins > 512:
+        assert eng.layout.persistent == 0
     if engine == "spec":
         assert eng.layout.persistent == 3      # 37 chains: the last block holds one chain of its pair
     eng.init(); eng.steps(n_it)

@@ -735,7 +735,7 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     double t_persist = rounds * (n * 2.0 * (blocks > 256 ? 2.0 : 1.0) / 2.2e10) + 6e-6;
     int k = 0;
     if (general) t_persist = n * c / 2.6e12 + 6e-6;            // four-chain kernel on 32-byte entries (measured: 2.6e12 evals/s)
-    const double t_spec = (p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general) * 1e-6;   // few chains: a team of CUs per pair
+    const double t_spec = (p.H > (general ? 136 : 264)) ? 1e30 : lr_spec_model(cfg, &k, general) * 1e-6;   // few chains: a team of CUs per pair
     if (k > 0 && t_spec < t_persist) t_persist = t_spec;
     const double t_launch = n * c / (general ? 2.6e12 : 5e12) + 14e-6;
     return t_persist <= t_launch;
@@ -755,7 +755,7 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, 
     static const int spec_env = lr_env_int("LR_SPEC", -1);
     const bool general = p.unit == LR_TAB_PAIRGEN;   // general times: the speculative (H <= 136) and four-chain kernels only
     int k = 0;
-    const double t_spec = (p.H > 136) ? 1e30 : lr_spec_model(cfg, &k, general);
+    const double t_spec = (p.H > (general ? 136 : 264)) ? 1e30 : lr_spec_model(cfg, &k, general);
     if (k > 0 && t_spec < 1e29 && cfg->engine_mode != 3 && cfg->engine_mode != 4 && spec_env != 0) {
         // the two-chain kernel with all 16 waves scanning wins only on long scans without room for a team
         // (measured at 256 pairs, 10k..1M lineages: 5.1 + 0.26 us per trip of its 1024 scanner lanes, 4.9 at least; the

@@ -511,6 +511,31 @@ __device__ __forceinline__ void lr_pair_planes_block_general(double2* tab, int H
         tab[5 * H + j] = make_double2(2.0 * sl.x, 2.0 * sl.y);
     }
 }
+// The six-plane scan table of a block from a table in the global-memory layout `src` ([S | E], general times: + their
+// slopes): copies the planes and derives the pair planes from `src` itself - no lane depends on another's writes.
+template <bool GENERAL>
+__device__ __forceinline__ void lr_build_scan_table(double2* scan, const double2* src, int H, int n_bins, int tid, int n_threads) {
+    if (GENERAL) {
+        for (int i = tid; i < 4 * H; i += n_threads) scan[i < 2 * H ? i : i + H] = src[i];
+        for (int j = tid; j <= n_bins + 1; j += n_threads) {
+            const double2 v = src[H + j], sl = src[3 * H + j];
+            scan[2 * H + j] = make_double2(2.0 * v.x, 2.0 * v.y);
+            scan[5 * H + j] = make_double2(2.0 * sl.x, 2.0 * sl.y);
+        }
+    } else {
+        for (int i = tid; i < 2 * H; i += n_threads) scan[i] = src[i];
+        const double2* E = src + H;
+        for (int j = tid; j <= n_bins + 1; j += n_threads) {
+            double2 v[LR_PAIR_DMAX + 1];
+#pragma unroll
+            for (int d = 0; d <= LR_PAIR_DMAX; ++d) v[d] = E[min(j + d, n_bins + 1)];
+#pragma unroll
+            for (int d = 0; d <= LR_PAIR_DMAX; ++d)
+                if (j + d <= n_bins + 1) scan[(2 + d) * H + j] = make_double2(v[0].x + v[d].x, v[0].y + v[d].y);
+        }
+    }
+}
+
 // global memory keeps a pair-general table as [S | E | slopes of S | slopes of E] (4 H entries); its place in the six
 // planes of the LDS image
 __host__ __device__ __forceinline__ int lr_pairgen_lds_entry(int i, int H) { return i < 2 * H ? i : i + H; }

@@ -311,12 +311,15 @@ __device__ __forceinline__ int lr_spec_turn(int role, int acc) {
 template <int H, int NW, int ENT>
 struct lr_spec_lds {
     static constexpr bool GENERAL_ENTRIES = ENT == 2;
-    static constexpr int TAB = LR_UNIT_PLANES * H;   // double2 per pair table
+    static constexpr int TAB = 2 * H * ENT;          // double2 per candidate pair table (the global-memory layout)
     // Pair tables (S' entries [0,H), E' [H,2H); (.x, .y) = (chain 0, chain 1)) for every combination of outcomes, in two
     // generations: pairs[g][d0][d1] holds candidate d0 of chain 0 beside candidate d1 of chain 1 for the iterations of
     // parity g.  A candidate wave writes its column into the two tables that contain it, so after the decisions the
     // scanners just switch to pairs[g][d0][d1]: no copy between the decision and the next scan.
-    double2 pairs[2][2][2][LR_UNIT_PLANES * H];   // six planes each: S, E, pair sums (unit resolution) / S, E, 2 E and their slopes (general)
+    double2 pairs[2][2][2][2 * H * ENT];   // S and E planes (general times: + their slopes), as in global memory
+    // what the scanner waves gather from: the six planes (lr_scan.h) of the table selected for this iteration, which they
+    // build behind the barrier (lr_build_scan_table) - the candidates write S and E only
+    double2 scan[LR_UNIT_PLANES * H];
     int cur_sel;                 // d0 * 2 + d1 of the pair table that stands when the kernel ends
     double red[NW][2];           // per scanner wave: partial sums of the two chains
     lr_spec_decision dec[2];     // [iteration parity]: what the deciding wave found
@@ -395,7 +398,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
         const double lA = sm.likA[lane & 1];
         double acc0 = 0.0, acc1 = 0.0;
-        const char* lbase = reinterpret_cast<const char*>(sm.pairs[it & 1][sel >> 1][sel & 1]);
+        const char* lbase = reinterpret_cast<const char*>(sm.scan);
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1, &first);
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
         if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
@@ -512,11 +515,10 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         sel = sm.dec[iter & 1].sel;
         role0 = lr_spec_turn(role0, sel >> 1), role1 = lr_spec_turn(role1, sel & 1);
         {
-            // The pair planes (lr_scan.h) of the table that was selected - the candidates wrote S and E only -, both
-            // chains at once, by all scanner lanes; the scanner waves then wait for each other on an LDS counter (the
-            // candidate waves are already building: no block barrier)
-            if (GENERAL) lr_pair_planes_block_general(sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, NSCAN);
-            else lr_pair_planes_block(sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, NSCAN);
+            // The scan table of the next iteration from the pair table that was selected (every scanner wave is past its
+            // scan of the old one: the barrier), both chains at once, by all scanner lanes; the scanner waves then wait
+            // for each other on an LDS counter (the candidate waves are already building: no block barrier)
+            lr_build_scan_table<GENERAL>(sm.scan, sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, NSCAN);
             LR_WAVE_LDS_ORDER();
             if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int want = (NW - 4) * ((int)iter + 1);
@@ -535,7 +537,7 @@ template <int H, int T, bool RJ, bool GENERAL>
 __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
-    constexpr int ES = GENERAL ? 6 * H : 2;  // the builders' `so`: doubles from a value to its slope in the LDS image
+    constexpr int ES = GENERAL ? 4 * H : 2;  // the builders' `so`: doubles from a value to its slope (lr_device.h)
     // the per-bin data constants come from their LDS copies (a global load per candidate would sit on the critical path)
     const double* br_lds = sm.br;
     const double* logbr_lds = sm.logbr;
@@ -710,10 +712,9 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         ctx.c0 = c0, ctx.C = C, ctx.team = team, ctx.rank = rank;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * H * ENT; i += T) sm.pairs[ctx.it0 & 1][0][0][GENERAL ? lr_pairgen_lds_entry(i, H) : i] = gpair[i];
+    for (int i = tid; i < 2 * H * ENT; i += T) sm.pairs[ctx.it0 & 1][0][0][i] = gpair[i];
     __syncthreads();
-    if (GENERAL) lr_pair_planes_block_general(sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
-    else lr_pair_planes_block(sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
+    lr_build_scan_table<GENERAL>(sm.scan, sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
     // draws of the first candidates (iteration it0 + 1); afterwards the last four scanner waves stay one iteration ahead
     if (rj && wave >= NW - 2 && c0 + (wave - (NW - 2)) < C)
         lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, &sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1]);
@@ -725,6 +726,6 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     {
         const int sel = sm.cur_sel;
         const double2* cur = sm.pairs[(ctx.it0 + (unsigned long long)n_iters) & 1][sel >> 1][sel & 1];
-        for (int i = tid; i < 2 * H * ENT; i += T) gpair[i] = cur[GENERAL ? lr_pairgen_lds_entry(i, H) : i];
+        for (int i = tid; i < 2 * H * ENT; i += T) gpair[i] = cur[i];
     }
 }

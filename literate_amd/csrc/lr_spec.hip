@@ -23,8 +23,8 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
         hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, true, GG>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
     else                                                                                                                      \
         hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, false, GG>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n)
-                // (H = 264 would not fit the eight pair tables in LDS - four planes of H entries on general times, six at
-                // unit resolution - and is never planned for the speculative kernel, see lr_persist_variant)
+                // (the eight candidate tables + the scan table: 352 H bytes at unit resolution, 608 H on general times, where
+                // H = 264 does not fit the LDS and is never planned for this kernel, see lr_persist_variant)
                 if (general) {
                     switch (e->plan.H) {
                         case 40: LR_SPEC_LAUNCH(40, true); break;
@@ -37,6 +37,7 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
                         case 40: LR_SPEC_LAUNCH(40, false); break;
                         case 72: LR_SPEC_LAUNCH(72, false); break;
                         case 136: LR_SPEC_LAUNCH(136, false); break;
+                        case 264: LR_SPEC_LAUNCH(264, false); break;
                         default: return LR_ERR_SIZE;
                     }
                 }

@@ -452,7 +452,7 @@ def test_cfg5_ddrate_50k_lineages_256_states():
                                                 (200, False, "auto"), (253, None, "auto"), (254, None, "auto"),
                                                 (60, None, "persistent4"), (134, None, "persistent4"),
                                                 (253, None, "persistent4"),
-                                                (30, None, "spec"), (64, None, "spec"), (65, None, "spec"), (128, None, "spec"), (120, None, "spec"),
+                                                (30, None, "spec"), (64, None, "spec"), (65, None, "spec"), (128, None, "spec"), (120, None, "spec"), (129, None, "spec"), (200, None, "spec"), (254, None, "spec"),
                                                 (120, False, "spec"),
                                                 (300, None, "auto"), (300, None, "persistent4"), (300, None, "persistent2"),
                                                 (300, False, "persistent4"), (512, None, "persistent4"), (513, None, "auto"),

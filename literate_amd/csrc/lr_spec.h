@@ -118,6 +118,22 @@ __device__ __forceinline__ void lr_spec_draw_part(const lr_step_args& a, int c, 
     }
 }
 
+// the same slot for a parametric sampler's draws (lr_dd_draws)
+__device__ __forceinline__ void lr_dd_draws_store(lr_draw_slot* q, const lr_dd_draws& d, int lane) {
+    double so = d.log_u;
+    so = (lane == 1) ? d.rr_a : so;
+    so = (lane == 2) ? d.rr_b : so;
+    so = (lane == 3) ? d.slide_u : so;
+    so = (lane == 4) ? d.z1 : so;
+    if (lane < 8) q->sc[lane] = so;
+    q->x[lane] = d.x, q->m[lane] = d.m, q->da[lane] = d.da;
+}
+__device__ __forceinline__ void lr_dd_draws_load(const lr_draw_slot* q, lr_dd_draws& d, int lane) {
+    const double v = q->sc[lane & 7];
+    d.log_u = lr_bcast(v, 0), d.rr_a = lr_bcast(v, 1), d.rr_b = lr_bcast(v, 2), d.slide_u = lr_bcast(v, 3), d.z1 = lr_bcast(v, 4);
+    d.x = q->x[lane], d.m = q->m[lane], d.da = q->da[lane];
+}
+
 struct lr_spec_args {
     unsigned long long* xchg;     // [2 parities][n_teams][LR_TEAM_MAX][LR_SPEC_GRANULES] granules (k > 1)
     unsigned int* status;         // engine status word: 0 ok, 1 = a team exchange timed out
@@ -365,9 +381,9 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     // Draw duty.  A block on its own is bound by its slowest wave before the barrier, so the duty is split over the last
     // four scanner waves, two per chain; in a team the last scanner to finish also runs the exchange and must not carry
     // more than its scan, so there the last two scanner waves (the smallest scan shares) take a chain each.
-    const bool split_draws = k_team == 1;
+    const bool split_draws = rj && k_team == 1;
     const int dch = split_draws ? (wave - (NW - 4)) >> 1 : wave - (NW - 2), dpart = (wave - (NW - 4)) & 1;
-    const bool drawer = rj && dch >= 0 && ctx.c0 + dch < ctx.C;
+    const bool drawer = dch >= 0 && ctx.c0 + dch < ctx.C;
     const int sid = tid - 4 * LR_WAVE;
     int sel = 0;
     int role0 = LR_SPEC_ROLES0, role1 = LR_SPEC_ROLES0;
@@ -505,8 +521,15 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         }
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
         if (drawer) {
-            if (split_draws) lr_spec_draw_part(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1], dpart);
-            else lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
+            if (!rj) {
+                lr_dd_draws dd;
+                lr_make_dd_draws(a, ctx.c0 + dch, lane, it + 2, dd);
+                lr_dd_draws_store(&sm.draws[dch][it & 1], dd, lane);
+            } else if (split_draws) {
+                lr_spec_draw_part(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1], dpart);
+            } else {
+                lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
+            }
         }
         LR_XSTAMP(dg_work);
         __syncthreads();                                                     // the decision and the candidates are in
@@ -582,7 +605,9 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(8); } }
             if (!rj) {
                 lr_dd_prop p;
-                const double P = lr_propose_dd<true, false>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds);
+                lr_dd_draws dd;
+                lr_dd_draws_load(&sm.draws[c][(it + 1) & 1], dd, lane);
+                const double P = lr_propose_dd<true, false>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, 0, &dd);
                 out->L[lane] = P;
                 if (lane == 0) {
                     out->sc[LR_SET_HASTING] = p.hasting, out->sc[LR_SET_PRIOR] = p.prior, out->sc[LR_SET_LOG_U] = p.log_u;
@@ -716,8 +741,15 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     __syncthreads();
     lr_build_scan_table<GENERAL>(sm.scan, sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
     // draws of the first candidates (iteration it0 + 1); afterwards the last four scanner waves stay one iteration ahead
-    if (rj && wave >= NW - 2 && c0 + (wave - (NW - 2)) < C)
-        lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, &sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1]);
+    if (wave >= NW - 2 && c0 + (wave - (NW - 2)) < C) {
+        if (rj) {
+            lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, &sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1]);
+        } else {
+            lr_dd_draws dd;
+            lr_make_dd_draws(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, dd);
+            lr_dd_draws_store(&sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1], dd, lane);
+        }
+    }
     __syncthreads();
     if (wave < 4) lr_spec_cand_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
     else lr_spec_scan_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);

@@ -767,10 +767,47 @@ struct lr_dd_prop {
     double hasting, prior, log_u;
     int move;
 };
+// the state-independent draws of one iteration of a parametric sampler (what lr_propose_dd draws itself when none are
+// given); a speculative engine makes them one iteration ahead
+struct lr_dd_draws {
+    double log_u, rr_a, rr_b, slide_u, z1;   // wave-uniform: log of the acceptance uniform, move selectors, sliding-window uniform, its normal
+    double da, x, m;                         // per parameter (lane): inclusion uniform, multiplier exponent (trend: or the normal step), exp(x)
+};
+__device__ __forceinline__ void lr_make_dd_draws(const lr_step_args& a, int c, int lane, uint64_t it, lr_dd_draws& d) {
+    const lr_mcmc_config& cfg = a.cfg;
+    const bool trend = cfg.sampler == 2;
+    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
+    const uint32_t purpose = trend ? (lane == 0 ? LR_P_TR_ACCEPT : LR_P_TR_MOVE)
+                                   : (lane == 0 ? LR_P_DD_ACCEPT : (lane == 1 ? LR_P_DD_MOVE : LR_P_DD_SLIDE));
+    const lr_u2 ud = lr_pair(rng, it, purpose, 0u);
+    const double lu = log(lane == 0 ? ud.a : 1.0);
+    d.log_u = lr_bcast(lu, 0);
+    d.rr_a = lr_bcast(ud.a, 1), d.rr_b = lr_bcast(ud.b, 1), d.slide_u = lr_bcast(ud.a, 2);
+    d.z1 = 0.0, d.da = 1.0, d.x = 0.0, d.m = 1.0;
+    if (trend) {
+        const lr_u2 u = lr_pair(rng, it, LR_P_TR_MULT, lane);
+        d.da = u.a;
+        if (d.rr_a < .33) {
+            d.x = lr_normal(rng, it, LR_P_TR_NORM, lane);
+        } else {
+            d.x = a.mult_l * (u.b - .5);
+            d.m = exp(d.x);
+        }
+    } else if (d.rr_b < 0.1 && (cfg.m_birth == 2 || cfg.m_death == 2)) {
+        if (cfg.m_death == -1) d.z1 = lr_normal(rng, it, LR_P_DD_SLIDE, 1);
+    } else {
+        const lr_u2 u = lr_pair(rng, it, LR_P_DD_MULT, lane);
+        d.da = u.a;
+        d.x = a.mult_l * (u.b - .5);
+        d.m = exp(d.x);
+    }
+}
+
 template <bool LDS_CONSTS = false, bool PAIR_PLANES = true>
 __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, int lane, uint64_t it, double A,
                                                 lr_dd_prop& p, double2* table, int table_es,
-                                                const double* aux_lds = nullptr, int table_dup = 0) {
+                                                const double* aux_lds = nullptr, int table_dup = 0,
+                                                const lr_dd_draws* pre = nullptr) {
     const lr_mcmc_config& cfg = a.cfg;
     const bool trend = cfg.sampler == 2;
     const int npar = trend ? LR_TR_NPAR : LR_DD_NPAR;
@@ -782,44 +819,51 @@ __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, in
     // selector and lane 2 the sliding-window uniform of the iteration
     const uint32_t purpose = trend ? (lane == 0 ? LR_P_TR_ACCEPT : LR_P_TR_MOVE)
                                    : (lane == 0 ? LR_P_DD_ACCEPT : (lane == 1 ? LR_P_DD_MOVE : LR_P_DD_SLIDE));
-    const lr_u2 ud = lr_pair(rng, it, purpose, 0u);
+    lr_u2 ud{0.0, 0.0};
+    if (!pre) ud = lr_pair(rng, it, purpose, 0u);
     // log of the acceptance uniform (DD:211, trend_rate.py:176), evaluated in lane 0 only
-    const double lu = log(lane == 0 ? ud.a : 1.0);
-    p.log_u = lr_bcast(lu, 0);
+    p.log_u = pre ? pre->log_u : lr_bcast(log(lane == 0 ? ud.a : 1.0), 0);
     double P = A, hasting = 0.0;
     int move_kind;
     if (trend) {
         // trend_rate.py:165-169: 33 % additive normal step on the slopes, else the vector multiplier
-        const double rr = lr_bcast(ud.a, 1);
+        const double rr = pre ? pre->rr_a : lr_bcast(ud.a, 1);
         double f_mult, f_norm;
         lr_trend_update_freq(cfg.m_birth, cfg.m_death, lane, &f_mult, &f_norm);
-        const lr_u2 d = lr_pair(rng, it, LR_P_TR_MULT, lane);
+        lr_u2 d{0.0, 0.0};
+        if (!pre) d = lr_pair(rng, it, LR_P_TR_MULT, lane);
+        const double da = pre ? pre->da : d.a;
         if (rr < .33) {
-            const double z = lr_normal(rng, it, LR_P_TR_NORM, lane);               // update_normal_nobound_vec (lib:140-146)
-            if (lane < npar && d.a < f_norm) P = A + z * .001;
+            const double z = pre ? pre->x : lr_normal(rng, it, LR_P_TR_NORM, lane);   // update_normal_nobound_vec (lib:140-146)
+            if (lane < npar && da < f_norm) P = A + z * .001;
             move_kind = 1;
         } else {
-            hasting = lr_wave_multiplier(P, npar, d.a < f_mult, d.b, a.mult_l, lane);   // lib:156-165
+            hasting = pre ? lr_wave_multiplier_pre(P, npar, da < f_mult, pre->x, pre->m, lane)
+                          : lr_wave_multiplier(P, npar, da < f_mult, d.b, a.mult_l, lane);   // lib:156-165
             move_kind = 0;
         }
     } else {
         // DD:195-207
-        const lr_u2 rr{lr_bcast(ud.a, 1), lr_bcast(ud.b, 1)};
+        const lr_u2 rr = pre ? lr_u2{pre->rr_a, pre->rr_b} : lr_u2{lr_bcast(ud.a, 1), lr_bcast(ud.b, 1)};
         if (rr.b < 0.1 && (cfg.m_birth == 2 || cfg.m_death == 2)) {
             // update_sliding_win(x0, m=0, M=PRESENT, d=1.5) (lib:124-128)
-            double ii = lr_bcast(A, 2) + (lr_bcast(ud.a, 2) - .5) * 1.5;
+            double ii = lr_bcast(A, 2) + ((pre ? pre->slide_u : lr_bcast(ud.a, 2)) - .5) * 1.5;
             if (ii > present) ii = present - (ii - present);
             ii = fabs(ii);
             if (lane == 2) P = ii;
             if (cfg.m_death == -1) {
-                const double z = lr_normal(rng, it, LR_P_DD_SLIDE, 1);              // update_normal_nobound(k, d=0.2) (lib:136-138)
+                const double z = pre ? pre->z1 : lr_normal(rng, it, LR_P_DD_SLIDE, 1);   // update_normal_nobound(k, d=0.2) (lib:136-138)
                 if (lane == 1) P = A + z * 0.2;
             }
             move_kind = 1;
         } else {
             const double f = lr_dd_update_freq(cfg.m_birth, cfg.m_death, lane);
-            const lr_u2 d = lr_pair(rng, it, LR_P_DD_MULT, lane);
-            hasting = lr_wave_multiplier(P, npar, d.a < f, d.b, a.mult_l, lane);   // lib:156-165
+            if (pre) {
+                hasting = lr_wave_multiplier_pre(P, npar, pre->da < f, pre->x, pre->m, lane);
+            } else {
+                const lr_u2 d = lr_pair(rng, it, LR_P_DD_MULT, lane);
+                hasting = lr_wave_multiplier(P, npar, d.a < f, d.b, a.mult_l, lane);   // lib:156-165
+            }
             move_kind = 0;
         }
     }

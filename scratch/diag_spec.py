@@ -11,7 +11,12 @@ ts, te, _ = synth.make_lineages(N, 128, 20, 0)
 if os.environ.get("LR_DIAG_DATA") == "metal_bands":
     G = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "binning_lik.npz"))
     ts, te, model = G["metal_bands/ts"], G["metal_bands/te"], 2
-eng = ChainEngine(ts, te, C, model=model, seed=1, s_freq=100, n_trace_slots=40, engine="spec", team=team)
+if os.environ.get("LR_DIAG_DATA") == "ddrate":
+    from literate_amd.ddrate import DDRateEngine
+    ts, te, _ = synth.make_lineages(50000, 64, 6, 0)
+    eng = DDRateEngine(ts, te, float(ts.min()), float(te.max()), C, m_birth=2, m_death=2, seed=1, s_freq=100, n_trace_slots=40)
+else:
+    eng = ChainEngine(ts, te, C, model=model, seed=1, s_freq=100, n_trace_slots=40, engine="spec", team=team)
 eng.init(); eng.steps(300); torch.cuda.synchronize()
 NIT = 2000
 lib = _hip.load()

@@ -689,7 +689,7 @@ static int lr_device_cus() {
 //     unit resolution   k = 1: max(3.0, 2.95 + 0.222 trips)     k > 1: max(3.4,  3.20 + 0.205 trips)
 //     general times     k = 1: max(3.0, 3.28 + 0.464 trips)     k > 1: max(3.45, 2.90 + 0.478 trips)
 // (the floor is the candidate build; a team pays the exchange behind its last scanner).  The parametric samplers build
-// their candidates more slowly (+0.9).  Returns the modelled time and the best team size in *k (0 = not applicable).
+// their candidates a little more slowly (+0.25; scratch/exp_dd_team.py).  Returns the modelled time and the best team size in *k (0 = not applicable).
 static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general = false) {
     const int pairs = (cfg->n_chains + 1) / 2;
     const int cus = lr_device_cus();
@@ -698,7 +698,7 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
     static const int k_env0 = lr_env_int("LR_SPEC_TEAM", 0);
     const int k_env = cfg->team_request > 0 ? cfg->team_request : k_env0;
     const double n8 = (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP);      // groups, for lineages sorted by birth time
-    const double extra = cfg->sampler ? 0.9 : 0.0;
+    const double extra = cfg->sampler ? 0.25 : 0.0;
     double best = 1e30;
     for (int k = 1; k <= LR_TEAM_MAX; k *= 2) {
         if (pairs * k > cus) break;

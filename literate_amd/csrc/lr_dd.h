@@ -92,8 +92,17 @@ __device__ __forceinline__ double lr_dd_prior(double v, double origin, double pr
 #define LR_DD_MAXP 4
 template <class F>
 __device__ __forceinline__ void lr_rates_build_tables_wave(F rates, int n_bins, int H, double2* __restrict__ tab, int lane,
-                                                           int unit, double fs0, double fe0, int es) {
+                                                           int unit, double fs0, double fe0, int es, int dup = 0) {
     double* tabd = reinterpret_cast<double*>(tab);
+    // dup != 0: every entry a second time `dup` doubles further on (the speculative kernel's second pair table)
+    auto put_S = [&](int j, double v, double R) {
+        lr_put_S(tabd, unit, es, j, v, R, fs0);
+        if (dup) lr_put_S(tabd + dup, unit, es, j, v, R, fs0);
+    };
+    auto put_E = [&](int j, double v, double R) {
+        lr_put_E(tabd, unit, es, j, v, R, fe0);
+        if (dup) lr_put_E(tabd + dup, unit, es, j, v, R, fe0);
+    };
     const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
     const int b0 = min(lane * P, n_bins), b1 = min(b0 + P, n_bins);
     double br[LR_DD_MAXP], dr[LR_DD_MAXP];
@@ -114,26 +123,26 @@ __device__ __forceinline__ void lr_rates_build_tables_wave(F rates, int n_bins, 
         const int b = b0 + i;
         if (i < P && b < b1) {
             const double logB = log(br[i]), logD = log(dr[i]), R = br[i] + dr[i];
-            lr_put_S(tabd, unit, es, b + 1, logB + cum, R, fs0);
-            lr_put_E(tabd, unit, es, H + b + 1, logD - cum, R, fe0);
+            put_S(b + 1, logB + cum, R);
+            put_E(H + b + 1, logD - cum, R);
             cum += R;
         }
     }
     if (lane == 0) {
-        lr_put_S(tabd, unit, es, 0, 0.0, 0.0, fs0), lr_put_E(tabd, unit, es, H, 0.0, 0.0, fe0);
-        lr_put_S(tabd, unit, es, n_bins + 1, totR, 0.0, fs0), lr_put_E(tabd, unit, es, H + n_bins + 1, -totR, 0.0, fe0);
+        put_S(0, 0.0, 0.0), put_E(H, 0.0, 0.0);
+        put_S(n_bins + 1, totR, 0.0), put_E(H + n_bins + 1, -totR, 0.0);
     }
 }
 
 __device__ inline void lr_dd_build_tables_wave(const lr_dd_params& p, const double* __restrict__ DT, int m_birth,
                                                int m_death, int n_bins, int H, double2* __restrict__ tab, int lane,
-                                               int unit, double fs0, double fe0, int es) {
+                                               int unit, double fs0, double fe0, int es, int dup = 0) {
     lr_rates_build_tables_wave(
         [&](int b, double* br, double* dr) {
             double ni, fr;
             lr_dd_bin_rates(p, (double)b, DT[b], m_birth, m_death, br, dr, &ni, &fr);
         },
-        n_bins, H, tab, lane, unit, fs0, fe0, es);
+        n_bins, H, tab, lane, unit, fs0, fe0, es, dup);
 }
 
 // ---- trend_rate.py: rates driven by a per-bin covariate ---------------------------------------

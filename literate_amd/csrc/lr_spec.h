@@ -607,7 +607,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 lr_dd_prop p;
                 lr_dd_draws dd;
                 lr_dd_draws_load(&sm.draws[c][(it + 1) & 1], dd, lane);
-                const double P = lr_propose_dd<true, false>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, 0, &dd);
+                const double P = lr_propose_dd<true, false>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, (int)(col1 - col0), &dd);
                 out->L[lane] = P;
                 if (lane == 0) {
                     out->sc[LR_SET_HASTING] = p.hasting, out->sc[LR_SET_PRIOR] = p.prior, out->sc[LR_SET_LOG_U] = p.log_u;
@@ -627,13 +627,6 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                                                                logbr_lds, (int)(col1 - col0));
                 lr_set_store(out, s, p, lane);
                 { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
-            }
-            if (!rj) {
-                LR_WAVE_LDS_ORDER();
-                for (int i = lane; i < 2 * H; i += LR_WAVE) {
-                    col1[2 * i] = col0[2 * i];
-                    if (GENERAL) col1[2 * i + ES] = col0[2 * i + ES];
-                }
             }
         }
         LR_XSTAMP(dg_work);

@@ -871,12 +871,13 @@ __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, in
         p.prior = lr_trend_prior(P, lane);
         const lr_trend_params tp = lr_trend_unpack(P);
         lr_rates_build_tables_wave([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
-                                   cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death, table_es);
+                                   cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death, table_es,
+                                   table_dup);
     } else {
         p.prior = lr_dd_prior(P, origin, present, k0, log_k0, lane);
         const lr_dd_params pp = lr_dd_unpack(P);
         lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es),
-                                cfg.frac_birth, cfg.frac_death, table_es);
+                                cfg.frac_birth, cfg.frac_death, table_es, table_dup);
     }
     if (LDS_CONSTS && PAIR_PLANES) {
         LR_WAVE_LDS_ORDER();

@@ -218,10 +218,14 @@ __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk,
 // to global memory costs an L2 round trip per field), the per-wave scratch, the state rows and the pair table.
 typedef __attribute__((address_space(3))) double lr_lds_f64;
 typedef __attribute__((address_space(3))) int lr_lds_i32;
+// PB: bins per lane of the one-pass table builder for the kernel's table size (0: choose at run time), ES: the builders'
+// `so` - both known to the calling kernel at compile time, so the builder dispatch and the layout switches fold away
+template <int PB, int ES>
 __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
                                                           __attribute__((address_space(3))) lr_seg_scratch* scratch3,
                                                           lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* table3,
-                                                          int table_es, lr_lds_f64* br3 /* [2][256]: br_length, log br_length */) {
+                                                          lr_lds_f64* br3 /* [2][LR_H_WIDE]: br_length, log br_length */) {
+    constexpr int table_es = ES;
     const lr_step_args& a = *(const lr_step_args*)a3;
     const double* br_lds = (const double*)br3;
     lr_chain_regs st;
@@ -229,8 +233,8 @@ __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((a
     if (a.cfg.sampler != 0)
         lr_dd_step_core<true>(st, a, 0, c, lane, lik, reinterpret_cast<double2*>((double*)table3), table_es, br_lds);
     else
-        lr_chain_step_core<true>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
-                                 table_es, br_lds, br_lds + LR_H_WIDE);
+        lr_chain_step_core<true, PB>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
+                                     table_es, br_lds, br_lds + LR_H_WIDE);
     lr_chain_store(st, (double*)st_f64, (int*)st_i32, lane);
 }
 
@@ -308,10 +312,10 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
             double lik = 0.0;
 #pragma unroll
             for (int w2 = 0; w2 < T / LR_WAVE; ++w2) lik += red[w2][wave];
-            lr_persist_step((const __attribute__((address_space(3))) lr_step_args*)&a_lds, c, lane,
-                            (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave], (lr_lds_f64*)st_f64[wave],
-                            (lr_lds_i32*)st_i32[wave], lik, (lr_lds_f64*)(reinterpret_cast<double*>(tab) + wave), 2,
-                            (lr_lds_f64*)&br_lds[0][0]);
+            lr_persist_step<(H <= 264 ? lr_bins_per_lane(H) : 0), 2>(
+                (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c, lane,
+                (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave], (lr_lds_f64*)st_f64[wave],
+                (lr_lds_i32*)st_i32[wave], lik, (lr_lds_f64*)(reinterpret_cast<double*>(tab) + wave), (lr_lds_f64*)&br_lds[0][0]);
         }
         __syncthreads();  // new tables ready
 #ifdef LR_DIAG
@@ -436,10 +440,11 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
                     double lik = 0.0;
 #pragma unroll
                     for (int w2 = 2; w2 < NW; ++w2) lik += red[ph][w2][wave];
-                    lr_persist_step((const __attribute__((address_space(3))) lr_step_args*)&a_lds, c, lane,
-                                    (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave],
-                                    (lr_lds_f64*)st_f64[2 * ph + wave], (lr_lds_i32*)st_i32[2 * ph + wave], lik,
-                                    (lr_lds_f64*)(reinterpret_cast<double*>(tab[ph]) + wave), ES, (lr_lds_f64*)&br_lds[0][0]);
+                    lr_persist_step<(H <= 264 ? lr_bins_per_lane(H) : 0), ES>(
+                        (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c, lane,
+                        (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave],
+                        (lr_lds_f64*)st_f64[2 * ph + wave], (lr_lds_i32*)st_i32[2 * ph + wave], lik,
+                        (lr_lds_f64*)(reinterpret_cast<double*>(tab[ph]) + wave), (lr_lds_f64*)&br_lds[0][0]);
                 }
             }
 #ifdef LR_DIAG

@@ -647,7 +647,7 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
 // (lik_sum, without the model constant), write the trace row, draw the next proposal and build its lookup
 // tables at `table` (global memory or LDS; see lr_chain_table for the addressing).
 // mode: 0 = regular step, 1 = finish init (adopt the evaluated initial state, then propose iteration 0)
-template <bool LDS_CONSTS = false>
+template <bool LDS_CONSTS = false, int PB = 0>
 __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
                                                    lr_seg_scratch* scratch_p, double lik_sum, double2* table,
                                                    int table_es = 2, const double* br_lds = nullptr,
@@ -709,7 +709,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
 
     // ---- propose iteration `it` (LRF:234-304) ----
     lr_rj_prop p;
-    lr_propose_rj<LDS_CONSTS>(a, c, lane, scratch_p, it, s, p, table, table_es, nullptr, br_lds, logbr_lds);
+    lr_propose_rj<LDS_CONSTS, PB>(a, c, lane, scratch_p, it, s, p, table, table_es, nullptr, br_lds, logbr_lds);
 
     // ---- back into the state registers ----
     st.pL = s.L, st.pM = s.M, st.ptL = s.tL, st.ptM = s.tM, st.peL = s.eL, st.peM = s.eM;

@@ -726,6 +726,23 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
 // engine (2 and 3 still need the prerequisites); auto picks the persistent kernel unless the chains are too few for the lineage count: a block
 // scans ALL lineages for its two chains, so with few chains and very long inputs the tiled launch-based scan,
 // which spreads one chain group over many CUs, is faster.
+// Measured iteration times (us, MI355X, scratch/exp_p2_vs_p4.py: 3k..3M lineages x 768 / 1024 / 1536 chains) of the two
+// persistent kernels that take more than 256 chain pairs, per round of 1024 chains:
+//   two-chain kernel (512-thread blocks, two per CU)   f2 = 5.0 + 0.0395 per 1000 lineages
+//   four-chain kernel                                  f4 = max(7.7, 3.8 + 0.044 per 1000 lineages)   (general times: 0.091)
+// and a remainder of at most 512 chains costs the two-chain kernel 0.77 of a round.
+static double lr_model_two_chain(const lr_mcmc_config* cfg) {
+    const double kn = (double)cfg->n_lineages * 1e-3;
+    const int C = cfg->n_chains, rem = C % 1024;
+    const double f2 = 5.0 + 0.0395 * kn;
+    return f2 * ((double)(C / 1024) + (rem == 0 ? 0.0 : (rem <= 512 ? 0.77 : 1.0)));
+}
+static double lr_model_four_chain(const lr_mcmc_config* cfg, bool general) {
+    const double kn = (double)cfg->n_lineages * 1e-3;
+    const double f4 = fmax(general ? 8.0 : 7.7, 3.8 + (general ? 0.091 : 0.044) * kn);
+    return f4 * (double)((cfg->n_chains + 1023) / 1024);
+}
+
 static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
     static const int env = lr_env_int("LR_PERSIST", -1);   // debugging override: 0 off, 1 on
     if (env == 0 || cfg->engine_mode == 1) return false;
@@ -735,24 +752,22 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264 && p.H != LR_H_WIDE) return false;
     if (env == 1 || cfg->engine_mode >= 2) return true;
     const double n = (double)cfg->n_lineages, c = (double)cfg->n_chains;
-    const int blocks = (cfg->n_chains + 1) / 2;
-    const double rounds = (double)((blocks + 511) / 512);
-    double t_persist = rounds * (n * 2.0 * (blocks > 256 ? 2.0 : 1.0) / 2.2e10) + 6e-6;
+    // the best persistent kernel for the shape (microseconds) against the tiled launches (measured: 7e12 evals/s at unit
+    // resolution, 3e12 on general times, 14 us of launches per iteration)
+    double t_persist = lr_model_four_chain(cfg, general);
+    if (!general) t_persist = fmin(t_persist, lr_model_two_chain(cfg));
     int k = 0;
-    if (general) t_persist = n * c / 2.6e12 + 6e-6;            // four-chain kernel on 32-byte entries (measured: 2.6e12 evals/s)
-    const double t_spec = (p.H > (general ? 136 : 264)) ? 1e30 : lr_spec_model(cfg, &k, general) * 1e-6;   // few chains: a team of CUs per pair
+    const double t_spec = (p.H > (general ? 136 : 264)) ? 1e30 : lr_spec_model(cfg, &k, general);   // few chains: a team of CUs per pair
     if (k > 0 && t_spec < t_persist) t_persist = t_spec;
-    const double t_launch = n * c / (general ? 2.6e12 : 5e12) + 14e-6;
+    const double t_launch = n * c / (general ? 3e12 : 7e12) * 1e6 + 14.0;
     return t_persist <= t_launch;
 }
 
 // Which persistent kernel: 1 = two chains per 512-thread block (lr_persist_kernel), 2 = four chains per 1024-thread
-// block in ping-pong (lr_persist4_kernel).  The four-chain block hides the chain step under the other pair's scan but
-// scans with 14 of its 16 waves, so it wins only while a step is a sizeable part of a scan (measured on cfg4-like
-// data: ahead for 25k..1M lineages since its waves got unequal shares, behind below), and it fills the chip in rounds of 1024 chains where the
-// two-chain kernel's remainder round is cheaper when at most 512 chains are left (C = 1536: 29.4 vs 33.5 us).
-// Model in units of one full round (15.2 us on cfg4): t4 = ceil(C/1024), t2 = 1.08 floor(C/1024) + (0.82 | 1.08 for
-// the remainder).
+// block in ping-pong (lr_persist4_kernel), 3 = the speculative team kernel (at most 256 chain pairs).  The four-chain
+// block hides the chain step under the other pair's scan, so beyond 256 pairs it wins while a scan is about as long as a
+// step (~70k..270k lineages, whole rounds of 1024 chains); the two-chain kernel, two blocks per CU, is ahead on short
+// scans (the step is all there is), on long ones (every wave scans) and on remainders of at most 512 chains.
 static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k) {
     if (team_k) *team_k = 0;
     if (!lr_persist_eligible(cfg, p)) return 0;
@@ -777,10 +792,7 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, 
     if (cfg->engine_mode == 3) return 2;
     if (cfg->engine_mode == 4) return 1;
     if (p4_env >= 0) return p4_env ? 2 : 1;
-    const int C = cfg->n_chains, rem = C % 1024;
-    const double t4 = (double)((C + 1023) / 1024);
-    const double t2 = 1.08 * (C / 1024) + (rem == 0 ? 0.0 : (rem <= 512 ? 0.82 : 1.08));
-    return (cfg->n_lineages >= 25000 && cfg->n_lineages <= 1000000 && t4 < t2) ? 2 : 1;
+    return lr_model_four_chain(cfg, false) < lr_model_two_chain(cfg) ? 2 : 1;
 }
 
 static int lr_check_cfg(const lr_mcmc_config* cfg) {

@@ -384,6 +384,23 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     const bool split_draws = rj && k_team == 1;
     const int dch = split_draws ? (wave - (NW - 4)) >> 1 : wave - (NW - 2), dpart = (wave - (NW - 4)) & 1;
     const bool drawer = dch >= 0 && ctx.c0 + dch < ctx.C;
+    // A block on its own is bound by whichever wave reaches the barrier last, and that used to be a drawer (scan table,
+    // scan, then the draws): there the drawers make their draws FIRST - they depend on nothing - while the other scanner
+    // waves build the scan table, and only then scan.  In a team the last scanner also runs the exchange, so the
+    // drawers scan first and draw behind the arrival.
+    const bool draws_first = k_team == 1;
+    const int n_build = draws_first ? (NW - 4) - (rj ? 4 : 2) : NW - 4;      // scanner waves 4 .. 4 + n_build - 1 build the scan table
+    auto draw_duty = [&](unsigned long long it_draw, unsigned long long slot) {
+        if (!rj) {
+            lr_dd_draws dd;
+            lr_make_dd_draws(a, ctx.c0 + dch, lane, it_draw, dd);
+            lr_dd_draws_store(&sm.draws[dch][slot], dd, lane);
+        } else if (split_draws) {
+            lr_spec_draw_part(a, ctx.c0 + dch, lane, it_draw, &sm.draws[dch][slot], dpart);
+        } else {
+            lr_spec_draw(a, ctx.c0 + dch, lane, it_draw, &sm.draws[dch][slot]);
+        }
+    };
     const int sid = tid - 4 * LR_WAVE;
     int sel = 0;
     int role0 = LR_SPEC_ROLES0, role1 = LR_SPEC_ROLES0;
@@ -520,17 +537,8 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
             }
         }
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
-        if (drawer) {
-            if (!rj) {
-                lr_dd_draws dd;
-                lr_make_dd_draws(a, ctx.c0 + dch, lane, it + 2, dd);
-                lr_dd_draws_store(&sm.draws[dch][it & 1], dd, lane);
-            } else if (split_draws) {
-                lr_spec_draw_part(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1], dpart);
-            } else {
-                lr_spec_draw(a, ctx.c0 + dch, lane, it + 2, &sm.draws[dch][it & 1]);
-            }
-        }
+        // (a block on its own has made these draws at the top of the iteration, see below)
+        if (drawer && !draws_first) draw_duty(it + 2, it & 1);
         LR_XSTAMP(dg_work);
         __syncthreads();                                                     // the decision and the candidates are in
         LR_XSTAMP(dg_wait1);
@@ -541,10 +549,15 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
             // The scan table of the next iteration from the pair table that was selected (every scanner wave is past its
             // scan of the old one: the barrier), both chains at once, by all scanner lanes; the scanner waves then wait
             // for each other on an LDS counter (the candidate waves are already building: no block barrier)
-            lr_build_scan_table<GENERAL>(sm.scan, sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, NSCAN);
-            LR_WAVE_LDS_ORDER();
-            if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int want = (NW - 4) * ((int)iter + 1);
+            if (wave - 4 < n_build) {
+                lr_build_scan_table<GENERAL>(sm.scan, sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, n_build * LR_WAVE);
+                LR_WAVE_LDS_ORDER();
+                if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (drawer && iter + 1 < ctx.n_iters) {
+                // the draws of iteration (it + 1) + 2, i.e. what the drawers of a team make behind their next scan
+                draw_duty(it + 3, (it + 1) & 1);
+            }
+            const int want = n_build * ((int)iter + 1);
             while (__hip_atomic_load(&sm.plane_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
         }
@@ -734,13 +747,17 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     __syncthreads();
     lr_build_scan_table<GENERAL>(sm.scan, sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
     // draws of the first candidates (iteration it0 + 1); afterwards the last four scanner waves stay one iteration ahead
+    // (a block on its own draws at the top of an iteration for the one after the next: it starts with two iterations' draws)
     if (wave >= NW - 2 && c0 + (wave - (NW - 2)) < C) {
-        if (rj) {
-            lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, &sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1]);
-        } else {
-            lr_dd_draws dd;
-            lr_make_dd_draws(a, c0 + (wave - (NW - 2)), lane, ctx.it0 + 1, dd);
-            lr_dd_draws_store(&sm.draws[wave - (NW - 2)][(ctx.it0 + 1) & 1], dd, lane);
+        for (unsigned long long ahead = 1; ahead <= (k_team == 1 ? 2ull : 1ull); ++ahead) {
+            const unsigned long long itd = ctx.it0 + ahead;
+            if (rj) {
+                lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, itd, &sm.draws[wave - (NW - 2)][itd & 1]);
+            } else {
+                lr_dd_draws dd;
+                lr_make_dd_draws(a, c0 + (wave - (NW - 2)), lane, itd, dd);
+                lr_dd_draws_store(&sm.draws[wave - (NW - 2)][itd & 1], dd, lane);
+            }
         }
     }
     __syncthreads();

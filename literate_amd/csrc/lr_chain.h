@@ -67,7 +67,7 @@ __device__ __forceinline__ double lr_wave_add_shift(double& R, double& T, int& K
     if (lane == 2) x = fabs(r_time);
     if (lane == 3) x = u;
     if (lane == 4) x = 1 - u;
-    const double lx = log(x);
+    const double lx = lr_log(x);
     const double logit = lr_bcast(lx, 0), log_rate = lr_bcast(lx, 1), log_rt = lr_bcast(lx, 2), log_u = lr_bcast(lx, 3);
     const double log_1mu = lr_bcast(lx, 4);
     // one packed exp: lane0 -> r1, lane1 -> r2
@@ -83,7 +83,7 @@ __device__ __forceinline__ double lr_wave_add_shift(double& R, double& T, int& K
     const double a = LR_SHAPE_BETA_RJ;
     const double log_beta = (a - 1.0) * log_1mu + (a - 1.0) * log_u - LR_BETALN_10_10;   // LRF:22-23
     const double log_q = log_rt - log_beta;
-    const double jac = 2 * log(r1 + r2) - log_rate;
+    const double jac = 2 * lr_log(r1 + r2) - log_rate;
     return log_q + jac;
 }
 
@@ -109,7 +109,7 @@ __device__ __forceinline__ double lr_wave_remove_shift(double& R, double& T, int
     if (lane == 3) x = r1 + r2;
     if (lane == 4) x = u;
     if (lane == 5) x = 1 - u;
-    const double lx = log(x);
+    const double lx = lr_log(x);
     const double l1 = lr_bcast(lx, 0), l2 = lr_bcast(lx, 1), log_dT = lr_bcast(lx, 2), log_sum = lr_bcast(lx, 3);
     const double log_u = lr_bcast(lx, 4), log_1mu = lr_bcast(lx, 5);
     const double rate_prime = exp(p1 * l1 + p2 * l2);
@@ -120,7 +120,7 @@ __device__ __forceinline__ double lr_wave_remove_shift(double& R, double& T, int
     const double a = LR_SHAPE_BETA_RJ;
     const double log_beta = (a - 1.0) * log_1mu + (a - 1.0) * log_u - LR_BETALN_10_10;
     const double log_q = -log_dT + log_beta;
-    const double jac = log(rate_prime) - (2 * log_sum);
+    const double jac = lr_log(rate_prime) - (2 * log_sum);
     return log_q + jac;
 }
 
@@ -129,7 +129,7 @@ __device__ __forceinline__ double lr_wave_remove_shift(double& R, double& T, int
 __device__ __forceinline__ double lr_wave_prior_gamma(double R, int K, double a, double b, int lane) {
     const double scale = 1. / b;
     const double y = R / scale;
-    const double v = (a - 1.0) * log(y) - y - lgamma(a) - log(scale);
+    const double v = (a - 1.0) * lr_log(y) - y - lgamma(a) - lr_log(scale);
     return lr_wave_sum(lane < K ? v : 0.0);
 }
 
@@ -144,8 +144,8 @@ __device__ __forceinline__ double lr_poisson_prior(int k, double rate, double lo
     return k * log_rate - rate - lr_log_factorial(k);
 }
 __device__ __forceinline__ double lr_wave_poisson_prior(int k, double rate, int lane) {
-    const double lf = lr_wave_sum((lane >= 1 && lane <= k) ? log((double)lane) : 0.0);
-    return k * log(rate) - rate - lf;
+    const double lf = lr_wave_sum((lane >= 1 && lane <= k) ? lr_log((double)lane) : 0.0);
+    return k * lr_log(rate) - rate - lf;
 }
 
 // integer bin edge of shift time j relative to the first one: floor (LRF:262 etc.) or round (LRF:129)
@@ -185,7 +185,7 @@ __device__ __forceinline__ void lr_wave_gamma2(const lr_stream& s, uint64_t it, 
         return;
     }
     bool ok = false;
-    if (v > 0.0) ok = (u <= 0.0) || (log(u) < 0.5 * x * x + d - d * v + d * log(v));
+    if (v > 0.0) ok = (u <= 0.0) || (lr_log(u) < 0.5 * x * x + d - d * v + d * lr_log(v));
     const unsigned long long m = __ballot(ok);
     const unsigned lo = (unsigned)(m & 0xffffffffull), hi_m = (unsigned)(m >> 32);
     const double val = d * v;

@@ -30,7 +30,7 @@ __device__ __forceinline__ void lr_dd_bin_rates(const lr_dd_params& p, double x,
     } else {
         niche = (m_birth == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / (1.0 + exp(-p.k * (x - p.x0)));
         frac = dt / niche;
-        lfrac = log(frac), niche_model = m_birth;
+        lfrac = lr_log(frac), niche_model = m_birth;
         br = p.l_max - p.l_max * exp(p.nuB * lfrac);
         if (br <= 0.0) br = LR_DD_SMALL;
     }
@@ -40,7 +40,7 @@ __device__ __forceinline__ void lr_dd_bin_rates(const lr_dd_params& p, double x,
         if (m_death != niche_model) {
             niche = (m_death == 1) ? 1.0 * (p.L + p.div_0) : p.div_0 + p.L / (1.0 + exp(-p.k * (x - p.x0)));
             frac = dt / niche;
-            lfrac = log(frac);
+            lfrac = lr_log(frac);
         }
         dr = p.m_max + p.m_max * exp(p.nuD * lfrac);
         if (dr <= 0.0) dr = LR_DD_SMALL;
@@ -122,7 +122,7 @@ __device__ __forceinline__ void lr_rates_build_tables_wave(F rates, int n_bins, 
     for (int i = 0; i < LR_DD_MAXP; ++i) {
         const int b = b0 + i;
         if (i < P && b < b1) {
-            const double logB = log(br[i]), logD = log(dr[i]), R = br[i] + dr[i];
+            const double logB = lr_log(br[i]), logD = lr_log(dr[i]), R = br[i] + dr[i];
             put_S(b + 1, logB + cum, R);
             put_E(H + b + 1, logD - cum, R);
             cum += R;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void lr_trend_bin_rates(const lr_trend_params& p, dou
                                                    double* br_, double* dr_) {
     // TREND ** exponent as exp(exponent * log(TREND)), one logarithm for both processes (TREND is in (0, 1])
     double br = 1.0 * p.l_min, dr = 1.0 * p.m_min;
-    const double lt = (const_birth && const_death) ? 0.0 : log(t);
+    const double lt = (const_birth && const_death) ? 0.0 : lr_log(t);
     if (!const_birth) {
         br = p.l_min + p.alpha * exp(p.delta * lt);
         if (br <= 0.0) br = LR_DD_SMALL;
@@ -201,7 +201,7 @@ __device__ __forceinline__ double lr_trend_prior(double v, int lane) {
     const double LOG10 = 2.302585092994046, HALF_LOG_2PI = 0.9189385332046727, LOG5 = 1.6094379124341003;
     const double LOG2 = 0.6931471805599453;
     const double y = (lane <= 1) ? (v - .001) / 10.0 : (v / .5);
-    const double ly = log((lane == 4 || lane == 5) && y > 0.0 ? y : 1.0);
+    const double ly = lr_log((lane == 4 || lane == 5) && y > 0.0 ? y : 1.0);
     double t = 0.0;
     if (lane <= 1) t = (y < 0.0) ? -INFINITY : -y - LOG10;
     if (lane == 2 || lane == 3) t = -0.5 * (v / 5.0) * (v / 5.0) - HALF_LOG_2PI - LOG5;

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/literate_hip.h"
+#include "lr_math.h"
 
 #define LR_WAVE 64
 
@@ -163,7 +164,7 @@ __device__ __forceinline__ lr_u2 lr_pair(const lr_stream& s, uint64_t it, uint32
 
 __device__ __forceinline__ double lr_normal(const lr_stream& s, uint64_t it, uint32_t purpose, uint32_t idx) {
     const lr_u2 u = lr_pair(s, it, purpose, idx);
-    return sqrt(-2.0 * log(1.0 - u.a)) * cospi(2.0 * u.b);   // cos(2 pi u_b) without the range reduction
+    return sqrt(-2.0 * lr_log(1.0 - u.a)) * cospi(2.0 * u.b);   // cos(2 pi u_b) without the range reduction
 }
 
 // standard Gamma(shape >= 1): attempt a uses idx base+2a (normal) and base+2a+1 (uniform)
@@ -177,7 +178,7 @@ __device__ inline double lr_gamma(const lr_stream& s, uint64_t it, uint32_t purp
         if (v <= 0.0) continue;
         const double u = lr_pair(s, it, purpose, base + 2 * a + 1).a;
         if (u <= 0.0) return d * v;
-        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v;
+        if (lr_log(u) < 0.5 * x * x + d - d * v + d * lr_log(v)) return d * v;
     }
     return d;
 }
@@ -243,7 +244,7 @@ __device__ __forceinline__ void lr_bin_terms(int model, double lam, double mu, d
                                              double* R, double* Rl, double* cterm) {
     *cterm = 0.0;
     if (model >= 2) {
-        *logB = log(lam), *logD = log(mu), *R = lam + mu, *Rl = lam;
+        *logB = lr_log(lam), *logD = lr_log(mu), *R = lam + mu, *Rl = lam;
         return;
     }
     if (!(k > 0.0)) {
@@ -251,11 +252,11 @@ __device__ __forceinline__ void lr_bin_terms(int model, double lam, double mu, d
         return;
     }
     if (model == 0) {
-        *logB = log(k * lam + 0.0), *R = lam + mu;
+        *logB = lr_log(k * lam + 0.0), *R = lam + mu;
     } else {
-        *logB = log(k * 0.0 + lam), *R = mu, *cterm = -lam;
+        *logB = lr_log(k * 0.0 + lam), *R = mu, *cterm = -lam;
     }
-    *logD = log(mu * k);
+    *logD = lr_log(mu * k);
     *Rl = 0.0;
 }
 

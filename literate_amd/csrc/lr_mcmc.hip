@@ -35,7 +35,7 @@ __global__ __launch_bounds__(LR_WAVE) void lr_rj_propose_score_kernel(
     if (mv == 0) {
         const bool ff = (lane < k) ? (dr[lane] != 0.0) : false;
         const double u = (lane < k) ? dr[kmax + lane] : 0.5;
-        score = lr_wave_multiplier(R, k, ff, u, 2.0 * log(mult_d), lane);
+        score = lr_wave_multiplier(R, k, ff, u, 2.0 * lr_log(mult_d), lane);
     } else if (mv == 1) {
         score = lr_wave_add_shift(R, T, k, index[c], dr[0], dr[1], lane);
     } else if (mv == 2) {
@@ -479,7 +479,7 @@ __global__ void lr_store_args_kernel(lr_step_args a, lr_step_args* dst) {
 // log(br_length) once per engine (data constant used by models 0/1)
 __global__ void lr_log_br_kernel(const double* __restrict__ br, int n_bins, double* __restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < n_bins) out[b] = (br && br[b] > 0.0) ? log(br[b]) : 0.0;
+    if (b < n_bins) out[b] = (br && br[b] > 0.0) ? lr_log(br[b]) : 0.0;
 }
 
 // initial state (LRF:580-583 or the caller's runMCMC argument) -> state rows and the tables of
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(LR_WAVE) void lr_chain_init_kernel(lr_step_args a, 
     double so = 0.0;
     if (lane == LR_S_GRATE_L || lane == LR_S_GRATE_M) so = 1.0;                       // LRF:222 (log = 0)
     if (lane == LR_S_POI) so = poi0;
-    if (lane == LR_S_LOG_POI) so = log(poi0);
+    if (lane == LR_S_LOG_POI) so = lr_log(poi0);
     if (lane == LR_S_CONST_A || lane == LR_S_CONST_P) so = constA;
     S[LR_ROW_SCALARS * LR_ROW + lane] = so;
     int io = 0;
@@ -978,7 +978,7 @@ __global__ void lr_dd_consts_kernel(const double* __restrict__ DT, int n_bins, d
     double m = -INFINITY;
     for (int b = lane; b < n_bins; b += LR_WAVE) m = fmax(m, DT[b]);
     m = -lr_wave_min(-m);
-    if (lane == 0) out[0] = m, out[1] = log(m);
+    if (lane == 0) out[0] = m, out[1] = lr_log(m);
 }
 
 // everything in the workspace that holds device addresses or derives from the data alone

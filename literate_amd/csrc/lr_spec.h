@@ -97,7 +97,7 @@ __device__ __forceinline__ void lr_spec_draw_part(const lr_step_args& a, int c, 
     } else {
         const uint32_t purpose = (lane == 0) ? LR_P_ACCEPT : (lane == 1 ? LR_P_MOVE : LR_P_RJ);
         const lr_u2 ud = lr_pair(rng, it, purpose, lane == 3 ? 1u : 0u);
-        const double lu = log(lane == 0 ? ud.a : 1.0);
+        const double lu = lr_log(lane == 0 ? ud.a : 1.0);
         const double r_a = lr_bcast(ud.a, 1), q_b = lr_bcast(ud.b, 2);
         double beta = 0.0;
         if (!(r_a < 0.8) && r_a < 0.999 && cfg.const_rates == 0 && q_b > 0.5) {

@@ -266,8 +266,8 @@ __global__ __launch_bounds__(LR_WAVE) void lr_binned_keiding_kernel(const double
     double sb = 0.0, sd = 0.0;
     for (int b = lane; b < n_bins; b += LR_WAVE) {
         const double lb = birth[(size_t)c * n_bins + b], ld = death[(size_t)c * n_bins + b];
-        sb += log(lb) * (double)n_spec[b] - lb * DT[b];
-        sd += log(ld) * (double)n_exti[b] - ld * DT[b];
+        sb += lr_log(lb) * (double)n_spec[b] - lb * DT[b];
+        sd += lr_log(ld) * (double)n_exti[b] - ld * DT[b];
     }
     sb = lr_wave_sum(sb), sd = lr_wave_sum(sd);
     if (lane == 0) out_birth[c] = sb, out_death[c] = sd;

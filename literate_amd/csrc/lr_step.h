@@ -321,8 +321,8 @@ __device__ __forceinline__ void lr_stage_segments(lr_seg_scratch* sc, double L, 
     const bool free63 = KM < LR_KMAX;
     double x = valid ? (hi ? Mhi : L) : 1.0;
     if (lane == LR_WAVE - 1 && free63) x = extra;
-    const double lx = log(x);
-    if (log_extra) *log_extra = free63 ? lr_bcast(lx, LR_WAVE - 1) : log(extra);
+    const double lx = lr_log(x);
+    if (log_extra) *log_extra = free63 ? lr_bcast(lx, LR_WAVE - 1) : lr_log(extra);
     sc->rate[hi][j] = x;
     sc->lograte[hi][j] = lx;
     if (lane <= LR_KMAX) sc->edge[0][lane] = eL, sc->edge[1][lane] = eM;
@@ -440,7 +440,7 @@ __device__ __forceinline__ void lr_make_rj_draws(const lr_step_args& a, int c, i
     const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
     const uint32_t purpose = (lane == 0) ? LR_P_ACCEPT : (lane == 1 ? LR_P_MOVE : LR_P_RJ);
     const lr_u2 ud = lr_pair(rng, it, purpose, lane == 3 ? 1u : 0u);
-    const double lu = log(lane == 0 ? ud.a : 1.0);
+    const double lu = lr_log(lane == 0 ? ud.a : 1.0);
     d.log_u = lr_bcast(lu, 0);
     d.r_a = lr_bcast(ud.a, 1), d.r_b = lr_bcast(ud.b, 1);
     d.q_a = lr_bcast(ud.a, 2), d.q_b = lr_bcast(ud.b, 2);
@@ -584,7 +584,7 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
             g1 = gm * (1. / (LR_HP_GAMMA_RATE + sM));
         }
         // one packed log for the three cached logarithms
-        const double lx = log(lane == 0 ? g0 : (lane == 1 ? g1 : (lane == 2 ? poi : 1.0)));
+        const double lx = lr_log(lane == 0 ? g0 : (lane == 1 ? g1 : (lane == 2 ? poi : 1.0)));
         lg0 = lr_bcast(lx, 0), lg1 = lr_bcast(lx, 1), lpoi = lr_bcast(lx, 2);
         gibbs = 1;
     }
@@ -780,7 +780,7 @@ __device__ __forceinline__ void lr_make_dd_draws(const lr_step_args& a, int c, i
     const uint32_t purpose = trend ? (lane == 0 ? LR_P_TR_ACCEPT : LR_P_TR_MOVE)
                                    : (lane == 0 ? LR_P_DD_ACCEPT : (lane == 1 ? LR_P_DD_MOVE : LR_P_DD_SLIDE));
     const lr_u2 ud = lr_pair(rng, it, purpose, 0u);
-    const double lu = log(lane == 0 ? ud.a : 1.0);
+    const double lu = lr_log(lane == 0 ? ud.a : 1.0);
     d.log_u = lr_bcast(lu, 0);
     d.rr_a = lr_bcast(ud.a, 1), d.rr_b = lr_bcast(ud.b, 1), d.slide_u = lr_bcast(ud.a, 2);
     d.z1 = 0.0, d.da = 1.0, d.x = 0.0, d.m = 1.0;
@@ -822,7 +822,7 @@ __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, in
     lr_u2 ud{0.0, 0.0};
     if (!pre) ud = lr_pair(rng, it, purpose, 0u);
     // log of the acceptance uniform (DD:211, trend_rate.py:176), evaluated in lane 0 only
-    p.log_u = pre ? pre->log_u : lr_bcast(log(lane == 0 ? ud.a : 1.0), 0);
+    p.log_u = pre ? pre->log_u : lr_bcast(lr_log(lane == 0 ? ud.a : 1.0), 0);
     double P = A, hasting = 0.0;
     int move_kind;
     if (trend) {

@@ -459,6 +459,9 @@ __device__ __forceinline__ void lr_make_rj_draws(const lr_step_args& a, int c, i
     }
 }
 
+#define LR_UD_LANE 32   /* first of the four lanes holding the wave-uniform draws of lr_propose_rj's one Philox call */
+static_assert(LR_KMAX <= LR_UD_LANE && LR_UD_LANE + 4 <= LR_WAVE, "one lane per rate below the wave-uniform draws");
+
 // update_multiplier_freq with the exponent and the factor already drawn
 __device__ __forceinline__ double lr_wave_multiplier_pre(double& R, int K, bool ff, double x, double m, int lane) {
     const bool active = (lane < K) && ff;
@@ -491,12 +494,15 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
     // two RJ pairs.  Same (iteration, purpose, index) addresses as separate calls would use, so the stream is
     // unchanged.  The logarithm of the acceptance uniform rides along in the packed log of the rates below and
     // waits with the proposal until it is decided, one step later.
+    // Lanes 0..31 draw the multiplier pairs of their rates in the same call (at most LR_KMAX = 32 rates; used by
+    // 40 % of the iterations, free in the others), the wave-uniform draws sit in lanes LR_UD_LANE + 0..3.
     lr_u2 ud{0.0, 0.0};
     if (!pre) {
-        const uint32_t purpose = (lane == 0) ? LR_P_ACCEPT : (lane == 1 ? LR_P_MOVE : LR_P_RJ);
-        ud = lr_pair(rng, it, purpose, lane == 3 ? 1u : 0u);
+        const int ul = lane - LR_UD_LANE;
+        const uint32_t purpose = (ul < 0) ? LR_P_MULT : ((ul == 0) ? LR_P_ACCEPT : (ul == 1 ? LR_P_MOVE : LR_P_RJ));
+        ud = lr_pair(rng, it, purpose, ul < 0 ? (uint32_t)lane : (ul == 3 ? 1u : 0u));
     }
-    const double u_next = pre ? 1.0 : lr_bcast(ud.a, 0);
+    const double u_next = pre ? 1.0 : lr_bcast(ud.a, LR_UD_LANE);
     LR_SSTAMP(2);
 
     double pL = L, pM = M, ptL = tL, ptM = tM;
@@ -506,14 +512,13 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
     const double sample_shift_mu = cfg.const_death_rate ? 0.0 : 0.5;
     const double b_freq = cfg.const_death_rate ? 0.7 : 0.4, d_freq = 0.8;
     const double fL = cfg.update_fraction, fM = cfg.const_death_rate ? 1.0 : cfg.update_fraction;
-    const lr_u2 r = pre ? lr_u2{pre->r_a, pre->r_b} : lr_u2{lr_bcast(ud.a, 1), lr_bcast(ud.b, 1)};
+    const lr_u2 r = pre ? lr_u2{pre->r_a, pre->r_b} : lr_u2{lr_bcast(ud.a, LR_UD_LANE + 1), lr_bcast(ud.b, LR_UD_LANE + 1)};
     if (r.a < b_freq) {
         if (r.b < .5 || KL == 1) {
             if (pre) {
                 hasting = lr_wave_multiplier_pre(pL, KL, pre->da < fL, pre->x, pre->m, lane);
             } else {
-                const lr_u2 d = lr_pair(rng, it, LR_P_MULT, lane);
-                hasting = lr_wave_multiplier(pL, KL, d.a < fL, d.b, a.mult_l, lane);
+                hasting = lr_wave_multiplier(pL, KL, ud.a < fL, ud.b, a.mult_l, lane);
             }
             move_kind = 0;
         } else {
@@ -525,8 +530,7 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
             if (pre) {
                 hasting = lr_wave_multiplier_pre(pM, KM, pre->da < fM, pre->x, pre->m, lane);
             } else {
-                const lr_u2 d = lr_pair(rng, it, LR_P_MULT, lane);
-                hasting = lr_wave_multiplier(pM, KM, d.a < fM, d.b, a.mult_l, lane);
+                hasting = lr_wave_multiplier(pM, KM, ud.a < fM, ud.b, a.mult_l, lane);
             }
             move_kind = 2;
         } else {
@@ -536,12 +540,12 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
     } else if (r.a < 0.999 && cfg.const_rates == 0) {
         // RJMCMC (LRF:71-97)
         move_kind = 4;
-        const lr_u2 q = pre ? lr_u2{pre->q_a, pre->q_b} : lr_u2{lr_bcast(ud.a, 2), lr_bcast(ud.b, 2)};
+        const lr_u2 q = pre ? lr_u2{pre->q_a, pre->q_b} : lr_u2{lr_bcast(ud.a, LR_UD_LANE + 2), lr_bcast(ud.b, LR_UD_LANE + 2)};
         const bool sideL = q.a > sample_shift_mu;
         double R = sideL ? L : M, T = sideL ? tL : tM;
         int K = sideL ? KL : KM;
         double score = 0.0;
-        const lr_u2 q2 = pre ? lr_u2{pre->q2_a, pre->q2_b} : lr_u2{lr_bcast(ud.a, 3), lr_bcast(ud.b, 3)};
+        const lr_u2 q2 = pre ? lr_u2{pre->q2_a, pre->q2_b} : lr_u2{lr_bcast(ud.a, LR_UD_LANE + 3), lr_bcast(ud.b, LR_UD_LANE + 3)};
         if (q.b > 0.5) {
             if (K >= LR_KMAX) {
                 invalid = 1;  // device cap on the number of rates; the reference has none

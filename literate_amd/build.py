@@ -7,14 +7,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libliterate_hip.so")
 SOURCES = ["lr_stats.hip", "lr_loglik.hip", "lr_mcmc.hip", "lr_spec.hip", "lr_pack.hip", "lr_sim.hip"]
-HEADERS = ["lr_device.h", "lr_chain.h", "lr_dd.h", "lr_scan.h", "lr_step.h", "lr_spec.h", "lr_engine.h", "lr_internal.h",
+HEADERS = ["lr_device.h", "lr_math.h", "lr_chain.h", "lr_dd.h", "lr_scan.h", "lr_step.h", "lr_spec.h", "lr_engine.h", "lr_internal.h",
            os.path.join("..", "..", "include", "literate_hip.h")]
 # Per translation unit.  The speculative kernel's loop body is ~8000 instructions at a 168-VGPR budget: machine LICM
 # hoists every literal of the inlined log/exp polynomials out of it and the allocator then spills them (592 bytes of
 # scratch, reloaded inside the candidate build); without the pass the kernel keeps 128 bytes and the few-chain shards
-# run 8-17 % faster (cfg3 4.7 -> 4.0 us per iteration).  The other kernels measure the same either way.
+# run 8-17 % faster (cfg3 4.7 -> 4.0 us per iteration).  lr_mcmc.hip: the persistent kernels' stepper waves run their
+# whole launch inside one function (lr_persist4_steppers) with the chain step inlined in its loop: with the pass that
+# function reloads ~480 hoisted values from scratch per step, without it a dozen.
 TU_FLAGS = {"lr_spec.hip": os.environ.get("LR_SPEC_FLAGS", "-mllvm -disable-machine-licm").split(),
-            "lr_mcmc.hip": os.environ.get("LR_MCMC_FLAGS", "").split()}
+            "lr_mcmc.hip": os.environ.get("LR_MCMC_FLAGS", "-mllvm -disable-machine-licm").split()}
 
 
 def _stale():

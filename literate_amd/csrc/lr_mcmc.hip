@@ -221,13 +221,14 @@ typedef __attribute__((address_space(3))) int lr_lds_i32;
 // PB: bins per lane of the one-pass table builder for the kernel's table size (0: choose at run time), ES: the builders'
 // `so` - both known to the calling kernel at compile time, so the builder dispatch and the layout switches fold away
 template <int PB, int ES>
-__device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
-                                                          __attribute__((address_space(3))) lr_seg_scratch* scratch3,
-                                                          lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* table3,
-                                                          lr_lds_f64* br3 /* [2][LR_H_WIDE]: br_length, log br_length */) {
+__device__ __forceinline__ void lr_persist_step_body(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
+                                                     __attribute__((address_space(3))) lr_seg_scratch* scratch3,
+                                                     lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* table3,
+                                                     lr_lds_f64* br3 /* [2][LR_H_WIDE]: br_length, log br_length */) {
     constexpr int table_es = ES;
     const lr_step_args& a = *(const lr_step_args*)a3;
     const double* br_lds = (const double*)br3;
+    LR_SSTAMP(0);
     lr_chain_regs st;
     lr_chain_load(st, (double*)st_f64, (int*)st_i32, lane);
     if (a.cfg.sampler != 0)
@@ -236,6 +237,84 @@ __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((a
         lr_chain_step_core<true, PB>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
                                      table_es, br_lds, br_lds + LR_H_WIDE);
     lr_chain_store(st, (double*)st_f64, (int*)st_i32, lane);
+    LR_SSTAMP(8);
+}
+
+template <int PB, int ES>
+__device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
+                                                          __attribute__((address_space(3))) lr_seg_scratch* scratch3,
+                                                          lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* table3,
+                                                          lr_lds_f64* br3) {
+    lr_persist_step_body<PB, ES>(a3, c, lane, scratch3, st_f64, st_i32, lik, table3, br3);
+}
+
+// The stepper waves' whole launch in the four-chain kernel as ONE call: a call per step costs the callee-saved
+// registers' round trip through scratch memory every time (24 dwords x 64 lanes out and back: 0.5 + 0.2 us of a 3.6 us
+// step, measured with in-kernel stamps), a call per launch costs it once.  The function keeps the step's own register
+// allocation (the reason the step is not inlined into the kernel) and executes the same barriers as the scanner
+// waves' loop in lr_persist4_kernel.
+//   st_f64 / st_i32: the four chains' state rows; red: [pair][wave][chain of the pair] scan sums; tab: the two pair
+//   tables, tab_doubles apart
+template <int PB, int ES, int NW>
+__device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute__((address_space(3))) lr_step_args* a3, int c0,
+                                                               int n_chains, int wave, int lane,
+                                                               __attribute__((address_space(3))) lr_seg_scratch* scratch3,
+                                                               lr_lds_f64* st_f64, lr_lds_i32* st_i32, lr_lds_f64* red,
+                                                               lr_lds_f64* tab, int tab_doubles, lr_lds_f64* br3, long long n_iters) {
+    for (long long iter = 0; iter < n_iters; ++iter) {
+#pragma unroll 1
+        for (int ph = 0; ph < 2; ++ph) {
+#ifdef LR_DIAG
+            const unsigned long long dq0 = wall_clock64();
+#endif
+            const int c = c0 + 2 * ph + wave;
+            if (c < n_chains) {
+                double lik = 0.0;
+#pragma unroll
+                for (int w2 = 2; w2 < NW; ++w2) lik += red[(ph * NW + w2) * 2 + wave];
+                lr_persist_step_body<PB, ES>(a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
+                                             st_i32 + (2 * ph + wave) * (LR_ISTATE_ROWS * LR_ROW), lik,
+                                             tab + ph * tab_doubles + wave, br3);
+            }
+#ifdef LR_DIAG
+            const unsigned long long dq1 = wall_clock64();
+#endif
+            __syncthreads();
+#ifdef LR_DIAG
+            if (lane == 0 && blockIdx.x < 64) {
+                atomicAdd(&lr_diag_step[16384 + (blockIdx.x * 16 + wave) * 4 + 0], dq1 - dq0);
+                atomicAdd(&lr_diag_step[16384 + (blockIdx.x * 16 + wave) * 4 + 1], wall_clock64() - dq1);
+            }
+#endif
+        }
+    }
+}
+
+// The same for the two-chain kernel, whose waves 0 and 1 scan their share like every other wave and then step: their
+// whole launch - scan, reduction, barrier, step, barrier - is one call.
+template <int H, int T, int PB>
+__device__ __attribute__((noinline)) void lr_persist2_steppers(const __attribute__((address_space(3))) lr_step_args* a3, int c, int wave,
+                                                               int lane, __attribute__((address_space(3))) lr_seg_scratch* scratch3,
+                                                               lr_lds_f64* st_f64, lr_lds_i32* st_i32, lr_lds_f64* red /* [T/64][2] */,
+                                                               lr_lds_f64* tab, lr_lds_f64* br3, const uint4* __restrict__ idx8,
+                                                               long long n8w, long long n_iters, int prio_shift, int grp) {
+    const int tid = wave * LR_WAVE + lane;
+    for (long long iter = 0; iter < n_iters; ++iter) {
+        if (prio_shift > 0) {
+            if (((wall_clock64() >> prio_shift) + grp) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        double acc0 = 0.0, acc1 = 0.0;
+        lr_persist_scan_pair<H>((const char*)(const double*)tab, idx8, n8w, tid, T, &acc0, &acc1);
+        const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
+        if (lane == 0) red[wave * 2 + 0] = s0, red[wave * 2 + 1] = s1;
+        __syncthreads();
+        double lik = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < T / LR_WAVE; ++w2) lik += red[w2 * 2 + wave];
+        lr_persist_step_body<PB, 2>(a3, c, lane, scratch3, st_f64, st_i32, lik, tab + wave, br3);
+        __syncthreads();
+    }
 }
 
 // T = threads per block: 512 (two blocks share a CU) or, when there are no more blocks than CUs anyway (at most 512
@@ -281,6 +360,15 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
     const int grp = (blockIdx.x >> 8) & 1;
 #ifdef LR_DIAG
     unsigned long long d_t0 = 0, d_t1 = 0, d_t2 = 0, d_scan = 0, d_red = 0, d_step = 0;
+#endif
+#ifndef LR_DIAG
+    if (stepper) {
+        lr_persist2_steppers<H, T, (H <= 264 ? lr_bins_per_lane(H) : 0)>(
+            (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c, wave, lane,
+            (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave], (lr_lds_f64*)st_f64[wave], (lr_lds_i32*)st_i32[wave],
+            (lr_lds_f64*)&red[0][0], (lr_lds_f64*)reinterpret_cast<double*>(tab), (lr_lds_f64*)&br_lds[0][0], idx8, n8w, n_iters,
+            prio_shift, grp);
+    } else
 #endif
     for (long long iter = 0; iter < n_iters; ++iter) {
         // Two blocks share a CU; the one dispatched second is the younger wave on every SIMD and loses issue
@@ -422,30 +510,25 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
     }
     __syncthreads();
+    // phase ph of an iteration: the steppers advance pair `ph`, the scanners score pair `1 - ph`
+    if (!scanner)
+        lr_persist4_steppers<(H <= 264 ? lr_bins_per_lane(H) : 0), ES, NW>(
+            (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c0, C, wave, lane,
+            (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave], (lr_lds_f64*)&st_f64[0][0], (lr_lds_i32*)&st_i32[0][0],
+            (lr_lds_f64*)&red[0][0][0], (lr_lds_f64*)reinterpret_cast<double*>(tab[0]), 2 * LR_UNIT_PLANES * H,
+            (lr_lds_f64*)&br_lds[0][0], n_iters);
+    else
     for (long long iter = 0; iter < n_iters; ++iter) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
-            // phase ph: steppers advance pair `ph`, scanners score pair `1 - ph`
 #ifdef LR_DIAG
             const unsigned long long dq0 = wall_clock64();
 #endif
-            if (scanner) {
+            {
                 double s0 = 0.0, s1 = 0.0;
                 lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
                 s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
                 if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
-            } else {
-                const int c = c0 + 2 * ph + wave;
-                if (c < C) {
-                    double lik = 0.0;
-#pragma unroll
-                    for (int w2 = 2; w2 < NW; ++w2) lik += red[ph][w2][wave];
-                    lr_persist_step<(H <= 264 ? lr_bins_per_lane(H) : 0), ES>(
-                        (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c, lane,
-                        (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave],
-                        (lr_lds_f64*)st_f64[2 * ph + wave], (lr_lds_i32*)st_i32[2 * ph + wave], lik,
-                        (lr_lds_f64*)(reinterpret_cast<double*>(tab[ph]) + wave), (lr_lds_f64*)&br_lds[0][0]);
-                }
             }
 #ifdef LR_DIAG
             const unsigned long long dq1 = wall_clock64();

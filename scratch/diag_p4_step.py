@@ -16,10 +16,10 @@ for rep in range(20):
     eng.steps(37 + rep); torch.cuda.synchronize()
     lib.lr_diag_dump_seg(seg, 64 * 16, 0)
     sg = np.frombuffer(seg, dtype=np.uint64).reshape(64, 16).astype(np.float64)
-    sg = sg[::4]                      # chains 0, 4, 8 ...: wave 0 of each block
-    order = [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 6, 7]
-    names = {1: 'load+bcast', 2: 'decide+draw ud', 3: 'move (+mult draws)', 4: 'stage (log)', 5: 'prior', 9: 'to builder', 10: 'marks', 11: 'rate reads',
-             12: 'f64 scan', 13: 'writes', 6: 'planes+after', 7: 'state back'}
+    sg = sg[::2]                      # even chains: wave 0 of each block
+    order = [15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 14]
+    names = {0: 'call + callee-saved stores', 14: 'callee-saved reloads + return', 1: 'state load + decide', 2: 'Philox call', 3: 'move', 4: 'stage segments (log)', 5: 'prior', 6: 'tables + planes',
+             7: 'bookkeeping', 8: 'state store'}
     for a_, b in zip(order[:-1], order[1:]):
         d = (sg[:, b] - sg[:, a_]) / 2400.0
         d = d[(d > 0) & (d < 20)]

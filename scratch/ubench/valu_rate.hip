@@ -34,6 +34,20 @@ __global__ void k(double* out, long long* cyc, double seed) {
             asm volatile("v_cvt_f64_u32 %0, %8\n v_cvt_f64_u32 %1, %8\n v_cvt_f64_u32 %2, %8\n v_cvt_f64_u32 %3, %8\n"
                          "v_cvt_f64_u32 %4, %8\n v_cvt_f64_u32 %5, %8\n v_cvt_f64_u32 %6, %8\n v_cvt_f64_u32 %7, %8\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i));
+        } else if (OP == 7) {
+            // 32 x 32 + 64 -> 64 multiply-add (the Philox rounds): vcc is the carry-out operand
+            asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                         "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i), "v"(i + 7) : "vcc");
+        } else if (OP == 8) {
+            asm volatile("v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3\n"
+                         "v_rcp_f64 %4, %4\n v_rcp_f64 %5, %5\n v_rcp_f64 %6, %6\n v_rcp_f64 %7, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (OP == 9) {
+            // the same fma as a dependent chain: the latency a lone wave sees
+            asm volatile("v_fma_f64 %0, %0, %2, %1\n v_fma_f64 %0, %0, %2, %1\n v_fma_f64 %0, %0, %2, %1\n v_fma_f64 %0, %0, %2, %1\n"
+                         "v_fma_f64 %0, %0, %2, %1\n v_fma_f64 %0, %0, %2, %1\n v_fma_f64 %0, %0, %2, %1\n v_fma_f64 %0, %0, %2, %1\n"
+                         : "+v"(a0) : "v"(b), "v"(c));
         } else if (OP == 6) {
             float f0 = (float)a0, f1 = (float)a1, f2 = (float)a2, f3 = (float)a3, fb = (float)b;
             asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4\n"
@@ -61,6 +75,10 @@ void run(const char* name, int threads) {
     hipFree(out); hipFree(cyc);
 }
 int main() {
+    for (int t : {64}) {
+        run<0>("v_add_f64", t); run<9>("v_fma_f64 dependent", t); run<7>("v_mad_u64_u32", t); run<8>("v_rcp_f64", t); run<5>("v_cvt_f64_u32", t);
+    }
+    for (int t : {1024}) { run<7>("v_mad_u64_u32", t); run<8>("v_rcp_f64", t); }
     for (int t : {256, 1024}) {
         run<0>("v_add_f64", t); run<1>("v_fma_f64", t); run<2>("v_mul_f64", t); run<3>("v_pk_add_f32", t);
         run<4>("v_lshl_add_u64", t); run<5>("v_cvt_f64_u32", t); run<6>("v_add_f32", t);

@@ -52,5 +52,16 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
+def device_asm(src, out_path):
+    """The device assembly of one translation unit, compiled with the flags of the library build (for
+    literate_amd.check_async_loads)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("LR_EXTRA_FLAGS", "").split()
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17"] + extra + TU_FLAGS.get(src, []) + \
+          ["-S", "--cuda-device-only", src, "-o", out_path]
+    subprocess.run(cmd, cwd=CSRC, check=True, stderr=subprocess.DEVNULL)
+    return out_path
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))

@@ -305,9 +305,11 @@ __device__ __attribute__((noinline)) void lr_persist2_steppers(const __attribute
             else __builtin_amdgcn_s_setprio(0);
         }
         double acc0 = 0.0, acc1 = 0.0;
-        lr_persist_scan_pair<H>((const char*)(const double*)tab, idx8, n8w, tid, T, &acc0, &acc1);
+        lr_scan_tail tail;
+        lr_persist_scan_pair<H, 1, true>((const char*)(const double*)tab, idx8, n8w, tid, T, &acc0, &acc1, nullptr, &tail);
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
         if (lane == 0) red[wave * 2 + 0] = s0, red[wave * 2 + 1] = s1;
+        lr_scan_drain(tail);
         __syncthreads();
         double lik = 0.0;
 #pragma unroll
@@ -383,7 +385,8 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
         d_t0 = wall_clock64();
 #endif
         double acc0 = 0.0, acc1 = 0.0;
-        lr_persist_scan_pair<H>(lbase, idx8, n8w, tid, T, &acc0, &acc1);
+        lr_scan_tail tail;
+        lr_persist_scan_pair<H, 1, true>(lbase, idx8, n8w, tid, T, &acc0, &acc1, nullptr, &tail);
 #ifdef LR_DIAG
         if (lane == 0 && blockIdx.x < 512) atomicAdd(&lr_diag_step[20000 + blockIdx.x * 8 + wave], wall_clock64() - d_t0);
 #endif
@@ -392,6 +395,7 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 #endif
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
         if (lane == 0) red[wave][0] = s0, red[wave][1] = s1;
+        lr_scan_drain(tail);      // the idle prefetch of the scan's last trip (lr_scan.h)
         __syncthreads();  // every scan is done: sums visible, table free to be rebuilt
 #ifdef LR_DIAG
         d_t2 = wall_clock64();
@@ -505,9 +509,11 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // prologue: pair 0's pending proposal is scanned so that phase A can step it
     if (scanner) {
         double s0 = 0.0, s1 = 0.0;
-        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL>(reinterpret_cast<const char*>(tab[0]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
+        lr_scan_tail tail;
+        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[0]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
         s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
         if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
+        lr_scan_drain(tail);
     }
     __syncthreads();
     // phase ph of an iteration: the steppers advance pair `ph`, the scanners score pair `1 - ph`
@@ -526,9 +532,11 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
 #endif
             {
                 double s0 = 0.0, s1 = 0.0;
-                lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1);
+                lr_scan_tail tail;
+                lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
                 s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
                 if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
+                lr_scan_drain(tail);      // the idle prefetch of the scan's last trip (lr_scan.h)
             }
 #ifdef LR_DIAG
             const unsigned long long dq1 = wall_clock64();

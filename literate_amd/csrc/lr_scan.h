@@ -327,20 +327,69 @@ __device__ __forceinline__ unsigned int lr_grp_off(const uint4& w, int k) {
 #define LR_PAIR_DMAX 3
 #define LR_UNIT_PLANES 6                /* S, E, E2[0..3] */
 
-// byte offset (entry * 16) of 16-bit field `hi` of a word / of byte 0: one byte-/word-select shift each (the loop is bound
-// by vector instruction issue: scratch/ubench/README.md)
-__device__ __forceinline__ unsigned int lr_word_off16(unsigned int v, int hi) {
+// byte offset (entry * 16) of 16-bit field `hi` of a word: one word-select shift (the loop is bound by vector instruction
+// issue: scratch/ubench/README.md).  `four` = a register holding 4 (lr_shift_four: kept out of the loop by hand)
+__device__ __forceinline__ unsigned int lr_word_off16(unsigned int v, int hi, unsigned int four) {
     unsigned int r;
-    const unsigned int sh = 4;
-    if (hi) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(sh), "v"(v));
-    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(sh), "v"(v));
+    if (hi) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(four), "v"(v));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(four), "v"(v));
     return r;
+}
+// the shift amount of lr_word_off16 in a register of its own for a whole scan (an SDWA operand cannot be a constant;
+// volatile: not rematerialised inside the loop when the translation unit is built without machine LICM)
+__device__ __forceinline__ unsigned int lr_shift_four() {
+    unsigned int r;
+    asm volatile("v_mov_b32 %0, 4" : "=v"(r));
+    return r;
+}
+
+// A 16-byte global load the compiler does not see (base: uniform pointer, off: 32-bit byte offset of the lane), and the
+// wait that makes its result - and every load issued before it - usable.  The scan loops issue the NEXT group's load
+// right after decoding the current one, into the same registers, and wait at the top of the next trip; written as
+// plain loads the compiler folds the two into one load at the loop top and waits for it on the spot.
+typedef unsigned int lr_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lr_gload16_async(lr_u32x4& w, const char* base, unsigned int off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(w) : "v"(off), "s"(base));
+}
+// (all outstanding loads but the newest `LEFT` have landed; `w` ties the uses of the loaded value behind the wait)
+// a pointer every lane of the wave holds alike, moved to scalar registers (the base operand of lr_gload16_async)
+__device__ __forceinline__ const char* lr_uniform_ptr(const void* p) {
+    const unsigned long long b = (unsigned long long)p;
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)b), hi = __builtin_amdgcn_readfirstlane((unsigned int)(b >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+template <int LEFT>
+__device__ __forceinline__ void lr_gload_wait(lr_u32x4& w) {
+    if (LEFT == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w));
+    else asm volatile("s_waitcnt vmcnt(1)" : "+v"(w));
+    static_assert(LEFT == 0 || LEFT == 1, "");
+}
+template <int LEFT>
+__device__ __forceinline__ void lr_gload_wait(lr_u32x4& a, lr_u32x4& b, lr_u32x4& c) {
+    if (LEFT == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+    else asm volatile("s_waitcnt vmcnt(1)" : "+v"(a), "+v"(b), "+v"(c));
+    static_assert(LEFT == 0 || LEFT == 1, "");
+}
+
+// the loads a scan leaves in flight when it returns (the idle prefetch of its last trip), and their wait
+struct lr_scan_tail {
+    lr_u32x4 w, f0, f1, f2;
+};
+__device__ __forceinline__ void lr_scan_drain(lr_scan_tail& t, bool with_fractions = false) {
+    lr_gload_wait<0>(t.w);
+    if (with_fractions) lr_gload_wait<0>(t.f0, t.f1, t.f2);
 }
 
 // Scan of `n8` groups against ONE pair table (unit resolution, six planes of 16-byte entries = the two chains' values)
 // by `n_scan` threads, this thread being number `sid`: the inner loop of the persistent engines.  Per group one 16-byte
-// load (the next one in flight while the current one is scored), ONE gather of the birth entry - it enters `count` times -
-// and one gather per slot.
+// load, ONE gather of the birth entry - it enters `count` times - and one gather per slot.  The loop costs what it
+// issues, so its control is pared down: a group's fields are decoded first and the NEXT group is then loaded into the
+// same registers (in flight while this one is scored, no copy), addressed by a 32-bit byte offset from the uniform base.
+// ASYNC: this loop; otherwise lr_persist_scan_pair_slice (plain loads), the better one for scans of one to three trips.
+// ZERO_TAIL: the caller scans to the end of the packed lineages, behind which the groups read as zeros (lr_groups_alloc:
+// a zero group gathers entry 0 = 0.0 with count 0): the trip count is then the wave's, kept in scalar registers, and
+// no lane is ever masked - a lane past the end scores zeros.  Otherwise (a tile or a team member's slice) every lane
+// tests its own index.
 // A lane's first group of every scan is the same group: a persistent kernel may keep it (and, on general times, its
 // fractions) in registers across iterations instead of waiting for the load at the top of each scan.
 struct lr_first_group {
@@ -348,14 +397,17 @@ struct lr_first_group {
     uint4 fw[4];
 };
 
+// the same scan with plain loads and a test per lane: for a tile or a team member's slice (short scans, often a single
+// trip that starts from the first group kept in registers: an idle prefetch behind it would cost a memory round trip)
 template <int H, int UNROLL = 1>
-__device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
+__device__ __forceinline__ void lr_persist_scan_pair_slice(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                      long long n8, long long sid, int n_scan, double* acc0_,
                                                      double* acc1_, const lr_first_group* first = nullptr) {
     double acc0 = *acc0_, acc1 = *acc1_;
     // 32-bit loop arithmetic (fewer than 2^31 groups): a 64-bit compare and add per trip are two instructions each
     const int n = (int)n8;
     int i = (int)sid;
+    const unsigned int four = lr_shift_four();
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     if (first) w = first->w;
     else if (i < n) w = idx8[i];
@@ -367,13 +419,13 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
         const double2 S = *reinterpret_cast<const double2*>(lbase + (cur.x & 0xfff0u));
         const double cnt = (double)(cur.x & 0xfu);
         double2 E[LR_SLOTS];
-        E[0] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.x, 1));
-        E[1] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 0));
-        E[2] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 1));
-        E[3] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 0));
-        E[4] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 1));
-        E[5] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 0));
-        E[6] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 1));
+        E[0] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.x, 1, four));
+        E[1] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 0, four));
+        E[2] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 1, four));
+        E[3] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 0, four));
+        E[4] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 1, four));
+        E[5] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 0, four));
+        E[6] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 1, four));
         // fixed pairwise tree over the slots, then the birth entry `count` times
         const double u0 = ((E[0].x + E[1].x) + (E[2].x + E[3].x)) + ((E[4].x + E[5].x) + E[6].x);
         const double u1 = ((E[0].y + E[1].y) + (E[2].y + E[3].y)) + ((E[4].y + E[5].y) + E[6].y);
@@ -381,6 +433,64 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
         acc1 += fma(cnt, S.y, u1);
         i = nx;
     }
+    *acc0_ = acc0, *acc1_ = acc1;
+}
+
+template <int H, int UNROLL = 1, bool ZERO_TAIL = false, bool ASYNC = ZERO_TAIL>
+__device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
+                                                     long long n8, long long sid, int n_scan, double* acc0_,
+                                                     double* acc1_, const lr_first_group* first = nullptr,
+                                                     lr_scan_tail* tail = nullptr) {
+    static_assert(ASYNC || !ZERO_TAIL, "the wave-uniform trip count comes with the hand-placed loads");
+    if (!ASYNC) {
+        lr_persist_scan_pair_slice<H, UNROLL>(lbase, idx8, n8, sid, n_scan, acc0_, acc1_, first);
+        if (tail) tail->w = lr_u32x4{0u, 0u, 0u, 0u};
+        return;
+    }
+    double acc0 = *acc0_, acc1 = *acc1_;
+    // 32-bit loop arithmetic (fewer than 2^27 groups)
+    const int n = ZERO_TAIL ? __builtin_amdgcn_readfirstlane((int)n8) : (int)n8;
+    const unsigned int four = lr_shift_four();
+    const char* gbase = lr_uniform_ptr(idx8);
+    const unsigned int stride_b = (unsigned int)n_scan * 16u;
+    const unsigned int end_b = (unsigned int)n * 16u;
+    unsigned int off = (unsigned int)sid * 16u;
+    int i0 = __builtin_amdgcn_readfirstlane((int)sid);
+    bool has = ZERO_TAIL ? (i0 < n) : (off < end_b);
+    lr_u32x4 w = {0u, 0u, 0u, 0u};
+    if (first) w = lr_u32x4{first->w.x, first->w.y, first->w.z, first->w.w};
+    else lr_gload16_async(w, gbase, off);
+#pragma unroll UNROLL
+    while (has) {
+        lr_gload_wait<0>(w);
+        const unsigned int oS = w.x & 0xfff0u;
+        const double cnt = (double)(w.x & 0xfu);
+        const unsigned int o0 = lr_word_off16(w.x, 1, four), o1 = lr_word_off16(w.y, 0, four), o2 = lr_word_off16(w.y, 1, four),
+                           o3 = lr_word_off16(w.z, 0, four), o4 = lr_word_off16(w.z, 1, four), o5 = lr_word_off16(w.w, 0, four),
+                           o6 = lr_word_off16(w.w, 1, four);
+        if (ZERO_TAIL) i0 += n_scan, has = i0 < n, off += has ? stride_b : 0u;
+        else off += stride_b, has = off < end_b;
+        // Unconditionally: a lane's last trip loads a group it will not score (behind a tile or slice the next one's,
+        // behind the data zeros: lr_groups_alloc keeps more spare groups than any stride).  Under a condition `w` becomes
+        // a merge of two values, which the compiler copies while the load is in flight (scratch/check_async_loads.py
+        // checks the compiled code for such reads).  ZERO_TAIL: the wave's last trip re-reads its current group - a
+        // line it has just had - so that the wait for this idle load is short.
+        lr_gload16_async(w, gbase, off);
+        const double2 S = *reinterpret_cast<const double2*>(lbase + oS);
+        const double2 E0 = *reinterpret_cast<const double2*>(lbase + o0), E1 = *reinterpret_cast<const double2*>(lbase + o1);
+        const double2 E2 = *reinterpret_cast<const double2*>(lbase + o2), E3 = *reinterpret_cast<const double2*>(lbase + o3);
+        const double2 E4 = *reinterpret_cast<const double2*>(lbase + o4), E5 = *reinterpret_cast<const double2*>(lbase + o5);
+        const double2 E6 = *reinterpret_cast<const double2*>(lbase + o6);
+        // fixed pairwise tree over the slots, then the birth entry `count` times
+        const double u0 = ((E0.x + E1.x) + (E2.x + E3.x)) + ((E4.x + E5.x) + E6.x);
+        const double u1 = ((E0.y + E1.y) + (E2.y + E3.y)) + ((E4.y + E5.y) + E6.y);
+        acc0 += fma(cnt, S.x, u0);
+        acc1 += fma(cnt, S.y, u1);
+    }
+    // the idle load of the last trip is still in flight: the caller drains it (lr_scan_drain) once it has done what does
+    // not need the registers - or it is waited for here
+    if (tail) tail->w = w;
+    else lr_gload_wait<0>(w);
     *acc0_ = acc0, *acc1_ = acc1;
 }
 
@@ -429,14 +539,16 @@ __device__ __forceinline__ void lr_pair_planes_block(double2* tab, int H, int n_
 //     sum_i (S.v + fs_i S.s + E_i.v + fe'_i E_i.s)  =  cnt S.v + (sum_i fs_i) S.s + sum_slots fma(fe'_slot, E*_slot.s, E*_slot.v)
 // Per group: 2 + 14 ds_read_b128; per slot and chain pair one conversion and four fp64 operations.
 #define LR_FRAC_ARRAYS 3
+// (plain loads, a test per lane: see lr_persist_scan_pair_slice)
 template <int H, int UNROLL = 1, bool PREFETCH = false>
-__device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
+__device__ __forceinline__ void lr_persist_scan_pair_general_slice(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                              const uint4* __restrict__ frac, long long fstride,
                                                              long long n8, long long sid, int n_scan, double* acc0_,
                                                              double* acc1_, const lr_first_group* first = nullptr) {
     double acc0 = *acc0_, acc1 = *acc1_;
     const int n = (int)n8;
     int i = (int)sid;
+    const unsigned int four = lr_shift_four();
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     uint4 fw[LR_FRAC_ARRAYS];
 #pragma unroll
@@ -473,8 +585,8 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
         const double2 Ss = *reinterpret_cast<const double2*>(pS + SLOPES);
         const double cnt = (double)(cur.x & 0xfu);
         const double sfs = __hiloint2double((int)fr[2].y, (int)fr[2].x);
-        const unsigned int off[LR_SLOTS] = {lr_word_off16(cur.x, 1), lr_word_off16(cur.y, 0), lr_word_off16(cur.y, 1), lr_word_off16(cur.z, 0),
-                                            lr_word_off16(cur.z, 1), lr_word_off16(cur.w, 0), lr_word_off16(cur.w, 1)};
+        const unsigned int off[LR_SLOTS] = {lr_word_off16(cur.x, 1, four), lr_word_off16(cur.y, 0, four), lr_word_off16(cur.y, 1, four), lr_word_off16(cur.z, 0, four),
+                                            lr_word_off16(cur.z, 1, four), lr_word_off16(cur.w, 0, four), lr_word_off16(cur.w, 1, four)};
         const unsigned int fq[LR_SLOTS] = {fr[0].x, fr[0].y, fr[0].z, fr[0].w, fr[1].x, fr[1].y, fr[1].z};
         double p0[LR_SLOTS], p1[LR_SLOTS];
 #pragma unroll
@@ -491,6 +603,110 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
         acc0 += fma(sfs, Ss.x, fma(cnt, Sv.x, u0));
         acc1 += fma(sfs, Ss.y, fma(cnt, Sv.y, u1));
         i = nx;
+    }
+    *acc0_ = acc0, *acc1_ = acc1;
+}
+
+template <int H, int UNROLL = 1, bool PREFETCH = false, bool ZERO_TAIL = false, bool ASYNC = ZERO_TAIL>
+__device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
+                                                             const uint4* __restrict__ frac, long long fstride,
+                                                             long long n8, long long sid, int n_scan, double* acc0_,
+                                                             double* acc1_, const lr_first_group* first = nullptr,
+                                                             lr_scan_tail* tail = nullptr) {
+    static_assert(ASYNC || !ZERO_TAIL, "the wave-uniform trip count comes with the hand-placed loads");
+    if (!ASYNC) {
+        lr_persist_scan_pair_general_slice<H, UNROLL, PREFETCH>(lbase, idx8, frac, fstride, n8, sid, n_scan, acc0_, acc1_, first);
+        if (tail) tail->w = tail->f0 = tail->f1 = tail->f2 = lr_u32x4{0u, 0u, 0u, 0u};
+        return;
+    }
+    double acc0 = *acc0_, acc1 = *acc1_;
+    const int n = ZERO_TAIL ? __builtin_amdgcn_readfirstlane((int)n8) : (int)n8;
+    const unsigned int four = lr_shift_four();
+    const char* gbase = lr_uniform_ptr(idx8);
+    const char* fb0 = lr_uniform_ptr(frac);
+    const char* fb1 = lr_uniform_ptr(frac + fstride);
+    const char* fb2 = lr_uniform_ptr(frac + 2 * fstride);
+    static_assert(LR_FRAC_ARRAYS == 3, "three fraction arrays");
+    const unsigned int stride_b = (unsigned int)n_scan * 16u;
+    const unsigned int end_b = (unsigned int)n * 16u;
+    unsigned int off = (unsigned int)sid * 16u;
+    int i0 = __builtin_amdgcn_readfirstlane((int)sid);
+    bool has = ZERO_TAIL ? (i0 < n) : (off < end_b);
+    lr_u32x4 w = {0u, 0u, 0u, 0u}, f0 = {0u, 0u, 0u, 0u}, f1 = {0u, 0u, 0u, 0u}, f2 = {0u, 0u, 0u, 0u};
+    if (first && PREFETCH) {
+        w = lr_u32x4{first->w.x, first->w.y, first->w.z, first->w.w};
+        f0 = lr_u32x4{first->fw[0].x, first->fw[0].y, first->fw[0].z, first->fw[0].w};
+        f1 = lr_u32x4{first->fw[1].x, first->fw[1].y, first->fw[1].z, first->fw[1].w};
+        f2 = lr_u32x4{first->fw[2].x, first->fw[2].y, first->fw[2].z, first->fw[2].w};
+    } else {
+        lr_gload16_async(w, gbase, off);
+        if (PREFETCH) lr_gload16_async(f0, fb0, off), lr_gload16_async(f1, fb1, off), lr_gload16_async(f2, fb2, off);
+    }
+    constexpr int SLOPES = 3 * H * 16;        // bytes from a value entry to its slope entry
+#pragma unroll UNROLL
+    while (has) {
+        // decode the group, then refill `w` with the next one (in flight while this one is scored)
+        if (PREFETCH) lr_gload_wait<0>(w), lr_gload_wait<0>(f0, f1, f2);
+        else lr_gload_wait<0>(w);
+        const unsigned int oS = w.x & 0xfff0u;
+        const double cnt = (double)(w.x & 0xfu);
+        const unsigned int o[LR_SLOTS] = {lr_word_off16(w.x, 1, four), lr_word_off16(w.y, 0, four), lr_word_off16(w.y, 1, four),
+                                          lr_word_off16(w.z, 0, four), lr_word_off16(w.z, 1, four), lr_word_off16(w.w, 0, four),
+                                          lr_word_off16(w.w, 1, four)};
+        double fe[LR_SLOTS], sfs = 0.0;
+        if (PREFETCH) {
+            // the fractions came with the group: turn them into doubles before their registers are refilled
+            const unsigned int fq[LR_SLOTS] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z};
+#pragma unroll
+            for (int k = 0; k < LR_SLOTS; ++k) fe[k] = (double)fq[k];
+            // (a move the compiler cannot postpone: read as plain registers, the sum would be copied out of f2 whenever
+            // convenient - after the refill below has been issued, for one)
+            unsigned int s_lo, s_hi;
+            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(s_lo), "=&v"(s_hi) : "v"(f2.x), "v"(f2.y));
+            sfs = __hiloint2double((int)s_hi, (int)s_lo);
+        } else {
+            lr_gload16_async(f0, fb0, off), lr_gload16_async(f1, fb1, off), lr_gload16_async(f2, fb2, off);
+        }
+        if (ZERO_TAIL) i0 += n_scan, has = i0 < n, off += has ? stride_b : 0u;
+        else off += stride_b, has = off < end_b;
+        // unconditionally (see lr_persist_scan_pair): a lane's last trip loads a group it will not score
+        lr_gload16_async(w, gbase, off);
+        if (PREFETCH) lr_gload16_async(f0, fb0, off), lr_gload16_async(f1, fb1, off), lr_gload16_async(f2, fb2, off);
+        const char* pS = lbase + oS;
+        const double2 Sv = *reinterpret_cast<const double2*>(pS);
+        const double2 Ss = *reinterpret_cast<const double2*>(pS + SLOPES);
+        double2 Ev[LR_SLOTS], Es[LR_SLOTS];
+#pragma unroll
+        for (int k = 0; k < LR_SLOTS; ++k) {
+            Ev[k] = *reinterpret_cast<const double2*>(lbase + o[k]);
+            Es[k] = *reinterpret_cast<const double2*>(lbase + o[k] + SLOPES);
+        }
+        if (!PREFETCH) {
+            // this group's fractions: everything but the next group's load has landed
+            lr_gload_wait<1>(f0, f1, f2);
+            const unsigned int fq[LR_SLOTS] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z};
+#pragma unroll
+            for (int k = 0; k < LR_SLOTS; ++k) fe[k] = (double)fq[k];
+            sfs = __hiloint2double((int)f2.y, (int)f2.x);
+        }
+        double p0[LR_SLOTS], p1[LR_SLOTS];
+#pragma unroll
+        for (int k = 0; k < LR_SLOTS; ++k) {
+            p0[k] = fma(fe[k], Es[k].x, Ev[k].x);
+            p1[k] = fma(fe[k], Es[k].y, Ev[k].y);
+        }
+        // the same fixed tree over the slots as the unit-resolution scan, then the birth side of the whole group
+        const double u0 = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + p0[6]);
+        const double u1 = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + p1[6]);
+        acc0 += fma(sfs, Ss.x, fma(cnt, Sv.x, u0));
+        acc1 += fma(sfs, Ss.y, fma(cnt, Sv.y, u1));
+    }
+    if (tail) {
+        tail->w = w;
+        if (PREFETCH) tail->f0 = f0, tail->f1 = f1, tail->f2 = f2;
+    } else {
+        lr_gload_wait<0>(w);
+        if (PREFETCH) lr_gload_wait<0>(f0, f1, f2);
     }
     *acc0_ = acc0, *acc1_ = acc1;
 }
@@ -547,12 +763,12 @@ struct lr_packed_lineages {
     long long fstride;
 };
 
-template <int H, bool GENERAL, int UNROLL = 1, bool PREFETCH = false>
+template <int H, bool GENERAL, int UNROLL = 1, bool PREFETCH = false, bool ZERO_TAIL = false, bool ASYNC = ZERO_TAIL>
 __device__ __forceinline__ void lr_persist_scan(const char* __restrict__ lbase, const lr_packed_lineages& pk, long long g0,
                                                 long long n8, long long sid, int n_scan, double* acc0, double* acc1,
-                                                const lr_first_group* first = nullptr) {
-    if (GENERAL) lr_persist_scan_pair_general<H, UNROLL, PREFETCH>(lbase, pk.idx8 + g0, pk.frac + g0, pk.fstride, n8, sid, n_scan, acc0, acc1, first);
-    else lr_persist_scan_pair<H, UNROLL>(lbase, pk.idx8 + g0, n8, sid, n_scan, acc0, acc1, first);
+                                                const lr_first_group* first = nullptr, lr_scan_tail* tail = nullptr) {
+    if (GENERAL) lr_persist_scan_pair_general<H, UNROLL, PREFETCH, ZERO_TAIL, ASYNC>(lbase, pk.idx8 + g0, pk.frac + g0, pk.fstride, n8, sid, n_scan, acc0, acc1, first, tail);
+    else lr_persist_scan_pair<H, UNROLL, ZERO_TAIL, ASYNC>(lbase, pk.idx8 + g0, n8, sid, n_scan, acc0, acc1, first, tail);
 }
 
 // the first group of lane `sid` (zeros when the lane has none)

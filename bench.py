@@ -105,11 +105,11 @@ def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
                threads_per_block=int(eng.layout.reserved1))
     if eng.layout.persistent:
         # What the scan loop is really bound by (scratch/ubench/README.md): vector instruction issue.  Per group of 14
-        # lineages and chain pair the compiled loop issues 30 VALU + 8 LDS + 1 global instruction (unit resolution) or
-        # 52 + 16 + 4 (general times) - counted in the ISA of lr_persist4_kernel<136, .> - and a SIMD issues one wave64
+        # lineages and chain pair the compiled loop issues 29 VALU + 8 LDS + 1 global instruction (unit resolution) or
+        # 51 + 16 + 4 (general times) - counted in the ISA of lr_persist4_kernel<136, .> - and a SIMD issues one wave64
         # vector instruction per 4.18 cycles whatever its kind (measured).  The chain steps share the same SIMDs, so the
-        # fraction below is the share of the chip's issue rate spent on SCAN instructions.
-        instr_per_eval = (39 if unit else 72) / 28.0
+        # fraction below is the share of the chip's issue rate spent on SCAN-LOOP instructions.
+        instr_per_eval = (38 if unit else 71) / 28.0
         peak = ISSUE_PEAK_LANE_INSTR_PER_S / instr_per_eval
         out["issue"] = dict(vector_instr_per_eval=instr_per_eval, cycles_per_wave_instr=ISSUE_CYCLES, peak_evals_per_s=peak,
                             frac=out["evals_per_s"] / peak)
@@ -441,9 +441,9 @@ def main():
                          "bound_note": "LDS gather bandwidth: per (lineage, chain) the scan gathers %.2f B of lookup-table "
                                        "entries from LDS (256 B/clk/CU x 256 CU x 2.4 GHz); no MFMA in a gather/scan/reduce.  "
                                        "Micro-benchmarks (scratch/ubench) show the scan loop is bound by vector instruction "
-                                       "issue before LDS bandwidth (see `issue`); with the pair-slot format the four-chain "
-                                       "kernel's iteration is two phases of one chain step's latency (~4.2 us of dependent fp64 "
-                                       "work on one wave) under which the scans hide" % fig["lds_bytes_per_eval"],
+                                       "issue before LDS bandwidth (see `issue`): the CU's issue slots are ~80 %% full "
+                                       "(scan loops, per-scan reductions and the two chain steps of a phase, each one wave "
+                                       "issuing an instruction every ~5 cycles)" % fig["lds_bytes_per_eval"],
                          "issue": fig.get("issue"),
                          "hbm": hbm,
                          "engine": {"persistent": fig["persistent"], "threads_per_block": fig["threads_per_block"],

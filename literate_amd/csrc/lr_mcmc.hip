@@ -216,15 +216,19 @@ __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk,
 // loop's, and both fit the 128-VGPR budget of 4 waves per SIMD without spilling
 // Every pointer is LDS-typed: the argument block (copied to LDS once per launch; reading it through the generic pointer
 // to global memory costs an L2 round trip per field), the per-wave scratch, the state rows and the pair table.
+#ifndef LR_P4_DRAW_AHEAD
+#define LR_P4_DRAW_AHEAD 1   /* four-chain kernel: the RJ sampler's draws are made one phase ahead by scanner waves */
+#endif
 typedef __attribute__((address_space(3))) double lr_lds_f64;
 typedef __attribute__((address_space(3))) int lr_lds_i32;
 // PB: bins per lane of the one-pass table builder for the kernel's table size (0: choose at run time), ES: the builders'
 // `so` - both known to the calling kernel at compile time, so the builder dispatch and the layout switches fold away
-template <int PB, int ES>
+template <int PB, int ES, bool PRE = false>
 __device__ __forceinline__ void lr_persist_step_body(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
                                                      __attribute__((address_space(3))) lr_seg_scratch* scratch3,
                                                      lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* table3,
-                                                     lr_lds_f64* br3 /* [2][LR_H_WIDE]: br_length, log br_length */) {
+                                                     lr_lds_f64* br3 /* [2][LR_H_WIDE]: br_length, log br_length */,
+                                                     const lr_draw_slot* draws = nullptr /* of the iteration proposed now, made ahead */) {
     constexpr int table_es = ES;
     const lr_step_args& a = *(const lr_step_args*)a3;
     const double* br_lds = (const double*)br3;
@@ -233,7 +237,12 @@ __device__ __forceinline__ void lr_persist_step_body(const __attribute__((addres
     lr_chain_load(st, (double*)st_f64, (int*)st_i32, lane);
     if (a.cfg.sampler != 0)
         lr_dd_step_core<true>(st, a, 0, c, lane, lik, reinterpret_cast<double2*>((double*)table3), table_es, br_lds);
-    else
+    else if (PRE) {
+        lr_rj_draws pre;
+        lr_draws_load(draws, pre, lane);
+        lr_chain_step_core<true, PB>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
+                                     table_es, br_lds, br_lds + LR_H_WIDE, &pre);
+    } else
         lr_chain_step_core<true, PB>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
                                      table_es, br_lds, br_lds + LR_H_WIDE);
     lr_chain_store(st, (double*)st_f64, (int*)st_i32, lane);
@@ -260,7 +269,8 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
                                                                int n_chains, int wave, int lane,
                                                                __attribute__((address_space(3))) lr_seg_scratch* scratch3,
                                                                lr_lds_f64* st_f64, lr_lds_i32* st_i32, lr_lds_f64* red,
-                                                               lr_lds_f64* tab, int tab_doubles, lr_lds_f64* br3, long long n_iters) {
+                                                               lr_lds_f64* tab, int tab_doubles, lr_lds_f64* br3, long long n_iters,
+                                                               const lr_draw_slot* draws /* [4]: made ahead (RJ sampler) */) {
     for (long long iter = 0; iter < n_iters; ++iter) {
 #pragma unroll 1
         for (int ph = 0; ph < 2; ++ph) {
@@ -272,9 +282,9 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
                 double lik = 0.0;
 #pragma unroll
                 for (int w2 = 2; w2 < NW; ++w2) lik += red[(ph * NW + w2) * 2 + wave];
-                lr_persist_step_body<PB, ES>(a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
+                lr_persist_step_body<PB, ES, LR_P4_DRAW_AHEAD != 0 && ES == 2 /* unit resolution */>(a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
                                              st_i32 + (2 * ph + wave) * (LR_ISTATE_ROWS * LR_ROW), lik,
-                                             tab + ph * tab_doubles + wave, br3);
+                                             tab + ph * tab_doubles + wave, br3, draws + (2 * ph + wave));
             }
 #ifdef LR_DIAG
             const unsigned long long dq1 = wall_clock64();
@@ -444,6 +454,7 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 #ifndef LR_P4_UNROLL
 #define LR_P4_UNROLL 1
 #endif
+
 #define LR_P4_SCANNERS ((LR_P4_THREADS / LR_WAVE - 2) * LR_WAVE)
 template <int H, bool GENERAL>
 __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
@@ -460,6 +471,12 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     __shared__ int st_i32[4][LR_ISTATE_ROWS * LR_ROW];
     __shared__ lr_step_args a_lds;
     __shared__ double br_lds[2][LR_H_WIDE];   // per-bin data constants of the table builders: br_length / DT / TREND, log br_length
+    // The state-independent draws of a chain's next proposal (acceptance uniform and its logarithm, move selectors,
+    // multiplier exponents and factors, the split move's beta variate), made one phase ahead by the scanner waves that
+    // finish first: the steppers are the kernel's critical path (one wave's instruction stream per chain step), the
+    // scanners of a phase wait 1-2 us at its barrier.  Same (iteration, purpose, index) Philox addresses as the draws
+    // made inside the step: the stream does not change.  RJ sampler only; the parametric samplers draw in the step.
+    __shared__ lr_draw_slot draws[4];
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     if (tid < (int)(sizeof(lr_step_args) / 4)) reinterpret_cast<int*>(&a_lds)[tid] = reinterpret_cast<const int*>(ap)[tid];
     for (int b = tid; b < LR_H_WIDE; b += blockDim.x) {
@@ -467,6 +484,16 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         br_lds[0][b] = (in && ap->br_length) ? ap->br_length[b] : 0.0;
         br_lds[1][b] = in ? ap->log_br[b] : 0.0;
     }
+    // (unit resolution only: on general times the scan loops are the longer side of a phase and have nothing to spare)
+    const bool draw_ahead = LR_P4_DRAW_AHEAD && !GENERAL && ap->cfg.sampler == 0;
+    // draw duty of scanner wave 2 + q, q < 4, for the pair `pr` that has just been scanned: part q >> 1 of chain q & 1
+    auto draw_duty = [&](int pr) {
+        const int q = wave - 2, k = q & 1, ch = 2 * pr + k;
+        if (!draw_ahead || q < 0 || q >= 4 || (int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
+        const int* I = st_i32[ch] + LR_IROW_SCALARS * LR_ROW;
+        const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + 1ull;
+        lr_spec_draw_part(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, &draws[ch], q >> 1);
+    };
     const int c0 = blockIdx.x * 4;
     const int C = a.cfg.n_chains;
     if (wave < 4 && c0 + wave < C) {
@@ -514,6 +541,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
         if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
         lr_scan_drain(tail);
+        draw_duty(0);
     }
     __syncthreads();
     // phase ph of an iteration: the steppers advance pair `ph`, the scanners score pair `1 - ph`
@@ -522,7 +550,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
             (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c0, C, wave, lane,
             (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave], (lr_lds_f64*)&st_f64[0][0], (lr_lds_i32*)&st_i32[0][0],
             (lr_lds_f64*)&red[0][0][0], (lr_lds_f64*)reinterpret_cast<double*>(tab[0]), 2 * LR_UNIT_PLANES * H,
-            (lr_lds_f64*)&br_lds[0][0], n_iters);
+            (lr_lds_f64*)&br_lds[0][0], n_iters, &draws[0]);
     else
     for (long long iter = 0; iter < n_iters; ++iter) {
 #pragma unroll
@@ -537,6 +565,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
                 s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
                 if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
                 lr_scan_drain(tail);      // the idle prefetch of the scan's last trip (lr_scan.h)
+                draw_duty(1 - ph);
             }
 #ifdef LR_DIAG
             const unsigned long long dq1 = wall_clock64();

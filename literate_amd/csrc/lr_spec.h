@@ -48,75 +48,8 @@ struct lr_set {
 #define LR_SETI_MOVE 4
 #define LR_SETI_SEG 5
 
-// the state-independent draws of one iteration of one chain (lr_rj_draws), made one iteration ahead
-struct lr_draw_slot {
-    double sc[8];                 // log_u, r_a, r_b, q_a, q_b, q2_a, q2_b, beta
-    double x[LR_ROW], m[LR_ROW], da[LR_ROW];
-};
-
-__device__ __forceinline__ void lr_draws_store(lr_draw_slot* q, const lr_rj_draws& d, int lane) {
-    double so = d.log_u;
-    so = (lane == 1) ? d.r_a : so;
-    so = (lane == 2) ? d.r_b : so;
-    so = (lane == 3) ? d.q_a : so;
-    so = (lane == 4) ? d.q_b : so;
-    so = (lane == 5) ? d.q2_a : so;
-    so = (lane == 6) ? d.q2_b : so;
-    so = (lane == 7) ? d.beta : so;
-    if (lane < 8) q->sc[lane] = so;
-    q->x[lane] = d.x, q->m[lane] = d.m, q->da[lane] = d.da;
-}
-
-__device__ __forceinline__ void lr_draws_load(const lr_draw_slot* q, lr_rj_draws& d, int lane) {
-    const double v = q->sc[lane & 7];          // one LDS read for the eight scalars
-    d.log_u = lr_bcast(v, 0), d.r_a = lr_bcast(v, 1), d.r_b = lr_bcast(v, 2), d.q_a = lr_bcast(v, 3);
-    d.q_b = lr_bcast(v, 4), d.q2_a = lr_bcast(v, 5), d.q2_b = lr_bcast(v, 6), d.beta = lr_bcast(v, 7);
-    d.x = q->x[lane], d.m = q->m[lane], d.da = q->da[lane];
-}
-
-// draw duty of a scanner wave: the draws of iteration `it` of chain c into `out`
-__device__ __forceinline__ void lr_spec_draw(const lr_step_args& a, int c, int lane, unsigned long long it,
-                                             lr_draw_slot* out) {
-    lr_rj_draws d;
-    lr_make_rj_draws(a, c, lane, it, d);
-    lr_draws_store(out, d, lane);
-}
-
-// The duty split over two waves (the two halves are independent Philox blocks, each a long dependency chain):
-// part 0 the wave-uniform draws (acceptance uniform and its log, move selectors, the RJ pairs, the split's beta),
-// part 1 the per-rate multiplier draws.  Part 1 runs whether or not the move turns out to be a multiplier move: the
-// proposal reads x / m / da in multiplier moves only.
-__device__ __forceinline__ void lr_spec_draw_part(const lr_step_args& a, int c, int lane, unsigned long long it,
-                                                  lr_draw_slot* out, int part) {
-    const lr_mcmc_config& cfg = a.cfg;
-    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
-    if (part) {
-        const lr_u2 u = lr_pair(rng, it, LR_P_MULT, lane);                 // LRF:165-176
-        const double x = a.mult_l * (u.b - .5);
-        out->x[lane] = x, out->m[lane] = exp(x), out->da[lane] = u.a;
-    } else {
-        const uint32_t purpose = (lane == 0) ? LR_P_ACCEPT : (lane == 1 ? LR_P_MOVE : LR_P_RJ);
-        const lr_u2 ud = lr_pair(rng, it, purpose, lane == 3 ? 1u : 0u);
-        const double lu = lr_log(lane == 0 ? ud.a : 1.0);
-        const double r_a = lr_bcast(ud.a, 1), q_b = lr_bcast(ud.b, 2);
-        double beta = 0.0;
-        if (!(r_a < 0.8) && r_a < 0.999 && cfg.const_rates == 0 && q_b > 0.5) {
-            double ga, gb;
-            lr_wave_gamma2(rng, it, LR_P_BETA_A, LR_SHAPE_BETA_RJ, LR_P_BETA_B, LR_SHAPE_BETA_RJ, lane, &ga, &gb);
-            beta = ga / (ga + gb);
-        }
-        // slots: log_u, r_a, r_b, q_a, q_b, q2_a, q2_b, beta  <-  lanes 0..3 of (ud.a, ud.b)
-        double so = lu;
-        so = (lane == 1) ? r_a : so;
-        so = (lane == 2) ? lr_bcast(ud.b, 1) : so;
-        so = (lane == 3) ? lr_bcast(ud.a, 2) : so;
-        so = (lane == 4) ? q_b : so;
-        so = (lane == 5) ? lr_bcast(ud.a, 3) : so;
-        so = (lane == 6) ? lr_bcast(ud.b, 3) : so;
-        so = (lane == 7) ? beta : so;
-        if (lane < 8) out->sc[lane] = so;
-    }
-}
+// (lr_draw_slot, lr_draws_store / lr_draws_load, lr_spec_draw, lr_spec_draw_part: lr_step.h - the four-chain persistent
+// kernel makes its draws ahead the same way)
 
 // the same slot for a parametric sampler's draws (lr_dd_draws)
 __device__ __forceinline__ void lr_dd_draws_store(lr_draw_slot* q, const lr_dd_draws& d, int lane) {

@@ -459,6 +459,76 @@ __device__ __forceinline__ void lr_make_rj_draws(const lr_step_args& a, int c, i
     }
 }
 
+// the state-independent draws of one iteration of one chain (lr_rj_draws), made one iteration ahead
+struct lr_draw_slot {
+    double sc[8];                 // log_u, r_a, r_b, q_a, q_b, q2_a, q2_b, beta
+    double x[LR_ROW], m[LR_ROW], da[LR_ROW];
+};
+
+__device__ __forceinline__ void lr_draws_store(lr_draw_slot* q, const lr_rj_draws& d, int lane) {
+    double so = d.log_u;
+    so = (lane == 1) ? d.r_a : so;
+    so = (lane == 2) ? d.r_b : so;
+    so = (lane == 3) ? d.q_a : so;
+    so = (lane == 4) ? d.q_b : so;
+    so = (lane == 5) ? d.q2_a : so;
+    so = (lane == 6) ? d.q2_b : so;
+    so = (lane == 7) ? d.beta : so;
+    if (lane < 8) q->sc[lane] = so;
+    q->x[lane] = d.x, q->m[lane] = d.m, q->da[lane] = d.da;
+}
+
+__device__ __forceinline__ void lr_draws_load(const lr_draw_slot* q, lr_rj_draws& d, int lane) {
+    const double v = q->sc[lane & 7];          // one LDS read for the eight scalars
+    d.log_u = lr_bcast(v, 0), d.r_a = lr_bcast(v, 1), d.r_b = lr_bcast(v, 2), d.q_a = lr_bcast(v, 3);
+    d.q_b = lr_bcast(v, 4), d.q2_a = lr_bcast(v, 5), d.q2_b = lr_bcast(v, 6), d.beta = lr_bcast(v, 7);
+    d.x = q->x[lane], d.m = q->m[lane], d.da = q->da[lane];
+}
+
+// draw duty of a scanner wave: the draws of iteration `it` of chain c into `out`
+__device__ __forceinline__ void lr_spec_draw(const lr_step_args& a, int c, int lane, unsigned long long it,
+                                             lr_draw_slot* out) {
+    lr_rj_draws d;
+    lr_make_rj_draws(a, c, lane, it, d);
+    lr_draws_store(out, d, lane);
+}
+
+// The duty split over two waves (the two halves are independent Philox blocks, each a long dependency chain):
+// part 0 the wave-uniform draws (acceptance uniform and its log, move selectors, the RJ pairs, the split's beta),
+// part 1 the per-rate multiplier draws.  Part 1 runs whether or not the move turns out to be a multiplier move: the
+// proposal reads x / m / da in multiplier moves only.
+__device__ __forceinline__ void lr_spec_draw_part(const lr_step_args& a, int c, int lane, unsigned long long it,
+                                                  lr_draw_slot* out, int part) {
+    const lr_mcmc_config& cfg = a.cfg;
+    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
+    if (part) {
+        const lr_u2 u = lr_pair(rng, it, LR_P_MULT, lane);                 // LRF:165-176
+        const double x = a.mult_l * (u.b - .5);
+        out->x[lane] = x, out->m[lane] = exp(x), out->da[lane] = u.a;
+    } else {
+        const uint32_t purpose = (lane == 0) ? LR_P_ACCEPT : (lane == 1 ? LR_P_MOVE : LR_P_RJ);
+        const lr_u2 ud = lr_pair(rng, it, purpose, lane == 3 ? 1u : 0u);
+        const double lu = lr_log(lane == 0 ? ud.a : 1.0);
+        const double r_a = lr_bcast(ud.a, 1), q_b = lr_bcast(ud.b, 2);
+        double beta = 0.0;
+        if (!(r_a < 0.8) && r_a < 0.999 && cfg.const_rates == 0 && q_b > 0.5) {
+            double ga, gb;
+            lr_wave_gamma2(rng, it, LR_P_BETA_A, LR_SHAPE_BETA_RJ, LR_P_BETA_B, LR_SHAPE_BETA_RJ, lane, &ga, &gb);
+            beta = ga / (ga + gb);
+        }
+        // slots: log_u, r_a, r_b, q_a, q_b, q2_a, q2_b, beta  <-  lanes 0..3 of (ud.a, ud.b)
+        double so = lu;
+        so = (lane == 1) ? r_a : so;
+        so = (lane == 2) ? lr_bcast(ud.b, 1) : so;
+        so = (lane == 3) ? lr_bcast(ud.a, 2) : so;
+        so = (lane == 4) ? q_b : so;
+        so = (lane == 5) ? lr_bcast(ud.a, 3) : so;
+        so = (lane == 6) ? lr_bcast(ud.b, 3) : so;
+        so = (lane == 7) ? beta : so;
+        if (lane < 8) out->sc[lane] = so;
+    }
+}
+
 #define LR_UD_LANE 32   /* first of the four lanes holding the wave-uniform draws of lr_propose_rj's one Philox call */
 static_assert(LR_KMAX <= LR_UD_LANE && LR_UD_LANE + 4 <= LR_WAVE, "one lane per rate below the wave-uniform draws");
 
@@ -655,7 +725,7 @@ template <bool LDS_CONSTS = false, int PB = 0>
 __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
                                                    lr_seg_scratch* scratch_p, double lik_sum, double2* table,
                                                    int table_es = 2, const double* br_lds = nullptr,
-                                                   const double* logbr_lds = nullptr) {
+                                                   const double* logbr_lds = nullptr, const lr_rj_draws* pre = nullptr) {
     const lr_mcmc_config& cfg = a.cfg;
     const double sc = st.sc;
     const int isc = st.isc;
@@ -713,7 +783,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
 
     // ---- propose iteration `it` (LRF:234-304) ----
     lr_rj_prop p;
-    lr_propose_rj<LDS_CONSTS, PB>(a, c, lane, scratch_p, it, s, p, table, table_es, nullptr, br_lds, logbr_lds);
+    lr_propose_rj<LDS_CONSTS, PB>(a, c, lane, scratch_p, it, s, p, table, table_es, pre, br_lds, logbr_lds);
 
     // ---- back into the state registers ----
     st.pL = s.L, st.pM = s.M, st.ptL = s.tL, st.ptM = s.tM, st.peL = s.eL, st.peM = s.eM;

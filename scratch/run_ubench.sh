@@ -7,3 +7,4 @@ echo "== lds_gather -probe" >> $out/ubench.txt; timeout -k 5 60 scratch/ubench/l
 echo "== lds_gather -mates" >> $out/ubench.txt; timeout -k 5 100 scratch/ubench/lds_gather -mates >> $out/ubench.txt 2>&1
 echo "== lds_gather idx8_cfg4.bin" >> $out/ubench.txt; timeout -k 5 60 scratch/ubench/lds_gather scratch/ubench/idx8_cfg4.bin >> $out/ubench.txt 2>&1
 echo "== scan_lab idx8_cfg4.bin" >> $out/ubench.txt; timeout -k 5 100 scratch/ubench/scan_lab scratch/ubench/idx8_cfg4.bin >> $out/ubench.txt 2>&1
+echo "== log_check" >> $out/ubench.txt; timeout -k 5 200 scratch/ubench/log_check >> $out/ubench.txt 2>&1

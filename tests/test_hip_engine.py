@@ -293,7 +293,7 @@ def test_cfg3_synthetic_10k_lineages_256_chains(G):
 
 
 @pytest.mark.parametrize("engine,C,kw", [("spec", 12, {}), ("spec", 128, {}), ("persistent2", 24, {}), ("persistent4", 24, {}),
-                                          ("spec", 6, dict(general=True))])
+                                          ("spec", 6, dict(general=True)), ("persistent4", 24, dict(general=True))])
 def test_long_inputs_and_few_chain_shards_keep_parity(engine, C, kw):
     """1.3 million lineages (the advisor's out-of-bounds case of round 1: more than 136 trips per scanner wave) and the
     128-chain shard of BASELINE.json configs[3] (1024 chains over 8 GPUs) under every persistent kernel: the accepted
@@ -624,10 +624,11 @@ def test_cfg1_fixed_two_shifts_engine_vs_reference_run(G, golden_dir):
     eng.close()
 
 
-@pytest.mark.parametrize("engine", ["auto", "launch"])
+@pytest.mark.parametrize("engine", ["auto", "launch", "persistent4", "persistent2"])
 def test_engine_tiny_input_three_lineages(engine):
     """Smallest inputs: three lineages (one extant), 9 unit bins, chains 1..5 - the scan's tile, pair and quad paths all
-    run ragged.  Rows against the oracle loop."""
+    run ragged; in the persistent kernels one packed group for 896 / 1024 scanning lanes (all but one score the zero
+    groups behind the data, most waves make no trip at all).  Rows against the oracle loop."""
     from literate_amd.engine import ChainEngine, split_trace_row
     from oracle import literate_oracle as lo
     from oracle import mcmc_oracle as mo

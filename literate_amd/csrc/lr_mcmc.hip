@@ -212,8 +212,9 @@ __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk,
         partials[(size_t)tile * n_chains + 2 * pair + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
-// the chain step of the persistent kernel as a real call: its ~120 live registers then do not add to the scan
-// loop's, and both fit the 128-VGPR budget of 4 waves per SIMD without spilling
+// The chain step of the persistent kernels lives in functions of its own (lr_persist4_steppers, lr_persist2_steppers:
+// the stepper waves' whole launch; lr_persist_step: one step, for the diagnostic build): its ~120 live registers then do
+// not add to the scan loop's, and both fit the 128-VGPR budget of 4 waves per SIMD.
 // Every pointer is LDS-typed: the argument block (copied to LDS once per launch; reading it through the generic pointer
 // to global memory costs an L2 round trip per field), the per-wave scratch, the state rows and the pair table.
 #ifndef LR_P4_DRAW_AHEAD

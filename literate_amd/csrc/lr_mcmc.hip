@@ -217,6 +217,9 @@ __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk,
 // not add to the scan loop's, and both fit the 128-VGPR budget of 4 waves per SIMD.
 // Every pointer is LDS-typed: the argument block (copied to LDS once per launch; reading it through the generic pointer
 // to global memory costs an L2 round trip per field), the per-wave scratch, the state rows and the pair table.
+#ifndef LR_P4_LAST_SUMS
+#define LR_P4_LAST_SUMS 1    /* four-chain kernel: the last scanner wave to finish reduces the block's scan sums */
+#endif
 #ifndef LR_P4_DRAW_AHEAD
 #define LR_P4_DRAW_AHEAD 1   /* four-chain kernel: the RJ sampler's draws are made one phase ahead by scanner waves */
 #endif
@@ -282,7 +285,7 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
             if (c < n_chains) {
                 double lik = 0.0;
 #pragma unroll
-                for (int w2 = 2; w2 < NW; ++w2) lik += red[(ph * NW + w2) * 2 + wave];
+                for (int w2 = 2; w2 < (LR_P4_LAST_SUMS != 0 && ES == 2 /* unit resolution: the block's sums in slot 2 */ ? 3 : NW); ++w2) lik += red[(ph * NW + w2) * 2 + wave];
                 lr_persist_step_body<PB, ES, LR_P4_DRAW_AHEAD != 0 && ES == 2 /* unit resolution */>(a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
                                              st_i32 + (2 * ph + wave) * (LR_ISTATE_ROWS * LR_ROW), lik,
                                              tab + ph * tab_doubles + wave, br3, draws + (2 * ph + wave));
@@ -466,7 +469,14 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     constexpr int ENT = GENERAL ? 2 : 1;                  // double2 per pair-table entry (LR_TAB_PAIRGEN / LR_TAB_UNIT)
     constexpr int ES = GENERAL ? 6 * H : 2;               // the builders' `so`: doubles from a value to its slope in the LDS image
     __shared__ double2 tab[2][LR_UNIT_PLANES * H];        // pair tables: S, E (general times: and their slopes) + the pair planes
-    __shared__ double red[2][NW][2];                      // [pair][scanner wave][chain of the pair]
+    __shared__ double red[2][NW][2];                      // [pair][scanner wave][chain of the pair]; LAST_SUMS: slot [2] = the block's sums
+    // Unit resolution: every scanner lane's two accumulators of the current scan, and the count of scanner waves that
+    // have left theirs: the wave that arrives LAST adds them up (one wave's reduction instead of fourteen: the kernel is
+    // bound by instruction issue) - per lane over the waves in wave order, then across the lanes: the same order whoever
+    // is last.  (On general times the scans are the longer side of a phase and the serial tail costs more than it saves.)
+    constexpr bool LAST_SUMS = LR_P4_LAST_SUMS != 0 && !GENERAL;
+    __shared__ double2 part[LAST_SUMS ? NW - 2 : 1][LR_WAVE];
+    __shared__ int arrived;
     __shared__ lr_seg_scratch scratch[2];
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
     __shared__ int st_i32[4][LR_ISTATE_ROWS * LR_ROW];
@@ -494,6 +504,28 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         const int* I = st_i32[ch] + LR_IROW_SCALARS * LR_ROW;
         const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + 1ull;
         lr_spec_draw_part(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, &draws[ch], q >> 1);
+    };
+    if (tid == 0) arrived = 0;
+    for (int i = tid; i < 2 * NW * 2; i += LR_P4_THREADS) (&red[0][0][0])[i] = 0.0;
+    int scans_done = 0;
+    // a scanner wave's end of scan number `scans_done` for pair `pr`: leave the lanes' sums, count in, and reduce if last
+    auto leave_sums = [&](int pr, double s0, double s1) {
+        part[wave - 2][lane] = make_double2(s0, s1);
+        int prev = 0;
+        if (lane == 0) prev = __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        if (prev == (NW - 2) * (scans_done + 1) - 1) {
+            asm volatile("" ::: "memory");     // the sums are read after the count was seen (a wave's LDS operations execute in order)
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW - 2; ++w) {
+                const double2 v = part[w][lane];
+                a0 += v.x, a1 += v.y;
+            }
+            a0 = lr_wave_sum(a0), a1 = lr_wave_sum(a1);
+            if (lane == 0) red[pr][2][0] = a0, red[pr][2][1] = a1;
+        }
+        ++scans_done;
     };
     const int c0 = blockIdx.x * 4;
     const int C = a.cfg.n_chains;
@@ -539,8 +571,12 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         double s0 = 0.0, s1 = 0.0;
         lr_scan_tail tail;
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[0]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
-        s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
-        if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
+        if (LAST_SUMS) {
+            leave_sums(0, s0, s1);
+        } else {
+            s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
+            if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
+        }
         lr_scan_drain(tail);
         draw_duty(0);
     }
@@ -563,8 +599,12 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
                 double s0 = 0.0, s1 = 0.0;
                 lr_scan_tail tail;
                 lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
-                s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
-                if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
+                if (LAST_SUMS) {
+                    leave_sums(1 - ph, s0, s1);
+                } else {
+                    s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
+                    if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
+                }
                 lr_scan_drain(tail);      // the idle prefetch of the scan's last trip (lr_scan.h)
                 draw_duty(1 - ph);
             }

@@ -441,9 +441,9 @@ def main():
                          "bound_note": "LDS gather bandwidth: per (lineage, chain) the scan gathers %.2f B of lookup-table "
                                        "entries from LDS (256 B/clk/CU x 256 CU x 2.4 GHz); no MFMA in a gather/scan/reduce.  "
                                        "Micro-benchmarks (scratch/ubench) show the scan loop is bound by vector instruction "
-                                       "issue before LDS bandwidth (see `issue`): the CU's issue slots are ~80 %% full "
-                                       "(scan loops, per-scan reductions and the two chain steps of a phase, each one wave "
-                                       "issuing an instruction every ~5 cycles)" % fig["lds_bytes_per_eval"],
+                                       "issue before LDS bandwidth (see `issue`): the CU's issue slots are ~83 %% full "
+                                       "(scan loops and the two chain steps of a phase, each one wave issuing an "
+                                       "instruction every ~5 cycles: a phase is as long as its step)" % fig["lds_bytes_per_eval"],
                          "issue": fig.get("issue"),
                          "hbm": hbm,
                          "engine": {"persistent": fig["persistent"], "threads_per_block": fig["threads_per_block"],

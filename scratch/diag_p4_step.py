@@ -17,8 +17,8 @@ for rep in range(20):
     lib.lr_diag_dump_seg(seg, 64 * 16, 0)
     sg = np.frombuffer(seg, dtype=np.uint64).reshape(64, 16).astype(np.float64)
     sg = sg[::2]                      # even chains: wave 0 of each block
-    order = [15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 14]
-    names = {0: 'call + callee-saved stores', 14: 'callee-saved reloads + return', 1: 'state load + decide', 2: 'Philox call', 3: 'move', 4: 'stage segments (log)', 5: 'prior', 6: 'tables + planes',
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+    names = {1: 'state load + decide', 2: 'Philox call', 3: 'move', 4: 'stage segments (log)', 5: 'prior', 6: 'tables + planes',
              7: 'bookkeeping', 8: 'state store'}
     for a_, b in zip(order[:-1], order[1:]):
         d = (sg[:, b] - sg[:, a_]) / 2400.0

@@ -26,6 +26,8 @@ def build_parser():
                    default=2, metavar=2)
     p.add_argument('-fix_death', type=float, help='Fix death rate (with -m_death -1)', default=0.1, metavar=0.1)
     p.add_argument('--chains', type=int, default=1, help='total number of independent chains (extension)')
+    p.add_argument('--block', type=int, default=0, help='iterations per device window (logs are flushed once per window; '
+                   'default: -p rounded up to ~50000)')
     return p
 
 
@@ -60,22 +62,40 @@ def main(argv=None):
         else:
             emp = (eng.n_spec / eng.DT, eng.n_exti / eng.DT)
     eng.init()
-    t_start, done = time.time(), 0
-    while done < args.n:
-        n = min(args.p * max(1, 50000 // max(args.p, 1)), args.n - done)
-        eng.steps(n)
-        done += n
+    stem = "%s_%s%s" % (os.path.splitext(args.d)[0], seed, model_suffix(args.m_birth, args.m_death))
+    paths = [stem + ("" if args.chains == 1 else "_c%d" % (offset + c)) + ".log" for c in range(n_local)]
+    # every rank writes the logs of its own chains, window by window while the next window runs (the reference writes,
+    # flushes and fsyncs every sample: DD:225-238 / trend_rate.py:183-195)
+    from literate_amd.engine import TraceStreamer
+    streamer = TraceStreamer(eng, gather=False)
+    for path in paths:
+        eng.start_log(path)
+
+    def flush_window():
+        rows, snap, (s0, s1, its) = streamer.collect()
+        with torch.cuda.stream(streamer.side):          # the per-bin log columns are recomputed on the side stream
+            for c, path in enumerate(paths):
+                eng.append_log(path, rows[:, c], emp)
         if rank == 0:
-            snap = eng.snapshot()
-            print(done, snap["likA"][0], snap["L"][0][:8])
+            print(its, snap["likA"][0], snap["L"][0][:8])
+            sys.stdout.flush()
+
+    t_start, done = time.time(), 0
+    block = args.block if args.block > 0 else args.p * max(1, 50000 // max(args.p, 1))
+    while done < args.n:
+        n = min(block, args.n - done)
+        eng.steps(n)
+        streamer.mark()
+        done += n
+        if len(streamer.pending) > 1:
+            flush_window()
+    while streamer.pending:
+        flush_window()
     torch.cuda.synchronize()
+    eng.check_status()
     if rank == 0 and args.n > 0:
         el = time.time() - t_start
         print("%d iterations x %d chains in %.2f s (%.0f iterations/s/chain)" % (args.n, args.chains, el, args.n / el))
-    stem = "%s_%s%s" % (os.path.splitext(args.d)[0], seed, model_suffix(args.m_birth, args.m_death))
-    for c in range(n_local):
-        g = offset + c
-        eng.write_log(stem + ("" if args.chains == 1 else "_c%d" % g) + ".log", c, emp, n_samples)
     eng.close()
     if world > 1:
         dist.barrier()

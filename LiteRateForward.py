@@ -49,6 +49,8 @@ def build_parser():
     p.add_argument('--combine', type=float, default=-1.0, help='with --chains > 1: also write COMBINED_{mcmc,sp_rates,'
                    'ex_rates,div}.log with this burn-in fraction dropped per chain (plotRJforward.v3.py combine_logs)')
     p.add_argument('--init_shifts', type=int, default=0, help='initial number of rate shifts per process')
+    p.add_argument('--block', type=int, default=0, help='iterations per device window: logs are written and flushed and '
+                   'the state is printed once per window, while the next one runs (default: -p rounded up to ~50000)')
     return p
 
 
@@ -91,11 +93,13 @@ def main(argv=None):
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        backend = os.environ.get("LR_DIST_BACKEND", "nccl")      # gloo: rehearsal of the sharded run on one GPU
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
     rseed = np.random.randint(0, 9999) if args.seed == -1 else args.seed
     if world > 1:
-        s = torch.tensor([rseed], device="cuda")
+        s = torch.tensor([rseed], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.broadcast(s, 0)
         rseed = int(s.item())
     np.random.seed(rseed)
@@ -146,32 +150,51 @@ def main(argv=None):
         done = eng.iterations
         if rank == 0:
             print("resumed from %s at iteration %d" % (ckpt, done))
-    t_start = time.time()
-    while done < args.n:
-        n = min(args.p * max(1, 50000 // max(args.p, 1)), args.n - done)
-        eng.steps(n)
-        done += n
-        if ckpt:
-            eng.save(ckpt)
+    # The logs are written as the run goes (the reference flushes every sample, LRF:334-359): a window's rows leave the
+    # device on a side stream - gathered over RCCL when the chains are sharded - while the next window runs.  A resumed
+    # run rewrites the rows the checkpoint holds first (they are all in the workspace), then appends.
+    from literate_amd.engine import TraceStreamer
+    streamer = TraceStreamer(eng, args.chains, n_local)
+    writer = None
+    if rank == 0 and n_samples:
+        writer = logs.ChainLogWriter(args.d, model, args.out, args.chains, emp, eng.n_bins, args.pyrate_output, true_root_age)
+    if done > 0:
+        streamer.mark()
+
+    def flush_window():
+        rows, snap, (s0, s1, its) = streamer.collect()
         if rank == 0:
-            snap = eng.snapshot()
-            print(done, snap["likA"][0], snap["priorA"][0])
+            if writer is not None:
+                writer.append(rows)
+            print(its, snap["likA"][0], snap["priorA"][0])
             print("\tsp.times:", snap["tL"][0]), print("\tex.times:", snap["tM"][0])
             print("\tsp.rates:", snap["L"][0]), print("\tex.rates:", snap["M"][0])
+            sys.stdout.flush()
+
+    t_start = time.time()
+    block = args.block if args.block > 0 else args.p * max(1, 50000 // max(args.p, 1))
+    while done < args.n:
+        n = min(block, args.n - done)
+        eng.steps(n)
+        streamer.mark()
+        done += n
+        if ckpt:
+            eng.save(ckpt)          # (synchronises; refuses to replace the checkpoint with a void run)
+        if len(streamer.pending) > 1:
+            flush_window()          # the window before this one, while this one runs
+    while streamer.pending:
+        flush_window()
     torch.cuda.synchronize()
+    eng.check_status()
     if rank == 0 and args.n > 0:
         el = time.time() - t_start
         print("%d iterations x %d chains in %.2f s (%.0f iterations/s/chain)" % (args.n, args.chains, el, args.n / el))
-    local = eng.trace[:n_samples][:, :n_local] if n_samples else eng.trace[:0]
-    rows = lrd.gather_traces(local.contiguous(), args.chains) if world > 1 else local
-    if rank == 0 and n_samples:
-        rows = rows.cpu().numpy()
-        for c in range(args.chains):
-            _, paths = logs.log_paths(args.d, model, args.out, None if args.chains == 1 else c)
-            logs.write_chain_logs(paths, rows[:, c], emp, eng.n_bins, args.pyrate_output, true_root_age)
-        if args.combine >= 0 and args.chains > 1:
-            files = [logs.log_paths(args.d, model, args.out, c)[1]["mcmc"] for c in range(args.chains)]
-            logs.combine_logs(files, os.path.dirname(files[0]), args.combine)
+    wtxt = eng.warning_text()
+    if wtxt:
+        print(wtxt, file=sys.stderr)
+    if rank == 0 and n_samples and args.combine >= 0 and args.chains > 1:
+        files = [logs.log_paths(args.d, model, args.out, c)[1]["mcmc"] for c in range(args.chains)]
+        logs.combine_logs(files, os.path.dirname(files[0]), args.combine)
     eng.close()
     if world > 1:
         dist.destroy_process_group()

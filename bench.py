@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
 """bench.py - RJMCMC birth-death likelihood loop on MI355X: lineage-log-lik evals/s.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1 without WORLD_SIZE: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one RJMCMC iteration of every chain on this GPU: one scan of the lineages scoring all pending proposals
 + the per-chain accept / trace / next-proposal step, all inside the persistent engine kernel (one launch runs the K
 timed iterations).  Workload (config.workload) = BASELINE.json configs[3] ("cfg4"): synthetic 100k lineages, 128 unit
 bins, 20 true shifts per process, 1024 chains per GPU; chains shard across ranks with no data-path collective (weak
-scaling), lineage arrays are replicated; the sampled trace rows are gathered over RCCL once at the end of the timed
-region.  Inputs are resident in HBM before timing.
+scaling), lineage arrays are replicated; the trace rows sampled inside the timed region (every --sample-every
+iterations) are gathered to rank 0 over RCCL before the clock stops.  Inputs are resident in HBM before timing.
 
 value = iterations x lineages x chains / time (one unit = one lineage's contribution to one chain's proposed-state
 log-likelihood: "iters/sec x lineages" of BASELINE.json, summed over chains).
@@ -103,6 +103,9 @@ def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
                lds_bytes_per_eval=lds_bytes_per_eval, lds_GBs=achieved, lds_frac=achieved / LDS_PEAK_GBS,
                unit_resolution_tables=unit, persistent=int(eng.layout.persistent),
                threads_per_block=int(eng.layout.reserved1))
+    out.update(eval_cost(eng))
+    # SURVEY 8(d)'s un-amortised "effective GB/s": 16 B (fp64 ts + te) per (lineage, chain) evaluation
+    out["effective_GBs_16B_per_eval"] = 16.0 * evals / (kernel_ms * 1e-3) / 1e9
     if eng.layout.persistent:
         # What the scan loop is really bound by (scratch/ubench/README.md): vector instruction issue.  Per group of 14
         # lineages and chain pair the compiled loop issues 29 VALU + 8 LDS + 1 global instruction (unit resolution) or
@@ -114,6 +117,28 @@ def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
         out["issue"] = dict(vector_instr_per_eval=instr_per_eval, cycles_per_wave_instr=ISSUE_CYCLES, peak_evals_per_s=peak,
                             frac=out["evals_per_s"] / peak)
     return out
+
+
+def eval_cost(eng):
+    """What one counted eval costs in the scan loop, per (lineage, chain), from the group format (csrc/lr_scan.h):
+    a 16-byte group = up to 14 lineages of one birth bin in 7 slots, scored for a chain PAIR with 1 birth gather
+    (applied `count` times by one fma) + 7 slot gathers (a slot = one lineage's death entry or the pre-summed entry of
+    two neighbouring lineages, planes derived from the chain's own table every iteration).  The aggregation level is
+    frozen at this: run-length on the birth side, pairs on the death side - no wider slots, no count-weighted slots."""
+    unit = bool(eng.unit_resolution)
+    if not eng.layout.persistent:
+        return dict(gathers_per_eval=2.0, fp64_ops_per_eval=3.0 if unit else 4.0, aggregation="none: launch-based scan, "
+                    "two table gathers per (lineage, chain)")
+    if unit:
+        # 8 ds_read_b128 serve 14 lineages x 2 chains; 6 + 6 adds, 2 fma, 2 accumulates, 1 conversion of the count
+        return dict(gathers_per_eval=8 / 28.0, fp64_ops_per_eval=17 / 28.0,
+                    aggregation="per group of <= 14 lineages of one birth bin: birth entry gathered once and multiplied by "
+                                "the run count; death entries gathered per slot of one lineage or a pre-summed pair")
+    # general times: value + slope entry per gather site (16 reads), per slot one conversion + 2 fma, 12 adds, 4 fma on the
+    # birth side, 2 accumulates, 1 conversion of the count
+    return dict(gathers_per_eval=16 / 28.0, fp64_ops_per_eval=(7 * 3 + 12 + 4 + 2 + 1) / 28.0,
+                aggregation="as at unit resolution, pairs only for two lineages that die in the same bin; every lineage "
+                            "keeps its own in-bin fractions (32-bit fixed point)")
 
 
 def side_config(name, steps, warmup):
@@ -162,7 +187,7 @@ def cpu_model_name():
         return "unknown"
 
 
-def cpu_baseline(ts, te, t0, n_bins, stats, start_time, end_time, budget_s=10.0):
+def cpu_baseline(ts, te, t0, n_bins, stats, start_time, end_time, budget_s=8.0):
     """CPU numbers beside the GPU one, all from the numpy port under oracle/, bounded to ~25 s:
     value      : per-lineage evaluator (oracle.per_lineage_loglik: O(N) gather form of get_BDlik) on ONE core,
     all_cores  : the same evaluator, one process per host core (fresh interpreters, no GPU),
@@ -176,14 +201,15 @@ def cpu_baseline(ts, te, t0, n_bins, stats, start_time, end_time, budget_s=10.0)
                sample="%d chain states x %d lineages (same synthetic lineages, model 0), %.1f s of numpy on 1 core"
                       % (n_eval, len(ts), el))
     try:
-        cores = min(len(os.sched_getaffinity(0)), 16)
+        cores = len(os.sched_getaffinity(0))           # every core this process may run on (all host cores)
     except AttributeError:
-        cores = min(os.cpu_count() or 1, 16)
+        cores = os.cpu_count() or 1
     if cores > 1:
         with mp.get_context("spawn").Pool(cores) as pool:
-            res = pool.map(_per_lineage_worker, [(ts, te, t0, n_bins, br, 6.0, 100 + i) for i in range(cores)])
+            res = pool.map(_per_lineage_worker, [(ts, te, t0, n_bins, br, 5.0, 100 + i) for i in range(cores)], chunksize=1)
         out["all_cores"] = dict(value=sum(n for n, _ in res) * len(ts) / max(e for _, e in res), cores=cores,
-                                sample="one process per core, 6 s each")
+                                sample="one process per core of sched_getaffinity (%d), 5 s each" % cores)
+    out["effective_GBs_16B_per_eval"] = 16.0 * out["value"] / 1e9
     from oracle import mcmc_oracle as mo
     n_it = 20000
     t_start = time.perf_counter()
@@ -267,6 +293,49 @@ def measure_traffic(workload, chains, steps, kname, engine, sample_every):
                        % (steps, kname, vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks ourselves - one process per GPU
+    under torch.distributed.run - BEFORE this process has touched the GPU (it never does), pass their output through and
+    exit with their code.  The child command is the one the driver uses for N > 1."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def roofline_object(fig, kname, kernel_ms, n_ev, n_lin, chains, passes, cb_pass):
+    """The `roofline` object of one measured kernel: LDS gather bytes against the LDS rate (what the gathers cost), the
+    issue-rate view (what the loop is really bound by) and SURVEY 8(d)'s HBM conventions as side fields."""
+    conv_bytes = 16.0 * n_lin * passes                          # SURVEY 8(d): 16 B x N x ceil(C/Cb) per launch
+    conv = conv_bytes / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "lds", "achieved": fig["lds_GBs"], "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": fig["lds_frac"],
+            "traffic": None, "traffic_note": "not measured",
+            "kernel": kname, "kernel_ms": kernel_ms, "iterations_per_launch": n_ev,
+            "evals_per_launch": float(n_ev) * n_lin * chains,
+            "lds_bytes_per_eval": fig["lds_bytes_per_eval"], "gathers_per_eval": fig["gathers_per_eval"],
+            "fp64_ops_per_eval": fig["fp64_ops_per_eval"], "aggregation": fig["aggregation"],
+            "kernel_evals_per_s": fig["evals_per_s"],
+            "bound_note": "LDS gather bandwidth: per (lineage, chain) the scan gathers %.2f B of lookup-table entries from "
+                          "LDS (256 B/clk/CU x 256 CU x 2.4 GHz); no MFMA in a gather/scan/reduce.  Micro-benchmarks "
+                          "(scratch/ubench) show the loop is bound by vector instruction issue before LDS bandwidth: see "
+                          "`issue`.  HBM is not the bound (the packed lineages and the tables are L2 / LDS resident): "
+                          "`hbm` holds SURVEY 8(d)'s figures, which exceed the HBM peak for that reason"
+                          % fig["lds_bytes_per_eval"],
+            "issue": fig.get("issue"),
+            "hbm": {"peak_GBs": HBM_PEAK_GBS,
+                    "algorithmic_GBs_16B_convention": conv, "frac_of_peak_16B_convention": conv / HBM_PEAK_GBS,
+                    "chains_per_pass_Cb": cb_pass,
+                    "effective_GBs_16B_per_eval": fig["effective_GBs_16B_per_eval"],
+                    "note": "SURVEY 8(d): a lineage pass priced at 16 B (fp64 ts + te) x N x ceil(C/Cb), and un-amortised at "
+                            "16 B per (lineage, chain).  The engine never re-reads ts/te: it reads them once, packs them into "
+                            "table indices that stay in L2 and scores Cb chains per pass from LDS, so both figures exceed "
+                            "the HBM peak; measured_GBs is what really reaches HBM"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,6 +354,8 @@ def main():
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))           # nothing above has imported torch or touched the GPU
 
     import torch
     import torch.distributed as dist
@@ -295,13 +366,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    # LR_DIST_BACKEND=gloo: rehearsal of the multi-rank path on ONE GPU (all ranks on device 0, host-staged gather);
-    # the real thing is one rank per GPU over RCCL
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # LR_DIST_BACKEND=gloo: rehearsal of the multi-rank path on ONE GPU (all ranks on device 0, host-staged gather, no
+    # teams of CUs: the ranks' kernels share the device); the real thing is one rank per GPU over RCCL
     backend = os.environ.get("LR_DIST_BACKEND", "nccl")
     if backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        if world > 1:
+            os.environ.setdefault("LR_SHARED_DEVICE", "1")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -312,7 +384,6 @@ def main():
 
     ts, te, model, label = make_workload(args.workload)
     n_lin = len(ts)
-    n_bins_req, n_shifts = WORKLOADS[args.workload][1], WORKLOADS[args.workload][2]
     base_chains = args.chains or WORKLOADS[args.workload][3]
 
     def barrier():
@@ -341,22 +412,29 @@ def main():
             torch.cuda.synchronize()
         eng.init()
         eng.steps(args.warmup)
+        s0 = -(-args.warmup // args.sample_every)               # trace rows the warm-up has sampled (iterations 0, s, ...)
+        s1 = -(-(args.warmup + args.steps) // args.sample_every)
 
-        def gather_traces():
-            # log-posterior trace rows sampled so far, gathered to rank 0 over RCCL / xGMI (literate_amd/dist.py; the
-            # same function runs under gloo in tests/test_host_cpu.py)
-            return gather_rows(eng.trace[:, :, :13], total_chains=total)
+        def gather_traces(a, b):
+            # the log-posterior rows sampled in iterations [a, b) gathered to rank 0 over RCCL / xGMI
+            # (literate_amd/dist.py; the same function runs under gloo in tests/test_host_cpu.py).  A region that
+            # samples nothing gathers nothing - on every rank alike
+            if b > a and world > 1:
+                gather_rows(eng.trace[a:b, :, :13].contiguous(), total_chains=total)
+            return b - a
 
-        gather_traces()     # untimed: loads the copy kernel and sets up the RCCL communicator (one-off costs)
+        if world > 1:       # untimed: sets up the RCCL communicator and loads the copy kernels (one-off costs)
+            gather_rows(eng.trace[0:1, :, :13].contiguous(), total_chains=total)
         barrier()
         t_begin = time.perf_counter()
-        # the K timed iterations, also bracketed by HIP events on the launch stream (roofline.kernel_ms for the
-        # persistent engine: the timed region IS its kernel, ceil(K/4096) launches)
+        # the K timed iterations, bracketed by HIP events on the launch stream too (roofline.kernel_ms for the
+        # persistent engine: the timed region IS its kernel, ceil(K/4096) launches); returns when they are done
         region_kernel_ms = eng.timed_steps(args.steps)
-        gather_traces()
-        barrier()
+        rows = gather_traces(s0, s1)
+        torch.cuda.synchronize()
         elapsed = time.perf_counter() - t_begin
         if world > 1:
+            dist.barrier()
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -364,9 +442,9 @@ def main():
         snap = eng.snapshot()
         assert np.all(snap["it"] == args.steps + args.warmup) and np.all(np.isfinite(snap["likA"]))
         assert snap["accepted"].min() > 0
-        return eng, chains, total, elapsed, region_kernel_ms
+        return eng, chains, total, elapsed, region_kernel_ms, rows
 
-    eng, chains, total_chains, elapsed, region_kernel_ms = timed_region(args.scaling)
+    eng, chains, total_chains, elapsed, region_kernel_ms, rows_gathered = timed_region(args.scaling)
     value = args.steps * n_lin * total_chains / elapsed
 
     out = None
@@ -395,7 +473,8 @@ def main():
             passes = -(-chains // cb)
             cb_pass = cb
         fig = kernel_figures(eng, n_lin, chains, n_ev, kernel_ms)
-        conv_bytes = 16.0 * n_lin * passes                          # 16 B x N x ceil(C/Cb) per iteration
+        roof = roofline_object(fig, kname, kernel_ms, n_ev, n_lin, chains, passes, cb_pass)
+        roof["frac_engine"] = value / world * fig["lds_bytes_per_eval"] / 1e9 / LDS_PEAK_GBS
         # yardstick beside the nominal 8 TB/s: device-to-device copy of 1 GiB, read + write bytes
         src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(src)
@@ -406,15 +485,12 @@ def main():
             dst.copy_(src)
         ev1.record()
         torch.cuda.synchronize()
-        copy_gbs = 10 * 2.0 * src.numel() / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        roof["hbm"]["copy_GBs_measured"] = 10 * 2.0 * src.numel() / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
         del src, dst
-        hbm = {"peak_GBs": HBM_PEAK_GBS, "copy_GBs_measured": copy_gbs,
-               "algorithmic_GBs_16B_convention": conv_bytes / (kernel_ms * 1e-3) / 1e9,
-               "chains_per_pass_Cb": cb_pass,
-               "note": "SURVEY 8(d) prices a lineage pass at 16 B (fp64 ts + te) x N x ceil(C/Cb); the engine reads the "
-                       "lineages as packed table indices that stay in L2 (and scores Cb chains per pass from LDS), so this "
-                       "figure may exceed the HBM peak: HBM is not what the kernel works against - see traffic / "
-                       "measured_GBs for the bytes that really reach HBM"}
+        roof["engine"] = {"persistent": fig["persistent"], "threads_per_block": fig["threads_per_block"],
+                          "chains_per_block": {1: 2, 2: 4, 3: 2}[int(eng.layout.persistent)] if persistent else cb,
+                          "team_blocks": int(eng.layout.team_blocks), "table_mode": int(eng.layout.table_mode),
+                          "unit_resolution_tables": unit, "us_per_iter_device": fig["us_per_iter"]}
         out = {
             "metric": "RJMCMC iters/sec x lineages (lineage-log-lik evals/s, summed over chains)",
             "value": value, "unit": "lineage-log-lik evals/s", "n_gpus": world, "steps": args.steps,
@@ -426,42 +502,33 @@ def main():
                            "DDRate sampler -m_birth 2 -m_death 2" if model == "dd" else "model_BDI %d, RJ prior on shifts" % model),
                        "lineages": n_lin, "chains_per_gpu": chains, "chains_total": total_chains,
                        "n_bins": eng.n_bins, "sample_every": args.sample_every,
+                       "trace_rows_gathered_in_region": rows_gathered,
                        "iters_per_s_per_chain": args.steps / elapsed,
-                       "eval_note": "one eval = one lineage scored under one chain's rates in one iteration; every iteration "
-                                    "reads every lineage's (birth bin, death bin) from the packed groups - two neighbouring "
-                                    "lineages of a birth bin may share one table gather through a pair-sum entry built from the "
-                                    "chain's rates in that iteration (DESIGN.md, Kernels); no per-bin event counts are used"},
-            "roofline": {"bound": "lds", "achieved": fig["lds_GBs"], "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                         "frac": fig["lds_frac"], "traffic": None, "traffic_note": "not measured",
-                         "kernel": kname, "kernel_ms": kernel_ms, "iterations_per_launch": n_ev,
-                         "evals_per_launch": float(n_ev) * n_lin * chains,
-                         "lds_bytes_per_eval": fig["lds_bytes_per_eval"],
-                         "kernel_evals_per_s": fig["evals_per_s"],
-                         "frac_engine": value / world * fig["lds_bytes_per_eval"] / 1e9 / LDS_PEAK_GBS,
-                         "bound_note": "LDS gather bandwidth: per (lineage, chain) the scan gathers %.2f B of lookup-table "
-                                       "entries from LDS (256 B/clk/CU x 256 CU x 2.4 GHz); no MFMA in a gather/scan/reduce.  "
-                                       "Micro-benchmarks (scratch/ubench) show the scan loop is bound by vector instruction "
-                                       "issue before LDS bandwidth (see `issue`): the CU's issue slots are ~83 %% full "
-                                       "(scan loops and the two chain steps of a phase, each one wave issuing an "
-                                       "instruction every ~5 cycles: a phase is as long as its step)" % fig["lds_bytes_per_eval"],
-                         "issue": fig.get("issue"),
-                         "hbm": hbm,
-                         "engine": {"persistent": fig["persistent"], "threads_per_block": fig["threads_per_block"],
-                                    "chains_per_block": {1: 2, 2: 4, 3: 2}[int(eng.layout.persistent)] if persistent else cb,
-                                    "team_blocks": int(eng.layout.team_blocks), "table_mode": int(eng.layout.table_mode),
-                                    "unit_resolution_tables": unit, "us_per_iter_device": fig["us_per_iter"]}},
+                       "wall_over_device": elapsed * 1e3 / region_kernel_ms,
+                       "eval_note": "one eval = one lineage scored under one chain's rates in one iteration.  The scan does NOT "
+                                    "spend two gathers per eval: lineages are sorted, a run of up to 14 lineages of one birth "
+                                    "bin shares ONE gather of the birth entry (multiplied by the run count - a per-birth-bin "
+                                    "event count) and two neighbouring lineages may share ONE gather of a pre-summed death "
+                                    "entry: %.2f gathers and %.2f fp64 operations per eval (roofline.gathers_per_eval, "
+                                    ".fp64_ops_per_eval).  Every lineage's own (birth bin, death bin) is still read from "
+                                    "the packed groups in every iteration and the cost stays O(N) per chain - the full "
+                                    "per-bin collapse the reference evaluates (LRF:137-162) is not taken, and the "
+                                    "aggregation is frozen at this level; co_headline (cfg4 on continuous times, every "
+                                    "lineage with its own in-bin fractions) is the figure without year-resolution sharing"
+                                    % (fig["gathers_per_eval"], fig["fp64_ops_per_eval"])},
+            "roofline": roof,
         }
     eng.close()
     del eng
 
     # ---- N > 1: the configuration as BASELINE.json words it (the chains in total, sharded) -----------------------
     if world > 1 and args.scaling == "weak":
-        eng2, chains2, total2, elapsed2, kms2 = timed_region("strong")
+        eng2, chains2, total2, elapsed2, kms2, rows2 = timed_region("strong")
         if rank == 0:
             out["strong_scaling"] = {"chains_total": total2, "chains_per_gpu": chains2,
                                      "value": args.steps * n_lin * total2 / elapsed2, "unit": out["unit"],
                                      "ms_per_step": elapsed2 / args.steps * 1e3, "kernel": eng2.kernel_name(),
-                                     "kernel_ms": kms2}
+                                     "kernel_ms": kms2, "trace_rows_gathered_in_region": rows2}
         eng2.close()
         del eng2
 
@@ -483,6 +550,16 @@ def main():
                     continue
                 cfgs[name] = side_config(name, 2000, 300)
             out["configs"] = cfgs
+            if "cfg4_general" in cfgs:
+                # the co-headline: the same workload on continuous times, where no two lineages share a fraction and
+                # pairs form only inside a death bin - 2000 iterations, device time
+                g = cfgs["cfg4_general"]
+                ms = g["us_per_iter"] * g["steps"] * 1e-3
+                out["co_headline"] = {
+                    "workload": g["workload"], "value": g["evals_per_s"], "unit": out["unit"], "steps": g["steps"],
+                    "us_per_iter_device": g["us_per_iter"], "timing": "HIP events around one 2000-iteration launch",
+                    "roofline": roofline_object(g, g["kernel"], ms, g["steps"], g["lineages"], g["chains"],
+                                                g["steps"] * ((g["chains"] + 1) // 2), 2)}
         if not args.no_cpu_baseline:
             if model == "dd":
                 out["cpu_baseline"] = cpu_baseline_dd(ts, te, budget_s=15.0)
@@ -501,6 +578,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -218,7 +218,8 @@ typedef struct lr_mcmc_layout {
     int32_t persistent;   /* 0: launch-per-iteration engine; 1 / 2: persistent kernel, 2 / 4 chains per block;
                            * 3: speculative team kernel (a chain pair per team of team_blocks blocks)             */
     int32_t reserved1;    /* threads per block of the persistent kernel (512 / 1024), 0 for the launch-based engine */
-    int64_t status;       /* engine status word (uint32): 0 ok, 1 = a team exchange of the speculative kernel timed out */
+    int64_t status;       /* engine status word (uint32): 0 ok, 1 = a team exchange of the speculative kernel timed out;
+                           * the uint32 behind it is the warning word (lr_mcmc_warnings)                                */
     int64_t xchg;         /* partial-sum exchange granules of the speculative kernel's teams (team_blocks > 1)        */
     int32_t team_blocks;  /* blocks (= CUs) that share one chain pair, each scanning 1/team_blocks of the lineages     */
     int32_t table_mode;   /* 0 chain-major general tables, 1 unit-resolution pair tables, 2 pair-general tables (persistent
@@ -314,6 +315,12 @@ int lr_mcmc_time_steps(lr_engine* e, int64_t n_iters, float* total_ms /* host */
 /* Blocks until `stream` is idle and copies the engine status word to *status (host): 0 = ok, 1 = a team exchange of the
  * speculative kernel timed out (its blocks were not all resident within two seconds) and the run is void.          */
 int lr_mcmc_status(lr_engine* e, int32_t* status /* host */, void* stream);
+/* Blocks until `stream` is idle and copies the engine's warning word to *warnings (host): a bit set of LR_WARN_*.
+ * LR_WARN_KCAP: at least one add-shift move (LRF:29-47) was proposed from a state that already holds LR_KMAX rates and
+ * was rejected for that reason alone - the reference has no such cap, the posterior on the number of shifts is
+ * truncated at LR_KMAX.  Cleared by lr_mcmc_init / lr_mcmc_restore.                                                  */
+#define LR_WARN_KCAP 2
+int lr_mcmc_warnings(lr_engine* e, int32_t* warnings /* host */, void* stream);
 /* measurement hook: name of the kernel lr_mcmc_steps spends its time in, as a kernel trace prints it (n >= 64). */
 int lr_mcmc_describe(const lr_engine* e, char* buf /* host */, int32_t n);
 int lr_mcmc_destroy(lr_engine* e);

@@ -11,6 +11,7 @@ ERRORS = {-1: "LR_ERR_NULL", -2: "LR_ERR_SIZE", -3: "LR_ERR_MODEL", -4: "LR_ERR_
           -6: "LR_ERR_STATE", -7: "LR_ERR_ORDER (lineages must be sorted by birth time for the persistent engines)"}
 
 LR_KMAX, LR_ROW, LR_MAX_BINS = 32, 64, 4094
+LR_WARN_KCAP = 2
 LR_STATE_ROWS, LR_ISTATE_ROWS = 9, 5
 LR_TRACE_HEAD = 13
 LR_TRACE_W = LR_TRACE_HEAD + 2 * (2 * LR_KMAX - 1)
@@ -68,6 +69,7 @@ SIGNATURES = {
     "lr_mcmc_restore": (c_i32, [c_vp, c_vp]),
     "lr_mcmc_describe": (c_i32, [c_vp, C.c_char_p, c_i32]),
     "lr_mcmc_status": (c_i32, [c_vp, C.POINTER(c_i32), c_vp]),
+    "lr_mcmc_warnings": (c_i32, [c_vp, C.POINTER(c_i32), c_vp]),
     "lr_mcmc_destroy": (c_i32, [c_vp]),
     "lr_debug_draws": (c_i32, [C.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
 }

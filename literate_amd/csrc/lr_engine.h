@@ -41,6 +41,7 @@ struct lr_engine {
     long long n8_alloc;       // ... allocated (zero-filled behind the data)
     lr_p4_shares p4;          // per scanner wave: trips more (+) or fewer (-) than the equal share (four-chain kernel)
     hipEvent_t fork;
+    hipEvent_t ev0, ev1;      // timing events of lr_mcmc_time_steps / lr_mcmc_time_scan, created once
 };
 
 

@@ -839,14 +839,15 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     return LR_OK;
 }
 
+// Compute units of the CURRENT device (the engine is planned and created with its device current: literate_amd/engine.py),
+// asked every time: a process may drive several devices.  LR_DEVICE_CUS overrides it (planner tests).  Without a device
+// to ask (planning on a GPU-less host: the CPU tests) an MI355X is assumed - lr_mcmc_create cannot succeed there anyway.
 static int lr_device_cus() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
-    return cus;
+    const char* v = getenv("LR_DEVICE_CUS");
+    if (v && atoi(v) > 0) return atoi(v);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n;
+    return 256;
 }
 
 // Speculative team kernel (lr_spec.h): one block per CU, a chain pair owned by a team of k blocks.  Model of an
@@ -862,7 +863,8 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
     *k_out = 0;
     if (pairs > cus) return 1e30;
     static const int k_env0 = lr_env_int("LR_SPEC_TEAM", 0);
-    const int k_env = cfg->team_request > 0 ? cfg->team_request : k_env0;
+    // (lr_check_cfg has refused a request that is not 1, 2, 4 or 8; a malformed LR_SPEC_TEAM is ignored)
+    const int k_env = cfg->team_request > 0 ? cfg->team_request : ((k_env0 == 1 || k_env0 == 2 || k_env0 == 4 || k_env0 == 8) ? k_env0 : 0);
     const double n8 = (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP);      // groups, for lineages sorted by birth time
     const double extra = cfg->sampler ? 0.25 : 0.0;
     double best = 1e30;
@@ -909,7 +911,8 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     if (env == 0 || cfg->engine_mode == 1) return false;
     if (!p.unit || cfg->n_bins + 2 > LR_H_WIDE || p.cb < 2) return false;
     const bool general = p.unit == LR_TAB_PAIRGEN;
-    if (cfg->n_lineages >= (1ll << 33)) return false;   // the scan loop counts 16-byte index groups in 32 bits
+    // the packing holds lineage indices as int32 and the scan loops address the groups by 32-bit byte offsets
+    if (cfg->n_lineages >= (1ll << 31) - 1 || lr_groups_alloc(cfg->n_lineages) * 16 >= (1ll << 32)) return false;
     if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264 && p.H != LR_H_WIDE) return false;
     if (env == 1 || cfg->engine_mode >= 2) return true;
     const double n = (double)cfg->n_lineages, c = (double)cfg->n_chains;
@@ -964,6 +967,8 @@ static int lr_check_cfg(const lr_mcmc_config* cfg) {
     if (cfg->t0 != floor(cfg->t0)) return LR_ERR_T0;
     if (!(cfg->end_time > cfg->start_time)) return LR_ERR_SIZE;
     if (cfg->sampler < 0 || cfg->sampler > 2) return LR_ERR_MODEL;
+    if (cfg->team_request != 0 && cfg->team_request != 1 && cfg->team_request != 2 && cfg->team_request != 4 && cfg->team_request != 8)
+        return LR_ERR_SIZE;       // a team is 1, 2, 4 or 8 blocks (LR_TEAM_MAX)
     if (cfg->sampler != 0) {
         if (cfg->model != LR_MODEL_KEIDING) return LR_ERR_MODEL;
         if (cfg->n_bins > LR_DD_MAXP * LR_WAVE) return LR_ERR_SIZE;
@@ -1050,10 +1055,21 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
     e->p4.n_slots = 8;
     e->fork = nullptr;
+    e->ev0 = e->ev1 = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
         lr_part& q = e->part[p];
         q.base = base[p], q.count = base[p + 1] - base[p], q.hA = hA[p], q.pipelined = pipelined[p];
         q.stream = nullptr, q.done = nullptr, q.graph_exec = nullptr, q.graph_units = 0;
+    }
+    {
+        // the two timing events of lr_mcmc_time_steps / lr_mcmc_time_scan live as long as the engine: creating and
+        // destroying them per call cost the host tens of microseconds inside every timed region
+        hipError_t he = hipEventCreate(&e->ev0);
+        if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+        if (he != hipSuccess) {
+            lr_mcmc_destroy(e);
+            return (int)he;
+        }
     }
     if (e->n_parts > 1) {
         hipError_t he = hipEventCreateWithFlags(&e->fork, hipEventDisableTiming);
@@ -1089,6 +1105,7 @@ lr_step_args lr_make_args(const lr_engine* e) {
     a.H = e->plan.H;
     a.unit = e->plan.unit;
     a.cb = e->plan.cb;
+    a.warn = (unsigned int*)(e->ws + e->lay.status) + 1;
     return a;
 }
 
@@ -1144,6 +1161,9 @@ __global__ void lr_dd_consts_kernel(const double* __restrict__ DT, int n_bins, d
 
 // everything in the workspace that holds device addresses or derives from the data alone
 static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipStream_t stream) {
+    // a fresh or restored run starts with a clear status and warning word (a checkpoint never carries a void run on:
+    // ChainEngine.save refuses to write one)
+    (void)hipMemsetAsync(e->ws + e->lay.status, 0, 256, stream);
     hipLaunchKernelGGL(lr_log_br_kernel, dim3((e->cfg.n_bins + 127) / 128), dim3(128), 0, stream, e->br_length,
                        e->cfg.n_bins, (double*)(e->ws + e->lay.bin_consts));
     if (e->cfg.sampler == 1)
@@ -1394,22 +1414,12 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
 extern "C" int lr_mcmc_time_steps(lr_engine* e, int64_t n_iters, float* total_ms, void* stream_) {
     if (!e || !total_ms) return LR_ERR_NULL;
     hipStream_t stream = (hipStream_t)stream_;
-    hipEvent_t t0, t1;
-    hipError_t he = hipEventCreate(&t0);
-    if (he != hipSuccess) return (int)he;
-    he = hipEventCreate(&t1);
-    if (he != hipSuccess) {
-        (void)hipEventDestroy(t0);
-        return (int)he;
-    }
-    int rc = (int)hipEventRecord(t0, stream);
+    int rc = (int)hipEventRecord(e->ev0, stream);
     if (rc == LR_OK) rc = lr_mcmc_steps(e, n_iters, stream_);
-    if (rc == LR_OK) rc = (int)hipEventRecord(t1, stream);
-    if (rc == LR_OK) rc = (int)hipEventSynchronize(t1);
+    if (rc == LR_OK) rc = (int)hipEventRecord(e->ev1, stream);
+    if (rc == LR_OK) rc = (int)hipEventSynchronize(e->ev1);
     float ms = 0.f;
-    if (rc == LR_OK) rc = (int)hipEventElapsedTime(&ms, t0, t1);
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
+    if (rc == LR_OK) rc = (int)hipEventElapsedTime(&ms, e->ev0, e->ev1);
     *total_ms = ms;
     return rc;
 }
@@ -1419,23 +1429,13 @@ extern "C" int lr_mcmc_time_scan(lr_engine* e, int32_t reps, float* avg_ms, void
     if (!e->initialised) return LR_ERR_STATE;
     if (reps < 1) return LR_ERR_SIZE;
     hipStream_t stream = (hipStream_t)stream_;
-    hipEvent_t t0, t1;
-    hipError_t he = hipEventCreate(&t0);
-    if (he != hipSuccess) return (int)he;
-    he = hipEventCreate(&t1);
-    if (he != hipSuccess) {
-        (void)hipEventDestroy(t0);
-        return (int)he;
-    }
     int rc = lr_enqueue_scan(e, stream);  // warm
-    if (rc == LR_OK) rc = (int)hipEventRecord(t0, stream);
+    if (rc == LR_OK) rc = (int)hipEventRecord(e->ev0, stream);
     for (int i = 0; i < reps && rc == LR_OK; ++i) rc = lr_enqueue_scan(e, stream);
-    if (rc == LR_OK) rc = (int)hipEventRecord(t1, stream);
-    if (rc == LR_OK) rc = (int)hipEventSynchronize(t1);
+    if (rc == LR_OK) rc = (int)hipEventRecord(e->ev1, stream);
+    if (rc == LR_OK) rc = (int)hipEventSynchronize(e->ev1);
     float ms = 0.f;
-    if (rc == LR_OK) rc = (int)hipEventElapsedTime(&ms, t0, t1);
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
+    if (rc == LR_OK) rc = (int)hipEventElapsedTime(&ms, e->ev0, e->ev1);
     *avg_ms = ms / reps;
     return rc;
 }
@@ -1446,6 +1446,15 @@ extern "C" int lr_mcmc_status(lr_engine* e, int32_t* status, void* stream_) {
     hipError_t he = hipMemcpyAsync(&v, e->ws + e->lay.status, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream_);
     if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream_);
     *status = (int32_t)v;
+    return (int)he;
+}
+
+extern "C" int lr_mcmc_warnings(lr_engine* e, int32_t* warnings, void* stream_) {
+    if (!e || !warnings) return LR_ERR_NULL;
+    unsigned int v = 0;
+    hipError_t he = hipMemcpyAsync(&v, e->ws + e->lay.status + 4, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream_);
+    if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream_);
+    *warnings = (int32_t)v;
     return (int)he;
 }
 
@@ -1478,6 +1487,8 @@ extern "C" int lr_mcmc_destroy(lr_engine* e) {
         if (q.stream) (void)hipStreamDestroy(q.stream);
     }
     if (e->fork) (void)hipEventDestroy(e->fork);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
     delete e;
     return LR_OK;
 }

@@ -663,7 +663,11 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         sm.br[b] = (in && a.br_length) ? a.br_length[b] : 0.0;
         sm.logbr[b] = in ? a.log_br[b] : 0.0;
     }
-    if (tid == 0) sm.abort_flag = 0, sm.cur_sel = 0, sm.scan_arrive = 0, sm.plane_arrive = 0, sm.args = a;
+    // a team whose exchange timed out in an earlier launch of this call has raised the status word: the run is void, and
+    // the launches queued behind it end here instead of iterating on a state that was never written back
+    if (tid == 0)
+        sm.abort_flag = (k_team > 1 && __hip_atomic_load((lr_gu32*)x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0,
+        sm.cur_sel = 0, sm.scan_arrive = 0, sm.plane_arrive = 0, sm.args = a;
     if (tid < 2) sm.likA[tid] = (c0 + tid < C) ? a.state_f64[((size_t)(c0 + tid) * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA] : 0.0;
     lr_spec_ctx ctx;
     {
@@ -676,6 +680,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         ctx.c0 = c0, ctx.C = C, ctx.team = team, ctx.rank = rank;
     }
     __syncthreads();
+    if (sm.abort_flag) return;
     for (int i = tid; i < 2 * H * ENT; i += T) sm.pairs[ctx.it0 & 1][0][0][i] = gpair[i];
     __syncthreads();
     lr_build_scan_table<GENERAL>(sm.scan, sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);

@@ -24,6 +24,7 @@ struct lr_step_args {
     double mult_l;          // 2 log d of the multiplier proposal (LRF:169)
     const double* dd_consts; // DD sampler: {max(DT), log max(DT)} = PRIOR_K0_L (DD:45) and its log
     int tab_stride, n_cls, tiles, H, unit, cb;
+    unsigned int* warn;     // engine warning word (LR_WARN_*), beside the status word
 };
 
 // where chain c's lookup table starts.  General layout: chain-major, tab_stride double2 per chain.
@@ -618,7 +619,11 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
         const lr_u2 q2 = pre ? lr_u2{pre->q2_a, pre->q2_b} : lr_u2{lr_bcast(ud.a, LR_UD_LANE + 3), lr_bcast(ud.b, LR_UD_LANE + 3)};
         if (q.b > 0.5) {
             if (K >= LR_KMAX) {
-                invalid = 1;  // device cap on the number of rates; the reference has none
+                // device cap on the number of rates; the reference has none (LRF:29-47): the proposal is rejected and
+                // the engine's warning word says so (the speculative kernel also raises it for a candidate that is
+                // built from a K = LR_KMAX proposal and never selected: the chain is at the cap either way)
+                invalid = 1;
+                if (lane == 0) __hip_atomic_fetch_or(a.warn, (unsigned int)LR_WARN_KCAP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 const int ind = min((int)(q2.a * K), K - 1);
                 const double delta = q2.b * (lr_bcast(T, ind + 1) - lr_bcast(T, ind));

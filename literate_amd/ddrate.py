@@ -38,7 +38,13 @@ class DDRateEngine(ChainEngine):
         """The rows DDRate.py writes for one chain (DD:219-235): [it, posterior, likelihood, likelihood_birth,
         likelihood_death, prior, args as logged (x0 + ORIGIN, L + div_0), l_i.., m_i.., niche_i.., nicheFrac_i..
         (+ adequacy when emp=(B_EMP, D_EMP))]."""
-        tr = self.trace_rows(n_samples)[:, chain]
+        return self.log_rows_from(self.trace_rows(n_samples)[:, chain], emp)
+
+    def log_rows_from(self, tr, emp=None):
+        """The same from given trace rows [samples, LR_TRACE_W] of one chain (a window of a streamed run)."""
+        tr = np.asarray(tr, dtype=float)
+        if len(tr) == 0:
+            return []
         args = tr[:, 4:12]
         b, d, ni, nf = [x.cpu().numpy() for x in ops.dd_rates(args, self.DT, self.m_birth, self.m_death)]
         lb, ld = [x.cpu().numpy() for x in ops.binned_keiding(b, d, self.n_spec, self.n_exti, self.DT)]
@@ -55,14 +61,31 @@ class DDRateEngine(ChainEngine):
             rows.append(np.array(row, dtype=float))
         return rows
 
-    def write_log(self, path, chain, emp=None, n_samples=None):
+    def log_head(self):
         n = len(self.DT)
         head = list(LOG_HEAD)
         for name in ("l_%s", "m_%s", "niche_%s", "nicheFrac_%s"):
             head += [name % i for i in range(n)]
-        head += ["corr_coeff", "rsquared", "gelman_r2"]
+        return head + ["corr_coeff", "rsquared", "gelman_r2"]
+
+    def write_log(self, path, chain, emp=None, n_samples=None):
+        self.start_log(path)
+        self.append_log(path, self.trace_rows(n_samples)[:, chain], emp)
+
+    def start_log(self, path):
         with open(path, "w") as f:
+            csv.writer(f, delimiter='\t').writerow(self.log_head())
+
+    def append_log(self, path, tr, emp=None):
+        """Append the rows of one window and push them to disk (the reference flushes and fsyncs every sample,
+        DD:236-238)."""
+        import os
+        rows = self.log_rows_from(tr, emp)
+        if not rows:
+            return
+        with open(path, "a") as f:
             w = csv.writer(f, delimiter='\t')
-            w.writerow(head)
-            for row in self.log_rows(chain, emp, n_samples):
+            for row in rows:
                 w.writerow([int(row[0])] + [float(v) for v in row[1:]])
+            f.flush()
+            os.fsync(f.fileno())

@@ -72,11 +72,12 @@ class ChainEngine:
             frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0,
             sampler=0 if dd is None else (2 if dd.get("kind") == "trend" else 1),
             m_birth=0 if dd is None else int(dd["m_birth"]), m_death=0 if dd is None else int(dd["m_death"]),
-            team_request=int(team), dd_present=0.0 if dd is None else float(dd.get("present", 0.0)),
+            team_request=int(team) or (1 if os.environ.get("LR_SHARED_DEVICE", "0") == "1" else 0), dd_present=0.0 if dd is None else float(dd.get("present", 0.0)),
             dd_init_death=0.0 if dd is None else float(dd.get("init_death", 0.1)))
         self.dd = dd
         self.layout = _hip.McmcLayout()
-        _hip.check(self.lib.lr_mcmc_query_layout(C.byref(self.cfg), C.byref(self.layout)), "lr_mcmc_query_layout")
+        with torch.cuda.device(self.device):      # the planner asks the CURRENT device for its compute units
+            _hip.check(self.lib.lr_mcmc_query_layout(C.byref(self.cfg), C.byref(self.layout)), "lr_mcmc_query_layout")
         self.workspace = torch.zeros(self.layout.total_bytes, dtype=torch.uint8, device=self.device)
         handle = C.c_void_p()
         br_ptr = _hip.ptr(self.br_length) if (model in (0, 1) or dd is not None) else None
@@ -153,8 +154,18 @@ class ChainEngine:
         _hip.check(rc, "lr_mcmc_init")
         self.iterations = 0
 
+    def _launch(self, fn, *args):
+        """An ABI call on this engine's device and torch's current stream there.  When that device already is the
+        current one (the normal case) the call goes straight through: the device guard of _hip.launch costs the host
+        tens of microseconds, which a short timed region (bench.py at --steps 20) would be charged for."""
+        import torch
+        idx = self.device.index
+        if idx is None or torch.cuda.current_device() == idx:
+            return fn(*args, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return _hip.launch(fn, self.device, *args)
+
     def steps(self, n):
-        _hip.check(_hip.launch(self.lib.lr_mcmc_steps, self.device, self.handle, int(n)), "lr_mcmc_steps")
+        _hip.check(self._launch(self.lib.lr_mcmc_steps, self.handle, int(n)), "lr_mcmc_steps")
         self.iterations += int(n)
 
     def time_scan(self, reps=20):
@@ -170,7 +181,24 @@ class ChainEngine:
         st = C.c_int32(0)
         _hip.check(_hip.launch(self.lib.lr_mcmc_status, self.device, self.handle, C.byref(st)), "lr_mcmc_status")
         if st.value != 0:
-            raise _hip.HipLibraryError("engine status %d: a team exchange timed out, the run is void" % st.value)
+            raise _hip.HipLibraryError("engine status %d: a team exchange timed out (the team's blocks were not all "
+                                       "resident: is the GPU shared? LR_SHARED_DEVICE=1 runs without teams), the run "
+                                       "is void" % st.value)
+
+    def warnings(self):
+        """Synchronise and return the engine's warning bits (include/literate_hip.h: LR_WARN_*)."""
+        w = C.c_int32(0)
+        _hip.check(_hip.launch(self.lib.lr_mcmc_warnings, self.device, self.handle, C.byref(w)), "lr_mcmc_warnings")
+        return int(w.value)
+
+    def warning_text(self):
+        """Human-readable form of warnings() for the CLIs ('' when there is none)."""
+        w = self.warnings()
+        if w & _hip.LR_WARN_KCAP:
+            return ("WARNING: an add-shift move was proposed from a state with %d rates and rejected: the device holds at "
+                    "most %d rates per process (the reference has no cap, LiteRateForward.py:29-47); the posterior of "
+                    "the number of shifts is truncated there" % (_hip.LR_KMAX, _hip.LR_KMAX))
+        return ""
 
     def kernel_name(self):
         """Name of the kernel steps() spends its time in, as rocprofv3's kernel trace prints it."""
@@ -181,8 +209,7 @@ class ChainEngine:
     def timed_steps(self, n):
         """steps(n) bracketed by HIP events on the launch stream; returns elapsed device ms (blocks)."""
         ms = C.c_float(0.0)
-        _hip.check(_hip.launch(self.lib.lr_mcmc_time_steps, self.device, self.handle, int(n), C.byref(ms)),
-                   "lr_mcmc_time_steps")
+        _hip.check(self._launch(self.lib.lr_mcmc_time_steps, self.handle, int(n), C.byref(ms)), "lr_mcmc_time_steps")
         self.iterations += int(n)
         return float(ms.value)
 
@@ -205,7 +232,7 @@ class ChainEngine:
         The workspace IS the run between two steps() calls; draws are addressed by (seed, chain, iteration), so a
         run resumed with load() continues bit-identically."""
         import torch
-        torch.cuda.synchronize(self.device)
+        self.check_status()          # (synchronises) a void run must not replace the last good checkpoint
         sig = self._signature()
         # written beside the target and renamed over it: a kill during save() leaves the previous checkpoint intact
         path = str(path)
@@ -247,16 +274,19 @@ class ChainEngine:
     def snapshot(self):
         """Accepted state of every chain as numpy: dict(L, M, tL, tM (lists), likA, priorA, K_l, K_m, ...)."""
         self.check_status()
-        S = self.state_f64.cpu().numpy()
-        I = self.state_i32.cpu().numpy()
+        return self.snapshot_from(self.state_f64.cpu().numpy(), self.state_i32.cpu().numpy())
+
+    def snapshot_from(self, S, I):
+        """snapshot() of host copies of the two state blocks (TraceStreamer takes them at a window's end)."""
         KL, KM = I[:, _hip.IROW_SCALARS, _hip.I_KL], I[:, _hip.IROW_SCALARS, _hip.I_KM]
         sc = S[:, _hip.ROW_SCALARS]
+        n = S.shape[0]
         return dict(
             K_l=KL.copy(), K_m=KM.copy(),
-            L=[S[c, _hip.ROW_L, :KL[c]].copy() for c in range(self.n_chains)],
-            M=[S[c, _hip.ROW_M, :KM[c]].copy() for c in range(self.n_chains)],
-            tL=[S[c, _hip.ROW_TL, :KL[c] + 1].copy() for c in range(self.n_chains)],
-            tM=[S[c, _hip.ROW_TM, :KM[c] + 1].copy() for c in range(self.n_chains)],
+            L=[S[c, _hip.ROW_L, :KL[c]].copy() for c in range(n)],
+            M=[S[c, _hip.ROW_M, :KM[c]].copy() for c in range(n)],
+            tL=[S[c, _hip.ROW_TL, :KL[c] + 1].copy() for c in range(n)],
+            tM=[S[c, _hip.ROW_TM, :KM[c] + 1].copy() for c in range(n)],
             likA=sc[:, _hip.S_LIKA].copy(), priorA=sc[:, _hip.S_PRIORA].copy(),
             gamma_rate=sc[:, [_hip.S_GRATE_L, _hip.S_GRATE_M]].copy(), poi=sc[:, _hip.S_POI].copy(),
             accepted=I[:, _hip.IROW_SCALARS, _hip.I_ACCEPTED].copy(),
@@ -264,10 +294,14 @@ class ChainEngine:
                | (I[:, _hip.IROW_SCALARS, _hip.I_IT_HI].astype(np.int64) << 32),
         )
 
+    def samples_done(self):
+        """Trace rows written so far: iterations 0, s, 2 s, ... below `iterations` (LRF:321)."""
+        return min(self.cfg.n_trace_slots, (self.iterations + self.cfg.s_freq - 1) // self.cfg.s_freq)
+
     def trace_rows(self, n_samples=None):
         """Trace buffer as numpy [samples, chains, LR_TRACE_W] (see include/literate_hip.h)."""
         self.check_status()
-        n_avail = min(self.cfg.n_trace_slots, (self.iterations + self.cfg.s_freq - 1) // self.cfg.s_freq)
+        n_avail = self.samples_done()
         n = n_avail if n_samples is None else min(n_samples, n_avail)
         return self.trace[:n].cpu().numpy()
 
@@ -283,3 +317,61 @@ def split_trace_row(row):
     sp = np.concatenate([rl[:kl], rl[K:K + kl - 1]])
     ex = np.concatenate([rm[:km], rm[K:K + km - 1]])
     return head, sp, ex
+
+
+class TraceStreamer:
+    """Streams a run out window by window (a window = the iterations of one steps() call = one print block): the
+    reference writes and flushes its logs at every sample (LRF:334-359, DD:236-238); here the rows a window sampled
+    and a copy of the chain states at its end leave the device on a SIDE stream - gathered to rank 0 over RCCL when
+    the chains are sharded - while the NEXT window already runs on the main stream.
+
+        eng.steps(n); st.mark()           # window k enqueued; its end recorded
+        eng.steps(n); st.mark()           # window k + 1 enqueued
+        rows, snap, win = st.collect()    # window k: [samples, total chains, LR_TRACE_W] on rank 0 (None elsewhere)
+
+    The trace keeps every sampled row resident (slot = sample number), so a window's rows are not touched by later
+    windows; the state blocks are copied device-to-device at the window's end on the main stream (a later launch
+    rewrites them)."""
+
+    def __init__(self, eng, total_chains=None, n_local=None, gather=True):
+        """gather=False: every rank keeps (and writes) the rows of its own chains (the DDRate / trend_rate CLIs)."""
+        import torch
+        self.eng, self.torch, self.gather = eng, torch, bool(gather)
+        self.total = eng.n_chains if total_chains is None else int(total_chains)
+        self.n_local = eng.n_chains if n_local is None else int(n_local)
+        self.side = torch.cuda.Stream(device=eng.device)
+        self.pending = []
+        self.done_samples = 0
+
+    def rewind(self, n_samples=0):
+        """Start (again) from sample `n_samples`: after load() the windows up to the checkpoint are re-read as one."""
+        self.done_samples = int(n_samples)
+
+    def mark(self):
+        torch, eng = self.torch, self.eng
+        with torch.cuda.device(eng.device):
+            S, I = eng.state_f64.clone(), eng.state_i32.clone()          # on the main stream, behind the window
+            st = eng.workspace[eng.layout.status:eng.layout.status + 8].clone()
+            ev = torch.cuda.Event()
+            ev.record()
+        s1 = eng.samples_done()
+        self.pending.append((self.done_samples, s1, eng.iterations, S, I, st, ev))
+        self.done_samples = s1
+
+    def collect(self):
+        """Oldest marked window -> (rows or None, snapshot dict, (first sample, end sample, iterations at its end))."""
+        from . import dist as lrd
+        torch, eng = self.torch, self.eng
+        s0, s1, its, S, I, st, ev = self.pending.pop(0)
+        with torch.cuda.device(eng.device), torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            status = st.view(torch.int32).cpu()
+            if int(status[0]) != 0:
+                raise _hip.HipLibraryError("engine status %d: a team exchange timed out, the run is void" % int(status[0]))
+            local = eng.trace[s0:s1][:, :self.n_local].contiguous()
+            # (a window without a sample is empty on every rank alike: no collective for it)
+            rows = lrd.gather_traces(local, self.total) if (self.gather and s1 > s0) else local
+            rows = rows.cpu().numpy() if rows is not None else None
+            snap = eng.snapshot_from(S.cpu().numpy(), I.cpu().numpy())
+        self.side.synchronize()
+        return rows, snap, (s0, s1, its)

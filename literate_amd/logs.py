@@ -62,32 +62,68 @@ def write_div_log(path, sp_events, ex_events, br_length):
             w.writerow(row)
 
 
+def _chain_lines(rows, emp, n_bins, pyrate_output, true_root_age):
+    """rows of ONE chain -> three lists of text lines (mcmc, sp_rates, ex_rates) in the reference's format (LRF:321-359)."""
+    lm, ls, le = [], [], []
+    for row in rows:
+        head, sp, ex = split_row(row)
+        kl, km = int(head[6]), int(head[7])
+        start, end = head[8], head[9]
+        vals = [str(int(head[0]))] + [str(float(v)) for v in head[1:6]] + [str(kl), str(km)]
+        if pyrate_output:
+            vals += [str(float(true_root_age)), str(float(true_root_age - end))]
+        else:
+            vals += [str(float(start)), str(float(end))]
+        vals += [str(float(v)) for v in head[10:13]]
+        if emp is not None:
+            lam = rates_per_bin(sp[:kl], sp[kl:], start, n_bins)
+            mu = rates_per_bin(ex[:km], ex[km:], start, n_bins)
+            with np.errstate(all="ignore"):
+                vals += [str(float(v)) for v in adequacy(emp[0], emp[1], lam, mu)]
+        lm.append('\t'.join(vals) + '\n')
+        if pyrate_output:
+            sp = np.concatenate([sp[:kl], true_root_age - sp[kl:]])
+            ex = np.concatenate([ex[:km], true_root_age - ex[km:]])
+        ls.append('\t'.join(str(float(v)) for v in sp) + '\n')
+        le.append('\t'.join(str(float(v)) for v in ex) + '\n')
+    return lm, ls, le
+
+
+class ChainLogWriter:
+    """The three per-chain logs of one run, written as the run goes: the reference opens them once (LRF:485-512) and
+    writes + flushes a row per sample (LRF:334-359); here every window of samples (TraceStreamer) is appended and
+    flushed as soon as it has left the device, so a killed run leaves complete, parseable logs up to its last window.
+    Files are opened per append (a thousand chains x three files would not fit a process's descriptor limit)."""
+
+    def __init__(self, data_file, model, out, n_chains, emp=None, n_bins=None, pyrate_output=False, true_root_age=0.0):
+        self.emp, self.n_bins, self.pyrate, self.root = emp, n_bins, pyrate_output, true_root_age
+        self.paths = [log_paths(data_file, model, out, None if n_chains == 1 else c)[1] for c in range(n_chains)]
+        head = '\t'.join(MCMC_HEAD + (ADEQUACY_HEAD if emp is not None else [])) + '\n'
+        for p in self.paths:
+            with open(p["mcmc"], "w") as f:
+                f.write(head)
+            open(p["sp_rates"], "w").close()
+            open(p["ex_rates"], "w").close()
+
+    def append(self, rows):
+        """rows: [samples, chains, LR_TRACE_W] of one window."""
+        if rows is None or len(rows) == 0:
+            return
+        for c, p in enumerate(self.paths):
+            lm, ls, le = _chain_lines(rows[:, c], self.emp, self.n_bins, self.pyrate, self.root)
+            for key, lines in (("mcmc", lm), ("sp_rates", ls), ("ex_rates", le)):
+                with open(p[key], "a") as f:
+                    f.writelines(lines)
+                    f.flush()
+
+
 def write_chain_logs(paths, rows, emp=None, n_bins=None, pyrate_output=False, true_root_age=0.0):
     """rows: [samples, LR_TRACE_W] of ONE chain.  emp=(B_EMP, D_EMP) adds the adequacy columns
     (-calc_adequacy 1, LRF:327-329); pyrate_output flips times to root_age - t (LRF:324-341)."""
+    lm, ls, le = _chain_lines(rows, emp, n_bins, pyrate_output, true_root_age)
     with open(paths["mcmc"], "w") as fm, open(paths["sp_rates"], "w") as fs, open(paths["ex_rates"], "w") as fe:
         fm.write('\t'.join(MCMC_HEAD + (ADEQUACY_HEAD if emp is not None else [])) + '\n')
-        for row in rows:
-            head, sp, ex = split_row(row)
-            kl, km = int(head[6]), int(head[7])
-            start, end = head[8], head[9]
-            vals = [str(int(head[0]))] + [str(float(v)) for v in head[1:6]] + [str(kl), str(km)]
-            if pyrate_output:
-                vals += [str(float(true_root_age)), str(float(true_root_age - end))]
-            else:
-                vals += [str(float(start)), str(float(end))]
-            vals += [str(float(v)) for v in head[10:13]]
-            if emp is not None:
-                lam = rates_per_bin(sp[:kl], sp[kl:], start, n_bins)
-                mu = rates_per_bin(ex[:km], ex[km:], start, n_bins)
-                with np.errstate(all="ignore"):
-                    vals += [str(float(v)) for v in adequacy(emp[0], emp[1], lam, mu)]
-            fm.write('\t'.join(vals) + '\n')
-            if pyrate_output:
-                sp = np.concatenate([sp[:kl], true_root_age - sp[kl:]])
-                ex = np.concatenate([ex[:km], true_root_age - ex[km:]])
-            fs.write('\t'.join(str(float(v)) for v in sp) + '\n')
-            fe.write('\t'.join(str(float(v)) for v in ex) + '\n')
+        fm.writelines(lm), fs.writelines(ls), fe.writelines(le)
 
 
 def combine_logs(mcmc_files, wd, burnin_pct):

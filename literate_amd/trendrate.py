@@ -51,7 +51,13 @@ class TrendRateEngine(ChainEngine):
 
     def log_rows(self, chain, emp=None, n_samples=None):
         """Rows as trend_rate.py writes them (:183-189)."""
-        tr = self.trace_rows(n_samples)[:, chain]
+        return self.log_rows_from(self.trace_rows(n_samples)[:, chain], emp)
+
+    def log_rows_from(self, tr, emp=None):
+        """The same from given trace rows [samples, LR_TRACE_W] of one chain (a window of a streamed run)."""
+        tr = np.asarray(tr, dtype=float)
+        if len(tr) == 0:
+            return []
         args = tr[:, 4:10]
         b, d = [x.cpu().numpy() for x in ops.trend_rates(args, self.trend, self.const_birth, self.const_death)]
         lb, ld = [x.cpu().numpy() for x in ops.binned_keiding(b, d, self.n_spec, self.n_exti, self.DT)]
@@ -64,12 +70,29 @@ class TrendRateEngine(ChainEngine):
             rows.append(np.array(row, dtype=float))
         return rows
 
-    def write_log(self, path, chain, emp=None, n_samples=None):
+    def log_head(self):
         n = len(self.DT)
-        head = list(LOG_HEAD) + ["l_%s" % i for i in range(n)] + ["m_%s" % i for i in range(n)]
-        head += ["corr_coeff", "rsquared", "gelman_r2"]
+        return list(LOG_HEAD) + ["l_%s" % i for i in range(n)] + ["m_%s" % i for i in range(n)] + \
+            ["corr_coeff", "rsquared", "gelman_r2"]
+
+    def write_log(self, path, chain, emp=None, n_samples=None):
+        self.start_log(path)
+        self.append_log(path, self.trace_rows(n_samples)[:, chain], emp)
+
+    def start_log(self, path):
         with open(path, "w") as f:
+            csv.writer(f, delimiter='\t').writerow(self.log_head())
+
+    def append_log(self, path, tr, emp=None):
+        """Append the rows of one window and push them to disk (the reference flushes and fsyncs every sample,
+        DD:236-238)."""
+        import os
+        rows = self.log_rows_from(tr, emp)
+        if not rows:
+            return
+        with open(path, "a") as f:
             w = csv.writer(f, delimiter='\t')
-            w.writerow(head)
-            for row in self.log_rows(chain, emp, n_samples):
+            for row in rows:
                 w.writerow([int(row[0])] + [float(v) for v in row[1:]])
+            f.flush()
+            os.fsync(f.fileno())

@@ -750,3 +750,154 @@ def test_parametric_samplers_resume_and_sharding(G, golden_dir, tmp_path, kind):
     assert torch.equal(bits(shard.trace[:, 0]), bits(full.trace[:, 4])) and torch.equal(bits(shard.trace[:, 1]), bits(full.trace[:, 5]))
     for e in (full, b, shard):
         e.close()
+
+
+def _accepted_rates(snap, n_bins, C):
+    from oracle import literate_oracle as lo
+    lam = np.stack([snap["L"][c][lo.get_rate_index(np.floor(snap["tL"][c]), n_bins)] for c in range(C)])
+    mu = np.stack([snap["M"][c][lo.get_rate_index(np.floor(snap["tM"][c]), n_bins)] for c in range(C)])
+    return lam, mu
+
+
+@pytest.mark.parametrize("engine,C,team,n_lin", [("spec", 128, 4, 100_000), ("persistent4", 1024, 0, 100_000),
+                                                ("spec", 6, 8, 1_300_000), ("persistent4", 24, 0, 1_300_000)])
+def test_general_times_off_grid_against_the_oracle_at_size(engine, C, team, n_lin):
+    """ARBITRARY fp64 lineage times (uniform jitter, NOT on the 2^-32 grid the packing is exact on) at the size of
+    bench.py's cfg4_general (100k lineages: 1024 chains under the four-chain kernel, the 128-chain shard under the
+    speculative kernel in teams of 4) and at 1.3 million lineages: the persistent engines carry the in-bin fractions as
+    32-bit fixed point (csrc/lr_pack.hip), narrower than the reference's fp64, so the log-likelihood EVERY chain carries
+    for its accepted state is checked against the ORACLE's fp64 per-lineage evaluation (BDIx:124-146 form) of that state
+    on the raw times, at the north star's 1e-9 relative."""
+    from literate_amd import synth
+    from literate_amd.engine import ChainEngine
+    from oracle import literate_oracle as lo
+    rng = np.random.default_rng(7)
+    ts, te, _ = synth.make_lineages(n_lin, n_bins=128, n_shifts=20, seed=0 if n_lin == 100_000 else 4)
+    ts = ts + rng.uniform(0.0, 1.0, n_lin) * 0.999                      # as bench.py make_workload("cfg4_general")
+    te = np.maximum(np.ceil(te) - 1.0 + rng.uniform(1e-3, 0.999, n_lin), ts + 1e-3)
+    assert np.any(np.round(ts * 2.0 ** 32) != ts * 2.0 ** 32)           # off the grid
+    n_it = 120 if n_lin == 100_000 else 40
+    eng = ChainEngine(ts, te, C, model=0, seed=2026, s_freq=10, n_trace_slots=n_it // 10, engine=engine, team=team)
+    assert not eng.unit_resolution and eng.layout.table_mode == 2
+    assert eng.layout.persistent == (3 if engine == "spec" else 2)
+    if team:
+        assert eng.layout.team_blocks == team
+    eng.init(); eng.steps(n_it // 2); eng.steps(n_it - n_it // 2)
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it) and np.all(snap["accepted"] > 0)
+    br = eng.br_length.cpu().numpy()
+    t0o, sp, ex, bro = lo.bin_events_cli(ts, te)
+    assert t0o == eng.t0 and np.allclose(br, bro, rtol=1e-12)
+    lam, mu = _accepted_rates(snap, eng.n_bins, C)
+    pre = lo.lineage_bins(ts, te, float(t0o), eng.n_bins)
+    worst = 0.0
+    for c in range(C):
+        ref = lo.per_lineage_loglik(ts, te, float(t0o), lam[c], mu[c], 0, bro, pre=pre)
+        worst = max(worst, abs(snap["likA"][c] - ref) / abs(ref))
+    assert worst < 1e-9, worst
+    eng.close()
+
+
+@pytest.mark.parametrize("model", [1, 2, 3])
+def test_cfg4_full_size_other_models_under_the_four_chain_kernel(model):
+    """Models 1, 2 and 3 at the bench size (1024 chains x 100k lineages, the four-chain persistent kernel; model 0 is
+    test_cfg4_full_size_1024_chains_100k_lineages): the accepted log-likelihood of EVERY chain against an independent
+    evaluation of its accepted state by lr_bd_loglik_batch, a sample of chains against the oracle's binned
+    calc_likelihood (LRF:137-162; model 3 on the te < end_time statistics, LRF:529-546), and two chains row by row
+    against the oracle loop."""
+    from literate_amd import ops, synth
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import literate_oracle as lo
+    from oracle import mcmc_oracle as mo
+    ts, te, _ = synth.make_lineages(100_000, n_bins=128, n_shifts=20, seed=0)
+    n_it, seed, C = 100, 2026, 1024
+    eng = ChainEngine(ts, te, C, model=model, seed=seed, s_freq=1, n_trace_slots=n_it, engine="persistent4")
+    assert eng.layout.persistent == 2 and eng.unit_resolution
+    eng.init(); eng.steps(60); eng.steps(n_it - 60)
+    tr = eng.trace_rows()
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it) and np.all(snap["accepted"] > 0) and np.all(np.isfinite(snap["likA"]))
+    t0, sp, ex, br = lo.bin_events_cli(ts, te)
+    stats = dict(sp=sp, ex=ex, br=br)
+    if model == 3:
+        stats["ex_dead"], stats["br_dead"] = lo.bin_events_dead(ts, te, te.max())
+    lam, mu = _accepted_rates(snap, eng.n_bins, C)
+    lik = ops.bd_loglik_batch(eng.ts, eng.te, eng.t0, lam, mu, model, br_length=br, end_time=eng.end_time).cpu().numpy()
+    assert np.allclose(lik, snap["likA"], rtol=1e-9)
+    for c in range(0, C, 97):
+        with np.errstate(all="ignore"):
+            assert lo.calc_likelihood(model, lam[c], mu[c], stats) == pytest.approx(snap["likA"][c], rel=1e-9)
+    for c in (2, 1021):
+        with np.errstate(all="ignore"):
+            ref = mo.run_mcmc(stats, ts.min(), te.max(), mo.Settings(model_BDI=model), mo.PhiloxDraws(seed, c), n_it, 1, k_max=32)
+        for i in range(n_it):
+            head, s_row, e_row = split_trace_row(tr[i, c])
+            assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9), (c, i)
+    eng.close()
+
+
+def test_cfg5_ddrate_sampler_at_size():
+    """BASELINE.json configs[4] at its size, the SAMPLER (DD:124-241; the likelihood alone is
+    test_cfg5_ddrate_50k_lineages_256_states): DDRateEngine on bench.py's cfg5 workload - 50k synthetic lineages,
+    256 chains, -m_birth 2 -m_death 2, the engine the bench line is quoted on.  Three chains row by row (scalars and the
+    4 x n_bins per-bin columns) against the oracle loop fed the same Philox draws, and all 256 accepted parameter
+    vectors re-evaluated by lr_dd_rates + lr_bd_loglik_batch (other kernels) and by the oracle's binned
+    likelihood_function (DD:71-107)."""
+    from literate_amd import ops, synth
+    from literate_amd.ddrate import DDRateEngine
+    from oracle import dd_mcmc_oracle as ddo
+    from oracle import literate_oracle as lo
+    ts, te, _ = synth.make_lineages(50_000, n_bins=64, n_shifts=6, seed=0)
+    n_it, s, seed, C = 600, 4, 2026, 256
+    eng = DDRateEngine(ts, te, float(ts.min()), float(te.max()), C, m_birth=2, m_death=2, seed=seed, s_freq=s,
+                       n_trace_slots=n_it // s)
+    assert eng.layout.persistent == 3          # the speculative kernel, as in bench.py's configs.cfg5
+    o, p, nsp, nex, dt, nb, tr_range = lo.create_bins(float(ts.min()), float(te.max()), ts, te, 0)
+    assert np.array_equal(eng.n_spec, nsp) and np.array_equal(eng.DT, dt) and (eng.origin, eng.present) == (o, p)
+    eng.init(); eng.steps(250); eng.steps(n_it - 250)
+    with np.errstate(all="ignore"):
+        emp = (nsp / dt, nex / dt)
+    moved = 0
+    for c in (0, 101, 255):
+        ref = ddo.run_dd_mcmc(nsp, nex, dt, tr_range, o, p, 2, 2, ddo.PhiloxDraws(seed, c), n_it, s, emp=emp)
+        got = eng.log_rows(c, emp=emp)
+        assert len(got) == len(ref) == n_it // s
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert g[0] == r[0]
+            assert np.allclose(g[1:-3], r[1:-3], rtol=1e-9, atol=1e-9, equal_nan=True), (c, i, g[:14], r[:14])
+            assert np.allclose(g[-3:], r[-3:], rtol=1e-7, atol=1e-9, equal_nan=True)
+        moved += len(set(np.round(np.array(ref)[:, 2], 6)))
+    assert moved > 3 * 20
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it)
+    args = np.stack([snap["L"][c][:8] for c in range(C)])
+    b, d, ni, nf = ops.dd_rates(args, dt, 2, 2)
+    lik = ops.bd_loglik_batch(ts, te, o, b, d, 2).cpu().numpy()
+    assert np.allclose(lik, snap["likA"], rtol=1e-9)
+    for c in range(0, C, 17):
+        with np.errstate(all="ignore"):
+            ref = lo.dd_likelihood_function(args[c], nsp, nex, dt, tr_range, 2, 2)
+        assert ref[0].sum() == pytest.approx(snap["likA"][c], rel=1e-9)
+    eng.close()
+
+
+def test_kmax_cap_raises_the_warning_word():
+    """The device holds at most LR_KMAX = 32 rates per process (the reference is unbounded, LRF:29-47): an add-shift
+    proposed from a state at the cap is rejected and the engine's warning word says so; a run that never gets there
+    carries no warning."""
+    from literate_amd import _hip, synth
+    from literate_amd.engine import ChainEngine
+    ts, te, _ = synth.make_lineages(3000, n_bins=200, n_shifts=4, seed=2)
+    C = 8
+    for engine in ("launch", "persistent4", "spec"):
+        eng = ChainEngine(ts, te, C, model=0, seed=4, s_freq=100, n_trace_slots=4, engine=engine, poisson_HP=200.0)
+        t = np.linspace(eng.start_time, eng.end_time, 33)          # 32 rates per process: every add-shift hits the cap
+        eng.init([np.full(32, .3)] * C, [np.full(32, .1)] * C, [t] * C, [t] * C)
+        assert eng.warnings() == 0
+        eng.steps(400)
+        assert eng.warnings() & _hip.LR_WARN_KCAP, engine
+        assert "truncated" in eng.warning_text()
+        eng.init()                                                     # a fresh run clears the word
+        eng.steps(50)
+        assert eng.warnings() == 0
+        eng.close()

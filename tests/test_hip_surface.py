@@ -103,7 +103,7 @@ def test_cli_end_to_end(G, tmp_path):
         for i, (a, b) in enumerate(zip(ts, te)):
             f.write("%d\t%g\t%g\n" % (i, root - a, root - b))
     cmd = [sys.executable, os.path.join(ROOT, "LiteRateForward.py"), "-d", str(data), "-TBP", "-n", "400", "-s", "20",
-           "-p", "200", "-seed", "31", "-model_BDI", "2", "--chains", "3", "--combine", "0.25"]
+           "-p", "200", "-seed", "31", "-model_BDI", "2", "--chains", "3", "--combine", "0.25", "--block", "90"]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, timeout=300)
     logdir = tmp_path / "literate_mcmc_logs"
     comb = open(logdir / "COMBINED_mcmc.log").read().splitlines()
@@ -125,6 +125,60 @@ def test_cli_end_to_end(G, tmp_path):
         assert np.allclose(mc[:, 13:], np.array(ref["mcmc"])[:, 13:], rtol=1e-8, equal_nan=True)
         sp_rows = [np.array(l.split(), float) for l in open(logdir / ("example_BDk_c%d_sp_rates.log" % c))]
         assert all(np.allclose(a, b, rtol=1e-10) for a, b in zip(sp_rows, ref["sp"]))
+    shutil.rmtree(logdir)
+
+
+def test_cli_logs_are_streamed_and_survive_a_kill(G, tmp_path):
+    """The logs are written and flushed window by window while the run goes on (the reference flushes every sample,
+    LRF:334-359): the files are read while the CLI is still running, then the process is KILLED mid-run - what it leaves
+    are complete, parseable logs whose rows are a prefix of the oracle loop's trajectory, up to the last flushed window."""
+    import signal
+    import time
+    from oracle import mcmc_oracle as mo
+    ts, te = G["example_TBP/ts"], G["example_TBP/te"] - 0.5
+    data = tmp_path / "example.tsv"
+    with open(data, "w") as f:
+        f.write("id\tts\tte\n")
+        for i, (a, b) in enumerate(zip(ts, te)):
+            f.write("%d\t%g\t%g\n" % (i, 24.0 - a, 24.0 - b))
+    n_total, s, block = 40_000_000, 500, 20_000                 # would take minutes: it is killed long before the end
+    cmd = [sys.executable, "-u", os.path.join(ROOT, "LiteRateForward.py"), "-d", str(data), "-TBP", "-n", str(n_total), "-s", str(s),
+           "-p", "1000", "-seed", "31", "-model_BDI", "2", "--chains", "2", "--block", str(block)]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    logdir = tmp_path / "literate_mcmc_logs"
+    windows = 0
+    try:
+        t_start = time.time()
+        for line in proc.stdout:                                 # the state line of a window follows its flush
+            if line.split() and line.split()[0].isdigit() and int(line.split()[0]) % block == 0 and "\t" not in line[:1]:
+                windows += 1
+                if windows == 3:
+                    break
+            assert time.time() - t_start < 240
+        assert proc.poll() is None                               # still running: the files are read in flight
+        in_flight = [open(logdir / ("example_BDk_c%d_mcmc.log" % c)).read() for c in range(2)]
+        for text in in_flight:
+            assert text.endswith("\n") and len(text.splitlines()) >= 1 + 3 * (block // s)
+    finally:
+        proc.send_signal(signal.SIGKILL)
+        proc.wait()
+    stats = dict(sp=G["example_TBP/sp"], ex=G["example_TBP/ex"], br=G["example_TBP/br"])
+    emp = (G["example_TBP/B_EMP"], G["example_TBP/D_EMP"])
+    for c in range(2):
+        text = open(logdir / ("example_BDk_c%d_mcmc.log" % c)).read()
+        assert text.endswith("\n") and text.startswith(in_flight[c])      # appended to, never rewritten
+        mc = np.loadtxt(logdir / ("example_BDk_c%d_mcmc.log" % c), skiprows=1)
+        n_rows = mc.shape[0]
+        assert mc.shape[1] == 16 and n_rows >= 3 * (block // s) and n_rows % (block // s) == 0     # whole windows only
+        assert np.array_equal(mc[:, 0], np.arange(n_rows) * s)
+        sp_rows = [np.array(l.split(), float) for l in open(logdir / ("example_BDk_c%d_sp_rates.log" % c))]
+        ex_rows = [np.array(l.split(), float) for l in open(logdir / ("example_BDk_c%d_ex_rates.log" % c))]
+        assert abs(len(sp_rows) - n_rows) <= block // s and abs(len(ex_rows) - n_rows) <= block // s   # (killed between files)
+        n_chk = 3 * (block // s)
+        with np.errstate(all="ignore"):
+            ref = mo.run_mcmc(stats, 0.0, 24.5, mo.Settings(model_BDI=2), mo.PhiloxDraws(31, c), n_chk * s, s, emp=emp, k_max=32)
+        assert np.allclose(mc[:n_chk, :13], np.array(ref["mcmc"])[:, :13], rtol=1e-9)
+        assert all(np.allclose(a, b, rtol=1e-10) for a, b in zip(sp_rows[:n_chk], ref["sp"]))
     shutil.rmtree(logdir)
 
 
@@ -237,8 +291,9 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     ranks to device 0 and stages the gather through the host.  The real runs use one rank per GPU over RCCL."""
     import json
     env = dict(os.environ, LR_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "300", "--warmup", "50",
+    env.pop("WORLD_SIZE", None)
+    # plain `python bench.py --gpus 2`, as the driver invokes it: bench.py starts its own two ranks (before touching the GPU)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "300", "--warmup", "50",
            "--chains", "64", "--workload", "cfg3", "--no-cpu-baseline"]
     out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=300, env=env).stdout
     lines = [l for l in out.splitlines() if l.startswith("{")]

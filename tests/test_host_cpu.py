@@ -225,3 +225,70 @@ def test_trace_gather_world2_gloo(total):
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert ret.get(timeout=5) is True
+
+
+def test_planner_refuses_teams_beyond_the_device():
+    """The speculative kernel's teams spin on each other's partial sums, so all blocks of a launch must be resident:
+    the planner never plans more blocks (chain pairs x team size) than the device has compute units, drops the
+    speculative kernel when the pairs alone exceed them, and refuses a team size that is not 1, 2, 4 or 8."""
+    import ctypes as C
+    from literate_amd import _hip
+    lib = _hip.load()
+
+    def layout(n_chains, team=0, cus=None, engine=0):
+        cfg = _hip.McmcConfig(n_lineages=100_000, n_bins=128, n_chains=n_chains, model=0, use_rate_HP=1, s_freq=100,
+                              n_trace_slots=4, update_fraction=0.75, t0=0.0, start_time=0.0, end_time=128.5, seed=1,
+                              unit_resolution=1, frac_birth=0.0, frac_death=0.5, team_request=team, engine_mode=engine)
+        lay = _hip.McmcLayout()
+        if cus is None:
+            os.environ.pop("LR_DEVICE_CUS", None)
+        else:
+            os.environ["LR_DEVICE_CUS"] = str(cus)
+        try:
+            return lib.lr_mcmc_query_layout(C.byref(cfg), C.byref(lay)), lay
+        finally:
+            os.environ.pop("LR_DEVICE_CUS", None)
+
+    rc, lay = layout(128)
+    assert rc == 0 and lay.persistent == 3 and lay.team_blocks == 4            # 64 pairs x 4 = 256 blocks on 256 CUs
+    for cus in (128, 100, 64):
+        rc, lay = layout(128, cus=cus)
+        assert rc == 0 and lay.persistent == 3 and 64 * lay.team_blocks <= cus, (cus, lay.team_blocks)
+    rc, lay = layout(128, cus=32)                                               # fewer CUs than chain pairs: no teams at all
+    assert rc == 0 and lay.persistent != 3
+    rc, lay = layout(128, team=8)                                               # 64 x 8 > 256: the request cannot be met
+    assert rc == 0 and not (lay.persistent == 3 and lay.team_blocks == 8)
+    rc, lay = layout(128, team=3)
+    assert rc == _hip.LR_ERR_SIZE
+    rc, lay = layout(16, team=8, engine=5)
+    assert rc == 0 and lay.persistent == 3 and lay.team_blocks == 8
+
+
+def test_bench_gpus_n_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher's environment (how the driver invokes it) must start N ranks itself
+    - torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1 - from a parent that has not imported torch,
+    and exit with the children's code."""
+    import importlib
+    import sys
+    monkeypatch.syspath_prepend(ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    torch_loaded_before = "torch" in sys.modules
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 1024
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch_loaded_before:
+        assert "torch" not in sys.modules          # the parent never got as far as importing torch

@@ -188,7 +188,8 @@ typedef struct lr_mcmc_config {
     int32_t sampler;          /* 0 = runMCMC (LRF), 1 = DDRate, 2 = trend_rate (below) */
     int32_t m_birth;          /* -m_birth (DD:25); sampler 2: -const_B flag          */
     int32_t m_death;          /* -m_death (DD:26); sampler 2: -const_D flag          */
-    int32_t team_request;     /* speculative kernel: blocks per chain pair, 0 = the library chooses (1, 2, 4 or 8)   */
+    int32_t team_request;     /* speculative kernel: bits 0-7 blocks per team (1, 2, 4, 8), bits 8-15 chains per team (1 or
+                               * 2); 0 in either field = the library chooses                                            */
     double dd_present;        /* PRESENT - as create_bins returns it (DD:36)        */
     double dd_init_death;     /* -fix_death (DD:27, 156)                            */
     /* sampler 2: the trend_rate.py loop (trend_rate.py:102-196): parameters [l_min,m_min,alpha,beta,delta,gamma],
@@ -226,6 +227,8 @@ typedef struct lr_mcmc_layout {
                            * engines on general lineage times: in-bin fractions packed as 32-bit fixed point)             */
     int64_t lineage_frac; /* [3][groups] uint4: fe' of the 7 slots + sum of fs (table_mode 2)                               */
     int64_t pack_tmp;     /* scratch of the lineage packing (two int32 per lineage + the scans' temporary storage)       */
+    int32_t spec_chains_per_team; /* speculative kernel: chains a team of blocks owns - 2 (a pair) or 1; 0 for the other engines */
+    int32_t reserved2;
 } lr_mcmc_layout;
 
 /* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */

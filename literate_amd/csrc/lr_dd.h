@@ -90,19 +90,12 @@ __device__ __forceinline__ double lr_dd_prior(double v, double origin, double pr
 // same table formats as lr_build_tables_segments_wave (general double2 entries, or unit-resolution entries `es`
 // doubles apart).  Lane l owns bins [l*P, (l+1)*P), P <= LR_DD_MAXP.
 #define LR_DD_MAXP 4
-template <class F>
+template <int CS = 2, class F>
 __device__ __forceinline__ void lr_rates_build_tables_wave(F rates, int n_bins, int H, double2* __restrict__ tab, int lane,
-                                                           int unit, double fs0, double fe0, int es, int dup = 0) {
+                                                           int unit, double fs0, double fe0, int es) {
     double* tabd = reinterpret_cast<double*>(tab);
-    // dup != 0: every entry a second time `dup` doubles further on (the speculative kernel's second pair table)
-    auto put_S = [&](int j, double v, double R) {
-        lr_put_S(tabd, unit, es, j, v, R, fs0);
-        if (dup) lr_put_S(tabd + dup, unit, es, j, v, R, fs0);
-    };
-    auto put_E = [&](int j, double v, double R) {
-        lr_put_E(tabd, unit, es, j, v, R, fe0);
-        if (dup) lr_put_E(tabd + dup, unit, es, j, v, R, fe0);
-    };
+    auto put_S = [&](int j, double v, double R) { lr_put_S<CS>(tabd, unit, es, j, v, R, fs0); };
+    auto put_E = [&](int j, double v, double R) { lr_put_E<CS>(tabd, unit, es, j, v, R, fe0); };
     const int P = (n_bins + LR_WAVE - 1) / LR_WAVE;
     const int b0 = min(lane * P, n_bins), b1 = min(b0 + P, n_bins);
     double br[LR_DD_MAXP], dr[LR_DD_MAXP];
@@ -134,15 +127,16 @@ __device__ __forceinline__ void lr_rates_build_tables_wave(F rates, int n_bins, 
     }
 }
 
+template <int CS = 2>
 __device__ inline void lr_dd_build_tables_wave(const lr_dd_params& p, const double* __restrict__ DT, int m_birth,
                                                int m_death, int n_bins, int H, double2* __restrict__ tab, int lane,
-                                               int unit, double fs0, double fe0, int es, int dup = 0) {
-    lr_rates_build_tables_wave(
+                                               int unit, double fs0, double fe0, int es) {
+    lr_rates_build_tables_wave<CS>(
         [&](int b, double* br, double* dr) {
             double ni, fr;
             lr_dd_bin_rates(p, (double)b, DT[b], m_birth, m_death, br, dr, &ni, &fr);
         },
-        n_bins, H, tab, lane, unit, fs0, fe0, es, dup);
+        n_bins, H, tab, lane, unit, fs0, fe0, es);
 }
 
 // ---- trend_rate.py: rates driven by a per-bin covariate ---------------------------------------

@@ -209,16 +209,21 @@ __host__ __device__ __forceinline__ int lr_tab_es(int mode, int H) { return mode
 // (lr_plan_scan picks H so that n_bins <= 64 * lr_bins_per_lane(H)): a kernel instantiated for H needs one builder only.
 __host__ __device__ constexpr int lr_bins_per_lane(int H) { return H <= 40 ? 1 : (H <= 136 ? 2 : (H <= 264 ? 4 : 8)); }
 
+// CS = doubles between consecutive entries of ONE chain in the packed layouts: 2 in a pair table (the two chains of a
+// pair side by side), 1 in a column of its own (the speculative kernel keeps every candidate's column apart and lets the
+// scanner waves interleave the two that are selected)
 // birth-side entry j: value v = logB + cum, exposure rate R
+template <int CS = 2>
 __device__ __forceinline__ void lr_put_S(double* tabd, int mode, int so, int j, double v, double R, double fs0) {
-    if (mode == LR_TAB_UNIT) tabd[2 * j] = v + fs0 * R;
-    else if (mode == LR_TAB_PAIRGEN) tabd[2 * j] = v, tabd[2 * j + so] = R * LR_FRAC_SCALE;
+    if (mode == LR_TAB_UNIT) tabd[CS * j] = v + fs0 * R;
+    else if (mode == LR_TAB_PAIRGEN) tabd[CS * j] = v, tabd[CS * j + so] = R * LR_FRAC_SCALE;
     else reinterpret_cast<double2*>(tabd)[j] = make_double2(v, R);
 }
 // death-side entry j (H + bin + 1): value v = logD - cum, exposure rate R
+template <int CS = 2>
 __device__ __forceinline__ void lr_put_E(double* tabd, int mode, int so, int j, double v, double R, double fe0) {
-    if (mode == LR_TAB_UNIT) tabd[2 * j] = v - fe0 * R;
-    else if (mode == LR_TAB_PAIRGEN) tabd[2 * j] = v - R, tabd[2 * j + so] = R * LR_FRAC_SCALE;
+    if (mode == LR_TAB_UNIT) tabd[CS * j] = v - fe0 * R;
+    else if (mode == LR_TAB_PAIRGEN) tabd[CS * j] = v - R, tabd[CS * j + so] = R * LR_FRAC_SCALE;
     else reinterpret_cast<double2*>(tabd)[j] = make_double2(v, -R);
 }
 

@@ -765,7 +765,7 @@ static int lr_partition(int n_chains, int cb, bool fused_ok, int base[LR_MAX_PAR
 // launch shape of the engine: as lr_plan_scan, but when the pipelined schedule applies the lineage tiles are
 // sized so that the fused launches that run concurrently (one per partition: step blocks of one half + scan
 // blocks of the other) fill the resident block slots of the chip (256 CUs x 4 blocks) exactly once.
-static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k);
+static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k, int* team_cpb);
 static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, cfg->unit_resolution, p);
     if (rc) return rc;
@@ -786,7 +786,7 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
             while (q.unit == LR_TAB_UNIT && q.cb > 2 && q.cb / 2 >= cfg->n_chains) q.cb >>= 1;
             q.tab_stride = q.unit == LR_TAB_UNIT ? q.H : 2 * q.H;
             q.groups = (cfg->n_chains + q.cb - 1) / q.cb;
-            if (lr_persist_variant(cfg, q, nullptr) != 0) {
+            if (lr_persist_variant(cfg, q, nullptr, nullptr) != 0) {
                 *p = q;
                 return LR_OK;
             }
@@ -797,7 +797,7 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
         // in-bin fractions packed as 32-bit fixed point; if none applies the plan stays the launch-based engine's
         lr_scan_plan q = *p;
         q.unit = LR_TAB_PAIRGEN, q.cb = 4;
-        if (lr_persist_variant(cfg, q, nullptr) != 0) {
+        if (lr_persist_variant(cfg, q, nullptr, nullptr) != 0) {
             *p = q;
             return LR_OK;
         }
@@ -813,7 +813,7 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
         while (q.unit == LR_TAB_UNIT && q.cb > 2 && q.cb / 2 >= cfg->n_chains) q.cb >>= 1;
         q.tab_stride = q.unit == LR_TAB_UNIT ? q.H : 2 * q.H;
         q.groups = (cfg->n_chains + q.cb - 1) / q.cb;
-        if (lr_persist_variant(cfg, q, nullptr) != 0) {
+        if (lr_persist_variant(cfg, q, nullptr, nullptr) != 0) {
             *p = q;
             return LR_OK;
         }
@@ -850,36 +850,64 @@ static int lr_device_cus() {
     return 256;
 }
 
-// Speculative team kernel (lr_spec.h): one block per CU, a chain pair owned by a team of k blocks.  Model of an
-// iteration in microseconds, fitted to MI355X measurements over 1k..200k lineages x k = 1, 2, 4, 8
-// (scratch/exp_teams.py, pair-slot group formats): with `trips` = groups / k / 512 scanner lanes,
-//     unit resolution   k = 1: max(3.0, 2.95 + 0.222 trips)     k > 1: max(3.4,  3.20 + 0.205 trips)
-//     general times     k = 1: max(3.0, 3.28 + 0.464 trips)     k > 1: max(3.45, 2.90 + 0.478 trips)
-// (the floor is the candidate build; a team pays the exchange behind its last scanner).  The parametric samplers build
-// their candidates a little more slowly (+0.25; scratch/exp_dd_team.py).  Returns the modelled time and the best team size in *k (0 = not applicable).
-static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general = false) {
-    const int pairs = (cfg->n_chains + 1) / 2;
+// Speculative team kernel (lr_spec.h): one block per CU, a chain pair - or a single chain - owned by a team of k blocks.
+// Model of an iteration in microseconds, fitted to MI355X measurements over 1k..200k lineages x k = 1, 2, 4, 8 x chains per
+// team (scratch/exp_teams.py, round 3: candidates with a column of their own, no-op moves copying it): with `trips` =
+// groups / k / 512 scanner lanes,
+//                        a team per PAIR                                  a team per CHAIN
+//     unit resolution    k = 1: max(2.95, 2.93 + 0.171 trips)             k = 1: max(2.40, 2.30 + 0.172 trips)
+//                        k > 1: max(3.40, 3.20 + 0.205 trips)             k > 1: max(3.00, 2.95 + 0.17 trips)
+//     general times      k = 1: max(2.90, 2.85 + 0.434 trips)             k = 1: max(2.50, 2.30 + 0.44 trips)
+//                        k > 1: max(3.45, 2.90 + 0.478 trips)             k > 1: max(3.10, 2.90 + 0.44 trips)
+//     DDRate / trend     k = 1: max(2.60, 2.70 + 0.18 trips)              k = 1: max(2.35, 2.25 + 0.182 trips)
+//                        k > 1: max(3.05, 2.70 + 0.21 trips)              k > 1: max(2.90, 2.65 + 0.18 trips)
+// (the floor is the candidate build - shorter with one chain per CU: half the candidate waves, and a no-op move copies its
+// column -; a team pays the exchange behind its last scanner; a team per chain scans for one chain what a team per pair
+// scans for two, so it needs the CUs: chains x k <= CUs).  Returns the modelled time, the best team size in *k
+// (0 = not applicable) and the chains per team.
+static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general = false, int* cpb_out = nullptr) {
     const int cus = lr_device_cus();
     *k_out = 0;
-    if (pairs > cus) return 1e30;
+    if (cpb_out) *cpb_out = 2;
     static const int k_env0 = lr_env_int("LR_SPEC_TEAM", 0);
     // (lr_check_cfg has refused a request that is not 1, 2, 4 or 8; a malformed LR_SPEC_TEAM is ignored)
-    const int k_env = cfg->team_request > 0 ? cfg->team_request : ((k_env0 == 1 || k_env0 == 2 || k_env0 == 4 || k_env0 == 8) ? k_env0 : 0);
+    const int k_req = cfg->team_request & 0xff, cpb_req = (cfg->team_request >> 8) & 0xff;
+    const int k_env = k_req > 0 ? k_req : ((k_env0 == 1 || k_env0 == 2 || k_env0 == 4 || k_env0 == 8) ? k_env0 : 0);
+    static const int cpb_env0 = lr_env_int("LR_SPEC_CPB", 0);       // 1 / 2 force the chains per team (A/B runs)
+    const int cpb_env = cpb_req > 0 ? cpb_req : cpb_env0;
     const double n8 = (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP);      // groups, for lineages sorted by birth time
-    const double extra = cfg->sampler ? 0.25 : 0.0;
     double best = 1e30;
-    for (int k = 1; k <= LR_TEAM_MAX; k *= 2) {
-        if (pairs * k > cus) break;
-        if (k_env > 0 && k != k_env) continue;
-        // (groups beyond an XCD's 4 MB of L2 stream from HBM with one group of prefetch per lane: measured 0.32 instead of
-        // 0.205 us per trip at 10M lineages, scratch/exp_fewchains.py)
-        const double slow = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) > 4.0e6 ? 1.55 : 1.0;
-        const double trips = slow * n8 / k / (double)(LR_SPEC_THREADS - 256);
-        double t;
-        if (!general) t = (k == 1) ? fmax(3.0, 2.95 + 0.222 * trips) : fmax(3.4, 3.20 + 0.205 * trips);
-        else t = (k == 1) ? fmax(3.0, 3.28 + 0.464 * trips) : fmax(3.45, 2.90 + 0.478 * trips);
-        t += extra;
-        if (t < best - 0.05) best = t, *k_out = k;
+    for (int cpb = 1; cpb <= 2; ++cpb) {
+        if (cpb_env != 0 && cpb != cpb_env) continue;
+        const int teams = (cfg->n_chains + cpb - 1) / cpb;
+        if (teams > cus) continue;
+        double best_c = 1e30;
+        int k_c = 0;
+        for (int k = 1; k <= LR_TEAM_MAX; k *= 2) {
+            if (teams * k > cus) break;
+            if (k_env > 0 && k != k_env) continue;
+            // (groups beyond an XCD's 4 MB of L2 stream from HBM with one group of prefetch per lane: measured 0.32 instead of
+            // 0.205 us per trip at 10M lineages, scratch/exp_fewchains.py)
+            const double slow = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) > 4.0e6 ? 1.55 : 1.0;
+            const double trips = slow * n8 / k / (double)(LR_SPEC_THREADS - 256);
+            double t;
+            if (cfg->sampler != 0) {
+                if (cpb == 2) t = (k == 1) ? fmax(2.60, 2.70 + 0.18 * trips) : fmax(3.05, 2.70 + 0.21 * trips);
+                else t = (k == 1) ? fmax(2.35, 2.25 + 0.182 * trips) : fmax(2.90, 2.65 + 0.18 * trips);
+                if (general) t += 0.26 * trips;
+            } else if (!general) {
+                if (cpb == 2) t = (k == 1) ? fmax(2.95, 2.93 + 0.171 * trips) : fmax(3.40, 3.20 + 0.205 * trips);
+                else t = (k == 1) ? fmax(2.40, 2.30 + 0.172 * trips) : fmax(3.00, 2.95 + 0.17 * trips);
+            } else {
+                if (cpb == 2) t = (k == 1) ? fmax(2.90, 2.85 + 0.434 * trips) : fmax(3.45, 2.90 + 0.478 * trips);
+                else t = (k == 1) ? fmax(2.50, 2.30 + 0.44 * trips) : fmax(3.10, 2.90 + 0.44 * trips);
+            }
+            if (t < best_c - 0.05) best_c = t, k_c = k;
+        }
+        if (k_c > 0 && best_c < best) {
+            best = best_c, *k_out = k_c;
+            if (cpb_out) *cpb_out = cpb;
+        }
     }
     return best;
 }
@@ -932,14 +960,15 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
 // block hides the chain step under the other pair's scan, so beyond 256 pairs it wins while a scan is about as long as a
 // step (~70k..270k lineages, whole rounds of 1024 chains); the two-chain kernel, two blocks per CU, is ahead on short
 // scans (the step is all there is), on long ones (every wave scans) and on remainders of at most 512 chains.
-static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k) {
+static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k, int* team_cpb = nullptr) {
     if (team_k) *team_k = 0;
+    if (team_cpb) *team_cpb = 0;
     if (!lr_persist_eligible(cfg, p)) return 0;
     static const int p4_env = lr_env_int("LR_PERSIST4", -1);
     static const int spec_env = lr_env_int("LR_SPEC", -1);
     const bool general = p.unit == LR_TAB_PAIRGEN;   // general times: the speculative (H <= 136) and four-chain kernels only
-    int k = 0;
-    const double t_spec = (p.H > (general ? 136 : 264)) ? 1e30 : lr_spec_model(cfg, &k, general);
+    int k = 0, cpb = 2;
+    const double t_spec = (p.H > (general ? 136 : 264)) ? 1e30 : lr_spec_model(cfg, &k, general, &cpb);
     if (k > 0 && t_spec < 1e29 && cfg->engine_mode != 3 && cfg->engine_mode != 4 && spec_env != 0) {
         // the two-chain kernel with all 16 waves scanning wins only on long scans without room for a team
         // (measured at 256 pairs, 10k..1M lineages: 5.1 + 0.26 us per trip of its 1024 scanner lanes, 4.9 at least; the
@@ -947,6 +976,7 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, 
         const double t_wide = general ? 1e30 : fmax(4.9, 5.1 + 0.262 * (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP) / 1024.0);
         if (cfg->engine_mode == 5 || spec_env == 1 || t_spec <= t_wide) {
             if (team_k) *team_k = k;
+            if (team_cpb) *team_cpb = cpb;
             return 3;
         }
     }
@@ -967,8 +997,12 @@ static int lr_check_cfg(const lr_mcmc_config* cfg) {
     if (cfg->t0 != floor(cfg->t0)) return LR_ERR_T0;
     if (!(cfg->end_time > cfg->start_time)) return LR_ERR_SIZE;
     if (cfg->sampler < 0 || cfg->sampler > 2) return LR_ERR_MODEL;
-    if (cfg->team_request != 0 && cfg->team_request != 1 && cfg->team_request != 2 && cfg->team_request != 4 && cfg->team_request != 8)
-        return LR_ERR_SIZE;       // a team is 1, 2, 4 or 8 blocks (LR_TEAM_MAX)
+    {
+        const int k_req = cfg->team_request & 0xff, cpb_req = (cfg->team_request >> 8) & 0xff;
+        if (cfg->team_request < 0 || cfg->team_request > 0xffff) return LR_ERR_SIZE;
+        if (k_req != 0 && k_req != 1 && k_req != 2 && k_req != 4 && k_req != 8) return LR_ERR_SIZE;   // a team is 1, 2, 4 or 8 blocks (LR_TEAM_MAX)
+        if (cpb_req > 2) return LR_ERR_SIZE;                                                           // ... of one chain or a pair
+    }
     if (cfg->sampler != 0) {
         if (cfg->model != LR_MODEL_KEIDING) return LR_ERR_MODEL;
         if (cfg->n_bins > LR_DD_MAXP * LR_WAVE) return LR_ERR_SIZE;
@@ -1003,14 +1037,15 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
     out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
     out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
-    int team_k = 0;
-    out->persistent = lr_persist_variant(cfg, p, &team_k);
+    int team_k = 0, team_cpb = 0;
+    out->persistent = lr_persist_variant(cfg, p, &team_k, &team_cpb);
+    out->spec_chains_per_team = team_cpb, out->reserved2 = 0;
     if (p.unit == LR_TAB_PAIRGEN && out->persistent == 0) return LR_ERR_STATE;   // (planned only when a kernel takes it)
     out->team_blocks = team_k;
     out->table_mode = p.unit;
     out->status = o, o += 256;   // engine status word
     // team exchange granules of the speculative kernel: [2 parities][pairs][LR_TEAM_MAX][LR_SPEC_GRANULES] x 8 bytes
-    out->xchg = o, o += (team_k > 1) ? lr_align_up64(2ll * ((C + 1) / 2) * LR_TEAM_MAX * LR_SPEC_GRANULES * 8, 256) : 0;
+    out->xchg = o, o += (team_k > 1) ? lr_align_up64(2ll * C * LR_TEAM_MAX * LR_SPEC_GRANULES * 8, 256) : 0;   // (room for a team per chain)
     out->total_bytes = o;
     out->table_stride = p.tab_stride;
     out->tiles = p.tiles;

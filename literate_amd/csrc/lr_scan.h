@@ -727,24 +727,26 @@ __device__ __forceinline__ void lr_pair_planes_block_general(double2* tab, int H
         tab[5 * H + j] = make_double2(2.0 * sl.x, 2.0 * sl.y);
     }
 }
-// The six-plane scan table of a block from a table in the global-memory layout `src` ([S | E], general times: + their
-// slopes): copies the planes and derives the pair planes from `src` itself - no lane depends on another's writes.
+// The six-plane scan table of a block from the COLUMNS of its two chains (`c0`, `c1`: one chain's [S | E] planes - general
+// times: + their slopes - entries 1 double apart; c1 = nullptr: no second chain, its half of every entry is zero): copies
+// the planes side by side and derives the pair planes from the columns themselves - no lane depends on another's writes.
 template <bool GENERAL>
-__device__ __forceinline__ void lr_build_scan_table(double2* scan, const double2* src, int H, int n_bins, int tid, int n_threads) {
+__device__ __forceinline__ void lr_build_scan_table(double2* scan, const double* c0, const double* c1, int H, int n_bins, int tid,
+                                                    int n_threads) {
+    auto at = [&](int i) { return make_double2(c0[i], c1 ? c1[i] : 0.0); };
     if (GENERAL) {
-        for (int i = tid; i < 4 * H; i += n_threads) scan[i < 2 * H ? i : i + H] = src[i];
+        for (int i = tid; i < 4 * H; i += n_threads) scan[i < 2 * H ? i : i + H] = at(i);
         for (int j = tid; j <= n_bins + 1; j += n_threads) {
-            const double2 v = src[H + j], sl = src[3 * H + j];
+            const double2 v = at(H + j), sl = at(3 * H + j);
             scan[2 * H + j] = make_double2(2.0 * v.x, 2.0 * v.y);
             scan[5 * H + j] = make_double2(2.0 * sl.x, 2.0 * sl.y);
         }
     } else {
-        for (int i = tid; i < 2 * H; i += n_threads) scan[i] = src[i];
-        const double2* E = src + H;
+        for (int i = tid; i < 2 * H; i += n_threads) scan[i] = at(i);
         for (int j = tid; j <= n_bins + 1; j += n_threads) {
             double2 v[LR_PAIR_DMAX + 1];
 #pragma unroll
-            for (int d = 0; d <= LR_PAIR_DMAX; ++d) v[d] = E[min(j + d, n_bins + 1)];
+            for (int d = 0; d <= LR_PAIR_DMAX; ++d) v[d] = at(H + min(j + d, n_bins + 1));
 #pragma unroll
             for (int d = 0; d <= LR_PAIR_DMAX; ++d)
                 if (j + d <= n_bins + 1) scan[(2 + d) * H + j] = make_double2(v[0].x + v[d].x, v[0].y + v[d].y);

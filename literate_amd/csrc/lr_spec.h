@@ -4,8 +4,10 @@
 // taken off the critical path by speculation: while the scanner waves score the pending proposal P, two candidate
 // waves per chain build the NEXT proposal for both outcomes - Q0 from the accepted state A (P rejected) and Q1 from P
 // (P accepted) - with their priors and lookup tables.  When the scan sums are in, every wave evaluates the
-// Metropolis-Hastings rule (a handful of flops on values in LDS), the pair table of the selected candidates is
-// copied in place and the next scan starts.  The draws are addressed by (seed, chain, iteration, purpose), so both
+// Metropolis-Hastings rule (a handful of flops on values in LDS), the scanner waves lay the columns of the two selected
+// candidates side by side into the scan table and the next scan starts.  Every state in flight (accepted A, pending P,
+// candidates Q0, Q1) owns its column of lookup-table entries, so a candidate whose move changes no rate and no bin edge
+// (the no-op "times" moves, the Gibbs step) copies its base state's column instead of building one.  The draws are addressed by (seed, chain, iteration, purpose), so both
 // candidates consume exactly the draws the sequential loop would: trajectories are those of lr_chain_step_core.
 // Per iteration: max(candidate build, scan) + two barriers, instead of scan + step.
 //
@@ -71,7 +73,9 @@ struct lr_spec_args {
     unsigned long long* xchg;     // [2 parities][n_teams][LR_TEAM_MAX][LR_SPEC_GRANULES] granules (k > 1)
     unsigned int* status;         // engine status word: 0 ok, 1 = a team exchange timed out
     int team_blocks;              // k
-    int n_teams;                  // chain pairs
+    int n_teams;                  // teams = chains / cpb (rounded up)
+    int cpb;                      // chains per team: 2 (a pair: every table gather serves two chains) or 1 (as many teams
+                                  // as chains: half the candidate work per CU and an iteration as short as ONE chain's move)
 };
 
 __device__ __forceinline__ void lr_set_load(const lr_set* q, lr_rj_state& s, int lane) {
@@ -261,15 +265,14 @@ template <int H, int NW, int ENT>
 struct lr_spec_lds {
     static constexpr bool GENERAL_ENTRIES = ENT == 2;
     static constexpr int TAB = 2 * H * ENT;          // double2 per candidate pair table (the global-memory layout)
-    // Pair tables (S' entries [0,H), E' [H,2H); (.x, .y) = (chain 0, chain 1)) for every combination of outcomes, in two
-    // generations: pairs[g][d0][d1] holds candidate d0 of chain 0 beside candidate d1 of chain 1 for the iterations of
-    // parity g.  A candidate wave writes its column into the two tables that contain it, so after the decisions the
-    // scanners just switch to pairs[g][d0][d1]: no copy between the decision and the next scan.
-    double2 pairs[2][2][2][2 * H * ENT];   // S and E planes (general times: + their slopes), as in global memory
-    // what the scanner waves gather from: the six planes (lr_scan.h) of the table selected for this iteration, which they
-    // build behind the barrier (lr_build_scan_table) - the candidates write S and E only
+    static constexpr int COL = 2 * H * ENT;          // doubles per column: S' entries [0,H), E' [H,2H) (general times: + slopes)
+    // One column of lookup-table entries per state in flight, entries 1 double apart: cols[chain][set] belongs to
+    // sets[chain][set] - the accepted state, the pending proposal and the two candidates being built.
+    double cols[2][4][2 * H * ENT];
+    // what the scanner waves gather from: the six planes (lr_scan.h) of the two pending columns side by side, which they
+    // lay out behind the barrier (lr_build_scan_table) - the candidates write S and E only
     double2 scan[LR_UNIT_PLANES * H];
-    int cur_sel;                 // d0 * 2 + d1 of the pair table that stands when the kernel ends
+    int final_p[2];              // set that holds each chain's pending proposal when the kernel ends
     double red[NW][2];           // per scanner wave: partial sums of the two chains
     lr_spec_decision dec[2];     // [iteration parity]: what the deciding wave found
     double likA[2];              // log-likelihood of the accepted state of the two chains
@@ -292,6 +295,7 @@ struct lr_spec_ctx {
     long long n_iters;
     unsigned long long it0;      // iteration of the proposal pending at entry
     int c0, C, team, rank;
+    int n_act;                   // chains of this block: 1 or 2
 };
 
 // The scanner role (waves 4..NW-1): per iteration one pass over the block's slice of the lineages against the pending
@@ -310,19 +314,27 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int k_team = ctx.x.team_blocks;
     constexpr bool rj = RJ;
-    const bool act1 = ctx.c0 + 1 < ctx.C;
+    const bool act1 = ctx.n_act > 1;
     // Draw duty.  A block on its own is bound by its slowest wave before the barrier, so the duty is split over the last
     // four scanner waves, two per chain; in a team the last scanner to finish also runs the exchange and must not carry
     // more than its scan, so there the last two scanner waves (the smallest scan shares) take a chain each.
+    // A team per chain (cpb 1): candidate waves 0, 1 keep SIMDs 0, 1 busy - a lone wave issues four instructions out of the
+    // five its SIMD can, so whatever else runs there crawls - while SIMDs 2, 3 carry no candidate: the draw duty then lies
+    // with waves 2, 3 (lr_spec_draw_role) and the scan table is built by the scanner waves of SIMDs 2, 3.
+    const bool single = ctx.x.cpb == 1;
     const bool split_draws = rj && k_team == 1;
     const int dch = split_draws ? (wave - (NW - 4)) >> 1 : wave - (NW - 2), dpart = (wave - (NW - 4)) & 1;
-    const bool drawer = dch >= 0 && ctx.c0 + dch < ctx.C;
+    const bool drawer = !single && dch >= 0 && dch < ctx.n_act;
     // A block on its own is bound by whichever wave reaches the barrier last, and that used to be a drawer (scan table,
     // scan, then the draws): there the drawers make their draws FIRST - they depend on nothing - while the other scanner
     // waves build the scan table, and only then scan.  In a team the last scanner also runs the exchange, so the
     // drawers scan first and draw behind the arrival.
     const bool draws_first = k_team == 1;
-    const int n_build = draws_first ? (NW - 4) - (rj ? 4 : 2) : NW - 4;      // scanner waves 4 .. 4 + n_build - 1 build the scan table
+    const int n_build = single ? (NW - 4) / 2 : (draws_first ? (NW - 4) - (rj ? 4 : 2) : NW - 4);   // scanner waves that build the scan table:
+    // waves 4 .. 4 + n_build - 1, or (cpb 1) the ones on SIMDs 2, 3 (wave & 2)
+    const bool builder = single ? (wave & 2) != 0 : wave - 4 < n_build;
+    const int build_id = single ? (((wave - 4) >> 2) * 2 + (wave & 1)) * LR_WAVE + lane : tid - 4 * LR_WAVE;
+    (void)build_id;
     auto draw_duty = [&](unsigned long long it_draw, unsigned long long slot) {
         if (!rj) {
             lr_dd_draws dd;
@@ -334,7 +346,10 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
             lr_spec_draw(a, ctx.c0 + dch, lane, it_draw, &sm.draws[dch][slot]);
         }
     };
-    const int sid = tid - 4 * LR_WAVE;
+    // every scanner lane strides over the block's slice (unequal shares between the SIMDs with and without a candidate
+    // wave measured slower at every split: a scanning wave is bound by its own trip latency, not by its SIMD's issue rate)
+    const long long part_g0 = ctx.g0, part_n = ctx.n8;
+    const int sid = tid - 4 * LR_WAVE, n_scan = NSCAN;
     int sel = 0;
     int role0 = LR_SPEC_ROLES0, role1 = LR_SPEC_ROLES0;
     // In a team the scanners and the exchange behind them are the critical path: they may be given priority over the
@@ -345,7 +360,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     }
     // every scan starts with the same group: kept in registers, no load to wait for at the top of an iteration
     lr_first_group first;
-    lr_load_first_group<GENERAL>(ctx.pk, ctx.g0, ctx.n8, sid, &first);
+    lr_load_first_group<GENERAL>(ctx.pk, part_g0, part_n, sid, &first);
     LR_XDECL();
     for (long long iter = 0; iter < ctx.n_iters; ++iter) {
         const unsigned long long it = ctx.it0 + (unsigned long long)iter;
@@ -365,7 +380,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         const double lA = sm.likA[lane & 1];
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(sm.scan);
-        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, ctx.g0, ctx.n8, sid, NSCAN, &acc0, &acc1, &first);
+        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, part_g0, part_n, sid, n_scan, &acc0, &acc1, &first);
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
         if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
         LR_XSTAMP(dg_a);
@@ -441,7 +456,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
                 double lik[2] = {0.0, 0.0}, lik_p[2] = {0.0, 0.0};
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    if (ctx.c0 + cc >= ctx.C) continue;
+                    if (cc >= ctx.n_act) continue;
                     const double v = cc ? v1 : v0;
                     const int iv = cc ? i1 : i0;
                     const int gibbs = lr_bcast_i(iv, LR_SETI_GIBBS), invalid = lr_bcast_i(iv, LR_SETI_INVALID);
@@ -479,11 +494,12 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         sel = sm.dec[iter & 1].sel;
         role0 = lr_spec_turn(role0, sel >> 1), role1 = lr_spec_turn(role1, sel & 1);
         {
-            // The scan table of the next iteration from the pair table that was selected (every scanner wave is past its
-            // scan of the old one: the barrier), both chains at once, by all scanner lanes; the scanner waves then wait
+            // The scan table of the next iteration from the columns of the proposals now pending (every scanner wave is past
+            // its scan of the old one: the barrier), both chains at once, by all scanner lanes; the scanner waves then wait
             // for each other on an LDS counter (the candidate waves are already building: no block barrier)
-            if (wave - 4 < n_build) {
-                lr_build_scan_table<GENERAL>(sm.scan, sm.pairs[(it + 1) & 1][sel >> 1][sel & 1], H, a.cfg.n_bins, sid, n_build * LR_WAVE);
+            if (builder) {
+                lr_build_scan_table<GENERAL>(sm.scan, sm.cols[0][(role0 >> 2) & 3], act1 ? sm.cols[1][(role1 >> 2) & 3] : nullptr, H,
+                                             a.cfg.n_bins, build_id, n_build * LR_WAVE);
                 LR_WAVE_LDS_ORDER();
                 if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else if (drawer && iter + 1 < ctx.n_iters) {
@@ -499,6 +515,29 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     LR_XDUMP();
 }
 
+// The draw role (a team per chain: waves 2, 3, which carry no candidate): per iteration the state-independent draws of
+// iteration it + 2 - wave 2 the wave-uniform ones, wave 3 the per-rate multiplier draws (lr_spec_draw_part; a parametric
+// sampler's come from wave 2 alone) - into the slot the candidates of the NEXT iteration read.  Same barrier per iteration
+// as the other roles.
+template <int H, int T, bool RJ, bool GENERAL>
+__device__ __forceinline__ void lr_spec_draw_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
+                                                  const lr_spec_ctx& ctx, int tid) {
+    const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    const int k_team = ctx.x.team_blocks;
+    for (long long iter = 0; iter < ctx.n_iters; ++iter) {
+        const unsigned long long it = ctx.it0 + (unsigned long long)iter;
+        if (RJ) {
+            lr_spec_draw_part(a, ctx.c0, lane, it + 2, &sm.draws[0][it & 1], wave - 2);
+        } else if (wave == 2) {
+            lr_dd_draws dd;
+            lr_make_dd_draws(a, ctx.c0, lane, it + 2, dd);
+            lr_dd_draws_store(&sm.draws[0][it & 1], dd, lane);
+        }
+        __syncthreads();
+        if (k_team > 1 && sm.abort_flag) return;
+    }
+}
+
 // The candidate role (waves 0..3; chain = wave / 2, outcome = wave % 2): build the candidate of iteration it + 1 while
 // the others scan, then - all four waves alike, each on its own SIMD - decide both chains, copy the selected pair
 // table, turn the roles of the sets; waves 0 and 2 keep the books (acceptance count, trace rows, final state).
@@ -506,7 +545,8 @@ template <int H, int T, bool RJ, bool GENERAL>
 __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
-    constexpr int ES = GENERAL ? 4 * H : 2;  // the builders' `so`: doubles from a value to its slope (lr_device.h)
+    constexpr int ES = GENERAL ? 2 * H : 2;  // the builders' `so`: doubles from a value to its slope inside a column (lr_device.h)
+    constexpr int COL = lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>::COL;
     // the per-bin data constants come from their LDS copies (a global load per candidate would sit on the critical path)
     const double* br_lds = sm.br;
     const double* logbr_lds = sm.logbr;
@@ -515,8 +555,8 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
     const int c0 = ctx.c0, C = ctx.C;
     const int k_team = ctx.x.team_blocks;
     constexpr bool rj = RJ;
-    const bool act1 = c0 + 1 < C;
-    const bool mine_active = c0 + c < C;
+    const bool act1 = ctx.n_act > 1;
+    const bool mine_active = c < ctx.n_act;
     // run state: which of a chain's four sets plays which role (bits 0-1 A, 2-3 P, 4-5 Q0, 6-7 Q1), the accepted
     // log-likelihoods; every candidate wave tracks both chains (all four take the same decisions)
     int role0 = LR_SPEC_ROLES0, role1 = LR_SPEC_ROLES0;
@@ -524,8 +564,6 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
     likA0 = a.state_f64[((size_t)c0 * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA];
     if (act1) likA1 = a.state_f64[((size_t)(c0 + 1) * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA];
     lr_spec_book bk = {0.0, 0ull, 0, 0};
-    int sel_last = 0;
-    (void)sel_last;
     {
         const int cm = min(c0 + c, C - 1);
         const int* Ic = a.state_i32 + ((size_t)cm * LR_ISTATE_ROWS + LR_IROW_SCALARS) * LR_ROW;
@@ -540,20 +578,19 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
         // ---- phase 1: the candidate of iteration it + 1 for outcome k of chain c ----
         if (mine_active) {
             const int role = c ? role1 : role0;
-            const lr_set* base = &sm.sets[c][(role >> (k ? 2 : 0)) & 3];
-            lr_set* out = &sm.sets[c][(role >> (k ? 6 : 4)) & 3];
-            // the candidate's column (component c) of the next generation's pair tables: built in the one where the other
-            // chain's outcome is 0, copied into the one where it is 1
-            const int g = (int)((it + 1) & 1);
-            double* col0 = reinterpret_cast<double*>(c ? sm.pairs[g][0][k] : sm.pairs[g][k][0]) + c;
-            double* col1 = reinterpret_cast<double*>(c ? sm.pairs[g][1][k] : sm.pairs[g][k][1]) + c;
-            double2* table = reinterpret_cast<double2*>(col0);
+            const int base_i = (role >> (k ? 2 : 0)) & 3, out_i = (role >> (k ? 6 : 4)) & 3;
+            const lr_set* base = &sm.sets[c][base_i];
+            lr_set* out = &sm.sets[c][out_i];
+            // the candidate's own column, and the column of the state it starts from
+            double2* table = reinterpret_cast<double2*>(sm.cols[c][out_i]);
+            const double* base_col = sm.cols[c][base_i];
             { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(8); } }
             if (!rj) {
                 lr_dd_prop p;
                 lr_dd_draws dd;
                 lr_dd_draws_load(&sm.draws[c][(it + 1) & 1], dd, lane);
-                const double P = lr_propose_dd<true, false>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, (int)(col1 - col0), &dd);
+                (void)base_col;
+                const double P = lr_propose_dd<true, false, 1>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, &dd);
                 out->L[lane] = P;
                 if (lane == 0) {
                     out->sc[LR_SET_HASTING] = p.hasting, out->sc[LR_SET_PRIOR] = p.prior, out->sc[LR_SET_LOG_U] = p.log_u;
@@ -568,9 +605,8 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 lr_rj_prop p;
                 lr_rj_draws d;
                 lr_draws_load(&sm.draws[c][(it + 1) & 1], d, lane);
-                // (the one-pass builder writes the column into both pair tables)
-                lr_propose_rj<true, lr_bins_per_lane(H), true, false>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
-                                                               logbr_lds, (int)(col1 - col0));
+                lr_propose_rj<true, lr_bins_per_lane(H), 1, false>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
+                                                                   logbr_lds, base_col, COL, base->sc[LR_SET_CONST]);
                 lr_set_store(out, s, p, lane);
                 { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
             }
@@ -589,7 +625,6 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             if (d0) likA0 = lr_bcast(dv, 0);
             if (d1) likA1 = lr_bcast(dv, 1);
             bk.lik_p = c ? lr_bcast(dv, 3) : lr_bcast(dv, 2);
-            sel_last = sel;
         }
         LR_XSTAMP(dg_b);
         role0 = lr_spec_turn(role0, d0), role1 = lr_spec_turn(role1, d1);
@@ -611,7 +646,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
         LR_XSTAMP(dg_p2);
     }
     LR_XDUMP();
-    if (tid == 0) sm.cur_sel = sel_last;
+    if (k == 0 && mine_active && lane == 0) sm.final_p[c] = ((c ? role1 : role0) >> 2) & 3;
     // pending proposal, accepted state and scalars back to global memory, in the layout every engine shares
     if (k == 0 && mine_active && ctx.rank == 0) {
         const int role = c ? role1 : role0;
@@ -628,26 +663,26 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
                                                                      lr_spec_args x, long long n_iters) {
     constexpr int NW = T / LR_WAVE;
     constexpr int ENT = GENERAL ? 2 : 1;
+    constexpr int COL = lr_spec_lds<H, NW, ENT>::COL;
     static_assert(sizeof(lr_spec_lds<H, NW, ENT>) <= 160 * 1024, "the block's LDS image must fit a CU");
     __shared__ lr_spec_lds<H, NW, ENT> sm;
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int k_team = x.team_blocks;
     const int team = blockIdx.x % x.n_teams, rank = blockIdx.x / x.n_teams;   // a team's blocks differ by a multiple of
-    const int c0 = team * 2;                                                   // n_teams: one XCD when 8 | n_teams
+    const int c0 = team * x.cpb;                                               // n_teams: one XCD when 8 | n_teams
     const int C = a.cfg.n_chains;
+    const int n_act = min(x.cpb, C - c0);
     constexpr bool rj = RJ;
-    const bool act1 = c0 + 1 < C;
-    double2* gpair = lr_chain_table(a, c0);
-    if (wave < 2 && c0 + wave < C) {
+    const bool act1 = n_act > 1;
+    if (wave < n_act) {
         const int c = c0 + wave;
         lr_sets_from_global(a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW, a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW,
                             &sm.sets[wave][0], &sm.sets[wave][1], lane);
     }
     {
-        // all pair tables start as zeros (the column of a missing second chain must stay zero); the pending pair table
-        // of iteration it0 goes to pairs[it0 & 1][0][0]
-        double2* z = &sm.pairs[0][0][0][0];
-        for (int i = tid; i < 8 * lr_spec_lds<H, NW, ENT>::TAB; i += T) z[i] = make_double2(0.0, 0.0);
+        // all columns start as zeros (entries no builder writes must not hold junk that would reach the workspace at exit)
+        double* z = &sm.cols[0][0][0];
+        for (int i = tid; i < 8 * COL; i += T) z[i] = 0.0;
     }
     {
         // sets 2, 3 start as zeros (the parametric samplers write one row only; rows never written must not hold junk
@@ -667,8 +702,8 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     // the launches queued behind it end here instead of iterating on a state that was never written back
     if (tid == 0)
         sm.abort_flag = (k_team > 1 && __hip_atomic_load((lr_gu32*)x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0,
-        sm.cur_sel = 0, sm.scan_arrive = 0, sm.plane_arrive = 0, sm.args = a;
-    if (tid < 2) sm.likA[tid] = (c0 + tid < C) ? a.state_f64[((size_t)(c0 + tid) * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA] : 0.0;
+        sm.final_p[0] = sm.final_p[1] = 1, sm.scan_arrive = 0, sm.plane_arrive = 0, sm.args = a;
+    if (tid < 2) sm.likA[tid] = (tid < n_act) ? a.state_f64[((size_t)(c0 + tid) * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA] : 0.0;
     lr_spec_ctx ctx;
     {
         const int* I0 = a.state_i32 + ((size_t)c0 * LR_ISTATE_ROWS + LR_IROW_SCALARS) * LR_ROW;
@@ -677,17 +712,35 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         const long long g_lo = min((long long)rank * per, n8), g_hi = min(g_lo + per, n8);
         ctx.pk = pk, ctx.g0 = g_lo, ctx.n8 = g_hi - g_lo, ctx.x = x, ctx.n_iters = n_iters;
         ctx.it0 = (unsigned long long)(unsigned)I0[LR_I_IT_LO] | ((unsigned long long)(unsigned)I0[LR_I_IT_HI] << 32);
-        ctx.c0 = c0, ctx.C = C, ctx.team = team, ctx.rank = rank;
+        ctx.c0 = c0, ctx.C = C, ctx.team = team, ctx.rank = rank, ctx.n_act = n_act;
     }
     __syncthreads();
     if (sm.abort_flag) return;
-    for (int i = tid; i < 2 * H * ENT; i += T) sm.pairs[ctx.it0 & 1][0][0][i] = gpair[i];
+    // The pending proposals' columns (set 1) from global memory, where a chain's entries are its component of its pair
+    // table, 2 doubles apart (lr_chain_table); the ACCEPTED states' columns (set 0) are not kept there: the RJ sampler
+    // builds them here, once per launch, from the accepted rates and edges - the doubles their proposals were scored with.
+    for (int cc = 0; cc < n_act; ++cc) {
+        const double* g = reinterpret_cast<const double*>(lr_chain_table(a, c0 + cc));
+        for (int i = tid; i < COL; i += T) sm.cols[cc][1][i] = g[2 * i];
+    }
+    if (rj && (wave == 0 || wave == 2) && (wave >> 1) < n_act) {
+        const int cc = wave >> 1;
+        lr_rj_state s;
+        lr_set_load(&sm.sets[cc][0], s, lane);
+        double logL, logM;
+        lr_stage_segments(&sm.scratch[wave], s.L, s.M, s.eL, s.eM, s.KL, s.KM, lane, &logL, &logM);
+        (void)lr_build_tables_segments<lr_bins_per_lane(H), 1>(&sm.scratch[wave], s.eL, s.eM, s.KL, s.KM, sm.br, sm.logbr, a.cfg.model,
+                                                               a.cfg.n_bins, a.n_cls, a.H, reinterpret_cast<double2*>(sm.cols[cc][0]), lane,
+                                                               GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, a.cfg.frac_birth, a.cfg.frac_death,
+                                                               GENERAL ? 2 * H : 2, nullptr);
+    }
     __syncthreads();
-    lr_build_scan_table<GENERAL>(sm.scan, sm.pairs[ctx.it0 & 1][0][0], H, a.cfg.n_bins, tid, T);
+    lr_build_scan_table<GENERAL>(sm.scan, sm.cols[0][1], act1 ? sm.cols[1][1] : nullptr, H, a.cfg.n_bins, tid, T);
     // draws of the first candidates (iteration it0 + 1); afterwards the last four scanner waves stay one iteration ahead
     // (a block on its own draws at the top of an iteration for the one after the next: it starts with two iterations' draws)
-    if (wave >= NW - 2 && c0 + (wave - (NW - 2)) < C) {
-        for (unsigned long long ahead = 1; ahead <= (k_team == 1 ? 2ull : 1ull); ++ahead) {
+    if (wave >= NW - 2 && wave - (NW - 2) < n_act) {
+        // (a team per chain: its draw role makes the draws of it0 + 2 in the first iteration)
+        for (unsigned long long ahead = 1; ahead <= ((k_team == 1 && x.cpb != 1) ? 2ull : 1ull); ++ahead) {
             const unsigned long long itd = ctx.it0 + ahead;
             if (rj) {
                 lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, itd, &sm.draws[wave - (NW - 2)][itd & 1]);
@@ -699,13 +752,15 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         }
     }
     __syncthreads();
-    if (wave < 4) lr_spec_cand_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
+    if (x.cpb == 1 && (wave == 2 || wave == 3)) lr_spec_draw_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
+    else if (wave < 4) lr_spec_cand_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
     else lr_spec_scan_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
     __syncthreads();
     if (sm.abort_flag || rank != 0) return;
-    {
-        const int sel = sm.cur_sel;
-        const double2* cur = sm.pairs[(ctx.it0 + (unsigned long long)n_iters) & 1][sel >> 1][sel & 1];
-        for (int i = tid; i < 2 * H * ENT; i += T) gpair[i] = cur[i];
+    // the pending proposals' columns back into their components of the pair tables
+    for (int cc = 0; cc < n_act; ++cc) {
+        double* g = reinterpret_cast<double*>(lr_chain_table(a, c0 + cc));
+        const double* col = sm.cols[cc][sm.final_p[cc]];
+        for (int i = tid; i < COL; i += T) g[2 * i] = col[i];
     }
 }

@@ -1,14 +1,17 @@
 // lr_spec.hip - host side of the speculative team engine (kernels: lr_spec.h)
+#include <cstdlib>
+
 #include "lr_engine.h"
 #include "lr_spec.h"
 
 int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages& pk, int64_t n_iters, hipStream_t stream) {
-    const int blocks = (e->cfg.n_chains + 1) / 2;
+    const int cpb = e->lay.spec_chains_per_team == 1 ? 1 : 2;
+    const int blocks = (e->cfg.n_chains + cpb - 1) / cpb;          // teams
     const bool general = e->plan.unit == LR_TAB_PAIRGEN;
             lr_spec_args x;
             x.xchg = (unsigned long long*)(e->ws + e->lay.xchg);
             x.status = (unsigned int*)(e->ws + e->lay.status);
-            x.team_blocks = e->lay.team_blocks, x.n_teams = blocks;
+            x.team_blocks = e->lay.team_blocks, x.n_teams = blocks, x.cpb = cpb;
             const size_t xbytes = (size_t)2 * blocks * LR_TEAM_MAX * LR_SPEC_GRANULES * 8;
             for (int64_t done = 0; done < n_iters;) {
                 const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short

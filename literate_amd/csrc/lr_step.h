@@ -155,24 +155,17 @@ struct lr_seg_cache {
     bool reuse;
 };
 
-// DUP: every entry is written a second time `dup` doubles further on (the speculative kernel keeps a candidate's column
-// in two pair tables; writing both beats copying one from the other afterwards)
-template <int P, bool DUP = false>
+// CS: doubles between consecutive entries of the chain's column (lr_put_S)
+template <int P, int CS = 2>
 __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scratch* sc, int eL, int eM, int KL,
                                                                 int KM, const double* __restrict__ br_length,
                                                                 const double* __restrict__ log_br, int model,
                                                                 int n_bins, int H, double2* __restrict__ tab,
                                                                 int lane, int unit, double fs0, double fe0, int es,
-                                                                lr_seg_cache* sg = nullptr, int dup = 0) {
+                                                                lr_seg_cache* sg = nullptr) {
     double* tabd = reinterpret_cast<double*>(tab);
-    auto put_S = [&](int j, double v, double R) {
-        lr_put_S(tabd, unit, es, j, v, R, fs0);
-        if (DUP) lr_put_S(tabd + dup, unit, es, j, v, R, fs0);
-    };
-    auto put_E = [&](int j, double v, double R) {
-        lr_put_E(tabd, unit, es, j, v, R, fe0);
-        if (DUP) lr_put_E(tabd + dup, unit, es, j, v, R, fe0);
-    };
+    auto put_S = [&](int j, double v, double R) { lr_put_S<CS>(tabd, unit, es, j, v, R, fs0); };
+    auto put_E = [&](int j, double v, double R) { lr_put_E<CS>(tabd, unit, es, j, v, R, fe0); };
     const int b0 = lane * P;
 #ifdef LR_DIAG
     const int c = blockIdx.x * 2 + ((threadIdx.x >> 7) & 1);
@@ -288,22 +281,26 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
 
 // dispatcher: fast one-pass builder when the shape allows, general two-pass builder otherwise; PB > 0: the caller is
 // instantiated for a table size whose bins-per-lane count is PB (lr_bins_per_lane) and has one table class
-template <int PB = 0, bool DUP = false>
+template <int PB = 0, int CS = 2>
 __device__ __forceinline__ double lr_build_tables_segments(const lr_seg_scratch* sc, int eL, int eM, int KL, int KM,
                                                            const double* __restrict__ br_length,
                                                            const double* __restrict__ log_br, int model, int n_bins,
                                                            int n_cls, int H, double2* __restrict__ tab, int lane,
                                                            int unit, double fs0, double fe0, int es = 2,
-                                                           lr_seg_cache* sg = nullptr, int dup = 0) {
+                                                           lr_seg_cache* sg = nullptr) {
+    static_assert(CS == 2 || PB > 0, "a column of its own is written by the one-pass builder only");
     if (PB > 0)
-        return lr_build_tables_segments_fast<(PB > 0 ? PB : 1), DUP>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab,
-                                                                     lane, unit, fs0, fe0, es, sg, dup);
-    if (n_cls == 1 && n_bins <= 2 * LR_WAVE)
-        return lr_build_tables_segments_fast<2>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
-                                                fs0, fe0, es, sg);
-    if (n_cls == 1 && n_bins <= 4 * LR_WAVE)
-        return lr_build_tables_segments_fast<4>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit,
-                                                fs0, fe0, es, sg);
+        return lr_build_tables_segments_fast<(PB > 0 ? PB : 1), CS>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab,
+                                                                    lane, unit, fs0, fe0, es, sg);
+    // (run-time dispatch: the bins-per-lane count of the table size, as the kernels instantiated for H use it - every
+    // builder of an engine then produces the same doubles for the same state, whichever kernel runs it)
+    if (n_cls == 1 && H <= 264) {
+        switch (lr_bins_per_lane(H)) {
+            case 1: return lr_build_tables_segments_fast<1>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit, fs0, fe0, es, sg);
+            case 2: return lr_build_tables_segments_fast<2>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit, fs0, fe0, es, sg);
+            default: return lr_build_tables_segments_fast<4>(sc, eL, eM, KL, KM, br_length, log_br, model, n_bins, H, tab, lane, unit, fs0, fe0, es, sg);
+        }
+    }
     if (sg) sg->reuse = false, sg->packL = sg->packM = -1;
     return lr_build_tables_segments_wave(sc, KL, KM, br_length, log_br, model, n_bins, n_cls, H, tab, lane, unit, fs0,
                                          fe0, es);
@@ -544,13 +541,19 @@ __device__ __forceinline__ double lr_wave_multiplier_pre(double& R, int K, bool 
 // hyper-parameters, every other move the rates / times of one process), `p` its bookkeeping, and its lookup tables
 // stand at `table`.  A pure function of (s, it, the chain's Philox stream, the data): the speculative engine calls it
 // on both possible outcomes of the pending decision.
-template <bool LDS_CONSTS = false, int PB = 0, bool DUP = false, bool PAIR_PLANES = true>
+// CS: doubles between consecutive entries of the chain's column at `table` (2: inside a pair table, 1: a column of its
+// own).  base_col (CS == 1 only): the column of the state `s` comes in as, `col_doubles` long, and base_const its model
+// constant: a proposal that changes no rate and no bin edge - the no-op "times" moves (LRF:178-195: 40 % of the
+// iterations once both processes hold a shift) and the Gibbs step - has the SAME lookup tables as its base state, so
+// its column is copied (a handful of LDS moves) instead of built (the largest single item of a proposal).  The copy
+// holds the very doubles a rebuild would produce - the builder is a pure function of rates and edges.
+template <bool LDS_CONSTS = false, int PB = 0, int CS = 2, bool PAIR_PLANES = true>
 __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int lane, lr_seg_scratch* scratch_p,
                                               uint64_t it, lr_rj_state& s, lr_rj_prop& p, double2* table,
                                               int table_es, const lr_rj_draws* pre = nullptr,
                                               const double* br_lds = nullptr, const double* logbr_lds = nullptr,
-                                              int table_dup = 0) {
-    static_assert(!DUP || PB > 0, "the duplicate column is written by the one-pass builder only");
+                                              const double* base_col = nullptr, int col_doubles = 0, double base_const = 0.0) {
+    static_assert(CS == 2 || (PB > 0 && !PAIR_PLANES), "a column of its own: one-pass builder, no pair planes");
     lr_seg_scratch& scratch = *scratch_p;
     const lr_mcmc_config& cfg = a.cfg;
     const int n_bins = cfg.n_bins;
@@ -699,21 +702,29 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
     // the ranks of the bins can be taken over from the state the proposal was made from while no edge moved (every
     // multiplier move and Gibbs step, most of the no-op times moves)
     lr_seg_cache sg{s.sgL, s.sgM, false};
-    if (pre && s.sg_valid && PKL == KL && PKM == KM)
-        sg.reuse = __ballot(lane <= LR_KMAX && (peL != eL || peM != eM)) == 0ull;
-    // (the per-bin data constants from the caller's LDS copies when it keeps some)
-    const double constP = lr_build_tables_segments<PB, DUP>(&scratch, peL, peM, PKL, PKM, LDS_CONSTS ? br_lds : a.br_length,
-                                                   LDS_CONSTS ? logbr_lds : a.log_br, cfg.model,
-                                                   n_bins, a.n_cls, a.H, table, lane,
-                                                   lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death,
-                                                   table_es, pre ? &sg : nullptr, table_dup);
-    s.sgL = sg.packL, s.sgM = sg.packM, s.sg_valid = (pre && sg.packL != -1) ? 1 : 0;
+    bool edges_same = false;
+    if ((pre && s.sg_valid) || base_col) edges_same = PKL == KL && PKM == KM && __ballot(lane <= LR_KMAX && (peL != eL || peM != eM)) == 0ull;
+    if (pre && s.sg_valid) sg.reuse = edges_same;
+    double constP;
+    if (CS == 1 && base_col && edges_same && (move_kind == 1 || move_kind == 3 || move_kind == 5)) {
+        double* col = reinterpret_cast<double*>(table);
+        for (int i = lane; i < col_doubles; i += LR_WAVE) col[i] = base_col[i];
+        constP = base_const;
+    } else {
+        // (the per-bin data constants from the caller's LDS copies when it keeps some)
+        constP = lr_build_tables_segments<PB, CS>(&scratch, peL, peM, PKL, PKM, LDS_CONSTS ? br_lds : a.br_length,
+                                                  LDS_CONSTS ? logbr_lds : a.log_br, cfg.model,
+                                                  n_bins, a.n_cls, a.H, table, lane,
+                                                  lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death,
+                                                  table_es, pre ? &sg : nullptr);
+        s.sgL = sg.packL, s.sgM = sg.packM, s.sg_valid = (pre && sg.packL != -1) ? 1 : 0;
+    }
     if (LDS_CONSTS && PAIR_PLANES) {
         // persistent engines: the pair planes the packed scan gathers from (lr_scan.h; the speculative kernel leaves them
         // to its scanner waves, which derive them for the selected table only)
         LR_WAVE_LDS_ORDER();
-        if (lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, n_bins, lane, DUP ? table_dup : 0);
-        else lr_pair_planes_wave_general(reinterpret_cast<double*>(table), a.H, n_bins, lane, DUP ? table_dup : 0);
+        if (lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, n_bins, lane, 0);
+        else lr_pair_planes_wave_general(reinterpret_cast<double*>(table), a.H, n_bins, lane, 0);
     }
     LR_SSTAMP(6);
     s.L = pL, s.M = pM, s.tL = ptL, s.tM = ptM, s.eL = peL, s.eM = peM, s.KL = PKL, s.KM = PKM;
@@ -882,11 +893,11 @@ __device__ __forceinline__ void lr_make_dd_draws(const lr_step_args& a, int c, i
     }
 }
 
-template <bool LDS_CONSTS = false, bool PAIR_PLANES = true>
+template <bool LDS_CONSTS = false, bool PAIR_PLANES = true, int CS = 2>
 __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, int lane, uint64_t it, double A,
                                                 lr_dd_prop& p, double2* table, int table_es,
-                                                const double* aux_lds = nullptr, int table_dup = 0,
-                                                const lr_dd_draws* pre = nullptr) {
+                                                const double* aux_lds = nullptr, const lr_dd_draws* pre = nullptr) {
+    static_assert(CS == 2 || !PAIR_PLANES, "a column of its own carries no pair planes");
     const lr_mcmc_config& cfg = a.cfg;
     const bool trend = cfg.sampler == 2;
     const int npar = trend ? LR_TR_NPAR : LR_DD_NPAR;
@@ -949,19 +960,18 @@ __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, in
     if (trend) {
         p.prior = lr_trend_prior(P, lane);
         const lr_trend_params tp = lr_trend_unpack(P);
-        lr_rates_build_tables_wave([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
-                                   cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death, table_es,
-                                   table_dup);
+        lr_rates_build_tables_wave<CS>([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
+                                       cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death, table_es);
     } else {
         p.prior = lr_dd_prior(P, origin, present, k0, log_k0, lane);
         const lr_dd_params pp = lr_dd_unpack(P);
-        lr_dd_build_tables_wave(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es),
-                                cfg.frac_birth, cfg.frac_death, table_es, table_dup);
+        lr_dd_build_tables_wave<CS>(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es),
+                                    cfg.frac_birth, cfg.frac_death, table_es);
     }
     if (LDS_CONSTS && PAIR_PLANES) {
         LR_WAVE_LDS_ORDER();
-        if (lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, table_dup);
-        else lr_pair_planes_wave_general(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, table_dup);
+        if (lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, 0);
+        else lr_pair_planes_wave_general(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, 0);
     }
     p.hasting = hasting, p.move = move_kind;
     return P;

@@ -15,7 +15,8 @@ from . import _hip, ops
 class ChainEngine:
     def __init__(self, ts, te, n_chains, model=0, seed=1, const_rates=0, const_death_rate=0, use_rate_HP=1,
                  poisson_HP=0.0, update_fraction=0.75, s_freq=1000, n_trace_slots=0, chain_offset=0,
-                 device=None, stats=None, sort_lineages=True, unit_resolution=None, engine="auto", dd=None, team=0):
+                 device=None, stats=None, sort_lineages=True, unit_resolution=None, engine="auto", dd=None, team=0,
+                 chains_per_team=0):
         """ts/te: lineage birth/death times (death_jitter already added, LRF:471).
 
         stats: optional (t0, n_bins, br_length) if the caller already binned the data; otherwise the
@@ -72,7 +73,8 @@ class ChainEngine:
             frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0,
             sampler=0 if dd is None else (2 if dd.get("kind") == "trend" else 1),
             m_birth=0 if dd is None else int(dd["m_birth"]), m_death=0 if dd is None else int(dd["m_death"]),
-            team_request=int(team) or (1 if os.environ.get("LR_SHARED_DEVICE", "0") == "1" else 0), dd_present=0.0 if dd is None else float(dd.get("present", 0.0)),
+            team_request=(int(team) or (1 if os.environ.get("LR_SHARED_DEVICE", "0") == "1" else 0)) | (int(chains_per_team) << 8),
+            dd_present=0.0 if dd is None else float(dd.get("present", 0.0)),
             dd_init_death=0.0 if dd is None else float(dd.get("init_death", 0.1)))
         self.dd = dd
         self.layout = _hip.McmcLayout()

@@ -10,15 +10,20 @@ G = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "bi
 only = sys.argv[1:]
 
 
-def run(name, mk, n=2000, warm=300):
+WARM = int(os.environ.get("LR_EXP_WARM", "300"))     # iterations before the timed ones (the chains start at K = 1)
+
+
+def run(name, mk, n=2000, warm=None):
     if only and not any(o in name for o in only):
         return
     eng = mk()
-    eng.init(); eng.steps(warm); torch.cuda.synchronize()
+    eng.init(); eng.steps(WARM if warm is None else warm); torch.cuda.synchronize()
     ms = eng.timed_steps(n)
     N, C = eng.ts.numel(), eng.n_chains
-    print('%-34s persistent=%d threads=%4d: %7.2f us/iter  %.3e evals/s' % (
-        name, eng.layout.persistent, eng.layout.reserved1, ms / n * 1e3, n * N * C / (ms * 1e-3)), flush=True)
+    snap = eng.snapshot()
+    print('%-34s persistent=%d threads=%4d team=%d x %d: %7.2f us/iter  %.3e evals/s   (mean K_l %.1f K_m %.1f)' % (
+        name, eng.layout.persistent, eng.layout.reserved1, eng.layout.team_blocks, eng.layout.spec_chains_per_team,
+        ms / n * 1e3, n * N * C / (ms * 1e-3), snap["K_l"].mean(), snap["K_m"].mean()), flush=True)
     eng.close()
 
 

@@ -36,6 +36,9 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        (2, dict(engine="persistent4")), (1, dict(engine="persistent2")),
                                        (0, dict(engine="spec")), (2, dict(engine="spec", team=2)),
                                        (0, dict(engine="spec", team=4)), (1, dict(engine="spec", team=8)),
+                                       (0, dict(engine="spec", team=1, cpt=1)), (2, dict(engine="spec", team=2, cpt=1)),
+                                       (1, dict(engine="spec", team=4, cpt=1)), (0, dict(engine="spec", team=1, cpt=2)),
+                                       (3, dict(engine="spec", team=8, cpt=1)), (0, dict(engine="spec", cpt=1, unit_resolution=False)),
                                        (3, dict(engine="launch")), (3, dict(engine="spec", team=2)),
                                        (3, dict(engine="persistent4")), (3, dict(engine="persistent2")),
                                        (3, dict(engine="spec", unit_resolution=False))])
@@ -45,11 +48,13 @@ def test_engine_follows_oracle_trajectory(G, model, kw):
     kw = dict(kw)
     ekw = dict(const_rates=kw.get("const_rates", 0), const_death_rate=kw.get("const_death_rate", 0),
                use_rate_HP=kw.get("use_rate_HP", 1), poisson_HP=kw.get("Poisson_HP", 0.0),
-               unit_resolution=kw.pop("unit_resolution", None), engine=kw.pop("engine", "auto"), team=kw.pop("team", 0))
+               unit_resolution=kw.pop("unit_resolution", None), engine=kw.pop("engine", "auto"), team=kw.pop("team", 0),
+               chains_per_team=kw.pop("cpt", 0))
     eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=model, seed=seed, s_freq=1,
                       n_trace_slots=n_it, chain_offset=off, **ekw)
     if ekw["engine"] == "spec":
         assert eng.layout.persistent == 3 and eng.layout.team_blocks == (ekw["team"] or eng.layout.team_blocks)
+        assert eng.layout.spec_chains_per_team == (ekw["chains_per_team"] or eng.layout.spec_chains_per_team)
     if ekw["engine"] == "persistent2":
         assert eng.layout.persistent == 1
     # binning done by the engine's own kernel must equal the reference's
@@ -521,7 +526,7 @@ def test_engine_chain_count_shapes(G, engine):
 
 
 @pytest.mark.parametrize("engine,C", [("launch", 24), ("persistent", 24), ("persistent", 10), ("persistent4", 10), ("spec", 9),
-                                      ("spec2", 10)])
+                                      ("spec2", 10), ("spec1x2", 7), ("spec2x1", 9)])
 def test_checkpoint_resume_is_bit_identical(G, tmp_path, engine, C):
     """save() after 130 iterations, load() into a fresh engine, 170 more: state, pending proposals and all 300
     trace rows equal an uninterrupted run bit for bit (draws are addressed by (seed, chain, iteration));
@@ -532,6 +537,10 @@ def test_checkpoint_resume_is_bit_identical(G, tmp_path, engine, C):
     kw = dict(model=0, seed=77, s_freq=1, n_trace_slots=300, engine=engine)
     if engine == "spec2":
         kw.update(engine="spec", team=2)       # a team of two blocks per chain pair
+    if engine == "spec1x2":
+        kw.update(engine="spec", team=2, chains_per_team=1)       # a team of two blocks per CHAIN
+    if engine == "spec2x1":
+        kw.update(engine="spec", team=1, chains_per_team=2)       # a block per chain pair
     full = ChainEngine(G[name + "/ts"], G[name + "/te"], C, **kw)
     full.init(); full.steps(300)
     a = ChainEngine(G[name + "/ts"], G[name + "/te"], C, **kw)

@@ -855,15 +855,16 @@ static int lr_device_cus() {
 // team (scratch/exp_teams.py, round 3: candidates with a column of their own, no-op moves copying it): with `trips` =
 // groups / k / 512 scanner lanes,
 //                        a team per PAIR                                  a team per CHAIN
-//     unit resolution    k = 1: max(2.95, 2.93 + 0.171 trips)             k = 1: max(2.40, 2.30 + 0.172 trips)
-//                        k > 1: max(3.40, 3.20 + 0.205 trips)             k > 1: max(3.00, 2.95 + 0.17 trips)
-//     general times      k = 1: max(2.90, 2.85 + 0.434 trips)             k = 1: max(2.50, 2.30 + 0.44 trips)
-//                        k > 1: max(3.45, 2.90 + 0.478 trips)             k > 1: max(3.10, 2.90 + 0.44 trips)
-//     DDRate / trend     k = 1: max(2.60, 2.70 + 0.18 trips)              k = 1: max(2.35, 2.25 + 0.182 trips)
-//                        k > 1: max(3.05, 2.70 + 0.21 trips)              k > 1: max(2.90, 2.65 + 0.18 trips)
-// (the floor is the candidate build - shorter with one chain per CU: half the candidate waves, and a no-op move copies its
-// column -; a team pays the exchange behind its last scanner; a team per chain scans for one chain what a team per pair
-// scans for two, so it needs the CUs: chains x k <= CUs).  Returns the modelled time, the best team size in *k
+//     unit resolution    k = 1: max(2.95, 2.93 + 0.171 trips)             k = 1: max(2.44, 1.62 + 0.20 trips)
+//                        k > 1: max(3.40, 3.20 + 0.205 trips)             k > 1: max(2.88, 2.45 + 0.165 trips) + 0.05 log2(k / 2)
+//     general times      k = 1: max(2.90, 2.85 + 0.434 trips)             k = 1: max(2.32, 1.50 + 0.46 trips)
+//                        k > 1: max(3.45, 2.90 + 0.478 trips)             k > 1: max(2.72, 2.10 + 0.46 trips) + 0.05 log2(k / 2)
+//     DDRate / trend     k = 1: max(2.60, 2.70 + 0.18 trips)              k = 1: max(2.43, 1.63 + 0.21 trips)
+//                        k > 1: max(3.05, 2.70 + 0.21 trips)              k > 1: max(2.90, 2.50 + 0.16 trips)
+// (the floor is the candidate build - shorter with one chain per CU: the table is built by a helper wave on a SIMD of its
+// own, a no-op move copies its table, and the scanners need no table build behind the barrier -; a team pays the exchange
+// behind its last scanner; a team per chain scans for one chain what a team per pair scans for two, so it needs the CUs:
+// chains x k <= CUs).  Returns the modelled time, the best team size in *k
 // (0 = not applicable) and the chains per team.
 static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general = false, int* cpb_out = nullptr) {
     const int cus = lr_device_cus();
@@ -893,14 +894,14 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
             double t;
             if (cfg->sampler != 0) {
                 if (cpb == 2) t = (k == 1) ? fmax(2.60, 2.70 + 0.18 * trips) : fmax(3.05, 2.70 + 0.21 * trips);
-                else t = (k == 1) ? fmax(2.35, 2.25 + 0.182 * trips) : fmax(2.90, 2.65 + 0.18 * trips);
+                else t = (k == 1) ? fmax(2.43, 1.63 + 0.21 * trips) : fmax(2.90, 2.50 + 0.16 * trips);
                 if (general) t += 0.26 * trips;
             } else if (!general) {
                 if (cpb == 2) t = (k == 1) ? fmax(2.95, 2.93 + 0.171 * trips) : fmax(3.40, 3.20 + 0.205 * trips);
-                else t = (k == 1) ? fmax(2.40, 2.30 + 0.172 * trips) : fmax(3.00, 2.95 + 0.17 * trips);
+                else t = (k == 1) ? fmax(2.44, 1.62 + 0.20 * trips) : fmax(2.88, 2.45 + 0.165 * trips) + (k == 4 ? 0.05 : (k == 8 ? 0.10 : 0.0));
             } else {
                 if (cpb == 2) t = (k == 1) ? fmax(2.90, 2.85 + 0.434 * trips) : fmax(3.45, 2.90 + 0.478 * trips);
-                else t = (k == 1) ? fmax(2.50, 2.30 + 0.44 * trips) : fmax(3.10, 2.90 + 0.44 * trips);
+                else t = (k == 1) ? fmax(2.32, 1.50 + 0.46 * trips) : fmax(2.72, 2.10 + 0.46 * trips) + (k == 4 ? 0.05 : (k == 8 ? 0.10 : 0.0));
             }
             if (t < best_c - 0.05) best_c = t, k_c = k;
         }
@@ -1500,7 +1501,8 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
     if (e->persistent) {
         const char* gen = e->plan.unit == LR_TAB_PAIRGEN ? "true" : "false";
         if (e->lay.persistent == 3)
-            snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d, %s, %s>", e->plan.H, e->lay.reserved1, e->cfg.sampler == 0 ? "true" : "false", gen);
+            snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d, %s, %s, %s>", e->plan.H, e->lay.reserved1, e->cfg.sampler == 0 ? "true" : "false", gen,
+                     e->lay.spec_chains_per_team == 1 ? "true" : "false");
         else if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s>", e->plan.H, gen);
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
     } else if (e->part[0].pipelined) {

@@ -90,10 +90,12 @@ __device__ __forceinline__ void lr_set_load(const lr_set* q, lr_rj_state& s, int
     s.priorPoi = lr_bcast(v, LR_SET_PRIORPOI);
 }
 
+// (p.table_by_helper: the rank cache, its valid flag and the model constant are the helper wave's to write)
 __device__ __forceinline__ void lr_set_store(lr_set* q, const lr_rj_state& s, const lr_rj_prop& p, int lane) {
+    const bool mine = !p.table_by_helper;
     q->L[lane] = s.L, q->M[lane] = s.M, q->tL[lane] = s.tL, q->tM[lane] = s.tM;
     q->eL[lane] = s.eL, q->eM[lane] = s.eM;
-    q->sgL[lane] = s.sgL, q->sgM[lane] = s.sgM;
+    if (mine) q->sgL[lane] = s.sgL, q->sgM[lane] = s.sgM;
     double so = 0.0;
     so = (lane == LR_SET_HASTING) ? p.hasting : so;
     so = (lane == LR_SET_PRIOR) ? p.prior : so;
@@ -106,7 +108,7 @@ __device__ __forceinline__ void lr_set_store(lr_set* q, const lr_rj_state& s, co
     so = (lane == LR_SET_LG1) ? s.lg1 : so;
     so = (lane == LR_SET_LPOI) ? s.lpoi : so;
     so = (lane == LR_SET_LOG_U) ? p.log_u : so;
-    if (lane < 16) q->sc[lane] = so;
+    if (lane < 16 && (mine || lane != LR_SET_CONST)) q->sc[lane] = so;
     int io = 0;
     io = (lane == LR_SETI_KL) ? s.KL : io;
     io = (lane == LR_SETI_KM) ? s.KM : io;
@@ -114,7 +116,7 @@ __device__ __forceinline__ void lr_set_store(lr_set* q, const lr_rj_state& s, co
     io = (lane == LR_SETI_INVALID) ? p.invalid : io;
     io = (lane == LR_SETI_MOVE) ? p.move : io;
     io = (lane == LR_SETI_SEG) ? s.sg_valid : io;
-    if (lane < 8) q->isc[lane] = io;
+    if (lane < 8 && (mine || lane != LR_SETI_SEG)) q->isc[lane] = io;
 }
 
 // chain state rows in global memory (include/literate_hip.h) -> the accepted set A and the pending set P
@@ -266,13 +268,22 @@ struct lr_spec_lds {
     static constexpr bool GENERAL_ENTRIES = ENT == 2;
     static constexpr int TAB = 2 * H * ENT;          // double2 per candidate pair table (the global-memory layout)
     static constexpr int COL = 2 * H * ENT;          // doubles per column: S' entries [0,H), E' [H,2H) (general times: + slopes)
-    // One column of lookup-table entries per state in flight, entries 1 double apart: cols[chain][set] belongs to
-    // sets[chain][set] - the accepted state, the pending proposal and the two candidates being built.
-    double cols[2][4][2 * H * ENT];
-    // what the scanner waves gather from: the six planes (lr_scan.h) of the two pending columns side by side, which they
-    // lay out behind the barrier (lr_build_scan_table) - the candidates write S and E only
-    double2 scan[LR_UNIT_PLANES * H];
+    union {
+        struct {
+            // A team per PAIR.  One column of lookup-table entries per state in flight, entries 1 double apart:
+            // cols[chain][set] belongs to sets[chain][set] - the accepted state, the pending proposal and the two
+            // candidates being built; and what the scanner waves gather from: the six planes (lr_scan.h) of the two
+            // pending columns side by side, which they lay out behind the barrier (lr_build_scan_table)
+            double cols[2][4][2 * H * ENT];
+            double2 scan[LR_UNIT_PLANES * H];
+        } pair;
+        // A team per CHAIN.  One whole scan table per state in flight - the six planes, (.x, .y) = (the chain, 0) - built
+        // by the candidate's helper wave with its pair planes: behind the barrier the scanner waves only switch to the
+        // table of the proposal that is now pending
+        double2 tabs[4][LR_UNIT_PLANES * H];
+    } t;
     int final_p[2];              // set that holds each chain's pending proposal when the kernel ends
+    lr_table_hand hand[2];       // a team per chain: candidate wave k -> its helper wave 2 + k
     double red[NW][2];           // per scanner wave: partial sums of the two chains
     lr_spec_decision dec[2];     // [iteration parity]: what the deciding wave found
     double likA[2];              // log-likelihood of the accepted state of the two chains
@@ -306,7 +317,7 @@ struct lr_spec_ctx {
 // built.  Behind the barrier every wave reads the outcome, turns the roles of the sets and goes on: the scanners to the
 // pair table of the selected candidates, the candidate waves to the next candidates.  The last two scanner waves also
 // have the draw duty.
-template <int H, int T, bool RJ, bool GENERAL>
+template <int H, int T, bool RJ, bool GENERAL, bool SINGLE>
 __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
@@ -318,10 +329,9 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     // Draw duty.  A block on its own is bound by its slowest wave before the barrier, so the duty is split over the last
     // four scanner waves, two per chain; in a team the last scanner to finish also runs the exchange and must not carry
     // more than its scan, so there the last two scanner waves (the smallest scan shares) take a chain each.
-    // A team per chain (cpb 1): candidate waves 0, 1 keep SIMDs 0, 1 busy - a lone wave issues four instructions out of the
-    // five its SIMD can, so whatever else runs there crawls - while SIMDs 2, 3 carry no candidate: the draw duty then lies
-    // with waves 2, 3 (lr_spec_draw_role) and the scan table is built by the scanner waves of SIMDs 2, 3.
-    const bool single = ctx.x.cpb == 1;
+    // A team per chain: the draw duty lies with the helper waves 2, 3 (lr_spec_help_role), and there is no scan table to
+    // build - every state in flight has its own.
+    constexpr bool single = SINGLE;
     const bool split_draws = rj && k_team == 1;
     const int dch = split_draws ? (wave - (NW - 4)) >> 1 : wave - (NW - 2), dpart = (wave - (NW - 4)) & 1;
     const bool drawer = !single && dch >= 0 && dch < ctx.n_act;
@@ -330,11 +340,10 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     // waves build the scan table, and only then scan.  In a team the last scanner also runs the exchange, so the
     // drawers scan first and draw behind the arrival.
     const bool draws_first = k_team == 1;
-    const int n_build = single ? (NW - 4) / 2 : (draws_first ? (NW - 4) - (rj ? 4 : 2) : NW - 4);   // scanner waves that build the scan table:
-    // waves 4 .. 4 + n_build - 1, or (cpb 1) the ones on SIMDs 2, 3 (wave & 2)
-    const bool builder = single ? (wave & 2) != 0 : wave - 4 < n_build;
-    const int build_id = single ? (((wave - 4) >> 2) * 2 + (wave & 1)) * LR_WAVE + lane : tid - 4 * LR_WAVE;
-    (void)build_id;
+    const int n_build = draws_first ? (NW - 4) - (rj ? 4 : 2) : NW - 4;      // scanner waves 4 .. 4 + n_build - 1 build the scan table
+    const bool builder = wave - 4 < n_build;
+    const int build_id = tid - 4 * LR_WAVE;
+    (void)build_id, (void)builder;
     auto draw_duty = [&](unsigned long long it_draw, unsigned long long slot) {
         if (!rj) {
             lr_dd_draws dd;
@@ -379,7 +388,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
         const double lA = sm.likA[lane & 1];
         double acc0 = 0.0, acc1 = 0.0;
-        const char* lbase = reinterpret_cast<const char*>(sm.scan);
+        const char* lbase = reinterpret_cast<const char*>(single ? sm.t.tabs[(role0 >> 2) & 3] : sm.t.pair.scan);
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, part_g0, part_n, sid, n_scan, &acc0, &acc1, &first);
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
         if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
@@ -493,12 +502,13 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         if (k_team > 1 && sm.abort_flag) return;
         sel = sm.dec[iter & 1].sel;
         role0 = lr_spec_turn(role0, sel >> 1), role1 = lr_spec_turn(role1, sel & 1);
-        {
+        if (!single) {
             // The scan table of the next iteration from the columns of the proposals now pending (every scanner wave is past
             // its scan of the old one: the barrier), both chains at once, by all scanner lanes; the scanner waves then wait
-            // for each other on an LDS counter (the candidate waves are already building: no block barrier)
+            // for each other on an LDS counter (the candidate waves are already building: no block barrier).
+            // (A team per chain: nothing to do - the next scan gathers from the pending proposal's own table.)
             if (builder) {
-                lr_build_scan_table<GENERAL>(sm.scan, sm.cols[0][(role0 >> 2) & 3], act1 ? sm.cols[1][(role1 >> 2) & 3] : nullptr, H,
+                lr_build_scan_table<GENERAL>(sm.t.pair.scan, sm.t.pair.cols[0][(role0 >> 2) & 3], act1 ? sm.t.pair.cols[1][(role1 >> 2) & 3] : nullptr, H,
                                              a.cfg.n_bins, build_id, n_build * LR_WAVE);
                 LR_WAVE_LDS_ORDER();
                 if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -515,19 +525,45 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     LR_XDUMP();
 }
 
-// The draw role (a team per chain: waves 2, 3, which carry no candidate): per iteration the state-independent draws of
-// iteration it + 2 - wave 2 the wave-uniform ones, wave 3 the per-rate multiplier draws (lr_spec_draw_part; a parametric
-// sampler's come from wave 2 alone) - into the slot the candidates of the NEXT iteration read.  Same barrier per iteration
-// as the other roles.
+// The helper role (a team per chain: waves 2, 3, on the SIMDs that carry no candidate wave).  Per iteration
+//  (i) the state-independent draws of iteration it + 2 - wave 2 the wave-uniform ones, wave 3 the per-rate multiplier draws
+//      (lr_spec_draw_part; a parametric sampler's come from wave 2 alone) - into the slot the candidates of the NEXT
+//      iteration read;
+//  (ii) RJ sampler: the lookup tables of candidate wave (wave - 2)'s proposal.  That wave hands its segments over as soon
+//      as they are staged and goes on with the guard, the prior and the set; this wave builds the column meanwhile and
+//      writes it, the model constant and the rank cache into the proposal's set: a candidate is two waves on two SIMDs for
+//      the longer half of its build.
+// Same barrier per iteration as the other roles.
 template <int H, int T, bool RJ, bool GENERAL>
-__device__ __forceinline__ void lr_spec_draw_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
+__device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int k_team = ctx.x.team_blocks;
+    const int k = wave - 2;
     for (long long iter = 0; iter < ctx.n_iters; ++iter) {
         const unsigned long long it = ctx.it0 + (unsigned long long)iter;
         if (RJ) {
-            lr_spec_draw_part(a, ctx.c0, lane, it + 2, &sm.draws[0][it & 1], wave - 2);
+            lr_spec_draw_part(a, ctx.c0, lane, it + 2, &sm.draws[0][it & 1], k);
+            lr_table_hand* hand = &sm.hand[k];
+            while (__hip_atomic_load(&hand->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)iter + 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            if (!hand->noop) {
+                lr_set* out = &sm.sets[0][hand->out_idx];
+                const lr_set* base = &sm.sets[0][hand->base_idx];
+                const lr_seg_scratch* sc = &sm.scratch[k];
+                lr_seg_cache sg{base->sgL[lane], base->sgM[lane], hand->reuse != 0};
+                const int eL = lane <= LR_KMAX ? sc->edge[0][lane] : 0, eM = lane <= LR_KMAX ? sc->edge[1][lane] : 0;
+                double* tabd = reinterpret_cast<double*>(sm.t.tabs[hand->out_idx]);
+                const double constP = lr_build_tables_segments<lr_bins_per_lane(H), 2>(
+                    sc, eL, eM, hand->KL, hand->KM, sm.br, sm.logbr, a.cfg.model, a.cfg.n_bins, a.n_cls, a.H,
+                    reinterpret_cast<double2*>(tabd), lane, GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, a.cfg.frac_birth,
+                    a.cfg.frac_death, GENERAL ? 6 * H : 2, &sg);
+                LR_WAVE_LDS_ORDER();
+                if (GENERAL) lr_pair_planes_wave_general(tabd, H, a.cfg.n_bins, lane, 0);
+                else lr_pair_planes_wave(tabd, H, a.cfg.n_bins, lane, 0);
+                out->sgL[lane] = sg.packL, out->sgM[lane] = sg.packM;
+                if (lane == 0) out->sc[LR_SET_CONST] = constP, out->isc[LR_SETI_SEG] = sg.packL != -1 ? 1 : 0;
+            }
         } else if (wave == 2) {
             lr_dd_draws dd;
             lr_make_dd_draws(a, ctx.c0, lane, it + 2, dd);
@@ -541,11 +577,12 @@ __device__ __forceinline__ void lr_spec_draw_role(lr_spec_lds<H, T / LR_WAVE, GE
 // The candidate role (waves 0..3; chain = wave / 2, outcome = wave % 2): build the candidate of iteration it + 1 while
 // the others scan, then - all four waves alike, each on its own SIMD - decide both chains, copy the selected pair
 // table, turn the roles of the sets; waves 0 and 2 keep the books (acceptance count, trace rows, final state).
-template <int H, int T, bool RJ, bool GENERAL>
+template <int H, int T, bool RJ, bool GENERAL, bool SINGLE>
 __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
-    constexpr int ES = GENERAL ? 2 * H : 2;  // the builders' `so`: doubles from a value to its slope inside a column (lr_device.h)
+    // the builders' `so`: doubles from a value to its slope - inside a column (a team per pair) / in the six-plane image
+    constexpr int ES = GENERAL ? (SINGLE ? 6 * H : 2 * H) : 2;
     constexpr int COL = lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>::COL;
     // the per-bin data constants come from their LDS copies (a global load per candidate would sit on the critical path)
     const double* br_lds = sm.br;
@@ -581,16 +618,17 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             const int base_i = (role >> (k ? 2 : 0)) & 3, out_i = (role >> (k ? 6 : 4)) & 3;
             const lr_set* base = &sm.sets[c][base_i];
             lr_set* out = &sm.sets[c][out_i];
-            // the candidate's own column, and the column of the state it starts from
-            double2* table = reinterpret_cast<double2*>(sm.cols[c][out_i]);
-            const double* base_col = sm.cols[c][base_i];
+            // the candidate's own column (a team per chain: its whole scan table), and that of the state it starts from
+            double2* table = SINGLE ? sm.t.tabs[out_i] : reinterpret_cast<double2*>(sm.t.pair.cols[c][out_i]);
+            const double* base_col = SINGLE ? reinterpret_cast<const double*>(sm.t.tabs[base_i]) : sm.t.pair.cols[c][base_i];
             { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(8); } }
             if (!rj) {
                 lr_dd_prop p;
                 lr_dd_draws dd;
                 lr_dd_draws_load(&sm.draws[c][(it + 1) & 1], dd, lane);
                 (void)base_col;
-                const double P = lr_propose_dd<true, false, 1>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, &dd);
+                const double P = SINGLE ? lr_propose_dd<true, true, 2>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, &dd)
+                                        : lr_propose_dd<true, false, 1>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, &dd);
                 out->L[lane] = P;
                 if (lane == 0) {
                     out->sc[LR_SET_HASTING] = p.hasting, out->sc[LR_SET_PRIOR] = p.prior, out->sc[LR_SET_LOG_U] = p.log_u;
@@ -605,8 +643,18 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 lr_rj_prop p;
                 lr_rj_draws d;
                 lr_draws_load(&sm.draws[c][(it + 1) & 1], d, lane);
-                lr_propose_rj<true, lr_bins_per_lane(H), 1, false>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
-                                                                   logbr_lds, base_col, COL, base->sc[LR_SET_CONST]);
+                if (SINGLE) {
+                    // the table is built by helper wave 2 + k from the segments this wave stages; a no-op move copies all
+                    // six planes of its base state's table
+                    lr_table_hand* hand = &sm.hand[k];
+                    if (lane == 0) hand->out_idx = out_i, hand->base_idx = base_i;
+                    lr_propose_rj<true, lr_bins_per_lane(H), 2, true, true>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
+                                                                            logbr_lds, base_col, LR_UNIT_PLANES * H, base->sc[LR_SET_CONST], hand,
+                                                                            (int)iter + 1);
+                } else {
+                    lr_propose_rj<true, lr_bins_per_lane(H), 1, false>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
+                                                                       logbr_lds, base_col, COL, base->sc[LR_SET_CONST]);
+                }
                 lr_set_store(out, s, p, lane);
                 { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
             }
@@ -658,20 +706,21 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
 
 // T threads: waves 0..3 are the candidate waves, the others scan.  The step arguments travel by value (kernarg
 // segment -> scalar registers); both roles are inlined, their loops live in disjoint branches of the kernel.
-template <int H, int T, bool RJ, bool GENERAL>
+template <int H, int T, bool RJ, bool GENERAL, bool SINGLE>
 __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_args a, lr_packed_lineages pk, long long n8,
                                                                      lr_spec_args x, long long n_iters) {
     constexpr int NW = T / LR_WAVE;
     constexpr int ENT = GENERAL ? 2 : 1;
     constexpr int COL = lr_spec_lds<H, NW, ENT>::COL;
+    constexpr int CPB = SINGLE ? 1 : 2;                   // (= x.cpb: the host picks the instantiation by it)
     static_assert(sizeof(lr_spec_lds<H, NW, ENT>) <= 160 * 1024, "the block's LDS image must fit a CU");
     __shared__ lr_spec_lds<H, NW, ENT> sm;
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int k_team = x.team_blocks;
     const int team = blockIdx.x % x.n_teams, rank = blockIdx.x / x.n_teams;   // a team's blocks differ by a multiple of
-    const int c0 = team * x.cpb;                                               // n_teams: one XCD when 8 | n_teams
+    const int c0 = team * CPB;                                                 // n_teams: one XCD when 8 | n_teams
     const int C = a.cfg.n_chains;
-    const int n_act = min(x.cpb, C - c0);
+    const int n_act = min(CPB, C - c0);
     constexpr bool rj = RJ;
     const bool act1 = n_act > 1;
     if (wave < n_act) {
@@ -680,9 +729,11 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
                             &sm.sets[wave][0], &sm.sets[wave][1], lane);
     }
     {
-        // all columns start as zeros (entries no builder writes must not hold junk that would reach the workspace at exit)
-        double* z = &sm.cols[0][0][0];
-        for (int i = tid; i < 8 * COL; i += T) z[i] = 0.0;
+        // all tables start as zeros (entries no builder writes - and, with a team per chain, the unused half of every
+        // entry - must not hold junk: they are gathered with count 0 / copied to the workspace at exit)
+        double* z = reinterpret_cast<double*>(&sm.t);
+        constexpr int N = sizeof(sm.t) / 8;
+        for (int i = tid; i < N; i += T) z[i] = 0.0;
     }
     {
         // sets 2, 3 start as zeros (the parametric samplers write one row only; rows never written must not hold junk
@@ -702,7 +753,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     // the launches queued behind it end here instead of iterating on a state that was never written back
     if (tid == 0)
         sm.abort_flag = (k_team > 1 && __hip_atomic_load((lr_gu32*)x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0,
-        sm.final_p[0] = sm.final_p[1] = 1, sm.scan_arrive = 0, sm.plane_arrive = 0, sm.args = a;
+        sm.final_p[0] = sm.final_p[1] = 1, sm.scan_arrive = 0, sm.plane_arrive = 0, sm.args = a, sm.hand[0].epoch = sm.hand[1].epoch = 0;
     if (tid < 2) sm.likA[tid] = (tid < n_act) ? a.state_f64[((size_t)(c0 + tid) * LR_STATE_ROWS + LR_ROW_SCALARS) * LR_ROW + LR_S_LIKA] : 0.0;
     lr_spec_ctx ctx;
     {
@@ -716,12 +767,17 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     }
     __syncthreads();
     if (sm.abort_flag) return;
-    // The pending proposals' columns (set 1) from global memory, where a chain's entries are its component of its pair
-    // table, 2 doubles apart (lr_chain_table); the ACCEPTED states' columns (set 0) are not kept there: the RJ sampler
+    // The pending proposals' entries (set 1) from global memory, where a chain's entries are its component of its pair
+    // table, 2 doubles apart (lr_chain_table); the ACCEPTED states' tables (set 0) are not kept there: the RJ sampler
     // builds them here, once per launch, from the accepted rates and edges - the doubles their proposals were scored with.
-    for (int cc = 0; cc < n_act; ++cc) {
-        const double* g = reinterpret_cast<const double*>(lr_chain_table(a, c0 + cc));
-        for (int i = tid; i < COL; i += T) sm.cols[cc][1][i] = g[2 * i];
+    if (SINGLE) {
+        const double* g = reinterpret_cast<const double*>(lr_chain_table(a, c0));
+        for (int i = tid; i < COL; i += T) sm.t.tabs[1][GENERAL ? lr_pairgen_lds_entry(i, H) : i].x = g[2 * i];
+    } else {
+        for (int cc = 0; cc < n_act; ++cc) {
+            const double* g = reinterpret_cast<const double*>(lr_chain_table(a, c0 + cc));
+            for (int i = tid; i < COL; i += T) sm.t.pair.cols[cc][1][i] = g[2 * i];
+        }
     }
     if (rj && (wave == 0 || wave == 2) && (wave >> 1) < n_act) {
         const int cc = wave >> 1;
@@ -729,18 +785,35 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         lr_set_load(&sm.sets[cc][0], s, lane);
         double logL, logM;
         lr_stage_segments(&sm.scratch[wave], s.L, s.M, s.eL, s.eM, s.KL, s.KM, lane, &logL, &logM);
-        (void)lr_build_tables_segments<lr_bins_per_lane(H), 1>(&sm.scratch[wave], s.eL, s.eM, s.KL, s.KM, sm.br, sm.logbr, a.cfg.model,
-                                                               a.cfg.n_bins, a.n_cls, a.H, reinterpret_cast<double2*>(sm.cols[cc][0]), lane,
-                                                               GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, a.cfg.frac_birth, a.cfg.frac_death,
-                                                               GENERAL ? 2 * H : 2, nullptr);
+        if (SINGLE) {
+            double* tabd = reinterpret_cast<double*>(sm.t.tabs[0]);
+            (void)lr_build_tables_segments<lr_bins_per_lane(H), 2>(&sm.scratch[wave], s.eL, s.eM, s.KL, s.KM, sm.br, sm.logbr, a.cfg.model,
+                                                                   a.cfg.n_bins, a.n_cls, a.H, reinterpret_cast<double2*>(tabd), lane,
+                                                                   GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, a.cfg.frac_birth, a.cfg.frac_death,
+                                                                   GENERAL ? 6 * H : 2, nullptr);
+            LR_WAVE_LDS_ORDER();
+            if (GENERAL) lr_pair_planes_wave_general(tabd, H, a.cfg.n_bins, lane, 0);
+            else lr_pair_planes_wave(tabd, H, a.cfg.n_bins, lane, 0);
+        } else {
+            (void)lr_build_tables_segments<lr_bins_per_lane(H), 1>(&sm.scratch[wave], s.eL, s.eM, s.KL, s.KM, sm.br, sm.logbr, a.cfg.model,
+                                                                   a.cfg.n_bins, a.n_cls, a.H, reinterpret_cast<double2*>(sm.t.pair.cols[cc][0]),
+                                                                   lane, GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, a.cfg.frac_birth,
+                                                                   a.cfg.frac_death, GENERAL ? 2 * H : 2, nullptr);
+        }
     }
     __syncthreads();
-    lr_build_scan_table<GENERAL>(sm.scan, sm.cols[0][1], act1 ? sm.cols[1][1] : nullptr, H, a.cfg.n_bins, tid, T);
+    if (SINGLE) {
+        // the pair planes of the pending proposal's table
+        if (GENERAL) lr_pair_planes_block_general(sm.t.tabs[1], H, a.cfg.n_bins, tid, T);
+        else lr_pair_planes_block(sm.t.tabs[1], H, a.cfg.n_bins, tid, T);
+    } else {
+        lr_build_scan_table<GENERAL>(sm.t.pair.scan, sm.t.pair.cols[0][1], act1 ? sm.t.pair.cols[1][1] : nullptr, H, a.cfg.n_bins, tid, T);
+    }
     // draws of the first candidates (iteration it0 + 1); afterwards the last four scanner waves stay one iteration ahead
     // (a block on its own draws at the top of an iteration for the one after the next: it starts with two iterations' draws)
     if (wave >= NW - 2 && wave - (NW - 2) < n_act) {
-        // (a team per chain: its draw role makes the draws of it0 + 2 in the first iteration)
-        for (unsigned long long ahead = 1; ahead <= ((k_team == 1 && x.cpb != 1) ? 2ull : 1ull); ++ahead) {
+        // (a team per chain: its helper waves make the draws of it0 + 2 in the first iteration)
+        for (unsigned long long ahead = 1; ahead <= ((k_team == 1 && !SINGLE) ? 2ull : 1ull); ++ahead) {
             const unsigned long long itd = ctx.it0 + ahead;
             if (rj) {
                 lr_spec_draw(a, c0 + (wave - (NW - 2)), lane, itd, &sm.draws[wave - (NW - 2)][itd & 1]);
@@ -752,15 +825,21 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         }
     }
     __syncthreads();
-    if (x.cpb == 1 && (wave == 2 || wave == 3)) lr_spec_draw_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
-    else if (wave < 4) lr_spec_cand_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
-    else lr_spec_scan_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
+    if (SINGLE && (wave == 2 || wave == 3)) lr_spec_help_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
+    else if (wave < 4) lr_spec_cand_role<H, T, RJ, GENERAL, SINGLE>(sm, a, ctx, tid);
+    else lr_spec_scan_role<H, T, RJ, GENERAL, SINGLE>(sm, a, ctx, tid);
     __syncthreads();
     if (sm.abort_flag || rank != 0) return;
-    // the pending proposals' columns back into their components of the pair tables
-    for (int cc = 0; cc < n_act; ++cc) {
-        double* g = reinterpret_cast<double*>(lr_chain_table(a, c0 + cc));
-        const double* col = sm.cols[cc][sm.final_p[cc]];
-        for (int i = tid; i < COL; i += T) g[2 * i] = col[i];
+    // the pending proposals' entries back into their components of the pair tables
+    if (SINGLE) {
+        double* g = reinterpret_cast<double*>(lr_chain_table(a, c0));
+        const double2* tab = sm.t.tabs[sm.final_p[0]];
+        for (int i = tid; i < COL; i += T) g[2 * i] = tab[GENERAL ? lr_pairgen_lds_entry(i, H) : i].x;
+    } else {
+        for (int cc = 0; cc < n_act; ++cc) {
+            double* g = reinterpret_cast<double*>(lr_chain_table(a, c0 + cc));
+            const double* col = sm.t.pair.cols[cc][sm.final_p[cc]];
+            for (int i = tid; i < COL; i += T) g[2 * i] = col[i];
+        }
     }
 }

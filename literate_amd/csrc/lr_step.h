@@ -380,6 +380,7 @@ struct lr_rj_prop {
     double hasting, prior, constP;        // Hastings / log q + log J term, log prior, model constant of its likelihood
     double log_u;                         // log of the acceptance uniform of the iteration that decides it
     int gibbs, invalid, move;             // Gibbs step (always accepted); fails the LRF:290 guard / the K cap; LR_I_MOVE kind
+    int table_by_helper;                  // the column, the model constant and the rank cache come from a helper wave
 };
 
 // The Metropolis-Hastings rule of LRF:305-313 for a pending proposal whose lineage scan returned lik_sum.
@@ -541,19 +542,35 @@ __device__ __forceinline__ double lr_wave_multiplier_pre(double& R, int K, bool 
 // hyper-parameters, every other move the rates / times of one process), `p` its bookkeeping, and its lookup tables
 // stand at `table`.  A pure function of (s, it, the chain's Philox stream, the data): the speculative engine calls it
 // on both possible outcomes of the pending decision.
+// hand-over of a proposal's table build to a helper wave (speculative kernel, a team per chain: lr_spec_help_role)
+struct lr_table_hand {
+    int epoch;             // launch-local number (iteration + 1) of the proposal whose segments stand in the scratch
+    int KL, KM;            // its numbers of rates
+    int reuse;             // the base state's bin ranks still hold (lr_seg_cache)
+    int noop;              // the candidate wave has copied its base state's column: nothing to build
+    int out_idx, base_idx; // sets of the proposal and of the state it was made from
+    int pad_;
+};
+
 // CS: doubles between consecutive entries of the chain's column at `table` (2: inside a pair table, 1: a column of its
 // own).  base_col (CS == 1 only): the column of the state `s` comes in as, `col_doubles` long, and base_const its model
 // constant: a proposal that changes no rate and no bin edge - the no-op "times" moves (LRF:178-195: 40 % of the
 // iterations once both processes hold a shift) and the Gibbs step - has the SAME lookup tables as its base state, so
 // its column is copied (a handful of LDS moves) instead of built (the largest single item of a proposal).  The copy
 // holds the very doubles a rebuild would produce - the builder is a pure function of rates and edges.
-template <bool LDS_CONSTS = false, int PB = 0, int CS = 2, bool PAIR_PLANES = true>
+// HAND (with `hand`): the table is built by ANOTHER wave: as soon as the proposal's segments stand in the scratch they are
+// handed over (epoch `hand_epoch`), this wave goes on with the guard and the prior and leaves the column, its pair planes,
+// the model constant and the rank cache of the proposal to the helper (p.table_by_helper) - this instance then holds no
+// table builder at all.  base_col is then the base state's whole table, `col_doubles` entries CS doubles apart.
+template <bool LDS_CONSTS = false, int PB = 0, int CS = 2, bool PAIR_PLANES = true, bool HAND = false>
 __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int lane, lr_seg_scratch* scratch_p,
                                               uint64_t it, lr_rj_state& s, lr_rj_prop& p, double2* table,
                                               int table_es, const lr_rj_draws* pre = nullptr,
                                               const double* br_lds = nullptr, const double* logbr_lds = nullptr,
-                                              const double* base_col = nullptr, int col_doubles = 0, double base_const = 0.0) {
+                                              const double* base_col = nullptr, int col_doubles = 0, double base_const = 0.0,
+                                              lr_table_hand* hand = nullptr, int hand_epoch = 0) {
     static_assert(CS == 2 || (PB > 0 && !PAIR_PLANES), "a column of its own: one-pass builder, no pair planes");
+    static_assert(!HAND || PB > 0, "a helper wave runs the one-pass builder");
     lr_seg_scratch& scratch = *scratch_p;
     const lr_mcmc_config& cfg = a.cfg;
     const int n_bins = cfg.n_bins;
@@ -677,6 +694,19 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
     lr_stage_segments(&scratch, pL, pM, peL, peM, PKL, PKM, lane, &logpL, &logpM, u_next, &log_u_next);
     if (pre) log_u_next = pre->log_u;
 
+    // the ranks of the bins can be taken over from the state the proposal was made from while no edge moved (every
+    // multiplier move and Gibbs step, most of the no-op times moves); then, if no rate changed either, so can its column
+    lr_seg_cache sg{s.sgL, s.sgM, false};
+    bool edges_same = false;
+    if ((pre && s.sg_valid) || base_col) edges_same = PKL == KL && PKM == KM && __ballot(lane <= LR_KMAX && (peL != eL || peM != eM)) == 0ull;
+    if (pre && s.sg_valid) sg.reuse = edges_same;
+    const bool same_table = base_col && edges_same && (move_kind == 1 || move_kind == 3 || move_kind == 5);
+    if (HAND) {
+        if (lane == 0) hand->KL = PKL, hand->KM = PKM, hand->reuse = sg.reuse ? 1 : 0, hand->noop = same_table ? 1 : 0;
+        LR_WAVE_LDS_ORDER();      // (a wave's LDS operations execute in order: the scratch and the fields stand before the epoch)
+        if (lane == 0) __hip_atomic_store(&hand->epoch, hand_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+
     LR_SSTAMP(4);
     // guard against tiny time frames (LRF:290-292) and the prior of the proposal (LRF:296-304)
     double priorP = -INFINITY;
@@ -699,17 +729,14 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
 
     LR_SSTAMP(5);
     // ---- lookup tables of the proposal ----
-    // the ranks of the bins can be taken over from the state the proposal was made from while no edge moved (every
-    // multiplier move and Gibbs step, most of the no-op times moves)
-    lr_seg_cache sg{s.sgL, s.sgM, false};
-    bool edges_same = false;
-    if ((pre && s.sg_valid) || base_col) edges_same = PKL == KL && PKM == KM && __ballot(lane <= LR_KMAX && (peL != eL || peM != eM)) == 0ull;
-    if (pre && s.sg_valid) sg.reuse = edges_same;
-    double constP;
-    if (CS == 1 && base_col && edges_same && (move_kind == 1 || move_kind == 3 || move_kind == 5)) {
+    double constP = 0.0;
+    p.table_by_helper = 0;
+    if (same_table) {
         double* col = reinterpret_cast<double*>(table);
-        for (int i = lane; i < col_doubles; i += LR_WAVE) col[i] = base_col[i];
+        for (int i = lane; i < col_doubles; i += LR_WAVE) col[CS * i] = base_col[CS * i];
         constP = base_const;
+    } else if (HAND) {
+        p.table_by_helper = 1;
     } else {
         // (the per-bin data constants from the caller's LDS copies when it keeps some)
         constP = lr_build_tables_segments<PB, CS>(&scratch, peL, peM, PKL, PKM, LDS_CONSTS ? br_lds : a.br_length,
@@ -719,9 +746,10 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
                                                   table_es, pre ? &sg : nullptr);
         s.sgL = sg.packL, s.sgM = sg.packM, s.sg_valid = (pre && sg.packL != -1) ? 1 : 0;
     }
-    if (LDS_CONSTS && PAIR_PLANES) {
-        // persistent engines: the pair planes the packed scan gathers from (lr_scan.h; the speculative kernel leaves them
-        // to its scanner waves, which derive them for the selected table only)
+    if (LDS_CONSTS && PAIR_PLANES && !HAND && !same_table) {
+        // persistent engines: the pair planes the packed scan gathers from (lr_scan.h; a team per pair of the speculative
+        // kernel leaves them to its scanner waves, which derive them for the selected columns only; a copied table
+        // brings its planes along)
         LR_WAVE_LDS_ORDER();
         if (lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, n_bins, lane, 0);
         else lr_pair_planes_wave_general(reinterpret_cast<double*>(table), a.H, n_bins, lane, 0);

@@ -321,7 +321,8 @@ def test_long_inputs_and_few_chain_shards_keep_parity(engine, C, kw):
     eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine)
     assert eng.layout.persistent == {"spec": 3, "persistent2": 1, "persistent4": 2}[engine]
     if engine == "spec":
-        assert eng.layout.team_blocks == (4 if C == 128 else 8)
+        # the 128-chain shard: a team of 2 CUs per chain (a team of 4 per pair on general times); few chains: teams of 8
+        assert (eng.layout.team_blocks, eng.layout.spec_chains_per_team) == (((4, 2) if general else (2, 1)) if C == 128 else (8, 1))
     assert eng.layout.table_mode == (2 if general else 1)
     eng.init(); eng.steps(25); eng.steps(n_it - 25)
     tr = eng.trace_rows()

@@ -43,9 +43,13 @@ def test_library_exports_every_declared_symbol():
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
     assert lay.chains_per_block == 16 and lay.table_stride == 136 and lay.pipelined == 1
     assert lay.persistent == 2 and lay.lineage_idx > 0 and lay.table_mode == 1   # auto: four-chain kernel for 1024 chains x 100k
-    cfg.n_chains = 128                                            # a 128-chain shard: speculative kernel, a team of 4 CUs per pair
+    cfg.n_chains = 128                                            # a 128-chain shard: speculative kernel, a team of 2 CUs per CHAIN
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
-    assert lay.persistent == 3 and lay.team_blocks == 4 and lay.xchg > 0 and lay.reserved1 == 768
+    assert lay.persistent == 3 and lay.team_blocks == 2 and lay.spec_chains_per_team == 1 and lay.xchg > 0 and lay.reserved1 == 768
+    cfg.team_request = 4 | (2 << 8)                               # ... or, asked for, a team of 4 CUs per chain PAIR
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
+    assert lay.persistent == 3 and lay.team_blocks == 4 and lay.spec_chains_per_team == 2
+    cfg.team_request = 0
     cfg.n_chains = 1024
     cfg.engine_mode = 1
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0
@@ -250,10 +254,11 @@ def test_planner_refuses_teams_beyond_the_device():
             os.environ.pop("LR_DEVICE_CUS", None)
 
     rc, lay = layout(128)
-    assert rc == 0 and lay.persistent == 3 and lay.team_blocks == 4            # 64 pairs x 4 = 256 blocks on 256 CUs
+    assert rc == 0 and lay.persistent == 3 and lay.team_blocks == 2 and lay.spec_chains_per_team == 1   # 128 chains x 2 = 256 blocks on 256 CUs
     for cus in (128, 100, 64):
         rc, lay = layout(128, cus=cus)
-        assert rc == 0 and lay.persistent == 3 and 64 * lay.team_blocks <= cus, (cus, lay.team_blocks)
+        teams = 128 if lay.spec_chains_per_team == 1 else 64
+        assert rc == 0 and lay.persistent == 3 and teams * lay.team_blocks <= cus, (cus, lay.team_blocks, lay.spec_chains_per_team)
     rc, lay = layout(128, cus=32)                                               # fewer CUs than chain pairs: no teams at all
     assert rc == 0 and lay.persistent != 3
     rc, lay = layout(128, team=8)                                               # 64 x 8 > 256: the request cannot be met

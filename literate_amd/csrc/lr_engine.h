@@ -65,7 +65,13 @@ static inline long long lr_groups_alloc(long long n_lineages) {
 
 // ---- speculative team engine (lr_spec.h / lr_spec.hip) ----
 #ifndef LR_SPEC_THREADS
-#define LR_SPEC_THREADS 768   /* 12 waves: 4 candidate + 8 scanner waves, 3 per SIMD = 168 VGPRs each */
+#define LR_SPEC_THREADS 768   /* a team per pair: 12 waves = 4 candidate + 8 scanner waves, 3 per SIMD = 168 VGPRs each */
+#endif
+#ifndef LR_SPEC_THREADS_SINGLE
+#define LR_SPEC_THREADS_SINGLE 768    /* a team per chain: 12 waves = 2 candidate + 2 helper + 8 scanner waves.  (1024 threads = 12
+                                         scanner waves fit without spills - with the table build on the helper waves no role needs
+                                         more than ~105 VGPRs - and take 5 % off a 100k-lineage scan on one CU, but every team
+                                         exchange and every short scan got 3-8 % slower: measured round 3, not used) */
 #endif
 #ifndef LR_SPEC_SCAN_UNROLL
 #define LR_SPEC_SCAN_UNROLL 1

@@ -890,7 +890,7 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
             // (groups beyond an XCD's 4 MB of L2 stream from HBM with one group of prefetch per lane: measured 0.32 instead of
             // 0.205 us per trip at 10M lineages, scratch/exp_fewchains.py)
             const double slow = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) > 4.0e6 ? 1.55 : 1.0;
-            const double trips = slow * n8 / k / (double)(LR_SPEC_THREADS - 256);
+            const double trips = slow * n8 / k / (double)((cpb == 1 ? LR_SPEC_THREADS_SINGLE : LR_SPEC_THREADS) - 256);
             double t;
             if (cfg->sampler != 0) {
                 if (cpb == 2) t = (k == 1) ? fmax(2.60, 2.70 + 0.18 * trips) : fmax(3.05, 2.70 + 0.21 * trips);
@@ -1061,7 +1061,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     {
         static const int wide_env = lr_env_int("LR_PERSIST_WIDE", -1);
         const bool wide = wide_env >= 0 ? wide_env != 0 : ((cfg->n_chains + 1) / 2 <= 256 && cfg->n_lineages >= 20000);
-        out->reserved1 = out->persistent == 3 ? LR_SPEC_THREADS : (out->persistent == 2 ? 1024 : (out->persistent == 1 ? (wide ? 1024 : 512) : 0));   // threads per persistent block
+        out->reserved1 = out->persistent == 3 ? (team_cpb == 1 ? LR_SPEC_THREADS_SINGLE : LR_SPEC_THREADS) : (out->persistent == 2 ? 1024 : (out->persistent == 1 ? (wide ? 1024 : 512) : 0));   // threads per persistent block
     }
     return LR_OK;
 }

@@ -529,10 +529,10 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
 //  (i) the state-independent draws of iteration it + 2 - wave 2 the wave-uniform ones, wave 3 the per-rate multiplier draws
 //      (lr_spec_draw_part; a parametric sampler's come from wave 2 alone) - into the slot the candidates of the NEXT
 //      iteration read;
-//  (ii) RJ sampler: the lookup tables of candidate wave (wave - 2)'s proposal.  That wave hands its segments over as soon
-//      as they are staged and goes on with the guard, the prior and the set; this wave builds the column meanwhile and
-//      writes it, the model constant and the rank cache into the proposal's set: a candidate is two waves on two SIMDs for
-//      the longer half of its build.
+//  (ii) the lookup tables of candidate wave (wave - 2)'s proposal.  That wave hands its segments (RJ sampler) or its
+//      parameter vector (parametric samplers) over as soon as they stand and goes on with the guard, the prior and the
+//      set; this wave builds the table with its pair planes meanwhile and - RJ - writes the model constant and the rank
+//      cache into the proposal's set: a candidate is two waves on two SIMDs for the longer half of its build.
 // Same barrier per iteration as the other roles.
 template <int H, int T, bool RJ, bool GENERAL>
 __device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
@@ -564,10 +564,18 @@ __device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GE
                 out->sgL[lane] = sg.packL, out->sgM[lane] = sg.packM;
                 if (lane == 0) out->sc[LR_SET_CONST] = constP, out->isc[LR_SETI_SEG] = sg.packL != -1 ? 1 : 0;
             }
-        } else if (wave == 2) {
-            lr_dd_draws dd;
-            lr_make_dd_draws(a, ctx.c0, lane, it + 2, dd);
-            lr_dd_draws_store(&sm.draws[0][it & 1], dd, lane);
+        } else {
+            if (wave == 2) {
+                lr_dd_draws dd;
+                lr_make_dd_draws(a, ctx.c0, lane, it + 2, dd);
+                lr_dd_draws_store(&sm.draws[0][it & 1], dd, lane);
+            }
+            // the lookup tables (and pair planes) of candidate wave k's proposal, from its parameter vector
+            lr_table_hand* hand = &sm.hand[k];
+            while (__hip_atomic_load(&hand->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)iter + 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const double P = lane < 8 ? hand->par[lane] : 0.0;
+            lr_param_tables<true, true, 2>(a, P, sm.br, sm.t.tabs[hand->out_idx], GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, GENERAL ? 6 * H : 2, lane);
         }
         __syncthreads();
         if (k_team > 1 && sm.abort_flag) return;
@@ -627,8 +635,15 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 lr_dd_draws dd;
                 lr_dd_draws_load(&sm.draws[c][(it + 1) & 1], dd, lane);
                 (void)base_col;
-                const double P = SINGLE ? lr_propose_dd<true, true, 2>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, &dd)
-                                        : lr_propose_dd<true, false, 1>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, &dd);
+                double P;
+                if (SINGLE) {
+                    // (the tables are built by helper wave 2 + k from the proposed parameter vector)
+                    lr_table_hand* hand = &sm.hand[k];
+                    if (lane == 0) hand->out_idx = out_i, hand->base_idx = base_i;
+                    P = lr_propose_dd<true, true, 2, true>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, &dd, hand, (int)iter + 1);
+                } else {
+                    P = lr_propose_dd<true, false, 1>(a, c0 + c, lane, it + 1, base->L[lane], p, table, ES, br_lds, &dd);
+                }
                 out->L[lane] = P;
                 if (lane == 0) {
                     out->sc[LR_SET_HASTING] = p.hasting, out->sc[LR_SET_PRIOR] = p.prior, out->sc[LR_SET_LOG_U] = p.log_u;

@@ -20,14 +20,14 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
                     const hipError_t he = hipMemsetAsync(x.xchg, 0, xbytes, stream);
                     if (he != hipSuccess) return (int)he;
                 }
-                const dim3 grid((unsigned)(blocks * x.team_blocks)), blk(LR_SPEC_THREADS);
+                const dim3 grid((unsigned)(blocks * x.team_blocks)), blk(cpb == 1 ? LR_SPEC_THREADS_SINGLE : LR_SPEC_THREADS);
 #define LR_SPEC_LAUNCH(HH, GG)                                                                                                \
     if (e->cfg.sampler == 0 && cpb == 1)                                                                                      \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, true, GG, true>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
+        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS_SINGLE, true, GG, true>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
     else if (e->cfg.sampler == 0)                                                                                             \
         hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, true, GG, false>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
     else if (cpb == 1)                                                                                                        \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, false, GG, true>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
+        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS_SINGLE, false, GG, true>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
     else                                                                                                                      \
         hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, false, GG, false>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n)
                 // (the eight candidate tables + the scan table: 352 H bytes at unit resolution, 608 H on general times, where

@@ -550,6 +550,7 @@ struct lr_table_hand {
     int noop;              // the candidate wave has copied its base state's column: nothing to build
     int out_idx, base_idx; // sets of the proposal and of the state it was made from
     int pad_;
+    double par[8];         // parametric samplers: the proposed parameter vector (what their tables are a function of)
 };
 
 // CS: doubles between consecutive entries of the chain's column at `table` (2: inside a pair table, 1: a column of its
@@ -921,10 +922,36 @@ __device__ __forceinline__ void lr_make_dd_draws(const lr_step_args& a, int c, i
     }
 }
 
-template <bool LDS_CONSTS = false, bool PAIR_PLANES = true, int CS = 2>
+// The lookup tables (and, PAIR_PLANES, the pair planes behind them) of a parametric sampler's parameter vector P (lane j
+// holds parameter j): DDRate's per-bin rates from the diversity trajectory `aux` = DT (DD:55-100) or trend_rate's from the
+// normalised covariate `aux` = TREND (trend_rate.py:73-88).
+template <bool LDS_CONSTS, bool PAIR_PLANES, int CS>
+__device__ __forceinline__ void lr_param_tables(const lr_step_args& a, double P, const double* aux, double2* table, int mode,
+                                                int table_es, int lane) {
+    const lr_mcmc_config& cfg = a.cfg;
+    if (cfg.sampler == 2) {
+        const lr_trend_params tp = lr_trend_unpack(P);
+        lr_rates_build_tables_wave<CS>([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
+                                       cfg.n_bins, a.H, table, lane, mode, cfg.frac_birth, cfg.frac_death, table_es);
+    } else {
+        const lr_dd_params pp = lr_dd_unpack(P);
+        lr_dd_build_tables_wave<CS>(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, mode, cfg.frac_birth, cfg.frac_death,
+                                    table_es);
+    }
+    if (LDS_CONSTS && PAIR_PLANES) {
+        LR_WAVE_LDS_ORDER();
+        if (mode == LR_TAB_UNIT) lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, 0);
+        else lr_pair_planes_wave_general(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, 0);
+    }
+}
+
+// HAND (with `hand`): the tables and their pair planes are built by a helper wave from the proposed parameter vector,
+// handed over (epoch `hand_epoch`) as soon as it stands; this wave goes on with the prior.
+template <bool LDS_CONSTS = false, bool PAIR_PLANES = true, int CS = 2, bool HAND = false>
 __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, int lane, uint64_t it, double A,
                                                 lr_dd_prop& p, double2* table, int table_es,
-                                                const double* aux_lds = nullptr, const lr_dd_draws* pre = nullptr) {
+                                                const double* aux_lds = nullptr, const lr_dd_draws* pre = nullptr,
+                                                lr_table_hand* hand = nullptr, int hand_epoch = 0) {
     static_assert(CS == 2 || !PAIR_PLANES, "a column of its own carries no pair planes");
     const lr_mcmc_config& cfg = a.cfg;
     const bool trend = cfg.sampler == 2;
@@ -985,21 +1012,15 @@ __device__ __forceinline__ double lr_propose_dd(const lr_step_args& a, int c, in
             move_kind = 0;
         }
     }
-    if (trend) {
-        p.prior = lr_trend_prior(P, lane);
-        const lr_trend_params tp = lr_trend_unpack(P);
-        lr_rates_build_tables_wave<CS>([&](int b, double* br, double* dr) { lr_trend_bin_rates(tp, aux[b], cfg.m_birth, cfg.m_death, br, dr); },
-                                       cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es), cfg.frac_birth, cfg.frac_death, table_es);
-    } else {
-        p.prior = lr_dd_prior(P, origin, present, k0, log_k0, lane);
-        const lr_dd_params pp = lr_dd_unpack(P);
-        lr_dd_build_tables_wave<CS>(pp, aux, cfg.m_birth, cfg.m_death, cfg.n_bins, a.H, table, lane, lr_tab_mode<LDS_CONSTS>(a, table_es),
-                                    cfg.frac_birth, cfg.frac_death, table_es);
-    }
-    if (LDS_CONSTS && PAIR_PLANES) {
+    if (HAND) {
+        if (lane < 8) hand->par[lane] = P;
         LR_WAVE_LDS_ORDER();
-        if (lr_tab_mode<LDS_CONSTS>(a, table_es) == LR_TAB_UNIT) lr_pair_planes_wave(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, 0);
-        else lr_pair_planes_wave_general(reinterpret_cast<double*>(table), a.H, cfg.n_bins, lane, 0);
+        if (lane == 0) __hip_atomic_store(&hand->epoch, hand_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        p.prior = trend ? lr_trend_prior(P, lane) : lr_dd_prior(P, origin, present, k0, log_k0, lane);
+    } else {
+        if (trend) p.prior = lr_trend_prior(P, lane);
+        else p.prior = lr_dd_prior(P, origin, present, k0, log_k0, lane);
+        lr_param_tables<LDS_CONSTS, PAIR_PLANES, CS>(a, P, aux, table, lr_tab_mode<LDS_CONSTS>(a, table_es), table_es, lane);
     }
     p.hasting = hasting, p.move = move_kind;
     return P;

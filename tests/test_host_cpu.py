@@ -48,7 +48,7 @@ def test_library_exports_every_declared_symbol():
     assert lay.persistent == 3 and lay.team_blocks == 2 and lay.spec_chains_per_team == 1 and lay.xchg > 0 and lay.reserved1 == 768
     cfg.team_request = 4 | (2 << 8)                               # ... or, asked for, a team of 4 CUs per chain PAIR
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0
-    assert lay.persistent == 3 and lay.team_blocks == 4 and lay.spec_chains_per_team == 2
+    assert lay.persistent == 3 and lay.team_blocks == 4 and lay.spec_chains_per_team == 2 and lay.reserved1 == 768
     cfg.team_request = 0
     cfg.n_chains = 1024
     cfg.engine_mode = 1

@@ -215,6 +215,24 @@ class ChainEngine:
         self.iterations += int(n)
         return float(ms.value)
 
+    def prepared_timed_steps(self, n):
+        """timed_steps(n) with every argument marshalled beforehand: returns a zero-argument callable that makes the one
+        ABI call (blocking) and returns the elapsed device ms.  For short timed regions (bench.py at --steps 20) the
+        Python side of a call is a measurable share of the wall clock."""
+        import torch
+        ms = C.c_float(0.0)
+        fn, handle, n_c, ms_ref = self.lib.lr_mcmc_time_steps, self.handle, C.c_int64(int(n)), C.byref(ms)
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+        def call():
+            rc = fn(handle, n_c, ms_ref, stream)
+            if rc:
+                _hip.check(rc, "lr_mcmc_time_steps")
+            self.iterations += int(n)
+            return float(ms.value)
+        return call
+
     # ---- checkpoint / resume (no reference counterpart; SURVEY section 8f N4) ----
     _CFG_KEYS = ("n_lineages", "n_bins", "n_chains", "model", "const_rates", "const_death_rate", "use_rate_HP",
                  "s_freq", "n_trace_slots", "poisson_HP", "update_fraction", "t0", "start_time", "end_time", "seed",

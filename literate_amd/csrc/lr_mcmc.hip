@@ -888,7 +888,7 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
             if (teams * k > cus) break;
             if (k_env > 0 && k != k_env) continue;
             // (groups beyond an XCD's 4 MB of L2 stream from HBM with one group of prefetch per lane: measured 0.32 instead of
-            // 0.205 us per trip at 10M lineages, scratch/exp_fewchains.py)
+            // 0.205 us per trip at 10M lineages; round-2 sweep)
             const double slow = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) > 4.0e6 ? 1.55 : 1.0;
             const double trips = slow * n8 / k / (double)((cpb == 1 ? LR_SPEC_THREADS_SINGLE : LR_SPEC_THREADS) - 256);
             double t;

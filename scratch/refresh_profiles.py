@@ -21,6 +21,14 @@ launch = {"source": "rocprofv3 --kernel-trace --stats --output-format csv -- pyt
           "timed_2000_iteration_launch_ms_kernel_trace": d[-1],
           "bench_hip_event_ms_for_the_timed_2000_iteration_launch": prof_bench["roofline"]["kernel_ms"]}
 json.dump(launch, open(os.path.join(root, "profiles/%s_launch_durations.json" % tag), "w"), indent=1)
+# duration of the profiled launch in the SQ-counter pass (its kernel trace): the clock of the busy fractions below.
+# (GRBM_GUI_ACTIVE / 8 served as that clock in round 2; on round 3's box the counter read 1.48 x the cycles the trace's
+# duration allows at 2.4 GHz, so the duration is used and the counter kept for the record.)
+sq_rows = []
+for f in glob.glob(os.path.join(src, "SQ_LDS_IDX_ACTIVE", "*", "*kernel_trace.csv")):
+    sq_rows += [r for r in csv.DictReader(open(f)) if kname.split("<")[0] in r["Kernel_Name"]]
+launch_ns = max(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sq_rows)
+cycles = launch_ns * 2.4                    # shader clock 2.4 GHz
 p = json.load(open(os.path.join(src, "pmc_summary.json")))
 k = [x for x in p if kname.split("<")[0] in x][0]
 v = {a: b["mean"] for a, b in p[k].items()}
@@ -28,12 +36,13 @@ summary = {"kernel": kname, "workload": "cfg4: 1024 chains x 100k lineages", "it
            "counters_mean_per_launch": v,
            "hbm_bytes_per_iteration": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / 1000,
            "correction": "gfx950: FETCH_SIZE counts half the bytes of 16 B/lane coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact; both in KiB",
-           "lds_busy_fraction": v["SQ_LDS_IDX_ACTIVE"] / v["GRBM_GUI_ACTIVE"] / 32,
-           "valu_busy_fraction": v["SQ_ACTIVE_INST_VALU"] / v["GRBM_GUI_ACTIVE"] / 32,
+           "profiled_launch_ms": launch_ns / 1e6, "cycles_at_2.4GHz": cycles,
+           "lds_busy_fraction": v["SQ_LDS_IDX_ACTIVE"] / cycles / 256,
+           "valu_busy_fraction": v["SQ_ACTIVE_INST_VALU"] / cycles / 256,
            "lds_bank_conflict_fraction": v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"],
            # wave64 vector instructions (VALU + LDS) per SIMD x 4.18 cycles each (scratch/ubench/valu_rate.hip) over the
-           # cycles of the launch (GRBM_GUI_ACTIVE sums the 8 XCDs): how full the SIMDs' issue ports are
-           "vector_issue_fraction": (v["SQ_INSTS_VALU"] + v["SQ_INSTS_LDS"]) / (256 * 4) * 4.18 / (v["GRBM_GUI_ACTIVE"] / 8),
+           # cycles of the launch: how full the SIMDs' issue ports are
+           "vector_issue_fraction": (v["SQ_INSTS_VALU"] + v["SQ_INSTS_LDS"]) / (256 * 4) * 4.18 / cycles,
            "vector_instructions_per_CU_per_iteration": (v["SQ_INSTS_VALU"] + v["SQ_INSTS_LDS"]) / 256 / 1000,
            "wave_cycles_split": {x: v[x] / v["SQ_WAVE_CYCLES"] for x in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS") if x in v},
            "source": "rocprofv3 --pmc <counter group> --kernel-trace (separate passes) -- python3 scratch/prof_persist.py (one launch of "

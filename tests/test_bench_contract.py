@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r02_bench_cfg4_1gpu.json = `python bench.py` on an MI355X) carries every field the
+"""The committed bench line (profiles/r03_bench_cfg4_1gpu.json = `python bench.py` on an MI355X) carries every field the
 driver's contract names, and the numbers in it are mutually consistent and agree with the committed rocprofv3 summary."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    b = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_cfg4_1gpu.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_cfg4_1gpu.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "configs"):
         assert k in b, k
@@ -39,15 +39,37 @@ def test_committed_bench_line_has_the_contract_fields():
         s = b["configs"][name]
         assert s["evals_per_s"] > 0 and s["us_per_iter"] > 0 and 0 < s["lds_frac"] < 1 and s["kernel"].startswith("lr_")
     assert b["configs"]["cfg5"]["cpu_baseline"]["kind"] == "port"
+    # the unit is stated for what it is: gathers and fp64 operations per counted eval, the un-amortised 16-B figure, the
+    # aggregation in words; every host core in the CPU leg; the co-headline on continuous times with its own roofline
+    assert r["gathers_per_eval"] == pytest.approx(8 / 28) and r["fp64_ops_per_eval"] == pytest.approx(17 / 28)
+    assert "pre-summed" in r["aggregation"] and "frozen" in cfg["eval_note"] and "no per-bin event counts" not in cfg["eval_note"]
+    assert h["effective_GBs_16B_per_eval"] == pytest.approx(16 * r["kernel_evals_per_s"] / 1e9)
+    assert h["frac_of_peak_16B_convention"] == pytest.approx(h["algorithmic_GBs_16B_convention"] / 8000.0)
+    assert c["all_cores"]["cores"] >= 16 and "sched_getaffinity" in c["all_cores"]["sample"]
+    co = b["co_headline"]
+    assert "continuous times" in co["workload"] and co["value"] == pytest.approx(b["configs"]["cfg4_general"]["evals_per_s"])
+    assert co["roofline"]["gathers_per_eval"] == pytest.approx(16 / 28) and 0 < co["roofline"]["frac"] < 1
+    assert cfg["wall_over_device"] == pytest.approx(b["ms_per_step"] * b["steps"] / r["kernel_ms"], rel=1e-6)
+
+
+def test_driver_args_bench_line_measures_the_kernel():
+    """profiles/r03_bench_cfg4_1gpu_driver_args.json = `python bench.py --steps 20 --warmup 5` (the driver's command): the
+    wall-clock figure stays within 25 % of the event-bracketed device time of the same region (round 2: 66 %)."""
+    b = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_cfg4_1gpu_driver_args.json")))
+    assert b["steps"] == 20 and b["warmup"] == 5 and b["n_gpus"] == 1
+    r = b["roofline"]
+    assert b["ms_per_step"] * 1e3 <= 1.25 * r["engine"]["us_per_iter_device"]
+    assert r["frac_engine"] >= 0.8 * r["frac"]
+    assert b["config"]["trace_rows_gathered_in_region"] == 0
 
 
 def test_profile_summary_agrees_with_the_bench_line():
-    """profiles/r02_launch_durations.json: the timed launch in rocprofv3's kernel trace against bench.py's HIP events of
-    the same (profiled) run; profiles/r02_pmc_1000it.json names the same kernel."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_launch_durations.json")))
+    """profiles/r03_launch_durations.json: the timed launch in rocprofv3's kernel trace against bench.py's HIP events of
+    the same (profiled) run; profiles/r03_pmc_1000it.json names the same kernel."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_launch_durations.json")))
     assert d["timed_2000_iteration_launch_ms_kernel_trace"] == pytest.approx(
         d["bench_hip_event_ms_for_the_timed_2000_iteration_launch"], rel=0.01)
-    p = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_1000it.json")))
-    b = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_cfg4_1gpu.json")))
+    p = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_1000it.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_cfg4_1gpu.json")))
     assert p["kernel"].split("<")[0] == b["roofline"]["kernel"].split("<")[0] == d["kernel"].split("<")[0]
     assert 0 < p["lds_busy_fraction"] < 1 and 0 < p["valu_busy_fraction"] < 1

@@ -182,6 +182,39 @@ def test_cli_logs_are_streamed_and_survive_a_kill(G, tmp_path):
     shutil.rmtree(logdir)
 
 
+def test_cli_two_ranks_stream_the_same_logs(G, tmp_path):
+    """The sharded CLI (chains split over two ranks, every window's rows gathered to rank 0 on a side stream while the next
+    window runs) writes the logs of the one-process run: same rows, same iterations, values equal to 1e-10 (a chain's
+    log-likelihood is a sum whose partition depends on how many chains an engine holds: last-digit differences).
+    Rehearsed with two ranks on ONE GPU (LR_DIST_BACKEND=gloo: host-staged gather); the real runs use one rank per GPU
+    over RCCL."""
+    ts, te = G["example_TBP/ts"], G["example_TBP/te"] - 0.5
+    data = tmp_path / "example.tsv"
+    with open(data, "w") as f:
+        f.write("id\tts\tte\n")
+        for i, (a, b) in enumerate(zip(ts, te)):
+            f.write("%d\t%g\t%g\n" % (i, 24.0 - a, 24.0 - b))
+    args = [os.path.join(ROOT, "LiteRateForward.py"), "-d", str(data), "-TBP", "-n", "600", "-s", "20", "-p", "200", "-seed", "31",
+            "-model_BDI", "2", "--chains", "5", "--block", "130"]
+    env = dict(os.environ, LR_SHARED_DEVICE="1")          # (no teams of CUs: the ranks of the rehearsal share one device)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    subprocess.run([sys.executable] + args + ["-out", "_one"], check=True, stdout=subprocess.DEVNULL, timeout=300, env=env)
+    env["LR_DIST_BACKEND"] = "gloo"
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29547"] + args + ["-out", "_two"], check=True, stdout=subprocess.DEVNULL, timeout=300, env=env)
+    logdir = tmp_path / "literate_mcmc_logs"
+    for c in range(5):
+        for kind in ("mcmc", "sp_rates", "ex_rates"):
+            a = open(logdir / ("example_BDk_one_c%d_%s.log" % (c, kind))).read().splitlines()
+            b = open(logdir / ("example_BDk_two_c%d_%s.log" % (c, kind))).read().splitlines()
+            assert len(a) == len(b) >= 30
+            for la, lb in zip(a[1:] if kind == "mcmc" else a, b[1:] if kind == "mcmc" else b):
+                va, vb = np.array(la.split("\t"), float), np.array(lb.split("\t"), float)
+                assert va.shape == vb.shape and np.allclose(va, vb, rtol=1e-10, atol=1e-12, equal_nan=True), (c, kind, la, lb)
+    shutil.rmtree(logdir)
+
+
 def test_cli_checkpoint_resume(G, tmp_path):
     """--checkpoint: a run stopped at -n 200 and continued to -n 400 writes the same logs as one run of 400
     (the flags that size the trace, -n and -s, have to match, so the first leg uses the engine API)."""
@@ -236,7 +269,7 @@ def test_ddrate_cli_end_to_end_and_shipped_log_kat(G, golden_dir, tmp_path):
         for i, (a, c) in enumerate(zip(ts, te)):
             f.write("%d\t%g\t%g\n" % (i, a, c))
     cmd = [sys.executable, os.path.join(ROOT, "DDRate.py"), "-d", str(data), "-n", "300", "-s", "10", "-p", "100",
-           "-seed", "21", "--chains", "2"]
+           "-seed", "21", "--chains", "2", "--block", "70"]          # five windows, the log appended and fsynced per window
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, timeout=300)
     origin, present, _ = D["meta"]
     with np.errstate(all="ignore"):

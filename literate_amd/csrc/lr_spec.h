@@ -76,6 +76,8 @@ struct lr_spec_args {
     int n_teams;                  // teams = chains / cpb (rounded up)
     int cpb;                      // chains per team: 2 (a pair: every table gather serves two chains) or 1 (as many teams
                                   // as chains: half the candidate work per CU and an iteration as short as ONE chain's move)
+    int cand_share_q16;           // a team per chain: share (x 2^16) of a block's groups that its two candidate waves scan
+                                  // once their candidates are built (long scans only: lr_launch_spec)
 };
 
 __device__ __forceinline__ void lr_set_load(const lr_set* q, lr_rj_state& s, int lane) {
@@ -307,7 +309,144 @@ struct lr_spec_ctx {
     unsigned long long it0;      // iteration of the proposal pending at entry
     int c0, C, team, rank;
     int n_act;                   // chains of this block: 1 or 2
+    long long cand_g0, cand_n;   // a team per chain: the candidate waves' share of the block's slice (behind the scanners')
 };
+
+// End of a wave's scan share: its sums to LDS, and - for the wave that arrives LAST among the block's scanning waves (the
+// scanner waves; a team per chain: + the two candidate waves) - the decision of the iteration: the block's sums added in
+// a fixed order (in a team: published and the team's swept), the Metropolis-Hastings tests, the outcome left in LDS.
+template <int H, int T, bool RJ, bool GENERAL, bool SINGLE>
+__device__ __forceinline__ void lr_spec_deliver(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_spec_ctx& ctx, long long iter,
+                                                int role0, int role1, double acc0, double acc1, int wave, int lane) {
+    constexpr int NW = T / LR_WAVE;
+    constexpr bool rj = RJ;
+    // (a team per chain: the two candidate waves scan - and count themselves in - only when they were given a share)
+    const int n_arrive = (NW - 4) + ((SINGLE && ctx.cand_n > 0) ? 2 : 0);
+    const int k_team = ctx.x.team_blocks;
+    const bool act1 = ctx.n_act > 1;
+    const unsigned long long it = ctx.it0 + (unsigned long long)iter;
+    {
+        const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
+        if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
+        // the scanner waves count themselves in on an LDS word (a wave's LDS operations execute in order: sums first,
+        // then the count); the wave that arrives last decides
+        int prev = 0;
+        if (lane == 0) prev = __hip_atomic_fetch_add(&sm.scan_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        if (prev == n_arrive * ((int)iter + 1) - 1) {
+            // What the decisions need beside the sums stands since the last barrier (lanes 0-15 the pending proposal's
+            // scalars, 16-31 the accepted state's)
+            const int cc1 = act1 ? 1 : 0;
+            const int r1 = act1 ? role1 : role0;
+            const lr_set* P0 = &sm.sets[0][(role0 >> 2) & 3];
+            const lr_set* A0 = &sm.sets[0][role0 & 3];
+            const lr_set* P1 = &sm.sets[cc1][(r1 >> 2) & 3];
+            const lr_set* A1 = &sm.sets[cc1][r1 & 3];
+            const double v0 = (lane & 16) ? A0->sc[lane & 15] : P0->sc[lane & 15];
+            const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
+            const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
+            const double lA = sm.likA[lane & 1];
+            
+            asm volatile("" ::: "memory");     // the sums are read after the count was seen
+            // the block's sums: one read per lane, then a fixed pairwise tree over the scanner waves' values
+            const double2 rv = *reinterpret_cast<const double2*>(&sm.red[lane < NW ? lane : NW - 1][0]);
+            double t0[NW - 4], t1[NW - 4];
+#pragma unroll
+            for (int w = 4; w < NW; ++w) t0[w - 4] = lr_bcast(rv.x, w), t1[w - 4] = lr_bcast(rv.y, w);
+#pragma unroll
+            for (int n = NW - 4; n > 1; n = (n + 1) / 2) {
+#pragma unroll
+                for (int j = 0; j < n / 2; ++j) t0[j] = t0[2 * j] + t0[2 * j + 1], t1[j] = t1[2 * j] + t1[2 * j + 1];
+                if (n & 1) t0[n / 2] = t0[n - 1], t1[n / 2] = t1[n - 1];
+            }
+            double sum0 = t0[0], sum1 = t1[0];
+            if (SINGLE && ctx.cand_n > 0) {
+                // (a team per chain on a long scan: the two candidate waves' shares, added behind the scanner waves' tree)
+                sum0 += lr_bcast(rv.x, 0), sum1 += lr_bcast(rv.y, 0);
+                sum0 += lr_bcast(rv.x, 1), sum1 += lr_bcast(rv.y, 1);
+            }
+            bool fail = false;
+            if (k_team > 1) {
+                // this block's sums published as four {epoch, half} granules; then the sweep over the team's
+                const unsigned int epoch = (unsigned int)iter + 1u;
+                lr_gu64* slot = (lr_gu64*)(ctx.x.xchg + ((size_t)(epoch & 1u) * ctx.x.n_teams + ctx.team) * (LR_TEAM_MAX * LR_SPEC_GRANULES));
+                if (lane < 4) {
+                    const double v = (lane < 2) ? sum0 : sum1;
+                    const unsigned int half = (lane & 1) ? (unsigned int)__double2hiint(v) : (unsigned int)__double2loint(v);
+                    __hip_atomic_store(slot + ctx.rank * LR_SPEC_GRANULES + lane, ((unsigned long long)epoch << 32) | half,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const bool mine = lane < 4 * k_team;
+                lr_gu64* g = slot + (lane >> 2) * LR_SPEC_GRANULES + (lane & 3);
+                unsigned long long v = (unsigned long long)epoch << 32;
+                const unsigned long long t_start = wall_clock64();
+                for (unsigned int spins = 0;; ++spins) {
+                    if (mine) v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((unsigned int)(v >> 32) == epoch)) break;
+                    if ((spins & 255u) == 255u) {
+                        // give up when the engine's status word is raised or after two seconds (uniform over the wave)
+                        const unsigned int st = __hip_atomic_load((lr_gu32*)ctx.x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (st != 0u || wall_clock64() - t_start > LR_SPEC_TIMEOUT_TICKS) {
+                            fail = true;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (fail) {
+                    if (lane == 0) {
+                        __hip_atomic_store((lr_gu32*)ctx.x.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sm.abort_flag = 1;
+                    }
+                } else {
+                    // [block][chain] halves sit in lanes 4 b + 2 c (+1): summed in block order through register broadcasts
+                    const int half = (int)(unsigned int)v;
+                    sum0 = 0.0, sum1 = 0.0;
+#pragma unroll
+                    for (int b = 0; b < LR_TEAM_MAX; ++b)
+                        if (b < k_team) {
+                            sum0 += __hiloint2double(lr_bcast_i(half, 4 * b + 1), lr_bcast_i(half, 4 * b));
+                            sum1 += __hiloint2double(lr_bcast_i(half, 4 * b + 3), lr_bcast_i(half, 4 * b + 2));
+                        }
+                }
+                
+            }
+            if (!fail) {
+                // the two Metropolis-Hastings tests (LRF:305-319; DD:204-219)
+                int d[2] = {0, 0};
+                double lik[2] = {0.0, 0.0}, lik_p[2] = {0.0, 0.0};
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    if (cc >= ctx.n_act) continue;
+                    const double v = cc ? v1 : v0;
+                    const int iv = cc ? i1 : i0;
+                    const int gibbs = lr_bcast_i(iv, LR_SETI_GIBBS), invalid = lr_bcast_i(iv, LR_SETI_INVALID);
+                    const double priorP = lr_bcast(v, LR_SET_PRIOR), priorA = lr_bcast(v, 16 + LR_SET_PRIOR);
+                    const double hasting = lr_bcast(v, LR_SET_HASTING), log_u = lr_bcast(v, LR_SET_LOG_U);
+                    const double likA = lr_bcast(lA, cc);
+                    const double lik_sum = cc ? sum1 : sum0;
+                    bool ok;
+                    if (rj) {
+                        ok = lr_mh_accept(gibbs, invalid, lik_sum, lr_bcast(v, LR_SET_CONST), likA, priorP, priorA, hasting, log_u, &lik[cc]);
+                        lik_p[cc] = invalid ? -INFINITY : lik[cc];
+                    } else {
+                        lik[cc] = lik_sum;
+                        ok = lr_dd_accept(lik[cc], likA, priorP, priorA, hasting, log_u, it);
+                        lik_p[cc] = lik[cc];
+                    }
+                    d[cc] = ok ? 1 : 0;
+                }
+                lr_spec_decision* out = &sm.dec[iter & 1];
+                if (lane < 2) {
+                    const double l = lane ? lik[1] : lik[0];
+                    out->lik[lane] = l, out->lik_p[lane] = lane ? lik_p[1] : lik_p[0];
+                    if (lane ? d[1] : d[0]) sm.likA[lane] = l;
+                }
+                if (lane == 2) out->sel = d[0] * 2 + d[1];
+            }
+        }
+    }
+}
 
 // The scanner role (waves 4..NW-1): per iteration one pass over the block's slice of the lineages against the pending
 // pair table and partial sums to LDS.  The wave that finishes LAST also takes the decision of the iteration: it adds up
@@ -374,125 +513,11 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     for (long long iter = 0; iter < ctx.n_iters; ++iter) {
         const unsigned long long it = ctx.it0 + (unsigned long long)iter;
         LR_XBEGIN();
-        // What the decisions need beside the sums stands since the last barrier: fetched now (four row reads, lanes 0-15
-        // the pending proposal's scalars, 16-31 the accepted state's; used by the deciding wave only, but which wave
-        // that will be is not known yet and the reads are free while the scan runs)
-        const int cc1 = act1 ? 1 : 0;
-        const int r1 = act1 ? role1 : role0;
-        const lr_set* P0 = &sm.sets[0][(role0 >> 2) & 3];
-        const lr_set* A0 = &sm.sets[0][role0 & 3];
-        const lr_set* P1 = &sm.sets[cc1][(r1 >> 2) & 3];
-        const lr_set* A1 = &sm.sets[cc1][r1 & 3];
-        const double v0 = (lane & 16) ? A0->sc[lane & 15] : P0->sc[lane & 15];
-        const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
-        const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
-        const double lA = sm.likA[lane & 1];
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(single ? sm.t.tabs[(role0 >> 2) & 3] : sm.t.pair.scan);
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, part_g0, part_n, sid, n_scan, &acc0, &acc1, &first);
-        const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
-        if (lane == 0) sm.red[wave][0] = s0, sm.red[wave][1] = s1;
         LR_XSTAMP(dg_a);
-        // the scanner waves count themselves in on an LDS word (a wave's LDS operations execute in order: sums first,
-        // then the count); the wave that arrives last decides
-        int prev = 0;
-        if (lane == 0) prev = __hip_atomic_fetch_add(&sm.scan_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        prev = __builtin_amdgcn_readfirstlane(prev);
-        if (prev == (NW - 4) * ((int)iter + 1) - 1) {
-            LR_XSTAMP(dg_b);
-            asm volatile("" ::: "memory");     // the sums are read after the count was seen
-            // the block's sums: one read per lane, then a fixed pairwise tree over the scanner waves' values
-            const double2 rv = *reinterpret_cast<const double2*>(&sm.red[lane < NW ? lane : NW - 1][0]);
-            double t0[NW - 4], t1[NW - 4];
-#pragma unroll
-            for (int w = 4; w < NW; ++w) t0[w - 4] = lr_bcast(rv.x, w), t1[w - 4] = lr_bcast(rv.y, w);
-#pragma unroll
-            for (int n = NW - 4; n > 1; n = (n + 1) / 2) {
-#pragma unroll
-                for (int j = 0; j < n / 2; ++j) t0[j] = t0[2 * j] + t0[2 * j + 1], t1[j] = t1[2 * j] + t1[2 * j + 1];
-                if (n & 1) t0[n / 2] = t0[n - 1], t1[n / 2] = t1[n - 1];
-            }
-            double sum0 = t0[0], sum1 = t1[0];
-            bool fail = false;
-            if (k_team > 1) {
-                // this block's sums published as four {epoch, half} granules; then the sweep over the team's
-                const unsigned int epoch = (unsigned int)iter + 1u;
-                lr_gu64* slot = (lr_gu64*)(ctx.x.xchg + ((size_t)(epoch & 1u) * ctx.x.n_teams + ctx.team) * (LR_TEAM_MAX * LR_SPEC_GRANULES));
-                if (lane < 4) {
-                    const double v = (lane < 2) ? sum0 : sum1;
-                    const unsigned int half = (lane & 1) ? (unsigned int)__double2hiint(v) : (unsigned int)__double2loint(v);
-                    __hip_atomic_store(slot + ctx.rank * LR_SPEC_GRANULES + lane, ((unsigned long long)epoch << 32) | half,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                const bool mine = lane < 4 * k_team;
-                lr_gu64* g = slot + (lane >> 2) * LR_SPEC_GRANULES + (lane & 3);
-                unsigned long long v = (unsigned long long)epoch << 32;
-                const unsigned long long t_start = wall_clock64();
-                for (unsigned int spins = 0;; ++spins) {
-                    if (mine) v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((unsigned int)(v >> 32) == epoch)) break;
-                    if ((spins & 255u) == 255u) {
-                        // give up when the engine's status word is raised or after two seconds (uniform over the wave)
-                        const unsigned int st = __hip_atomic_load((lr_gu32*)ctx.x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (st != 0u || wall_clock64() - t_start > LR_SPEC_TIMEOUT_TICKS) {
-                            fail = true;
-                            break;
-                        }
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (fail) {
-                    if (lane == 0) {
-                        __hip_atomic_store((lr_gu32*)ctx.x.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sm.abort_flag = 1;
-                    }
-                } else {
-                    // [block][chain] halves sit in lanes 4 b + 2 c (+1): summed in block order through register broadcasts
-                    const int half = (int)(unsigned int)v;
-                    sum0 = 0.0, sum1 = 0.0;
-#pragma unroll
-                    for (int b = 0; b < LR_TEAM_MAX; ++b)
-                        if (b < k_team) {
-                            sum0 += __hiloint2double(lr_bcast_i(half, 4 * b + 1), lr_bcast_i(half, 4 * b));
-                            sum1 += __hiloint2double(lr_bcast_i(half, 4 * b + 3), lr_bcast_i(half, 4 * b + 2));
-                        }
-                }
-                LR_XSTAMP(dg_c);
-            }
-            if (!fail) {
-                // the two Metropolis-Hastings tests (LRF:305-319; DD:204-219)
-                int d[2] = {0, 0};
-                double lik[2] = {0.0, 0.0}, lik_p[2] = {0.0, 0.0};
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    if (cc >= ctx.n_act) continue;
-                    const double v = cc ? v1 : v0;
-                    const int iv = cc ? i1 : i0;
-                    const int gibbs = lr_bcast_i(iv, LR_SETI_GIBBS), invalid = lr_bcast_i(iv, LR_SETI_INVALID);
-                    const double priorP = lr_bcast(v, LR_SET_PRIOR), priorA = lr_bcast(v, 16 + LR_SET_PRIOR);
-                    const double hasting = lr_bcast(v, LR_SET_HASTING), log_u = lr_bcast(v, LR_SET_LOG_U);
-                    const double likA = lr_bcast(lA, cc);
-                    const double lik_sum = cc ? sum1 : sum0;
-                    bool ok;
-                    if (rj) {
-                        ok = lr_mh_accept(gibbs, invalid, lik_sum, lr_bcast(v, LR_SET_CONST), likA, priorP, priorA, hasting, log_u, &lik[cc]);
-                        lik_p[cc] = invalid ? -INFINITY : lik[cc];
-                    } else {
-                        lik[cc] = lik_sum;
-                        ok = lr_dd_accept(lik[cc], likA, priorP, priorA, hasting, log_u, it);
-                        lik_p[cc] = lik[cc];
-                    }
-                    d[cc] = ok ? 1 : 0;
-                }
-                lr_spec_decision* out = &sm.dec[iter & 1];
-                if (lane < 2) {
-                    const double l = lane ? lik[1] : lik[0];
-                    out->lik[lane] = l, out->lik_p[lane] = lane ? lik_p[1] : lik_p[0];
-                    if (lane ? d[1] : d[0]) sm.likA[lane] = l;
-                }
-                if (lane == 2) out->sel = d[0] * 2 + d[1];
-            }
-        }
+        lr_spec_deliver<H, T, RJ, GENERAL, SINGLE>(sm, ctx, iter, role0, role1, acc0, acc1, wave, lane);
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
         // (a block on its own has made these draws at the top of the iteration, see below)
         if (drawer && !draws_first) draw_duty(it + 2, it & 1);
@@ -674,6 +699,14 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
             }
         }
+        if (SINGLE && ctx.cand_n > 0) {
+            // a team per chain on a long scan: this wave's share of it (the tail of the block's slice), then its sums - it
+            // may be the wave that arrives last and decides
+            double acc0 = 0.0, acc1 = 0.0;
+            lr_persist_scan<H, GENERAL, 1, false>(reinterpret_cast<const char*>(sm.t.tabs[(role0 >> 2) & 3]), ctx.pk, ctx.cand_g0, ctx.cand_n,
+                                                  k * LR_WAVE + lane, 2 * LR_WAVE, &acc0, &acc1, nullptr);
+            lr_spec_deliver<H, T, RJ, GENERAL, SINGLE>(sm, ctx, iter, role0, role1, acc0, acc1, wave, lane);
+        }
         LR_XSTAMP(dg_work);
         __syncthreads();                                                     // the decision and the candidates are in
         LR_XSTAMP(dg_wait1);
@@ -776,7 +809,10 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         // this block's slice of the packed lineage indices
         const long long per = (n8 + k_team - 1) / k_team;
         const long long g_lo = min((long long)rank * per, n8), g_hi = min(g_lo + per, n8);
-        ctx.pk = pk, ctx.g0 = g_lo, ctx.n8 = g_hi - g_lo, ctx.x = x, ctx.n_iters = n_iters;
+        // (a team per chain: the tail of the slice is the candidate waves', scanned once their candidates stand)
+        const long long n_c = SINGLE ? ((g_hi - g_lo) * (long long)x.cand_share_q16) >> 16 : 0;
+        ctx.pk = pk, ctx.g0 = g_lo, ctx.n8 = g_hi - g_lo - n_c, ctx.x = x, ctx.n_iters = n_iters;
+        ctx.cand_g0 = g_hi - n_c, ctx.cand_n = n_c;
         ctx.it0 = (unsigned long long)(unsigned)I0[LR_I_IT_LO] | ((unsigned long long)(unsigned)I0[LR_I_IT_HI] << 32);
         ctx.c0 = c0, ctx.C = C, ctx.team = team, ctx.rank = rank, ctx.n_act = n_act;
     }

@@ -12,6 +12,24 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
             x.xchg = (unsigned long long*)(e->ws + e->lay.xchg);
             x.status = (unsigned int*)(e->ws + e->lay.status);
             x.team_blocks = e->lay.team_blocks, x.n_teams = blocks, x.cpb = cpb;
+            {
+                // A team per chain under a PARAMETRIC sampler: the tables are the helper waves', so the two candidate waves
+                // idle after ~0.9 us of an iteration in which a scanner wave makes a trip per ~0.3 us.  On a long scan they take
+                // a share: with W wave-trips per block and d = 3 trips they are late by, all ten waves finish together when the
+                // eight scanners make t = (W + 2 d) / 10 trips and the two candidates t - d: share = 2 (t - d) / W, nothing when
+                // the scan is shorter than their build.  (The RJ sampler's candidate waves are busy for ~1.9 us and a wave that
+                // arrives last also decides: every share measured slower there.)  LR_SPEC_CAND_PCT overrides it (A/B runs).
+                const double W = (double)((e->n8 + x.team_blocks - 1) / x.team_blocks) / 64.0;
+                const double d = 3.0;
+                const double t = (W + 2.0 * d) / 10.0;
+                // (not in a team: the wave that arrives last also runs the exchange - measured 10-18 % slower with a share)
+                double share = (e->cfg.sampler != 0 && x.team_blocks == 1 && t > d && W > 0.0) ? 2.0 * (t - d) / W : 0.0;
+                const char* env = getenv("LR_SPEC_CAND_PCT");
+                if (env) share = atof(env) / 100.0;
+                if (share > 0.5) share = 0.5;
+                if (share < 0.0) share = 0.0;
+                x.cand_share_q16 = cpb == 1 ? (int)(share * 65536.0) : 0;
+            }
             const size_t xbytes = (size_t)2 * blocks * LR_TEAM_MAX * LR_SPEC_GRANULES * 8;
             for (int64_t done = 0; done < n_iters;) {
                 const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short

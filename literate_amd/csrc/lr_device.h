@@ -60,6 +60,21 @@ __device__ __forceinline__ double lr_wave_inclusive_scan(double x) {
     v += lr_dpp_zero<LR_DPP_ROW_BCAST31, 0xc, 0xf>(v);
     return v;
 }
+// Every lane l gets v[l & 31] (lr_half_lo) / v[32 + (l & 31)] (lr_half_hi): gfx950's v_permlane32_swap exchanges the
+// upper 32 lanes of one register with the lower 32 of another inside the VALU - no trip through the LDS crossbar as a
+// ds_bpermute (__shfl) would make, and the chain step is one wave's instruction stream.
+__device__ __forceinline__ double lr_half_lo(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
+__device__ __forceinline__ double lr_half_hi(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
 __device__ __forceinline__ double lr_readlane_f64(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
                             __builtin_amdgcn_readlane(__double2loint(v), l));

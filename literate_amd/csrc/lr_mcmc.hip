@@ -859,7 +859,7 @@ static int lr_device_cus() {
 //                        k > 1: max(3.40, 3.20 + 0.205 trips)             k > 1: max(2.88, 2.45 + 0.165 trips) + 0.05 log2(k / 2)
 //     general times      k = 1: max(2.90, 2.85 + 0.434 trips)             k = 1: max(2.32, 1.50 + 0.46 trips)
 //                        k > 1: max(3.45, 2.90 + 0.478 trips)             k > 1: max(2.72, 2.10 + 0.46 trips) + 0.05 log2(k / 2)
-//     DDRate / trend     k = 1: max(2.60, 2.70 + 0.18 trips)              k = 1: max(2.43, 1.63 + 0.21 trips)
+//     DDRate / trend     k = 1: max(2.60, 2.70 + 0.18 trips)              k = 1: max(2.30, 1.45 + 0.20 trips)
 //                        k > 1: max(3.05, 2.70 + 0.21 trips)              k > 1: max(2.90, 2.50 + 0.16 trips)
 // (the floor is the candidate build - shorter with one chain per CU: the table is built by a helper wave on a SIMD of its
 // own, a no-op move copies its table, and the scanners need no table build behind the barrier -; a team pays the exchange
@@ -894,7 +894,7 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
             double t;
             if (cfg->sampler != 0) {
                 if (cpb == 2) t = (k == 1) ? fmax(2.60, 2.70 + 0.18 * trips) : fmax(3.05, 2.70 + 0.21 * trips);
-                else t = (k == 1) ? fmax(2.43, 1.63 + 0.21 * trips) : fmax(2.90, 2.50 + 0.16 * trips);
+                else t = (k == 1) ? fmax(2.30, 1.45 + 0.20 * trips) : fmax(2.90, 2.50 + 0.16 * trips);
                 if (general) t += 0.26 * trips;
             } else if (!general) {
                 if (cpb == 2) t = (k == 1) ? fmax(2.95, 2.93 + 0.171 * trips) : fmax(3.40, 3.20 + 0.205 * trips);

@@ -78,6 +78,9 @@ struct lr_spec_args {
                                   // as chains: half the candidate work per CU and an iteration as short as ONE chain's move)
     int cand_share_q16;           // a team per chain: share (x 2^16) of a block's groups that its two candidate waves scan
                                   // once their candidates are built (long scans only: lr_launch_spec)
+    int planes_by_scanners;       // a team per chain: 1 = the pair planes of the table that becomes pending are derived by
+                                  // the scanner waves behind the barrier (short scans: the helper waves' build is the longer
+                                  // path), 0 = by the helper wave that builds the table (long scans: the scan is)
 };
 
 __device__ __forceinline__ void lr_set_load(const lr_set* q, lr_rj_state& s, int lane) {
@@ -312,18 +315,41 @@ struct lr_spec_ctx {
     long long cand_g0, cand_n;   // a team per chain: the candidate waves' share of the block's slice (behind the scanners')
 };
 
+// What a decision needs beside the scan sums: lanes 0-15 the pending proposal's scalars, 16-31 the accepted state's, of
+// both chains; they stand since the last barrier, so a scanning wave fetches them BEFORE its scan (four row reads that
+// are free while the scan runs; used by the deciding wave only, but which wave that will be is not known yet).
+struct lr_spec_dec_in {
+    double v0, v1, lA;
+    int i0, i1;
+};
+template <class LDS>
+__device__ __forceinline__ lr_spec_dec_in lr_spec_dec_fetch(const LDS& sm, const lr_spec_ctx& ctx, int role0, int role1, int lane) {
+    const bool act1 = ctx.n_act > 1;
+    const int cc1 = act1 ? 1 : 0;
+    const int r1 = act1 ? role1 : role0;
+    const lr_set* P0 = &sm.sets[0][(role0 >> 2) & 3];
+    const lr_set* A0 = &sm.sets[0][role0 & 3];
+    const lr_set* P1 = &sm.sets[cc1][(r1 >> 2) & 3];
+    const lr_set* A1 = &sm.sets[cc1][r1 & 3];
+    lr_spec_dec_in in;
+    in.v0 = (lane & 16) ? A0->sc[lane & 15] : P0->sc[lane & 15];
+    in.v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
+    in.i0 = P0->isc[lane & 7], in.i1 = P1->isc[lane & 7];
+    in.lA = sm.likA[lane & 1];
+    return in;
+}
+
 // End of a wave's scan share: its sums to LDS, and - for the wave that arrives LAST among the block's scanning waves (the
 // scanner waves; a team per chain: + the two candidate waves) - the decision of the iteration: the block's sums added in
 // a fixed order (in a team: published and the team's swept), the Metropolis-Hastings tests, the outcome left in LDS.
 template <int H, int T, bool RJ, bool GENERAL, bool SINGLE>
 __device__ __forceinline__ void lr_spec_deliver(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_spec_ctx& ctx, long long iter,
-                                                int role0, int role1, double acc0, double acc1, int wave, int lane) {
+                                                const lr_spec_dec_in& in, double acc0, double acc1, int wave, int lane) {
     constexpr int NW = T / LR_WAVE;
     constexpr bool rj = RJ;
     // (a team per chain: the two candidate waves scan - and count themselves in - only when they were given a share)
     const int n_arrive = (NW - 4) + ((SINGLE && ctx.cand_n > 0) ? 2 : 0);
     const int k_team = ctx.x.team_blocks;
-    const bool act1 = ctx.n_act > 1;
     const unsigned long long it = ctx.it0 + (unsigned long long)iter;
     {
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
@@ -334,19 +360,8 @@ __device__ __forceinline__ void lr_spec_deliver(lr_spec_lds<H, T / LR_WAVE, GENE
         if (lane == 0) prev = __hip_atomic_fetch_add(&sm.scan_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         prev = __builtin_amdgcn_readfirstlane(prev);
         if (prev == n_arrive * ((int)iter + 1) - 1) {
-            // What the decisions need beside the sums stands since the last barrier (lanes 0-15 the pending proposal's
-            // scalars, 16-31 the accepted state's)
-            const int cc1 = act1 ? 1 : 0;
-            const int r1 = act1 ? role1 : role0;
-            const lr_set* P0 = &sm.sets[0][(role0 >> 2) & 3];
-            const lr_set* A0 = &sm.sets[0][role0 & 3];
-            const lr_set* P1 = &sm.sets[cc1][(r1 >> 2) & 3];
-            const lr_set* A1 = &sm.sets[cc1][r1 & 3];
-            const double v0 = (lane & 16) ? A0->sc[lane & 15] : P0->sc[lane & 15];
-            const double v1 = (lane & 16) ? A1->sc[lane & 15] : P1->sc[lane & 15];
-            const int i0 = P0->isc[lane & 7], i1 = P1->isc[lane & 7];
-            const double lA = sm.likA[lane & 1];
-            
+            const double v0 = in.v0, v1 = in.v1, lA = in.lA;
+            const int i0 = in.i0, i1 = in.i1;
             asm volatile("" ::: "memory");     // the sums are read after the count was seen
             // the block's sums: one read per lane, then a fixed pairwise tree over the scanner waves' values
             const double2 rv = *reinterpret_cast<const double2*>(&sm.red[lane < NW ? lane : NW - 1][0]);
@@ -513,11 +528,12 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     for (long long iter = 0; iter < ctx.n_iters; ++iter) {
         const unsigned long long it = ctx.it0 + (unsigned long long)iter;
         LR_XBEGIN();
+        const lr_spec_dec_in dec_in = lr_spec_dec_fetch(sm, ctx, role0, role1, lane);
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(single ? sm.t.tabs[(role0 >> 2) & 3] : sm.t.pair.scan);
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, part_g0, part_n, sid, n_scan, &acc0, &acc1, &first);
         LR_XSTAMP(dg_a);
-        lr_spec_deliver<H, T, RJ, GENERAL, SINGLE>(sm, ctx, iter, role0, role1, acc0, acc1, wave, lane);
+        lr_spec_deliver<H, T, RJ, GENERAL, SINGLE>(sm, ctx, iter, dec_in, acc0, acc1, wave, lane);
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
         // (a block on its own has made these draws at the top of the iteration, see below)
         if (drawer && !draws_first) draw_duty(it + 2, it & 1);
@@ -527,6 +543,18 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         if (k_team > 1 && sm.abort_flag) return;
         sel = sm.dec[iter & 1].sel;
         role0 = lr_spec_turn(role0, sel >> 1), role1 = lr_spec_turn(role1, sel & 1);
+        if (single && ctx.x.planes_by_scanners) {
+            // a team per chain on a short scan: the pair planes of the table that is pending now, by all scanner lanes; the
+            // scanner waves then wait for each other on an LDS counter
+            double2* tab = sm.t.tabs[(role0 >> 2) & 3];
+            if (GENERAL) lr_pair_planes_block_general(tab, H, a.cfg.n_bins, tid - 4 * LR_WAVE, NSCAN);
+            else lr_pair_planes_block(tab, H, a.cfg.n_bins, tid - 4 * LR_WAVE, NSCAN);
+            LR_WAVE_LDS_ORDER();
+            if (lane == 0) __hip_atomic_fetch_add(&sm.plane_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int want = (NW - 4) * ((int)iter + 1);
+            while (__hip_atomic_load(&sm.plane_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        }
         if (!single) {
             // The scan table of the next iteration from the columns of the proposals now pending (every scanner wave is past
             // its scan of the old one: the barrier), both chains at once, by all scanner lanes; the scanner waves then wait
@@ -583,9 +611,11 @@ __device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GE
                     sc, eL, eM, hand->KL, hand->KM, sm.br, sm.logbr, a.cfg.model, a.cfg.n_bins, a.n_cls, a.H,
                     reinterpret_cast<double2*>(tabd), lane, GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, a.cfg.frac_birth,
                     a.cfg.frac_death, GENERAL ? 6 * H : 2, &sg);
-                LR_WAVE_LDS_ORDER();
-                if (GENERAL) lr_pair_planes_wave_general(tabd, H, a.cfg.n_bins, lane, 0);
-                else lr_pair_planes_wave(tabd, H, a.cfg.n_bins, lane, 0);
+                if (!ctx.x.planes_by_scanners) {
+                    LR_WAVE_LDS_ORDER();
+                    if (GENERAL) lr_pair_planes_wave_general(tabd, H, a.cfg.n_bins, lane, 0);
+                    else lr_pair_planes_wave(tabd, H, a.cfg.n_bins, lane, 0);
+                }
                 out->sgL[lane] = sg.packL, out->sgM[lane] = sg.packM;
                 if (lane == 0) out->sc[LR_SET_CONST] = constP, out->isc[LR_SETI_SEG] = sg.packL != -1 ? 1 : 0;
             }
@@ -600,7 +630,10 @@ __device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GE
             while (__hip_atomic_load(&hand->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)iter + 1) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
             const double P = lane < 8 ? hand->par[lane] : 0.0;
-            lr_param_tables<true, true, 2>(a, P, sm.br, sm.t.tabs[hand->out_idx], GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, GENERAL ? 6 * H : 2, lane);
+            if (ctx.x.planes_by_scanners)
+                lr_param_tables<true, false, 2>(a, P, sm.br, sm.t.tabs[hand->out_idx], GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, GENERAL ? 6 * H : 2, lane);
+            else
+                lr_param_tables<true, true, 2>(a, P, sm.br, sm.t.tabs[hand->out_idx], GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, GENERAL ? 6 * H : 2, lane);
         }
         __syncthreads();
         if (k_team > 1 && sm.abort_flag) return;
@@ -688,9 +721,11 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                     // six planes of its base state's table
                     lr_table_hand* hand = &sm.hand[k];
                     if (lane == 0) hand->out_idx = out_i, hand->base_idx = base_i;
+                    // (a copied table brings its pair planes along unless the scanner waves derive them anyway; the planes of a
+                    // general-times table lie behind its slopes: S | E | 2E | slopes)
+                    const int n_copy = (ctx.x.planes_by_scanners && !GENERAL) ? 2 * H : LR_UNIT_PLANES * H;
                     lr_propose_rj<true, lr_bins_per_lane(H), 2, true, true>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
-                                                                            logbr_lds, base_col, LR_UNIT_PLANES * H, base->sc[LR_SET_CONST], hand,
-                                                                            (int)iter + 1);
+                                                                            logbr_lds, base_col, n_copy, base->sc[LR_SET_CONST], hand, (int)iter + 1);
                 } else {
                     lr_propose_rj<true, lr_bins_per_lane(H), 1, false>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
                                                                        logbr_lds, base_col, COL, base->sc[LR_SET_CONST]);
@@ -702,10 +737,11 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
         if (SINGLE && ctx.cand_n > 0) {
             // a team per chain on a long scan: this wave's share of it (the tail of the block's slice), then its sums - it
             // may be the wave that arrives last and decides
+            const lr_spec_dec_in dec_in = lr_spec_dec_fetch(sm, ctx, role0, role1, lane);
             double acc0 = 0.0, acc1 = 0.0;
             lr_persist_scan<H, GENERAL, 1, false>(reinterpret_cast<const char*>(sm.t.tabs[(role0 >> 2) & 3]), ctx.pk, ctx.cand_g0, ctx.cand_n,
                                                   k * LR_WAVE + lane, 2 * LR_WAVE, &acc0, &acc1, nullptr);
-            lr_spec_deliver<H, T, RJ, GENERAL, SINGLE>(sm, ctx, iter, role0, role1, acc0, acc1, wave, lane);
+            lr_spec_deliver<H, T, RJ, GENERAL, SINGLE>(sm, ctx, iter, dec_in, acc0, acc1, wave, lane);
         }
         LR_XSTAMP(dg_work);
         __syncthreads();                                                     // the decision and the candidates are in

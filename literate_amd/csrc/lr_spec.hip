@@ -29,6 +29,12 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
                 if (share > 0.5) share = 0.5;
                 if (share < 0.0) share = 0.0;
                 x.cand_share_q16 = cpb == 1 ? (int)(share * 65536.0) : 0;
+                // who derives the pair planes of a candidate's table (a team per chain): on short scans - at most 3 trips per
+                // scanner lane - the helper waves' table build is the longer path of an iteration and the scanner waves take
+                // the planes (of the ONE table that becomes pending); on long scans the helper keeps them.
+                // LR_SPEC_PLANES_BY_SCANNERS = 0 / 1 overrides it (A/B runs).
+                const char* envp = getenv("LR_SPEC_PLANES_BY_SCANNERS");
+                x.planes_by_scanners = envp ? (atoi(envp) != 0) : (W / 8.0 <= 3.0 && x.team_blocks == 1);
             }
             const size_t xbytes = (size_t)2 * blocks * LR_TEAM_MAX * LR_SPEC_GRANULES * 8;
             for (int64_t done = 0; done < n_iters;) {

@@ -311,7 +311,7 @@ __device__ __forceinline__ double lr_build_tables_segments(const lr_seg_scratch*
 __device__ __forceinline__ void lr_stage_segments(lr_seg_scratch* sc, double L, double M, int eL, int eM, int KL,
                                                   int KM, int lane, double* logL, double* logM, double extra = 1.0,
                                                   double* log_extra = nullptr) {
-    const double Mhi = __shfl(M, lane & 31, LR_WAVE);
+    const double Mhi = lr_half_lo(M);                   // lane l <- M[l & 31]
     const bool hi = lane >= 32;
     const int j = lane & 31;
     const bool valid = hi ? (j < KM) : (j < KL);
@@ -325,7 +325,7 @@ __device__ __forceinline__ void lr_stage_segments(lr_seg_scratch* sc, double L, 
     sc->lograte[hi][j] = lx;
     if (lane <= LR_KMAX) sc->edge[0][lane] = eL, sc->edge[1][lane] = eM;
     *logL = lx;                                        // valid on lanes < 32
-    *logM = __shfl(lx, 32 + (lane & 31), LR_WAVE);     // lane j gets log M[j]
+    *logM = lr_half_hi(lx);                            // lane j gets log M[j]
     // the scratch is private to this wave: only the compiler must be kept from moving the reads of the table builders
     // above these writes
     LR_WAVE_LDS_ORDER();

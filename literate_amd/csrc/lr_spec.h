@@ -347,8 +347,9 @@ __device__ __forceinline__ void lr_spec_deliver(lr_spec_lds<H, T / LR_WAVE, GENE
                                                 const lr_spec_dec_in& in, double acc0, double acc1, int wave, int lane) {
     constexpr int NW = T / LR_WAVE;
     constexpr bool rj = RJ;
-    // (a team per chain: the two candidate waves scan - and count themselves in - only when they were given a share)
-    const int n_arrive = (NW - 4) + ((SINGLE && ctx.cand_n > 0) ? 2 : 0);
+    // (a team per chain under a parametric sampler: the two candidate waves scan - and count themselves in - when they
+    // were given a share; the RJ sampler's never are: lr_launch_spec)
+    const int n_arrive = (NW - 4) + ((SINGLE && !RJ && ctx.cand_n > 0) ? 2 : 0);
     const int k_team = ctx.x.team_blocks;
     const unsigned long long it = ctx.it0 + (unsigned long long)iter;
     {
@@ -375,7 +376,7 @@ __device__ __forceinline__ void lr_spec_deliver(lr_spec_lds<H, T / LR_WAVE, GENE
                 if (n & 1) t0[n / 2] = t0[n - 1], t1[n / 2] = t1[n - 1];
             }
             double sum0 = t0[0], sum1 = t1[0];
-            if (SINGLE && ctx.cand_n > 0) {
+            if (SINGLE && !RJ && ctx.cand_n > 0) {
                 // (a team per chain on a long scan: the two candidate waves' shares, added behind the scanner waves' tree)
                 sum0 += lr_bcast(rv.x, 0), sum1 += lr_bcast(rv.y, 0);
                 sum0 += lr_bcast(rv.x, 1), sum1 += lr_bcast(rv.y, 1);
@@ -734,7 +735,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                 { const int lc_ = c; { const int c = c0 + lc_; (void)c; LR_SSTAMP(7); } }
             }
         }
-        if (SINGLE && ctx.cand_n > 0) {
+        if (SINGLE && !RJ && ctx.cand_n > 0) {
             // a team per chain on a long scan: this wave's share of it (the tail of the block's slice), then its sums - it
             // may be the wave that arrives last and decides
             const lr_spec_dec_in dec_in = lr_spec_dec_fetch(sm, ctx, role0, role1, lane);
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         const long long per = (n8 + k_team - 1) / k_team;
         const long long g_lo = min((long long)rank * per, n8), g_hi = min(g_lo + per, n8);
         // (a team per chain: the tail of the slice is the candidate waves', scanned once their candidates stand)
-        const long long n_c = SINGLE ? ((g_hi - g_lo) * (long long)x.cand_share_q16) >> 16 : 0;
+        const long long n_c = (SINGLE && !RJ) ? ((g_hi - g_lo) * (long long)x.cand_share_q16) >> 16 : 0;
         ctx.pk = pk, ctx.g0 = g_lo, ctx.n8 = g_hi - g_lo - n_c, ctx.x = x, ctx.n_iters = n_iters;
         ctx.cand_g0 = g_hi - n_c, ctx.cand_n = n_c;
         ctx.it0 = (unsigned long long)(unsigned)I0[LR_I_IT_LO] | ((unsigned long long)(unsigned)I0[LR_I_IT_HI] << 32);

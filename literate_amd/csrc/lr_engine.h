@@ -83,6 +83,19 @@ static inline long long lr_groups_alloc(long long n_lineages) {
 #define LR_SPEC_GRANULES 16      /* 8-byte granules reserved per block and parity: one 128-byte line */
 #define LR_SPEC_TIMEOUT_TICKS 200000000ull   /* 2 s of the 100 MHz wall clock */
 
+// Which instantiation of the speculative kernel an engine runs (lr_spec.h): 0 = a team per pair; a team per chain with the
+// pair planes of a candidate's table derived 1 = by the helper wave that builds it (long scans: the scan is the longer
+// path of an iteration) or 2 = by the scanner waves, for the ONE table that becomes pending (short scans - at most 3 trips
+// per scanner lane, no team exchange -: the helper waves' build is).  LR_SPEC_PLANES_BY_SCANNERS = 0 / 1 overrides the rule.
+static inline int lr_spec_mode(const lr_engine* e) {
+    if (e->lay.spec_chains_per_team != 1) return 0;
+    const int k = e->lay.team_blocks > 0 ? e->lay.team_blocks : 1;
+    const double trips = (double)((e->n8 + k - 1) / k) / 64.0 / 8.0;
+    const char* env = getenv("LR_SPEC_PLANES_BY_SCANNERS");
+    const bool by_scanners = env ? atoi(env) != 0 : (trips <= 3.0 && k == 1);
+    return by_scanners ? 2 : 1;
+}
+
 // lr_mcmc.hip
 lr_step_args lr_make_args(const lr_engine* e);
 // lr_pack.hip: (re)builds the packed lineages in the workspace and the scanner-wave shares; blocks on `stream` once

@@ -1501,8 +1501,8 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
     if (e->persistent) {
         const char* gen = e->plan.unit == LR_TAB_PAIRGEN ? "true" : "false";
         if (e->lay.persistent == 3)
-            snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d, %s, %s, %s>", e->plan.H, e->lay.reserved1, e->cfg.sampler == 0 ? "true" : "false", gen,
-                     e->lay.spec_chains_per_team == 1 ? "true" : "false");
+            snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d, %s, %s, %d>", e->plan.H, e->lay.reserved1, e->cfg.sampler == 0 ? "true" : "false", gen,
+                     lr_spec_mode(e));
         else if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s>", e->plan.H, gen);
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
     } else if (e->part[0].pipelined) {

@@ -78,9 +78,6 @@ struct lr_spec_args {
                                   // as chains: half the candidate work per CU and an iteration as short as ONE chain's move)
     int cand_share_q16;           // a team per chain: share (x 2^16) of a block's groups that its two candidate waves scan
                                   // once their candidates are built (long scans only: lr_launch_spec)
-    int planes_by_scanners;       // a team per chain: 1 = the pair planes of the table that becomes pending are derived by
-                                  // the scanner waves behind the barrier (short scans: the helper waves' build is the longer
-                                  // path), 0 = by the helper wave that builds the table (long scans: the scan is)
 };
 
 __device__ __forceinline__ void lr_set_load(const lr_set* q, lr_rj_state& s, int lane) {
@@ -472,7 +469,11 @@ __device__ __forceinline__ void lr_spec_deliver(lr_spec_lds<H, T / LR_WAVE, GENE
 // built.  Behind the barrier every wave reads the outcome, turns the roles of the sets and goes on: the scanners to the
 // pair table of the selected candidates, the candidate waves to the next candidates.  The last two scanner waves also
 // have the draw duty.
-template <int H, int T, bool RJ, bool GENERAL, bool SINGLE>
+// MODE: 0 = a team per pair, 1 = a team per chain (pair planes by the helper waves), 2 = a team per chain on a short scan
+// (pair planes by the scanner waves) - a template parameter rather than a run-time switch: every path that is compiled in
+// costs instruction-cache room and registers in a kernel of ~9000 instructions (taking a dead path out of the RJ kernels
+// was worth 4 % on cfg2)
+template <int H, int T, bool RJ, bool GENERAL, int MODE>
 __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
@@ -486,6 +487,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
     // more than its scan, so there the last two scanner waves (the smallest scan shares) take a chain each.
     // A team per chain: the draw duty lies with the helper waves 2, 3 (lr_spec_help_role), and there is no scan table to
     // build - every state in flight has its own.
+    constexpr bool SINGLE = MODE != 0, PLANES_BY_SCANNERS = MODE == 2;
     constexpr bool single = SINGLE;
     const bool split_draws = rj && k_team == 1;
     const int dch = split_draws ? (wave - (NW - 4)) >> 1 : wave - (NW - 2), dpart = (wave - (NW - 4)) & 1;
@@ -544,7 +546,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         if (k_team > 1 && sm.abort_flag) return;
         sel = sm.dec[iter & 1].sel;
         role0 = lr_spec_turn(role0, sel >> 1), role1 = lr_spec_turn(role1, sel & 1);
-        if (single && ctx.x.planes_by_scanners) {
+        if (PLANES_BY_SCANNERS) {
             // a team per chain on a short scan: the pair planes of the table that is pending now, by all scanner lanes; the
             // scanner waves then wait for each other on an LDS counter
             double2* tab = sm.t.tabs[(role0 >> 2) & 3];
@@ -588,7 +590,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
 //      set; this wave builds the table with its pair planes meanwhile and - RJ - writes the model constant and the rank
 //      cache into the proposal's set: a candidate is two waves on two SIMDs for the longer half of its build.
 // Same barrier per iteration as the other roles.
-template <int H, int T, bool RJ, bool GENERAL>
+template <int H, int T, bool RJ, bool GENERAL, int MODE>
 __device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
@@ -612,7 +614,7 @@ __device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GE
                     sc, eL, eM, hand->KL, hand->KM, sm.br, sm.logbr, a.cfg.model, a.cfg.n_bins, a.n_cls, a.H,
                     reinterpret_cast<double2*>(tabd), lane, GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, a.cfg.frac_birth,
                     a.cfg.frac_death, GENERAL ? 6 * H : 2, &sg);
-                if (!ctx.x.planes_by_scanners) {
+                if (MODE != 2) {
                     LR_WAVE_LDS_ORDER();
                     if (GENERAL) lr_pair_planes_wave_general(tabd, H, a.cfg.n_bins, lane, 0);
                     else lr_pair_planes_wave(tabd, H, a.cfg.n_bins, lane, 0);
@@ -631,10 +633,7 @@ __device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GE
             while (__hip_atomic_load(&hand->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)iter + 1) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
             const double P = lane < 8 ? hand->par[lane] : 0.0;
-            if (ctx.x.planes_by_scanners)
-                lr_param_tables<true, false, 2>(a, P, sm.br, sm.t.tabs[hand->out_idx], GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, GENERAL ? 6 * H : 2, lane);
-            else
-                lr_param_tables<true, true, 2>(a, P, sm.br, sm.t.tabs[hand->out_idx], GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, GENERAL ? 6 * H : 2, lane);
+            lr_param_tables<true, MODE != 2, 2>(a, P, sm.br, sm.t.tabs[hand->out_idx], GENERAL ? LR_TAB_PAIRGEN : LR_TAB_UNIT, GENERAL ? 6 * H : 2, lane);
         }
         __syncthreads();
         if (k_team > 1 && sm.abort_flag) return;
@@ -644,10 +643,11 @@ __device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GE
 // The candidate role (waves 0..3; chain = wave / 2, outcome = wave % 2): build the candidate of iteration it + 1 while
 // the others scan, then - all four waves alike, each on its own SIMD - decide both chains, copy the selected pair
 // table, turn the roles of the sets; waves 0 and 2 keep the books (acceptance count, trace rows, final state).
-template <int H, int T, bool RJ, bool GENERAL, bool SINGLE>
+template <int H, int T, bool RJ, bool GENERAL, int MODE>
 __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
+    constexpr bool SINGLE = MODE != 0;
     // the builders' `so`: doubles from a value to its slope - inside a column (a team per pair) / in the six-plane image
     constexpr int ES = GENERAL ? (SINGLE ? 6 * H : 2 * H) : 2;
     constexpr int COL = lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>::COL;
@@ -724,7 +724,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
                     if (lane == 0) hand->out_idx = out_i, hand->base_idx = base_i;
                     // (a copied table brings its pair planes along unless the scanner waves derive them anyway; the planes of a
                     // general-times table lie behind its slopes: S | E | 2E | slopes)
-                    const int n_copy = (ctx.x.planes_by_scanners && !GENERAL) ? 2 * H : LR_UNIT_PLANES * H;
+                    constexpr int n_copy = (MODE == 2 && !GENERAL) ? 2 * H : LR_UNIT_PLANES * H;
                     lr_propose_rj<true, lr_bins_per_lane(H), 2, true, true>(a, c0 + c, lane, &sm.scratch[wave], it + 1, s, p, table, ES, &d, br_lds,
                                                                             logbr_lds, base_col, n_copy, base->sc[LR_SET_CONST], hand, (int)iter + 1);
                 } else {
@@ -791,12 +791,13 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
 
 // T threads: waves 0..3 are the candidate waves, the others scan.  The step arguments travel by value (kernarg
 // segment -> scalar registers); both roles are inlined, their loops live in disjoint branches of the kernel.
-template <int H, int T, bool RJ, bool GENERAL, bool SINGLE>
+template <int H, int T, bool RJ, bool GENERAL, int MODE>
 __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_args a, lr_packed_lineages pk, long long n8,
                                                                      lr_spec_args x, long long n_iters) {
     constexpr int NW = T / LR_WAVE;
     constexpr int ENT = GENERAL ? 2 : 1;
     constexpr int COL = lr_spec_lds<H, NW, ENT>::COL;
+    constexpr bool SINGLE = MODE != 0;
     constexpr int CPB = SINGLE ? 1 : 2;                   // (= x.cpb: the host picks the instantiation by it)
     static_assert(sizeof(lr_spec_lds<H, NW, ENT>) <= 160 * 1024, "the block's LDS image must fit a CU");
     __shared__ lr_spec_lds<H, NW, ENT> sm;
@@ -913,9 +914,9 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
         }
     }
     __syncthreads();
-    if (SINGLE && (wave == 2 || wave == 3)) lr_spec_help_role<H, T, RJ, GENERAL>(sm, a, ctx, tid);
-    else if (wave < 4) lr_spec_cand_role<H, T, RJ, GENERAL, SINGLE>(sm, a, ctx, tid);
-    else lr_spec_scan_role<H, T, RJ, GENERAL, SINGLE>(sm, a, ctx, tid);
+    if (SINGLE && (wave == 2 || wave == 3)) lr_spec_help_role<H, T, RJ, GENERAL, MODE>(sm, a, ctx, tid);
+    else if (wave < 4) lr_spec_cand_role<H, T, RJ, GENERAL, MODE>(sm, a, ctx, tid);
+    else lr_spec_scan_role<H, T, RJ, GENERAL, MODE>(sm, a, ctx, tid);
     __syncthreads();
     if (sm.abort_flag || rank != 0) return;
     // the pending proposals' entries back into their components of the pair tables

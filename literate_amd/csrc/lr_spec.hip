@@ -6,6 +6,7 @@
 
 int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages& pk, int64_t n_iters, hipStream_t stream) {
     const int cpb = e->lay.spec_chains_per_team == 1 ? 1 : 2;
+    const int mode = lr_spec_mode(e);
     const int blocks = (e->cfg.n_chains + cpb - 1) / cpb;          // teams
     const bool general = e->plan.unit == LR_TAB_PAIRGEN;
             lr_spec_args x;
@@ -29,12 +30,6 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
                 if (share > 0.5) share = 0.5;
                 if (share < 0.0) share = 0.0;
                 x.cand_share_q16 = cpb == 1 ? (int)(share * 65536.0) : 0;
-                // who derives the pair planes of a candidate's table (a team per chain): on short scans - at most 3 trips per
-                // scanner lane - the helper waves' table build is the longer path of an iteration and the scanner waves take
-                // the planes (of the ONE table that becomes pending); on long scans the helper keeps them.
-                // LR_SPEC_PLANES_BY_SCANNERS = 0 / 1 overrides it (A/B runs).
-                const char* envp = getenv("LR_SPEC_PLANES_BY_SCANNERS");
-                x.planes_by_scanners = envp ? (atoi(envp) != 0) : (W / 8.0 <= 3.0 && x.team_blocks == 1);
             }
             const size_t xbytes = (size_t)2 * blocks * LR_TEAM_MAX * LR_SPEC_GRANULES * 8;
             for (int64_t done = 0; done < n_iters;) {
@@ -45,15 +40,18 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
                     if (he != hipSuccess) return (int)he;
                 }
                 const dim3 grid((unsigned)(blocks * x.team_blocks)), blk(cpb == 1 ? LR_SPEC_THREADS_SINGLE : LR_SPEC_THREADS);
-#define LR_SPEC_LAUNCH(HH, GG)                                                                                                \
-    if (e->cfg.sampler == 0 && cpb == 1)                                                                                      \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS_SINGLE, true, GG, true>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
-    else if (e->cfg.sampler == 0)                                                                                             \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, true, GG, false>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
-    else if (cpb == 1)                                                                                                        \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS_SINGLE, false, GG, true>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n); \
-    else                                                                                                                      \
-        hipLaunchKernelGGL((lr_spec_kernel<HH, LR_SPEC_THREADS, false, GG, false>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n)
+#define LR_SPEC_LAUNCH_M(HH, GG, RR, MM) \
+    hipLaunchKernelGGL((lr_spec_kernel<HH, (MM) != 0 ? LR_SPEC_THREADS_SINGLE : LR_SPEC_THREADS, RR, GG, MM>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n)
+#define LR_SPEC_LAUNCH(HH, GG)                                                         \
+    if (e->cfg.sampler == 0) {                                                         \
+        if (mode == 2) LR_SPEC_LAUNCH_M(HH, GG, true, 2);                              \
+        else if (mode == 1) LR_SPEC_LAUNCH_M(HH, GG, true, 1);                         \
+        else LR_SPEC_LAUNCH_M(HH, GG, true, 0);                                        \
+    } else {                                                                           \
+        if (mode == 2) LR_SPEC_LAUNCH_M(HH, GG, false, 2);                             \
+        else if (mode == 1) LR_SPEC_LAUNCH_M(HH, GG, false, 1);                        \
+        else LR_SPEC_LAUNCH_M(HH, GG, false, 0);                                       \
+    }
                 // (the eight candidate tables + the scan table: 352 H bytes at unit resolution, 608 H on general times, where
                 // H = 264 does not fit the LDS and is never planned for this kernel, see lr_persist_variant)
                 if (general) {
@@ -73,6 +71,7 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
                     }
                 }
 #undef LR_SPEC_LAUNCH
+#undef LR_SPEC_LAUNCH_M
                 const int rc = (int)hipGetLastError();
                 if (rc) return rc;
                 done += n;

@@ -227,7 +227,10 @@ typedef __attribute__((address_space(3))) double lr_lds_f64;
 typedef __attribute__((address_space(3))) int lr_lds_i32;
 // PB: bins per lane of the one-pass table builder for the kernel's table size (0: choose at run time), ES: the builders'
 // `so` - both known to the calling kernel at compile time, so the builder dispatch and the layout switches fold away
-template <int PB, int ES, bool PRE = false>
+// SAMPLER: -1 = both chain steps compiled in, chosen at run time (two-chain kernel); 0 = the RJ sampler's only; 1 = the
+// parametric samplers' only (four-chain kernel: the launch picks the instantiation - a stepper function that carries one
+// step is a third smaller, and the kernel's instruction footprint is shared by two CUs' instruction cache)
+template <int PB, int ES, bool PRE = false, int SAMPLER = -1>
 __device__ __forceinline__ void lr_persist_step_body(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
                                                      __attribute__((address_space(3))) lr_seg_scratch* scratch3,
                                                      lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* table3,
@@ -239,7 +242,7 @@ __device__ __forceinline__ void lr_persist_step_body(const __attribute__((addres
     LR_SSTAMP(0);
     lr_chain_regs st;
     lr_chain_load(st, (double*)st_f64, (int*)st_i32, lane);
-    if (a.cfg.sampler != 0)
+    if (SAMPLER == 1 || (SAMPLER == -1 && a.cfg.sampler != 0))
         lr_dd_step_core<true>(st, a, 0, c, lane, lik, reinterpret_cast<double2*>((double*)table3), table_es, br_lds);
     else if (PRE) {
         lr_rj_draws pre;
@@ -268,7 +271,7 @@ __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((a
 // waves' loop in lr_persist4_kernel.
 //   st_f64 / st_i32: the four chains' state rows; red: [pair][wave][chain of the pair] scan sums; tab: the two pair
 //   tables, tab_doubles apart
-template <int PB, int ES, int NW>
+template <int PB, int ES, int NW, int SAMPLER>
 __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute__((address_space(3))) lr_step_args* a3, int c0,
                                                                int n_chains, int wave, int lane,
                                                                __attribute__((address_space(3))) lr_seg_scratch* scratch3,
@@ -286,7 +289,7 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
                 double lik = 0.0;
 #pragma unroll
                 for (int w2 = 2; w2 < (LR_P4_LAST_SUMS != 0 && ES == 2 /* unit resolution: the block's sums in slot 2 */ ? 3 : NW); ++w2) lik += red[(ph * NW + w2) * 2 + wave];
-                lr_persist_step_body<PB, ES, LR_P4_DRAW_AHEAD != 0 && ES == 2 /* unit resolution */>(a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
+                lr_persist_step_body<PB, ES, LR_P4_DRAW_AHEAD != 0 && ES == 2 /* unit resolution */ && SAMPLER == 0, SAMPLER>(a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
                                              st_i32 + (2 * ph + wave) * (LR_ISTATE_ROWS * LR_ROW), lik,
                                              tab + ph * tab_doubles + wave, br3, draws + (2 * ph + wave));
             }
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 #endif
 
 #define LR_P4_SCANNERS ((LR_P4_THREADS / LR_WAVE - 2) * LR_WAVE)
-template <int H, bool GENERAL>
+template <int H, bool GENERAL, bool PARAM /* a parametric sampler's chain step (DDRate, trend_rate) instead of the RJ sampler's */>
 __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
                                                                        lr_packed_lineages pk, long long n8,
                                                                        lr_p4_shares sh, long long n_iters) {
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         br_lds[1][b] = in ? ap->log_br[b] : 0.0;
     }
     // (unit resolution only: on general times the scan loops are the longer side of a phase and have nothing to spare)
-    const bool draw_ahead = LR_P4_DRAW_AHEAD && !GENERAL && ap->cfg.sampler == 0;
+    constexpr bool draw_ahead = LR_P4_DRAW_AHEAD && !GENERAL && !PARAM;
     // draw duty of scanner wave 2 + q, q < 4, for the pair `pr` that has just been scanned: part q >> 1 of chain q & 1
     auto draw_duty = [&](int pr) {
         const int q = wave - 2, k = q & 1, ch = 2 * pr + k;
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     __syncthreads();
     // phase ph of an iteration: the steppers advance pair `ph`, the scanners score pair `1 - ph`
     if (!scanner)
-        lr_persist4_steppers<(H <= 264 ? lr_bins_per_lane(H) : 0), ES, NW>(
+        lr_persist4_steppers<(H <= 264 ? lr_bins_per_lane(H) : 0), ES, NW, PARAM ? 1 : 0>(
             (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c0, C, wave, lane,
             (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave], (lr_lds_f64*)&st_f64[0][0], (lr_lds_i32*)&st_i32[0][0],
             (lr_lds_f64*)&red[0][0][0], (lr_lds_f64*)reinterpret_cast<double*>(tab[0]), 2 * LR_UNIT_PLANES * H,
@@ -1394,6 +1397,7 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         const lr_step_args* ap = (const lr_step_args*)(e->ws + e->lay.args_blob);
         const int blocks = (e->cfg.n_chains + 1) / 2;
         const bool p4 = e->lay.persistent == 2;
+        const bool param = e->cfg.sampler != 0;
         static const int prio = lr_env_int("LR_PERSIST_PRIO", 12);   // clock bits per priority slice, 0 = off
         // one block per CU at most: give it the whole CU (16 waves on the one pair)
         static const int wide_env = lr_env_int("LR_PERSIST_WIDE", -1);
@@ -1404,12 +1408,11 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
 #define LR_P_LAUNCH(HH)                                                                                                       \
     if (p4) {                                                                                                                 \
-        if (general)                                                                                                          \
-            hipLaunchKernelGGL((lr_persist4_kernel<HH, true>), dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, \
-                               pk, e->n8, e->p4, (long long)n);                                                               \
-        else                                                                                                                  \
-            hipLaunchKernelGGL((lr_persist4_kernel<HH, false>), dim3((e->cfg.n_chains + 3) / 4), dim3(LR_P4_THREADS), 0, stream, ap, \
-                               pk, e->n8, e->p4, (long long)n);                                                               \
+        const dim3 g4((e->cfg.n_chains + 3) / 4), b4(LR_P4_THREADS);                                                          \
+        if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);   \
+        else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);      \
+        else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);        \
+        else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);                  \
     } else if (wide) {                                                                                                        \
         hipLaunchKernelGGL((lr_persist_kernel<HH, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); \
     } else {                                                                                                                  \
@@ -1503,7 +1506,7 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
         if (e->lay.persistent == 3)
             snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d, %s, %s, %d>", e->plan.H, e->lay.reserved1, e->cfg.sampler == 0 ? "true" : "false", gen,
                      lr_spec_mode(e));
-        else if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s>", e->plan.H, gen);
+        else if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s, %s>", e->plan.H, gen, e->cfg.sampler != 0 ? "true" : "false");
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
     } else if (e->part[0].pipelined) {
         snprintf(buf, (size_t)n, "lr_fused_iter_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");

@@ -1,25 +1,36 @@
-// lr_spec.h - the speculative team engine: persistent kernel for shards with at most one chain pair per CU.
+// lr_spec.h - the speculative team engine: persistent kernel for shards with at most one team (a chain pair or a single
+// chain) per CU.
 //
 // The chain step is a serial fp64 stream of ~3 us that needs the lineage scan for ONE bit (accept / reject).  So it is
-// taken off the critical path by speculation: while the scanner waves score the pending proposal P, two candidate
-// waves per chain build the NEXT proposal for both outcomes - Q0 from the accepted state A (P rejected) and Q1 from P
-// (P accepted) - with their priors and lookup tables.  When the scan sums are in, every wave evaluates the
-// Metropolis-Hastings rule (a handful of flops on values in LDS), the scanner waves lay the columns of the two selected
-// candidates side by side into the scan table and the next scan starts.  Every state in flight (accepted A, pending P,
-// candidates Q0, Q1) owns its column of lookup-table entries, so a candidate whose move changes no rate and no bin edge
-// (the no-op "times" moves, the Gibbs step) copies its base state's column instead of building one.  The draws are addressed by (seed, chain, iteration, purpose), so both
-// candidates consume exactly the draws the sequential loop would: trajectories are those of lr_chain_step_core.
-// Per iteration: max(candidate build, scan) + two barriers, instead of scan + step.
+// taken off the critical path by speculation: while the scanner waves score the pending proposal P, candidate waves
+// build the NEXT proposal for both outcomes - Q0 from the accepted state A (P rejected) and Q1 from P (P accepted) -
+// with their priors and lookup tables.  The draws are addressed by (seed, chain, iteration, purpose), so both candidates
+// consume exactly the draws the sequential loop would: trajectories are those of lr_chain_step_core.  ONE barrier per
+// iteration: the scanning wave that finishes last adds the sums in a fixed order, runs the Metropolis-Hastings tests and
+// leaves the decision in LDS (lr_spec_deliver); behind the barrier every wave turns the roles of the four sets
+// (A, P, Q0, Q1).  Every state in flight owns its lookup-table entries, so a proposal whose move changes no rate and no
+// bin edge (the no-op "times" moves, the Gibbs step) copies its base state's entries instead of building them.
 //
-// Teams.  With fewer chain pairs than CUs a pair is owned by a TEAM of k blocks (k = 2, 4, 8; one block per CU).
-// Every block of the team runs the same candidate waves on the same state - a replicated state machine, so no table
-// or state ever crosses a CU boundary - and scans its own 1/k slice of the lineages.  The only exchange is the two
-// partial sums per block and iteration: 8-byte {epoch tag, 32-bit half} granules written with one agent-scope store
-// each and swept by one wave of every block until all tags carry the iteration's epoch (cdna_hip_programming.md
-// Guideline 16, form R2; parity-double-buffered, zeroed before every launch).  Every block adds the k partial sums in
-// block order, so all of them take bit-identical decisions; only block 0 of a team writes trace rows and the final
-// state.  Results never depend on dispatch order or placement; a sweep that does not complete within two seconds
-// raises the engine's status word and ends the launch (every block polls that word too).
+// Two kinds of team (template MODE of the kernel):
+//   a team per PAIR (MODE 0): waves 0..3 are the candidate waves (chain = wave / 2, outcome = wave % 2), each with a column
+//     of its own; behind the barrier the scanner waves lay the two pending columns side by side into the six-plane scan
+//     table (lr_build_scan_table) - every gather then serves two chains;
+//   a team per CHAIN (MODE 1, 2): waves 0, 1 are the candidate waves of the one chain, waves 2, 3 their HELPER waves on
+//     the two SIMDs that carry no candidate: a candidate hands its staged segments (RJ) or parameter vector (DDRate /
+//     trend_rate) over through LDS as soon as they stand and goes on with guard, prior and set, its helper builds the
+//     table meanwhile (and makes the draws of the iteration after the next).  Every state owns a whole scan table
+//     ((.x, .y) = (the chain, 0)), so behind the barrier the scanners only switch tables.  MODE 2 (short scans): the
+//     helper stops at the S and E planes and the scanner waves derive the pair planes of the table that becomes pending.
+//
+// Teams of blocks.  With fewer teams than CUs a team is k blocks (k = 2, 4, 8; one block per CU).  Every block of the
+// team runs the same candidate waves on the same state - a replicated state machine, so no table or state ever crosses a
+// CU boundary - and scans its own 1/k slice of the lineages.  The only exchange is the two partial sums per block and
+// iteration: 8-byte {epoch tag, 32-bit half} granules written with one agent-scope store each and swept by one wave of
+// every block until all tags carry the iteration's epoch (cdna_hip_programming.md Guideline 16, form R2; parity-double-
+// buffered, zeroed before every launch).  Every block adds the k partial sums in block order, so all of them take
+// bit-identical decisions; only block 0 of a team writes trace rows and the final state.  Results never depend on
+// dispatch order or placement; a sweep that does not complete within two seconds raises the engine's status word and ends
+// the launch (every block polls that word too; later launches of the call end at entry).
 #pragma once
 #include "lr_scan.h"
 #include "lr_step.h"

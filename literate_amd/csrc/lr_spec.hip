@@ -52,8 +52,7 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
         else if (mode == 1) LR_SPEC_LAUNCH_M(HH, GG, false, 1);                        \
         else LR_SPEC_LAUNCH_M(HH, GG, false, 0);                                       \
     }
-                // (the eight candidate tables + the scan table: 352 H bytes at unit resolution, 608 H on general times, where
-                // H = 264 does not fit the LDS and is never planned for this kernel, see lr_persist_variant)
+                // (general times: H = 264 is never planned for this kernel, see lr_persist_variant)
                 if (general) {
                     switch (e->plan.H) {
                         case 40: LR_SPEC_LAUNCH(40, true); break;

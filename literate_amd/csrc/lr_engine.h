@@ -22,7 +22,8 @@ struct lr_part {
 // k_tot; the deltas sum to zero.  The trips given up are stored, in slot / trip order, behind the takers' own shares.
 struct lr_p4_shares {
     int delta[16];
-    int n_slots;          // scanner waves striding over the groups: 14 (four-chain kernel) or 8 (two-chain kernel)
+    int n_slots;          // scanner waves striding over the groups: 14 (four-chain kernel; 12 with helper waves) or 8 (two-chain kernel)
+    int help_trips;       // four-chain kernel with helper waves: trips of the scan each helper wave makes before its hand-over arrives
 };
 
 struct lr_engine {
@@ -83,17 +84,26 @@ static inline long long lr_groups_alloc(long long n_lineages) {
 #define LR_SPEC_GRANULES 16      /* 8-byte granules reserved per block and parity: one 128-byte line */
 #define LR_SPEC_TIMEOUT_TICKS 200000000ull   /* 2 s of the 100 MHz wall clock */
 
-// Which instantiation of the speculative kernel an engine runs (lr_spec.h): 0 = a team per pair; a team per chain with the
-// pair planes of a candidate's table derived 1 = by the helper wave that builds it (long scans: the scan is the longer
-// path of an iteration) or 2 = by the scanner waves, for the ONE table that becomes pending (short scans - at most 3 trips
-// per scanner lane, no team exchange -: the helper waves' build is).  LR_SPEC_PLANES_BY_SCANNERS = 0 / 1 overrides the rule.
+// Four-chain kernel: helper waves (lr_persist4_kernel's HELP) under the RJ sampler at unit resolution; LR_P4_HELP = 0: the
+// form with fourteen scanner waves (A/B runs)
+static inline bool lr_p4_help(const lr_engine* e) {
+    static const char* env = getenv("LR_P4_HELP");
+    if (e->lay.persistent != 2 || e->plan.unit == LR_TAB_PAIRGEN || e->cfg.sampler != 0 || e->plan.H > 264) return false;
+    return env ? atoi(env) != 0 : true;
+}
+
+// Which instantiation of the speculative kernel an engine runs (lr_spec.h): 0 = a team per pair; a team per chain: 1 = in
+// a team of several blocks, 2 = on its own CU with the pair planes of a candidate's table derived by the scanner waves for
+// the ONE table that becomes pending (short scans - at most 3 trips per scanner lane -: the helper waves' build is the
+// longer path of an iteration), 3 = on its own CU with the planes derived by the helper wave that builds the table (long
+// scans: the scan is).  LR_SPEC_PLANES_BY_SCANNERS = 0 / 1 overrides the rule between 2 and 3.
 static inline int lr_spec_mode(const lr_engine* e) {
     if (e->lay.spec_chains_per_team != 1) return 0;
-    const int k = e->lay.team_blocks > 0 ? e->lay.team_blocks : 1;
-    const double trips = (double)((e->n8 + k - 1) / k) / 64.0 / 8.0;
+    if (e->lay.team_blocks > 1) return 1;
+    const double trips = (double)e->n8 / 64.0 / 8.0;
     const char* env = getenv("LR_SPEC_PLANES_BY_SCANNERS");
-    const bool by_scanners = env ? atoi(env) != 0 : (trips <= 3.0 && k == 1);
-    return by_scanners ? 2 : 1;
+    const bool by_scanners = env ? atoi(env) != 0 : trips <= 3.0;
+    return by_scanners ? 2 : 3;
 }
 
 // lr_mcmc.hip

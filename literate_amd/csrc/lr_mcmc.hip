@@ -230,12 +230,14 @@ typedef __attribute__((address_space(3))) int lr_lds_i32;
 // SAMPLER: -1 = both chain steps compiled in, chosen at run time (two-chain kernel); 0 = the RJ sampler's only; 1 = the
 // parametric samplers' only (four-chain kernel: the launch picks the instantiation - a stepper function that carries one
 // step is a third smaller, and the kernel's instruction footprint is shared by two CUs' instruction cache)
-template <int PB, int ES, bool PRE = false, int SAMPLER = -1>
+// HAND: the proposal's tables are built by a helper wave from the segments this wave hands over (`hand`, epoch `hand_epoch`)
+template <int PB, int ES, bool PRE = false, int SAMPLER = -1, bool HAND = false>
 __device__ __forceinline__ void lr_persist_step_body(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
                                                      __attribute__((address_space(3))) lr_seg_scratch* scratch3,
                                                      lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* table3,
                                                      lr_lds_f64* br3 /* [2][LR_H_WIDE]: br_length, log br_length */,
-                                                     const lr_draw_slot* draws = nullptr /* of the iteration proposed now, made ahead */) {
+                                                     const lr_draw_slot* draws = nullptr /* of the iteration proposed now, made ahead */,
+                                                     lr_table_hand* hand = nullptr, int hand_epoch = 0) {
     constexpr int table_es = ES;
     const lr_step_args& a = *(const lr_step_args*)a3;
     const double* br_lds = (const double*)br3;
@@ -247,13 +249,38 @@ __device__ __forceinline__ void lr_persist_step_body(const __attribute__((addres
     else if (PRE) {
         lr_rj_draws pre;
         lr_draws_load(draws, pre, lane);
-        lr_chain_step_core<true, PB>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
-                                     table_es, br_lds, br_lds + LR_H_WIDE, &pre);
+        lr_chain_step_core<true, PB, HAND>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
+                                           table_es, br_lds, br_lds + LR_H_WIDE, &pre, hand, hand_epoch);
     } else
         lr_chain_step_core<true, PB>(st, a, 0, c, lane, (lr_seg_scratch*)scratch3, lik, reinterpret_cast<double2*>((double*)table3),
                                      table_es, br_lds, br_lds + LR_H_WIDE);
-    lr_chain_store(st, (double*)st_f64, (int*)st_i32, lane);
+    if (HAND) lr_chain_store_handed(st, (double*)st_f64, (int*)st_i32, lane);
+    else lr_chain_store(st, (double*)st_f64, (int*)st_i32, lane);
     LR_SSTAMP(8);
+}
+
+// End of a wave's share of scan number `scans_done` in the four-chain kernel: the lanes' sums into slot `slot` of
+// `part`, count in, and - the wave that arrives LAST of the NA scanning waves - add the block's sums up, per lane over the
+// slots in slot order, then across the lanes (the same order whoever is last), into out[0..1].
+template <int NA>
+__device__ __forceinline__ void lr_p4_leave_sums(double2 (*part)[LR_WAVE], int* arrived, double* out, int slot, int lane,
+                                                 int& scans_done, double s0, double s1) {
+    part[slot][lane] = make_double2(s0, s1);
+    int prev = 0;
+    if (lane == 0) prev = __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    prev = __builtin_amdgcn_readfirstlane(prev);
+    if (prev == NA * (scans_done + 1) - 1) {
+        asm volatile("" ::: "memory");     // the sums are read after the count was seen (a wave's LDS operations execute in order)
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NA; ++w) {
+            const double2 v = part[w][lane];
+            a0 += v.x, a1 += v.y;
+        }
+        a0 = lr_wave_sum(a0), a1 = lr_wave_sum(a1);
+        if (lane == 0) out[0] = a0, out[1] = a1;
+    }
+    ++scans_done;
 }
 
 template <int PB, int ES>
@@ -271,13 +298,16 @@ __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((a
 // waves' loop in lr_persist4_kernel.
 //   st_f64 / st_i32: the four chains' state rows; red: [pair][wave][chain of the pair] scan sums; tab: the two pair
 //   tables, tab_doubles apart
-template <int PB, int ES, int NW, int SAMPLER>
+//   HELP: waves 2, 3 are helper waves - hands[wave] is this stepper's hand-over to wave 2 + wave (lr_persist4_kernel)
+template <int PB, int ES, int NW, int SAMPLER, bool HELP>
 __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute__((address_space(3))) lr_step_args* a3, int c0,
                                                                int n_chains, int wave, int lane,
                                                                __attribute__((address_space(3))) lr_seg_scratch* scratch3,
                                                                lr_lds_f64* st_f64, lr_lds_i32* st_i32, lr_lds_f64* red,
                                                                lr_lds_f64* tab, int tab_doubles, lr_lds_f64* br3, long long n_iters,
-                                                               const lr_draw_slot* draws /* [4]: made ahead (RJ sampler) */) {
+                                                               const lr_draw_slot* draws /* [4]: made ahead (RJ sampler) */,
+                                                               lr_table_hand* hands /* [2] */) {
+    static_assert(!HELP || (LR_P4_DRAW_AHEAD != 0 && ES == 2 && SAMPLER == 0 && LR_P4_LAST_SUMS != 0), "helper waves: RJ sampler at unit resolution");
     for (long long iter = 0; iter < n_iters; ++iter) {
 #pragma unroll 1
         for (int ph = 0; ph < 2; ++ph) {
@@ -289,9 +319,10 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
                 double lik = 0.0;
 #pragma unroll
                 for (int w2 = 2; w2 < (LR_P4_LAST_SUMS != 0 && ES == 2 /* unit resolution: the block's sums in slot 2 */ ? 3 : NW); ++w2) lik += red[(ph * NW + w2) * 2 + wave];
-                lr_persist_step_body<PB, ES, LR_P4_DRAW_AHEAD != 0 && ES == 2 /* unit resolution */ && SAMPLER == 0, SAMPLER>(a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
-                                             st_i32 + (2 * ph + wave) * (LR_ISTATE_ROWS * LR_ROW), lik,
-                                             tab + ph * tab_doubles + wave, br3, draws + (2 * ph + wave));
+                lr_persist_step_body<PB, ES, LR_P4_DRAW_AHEAD != 0 && ES == 2 /* unit resolution */ && SAMPLER == 0, SAMPLER, HELP>(
+                    a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
+                    st_i32 + (2 * ph + wave) * (LR_ISTATE_ROWS * LR_ROW), lik, tab + ph * tab_doubles + wave, br3,
+                    draws + (2 * ph + wave), HELP ? hands + wave : nullptr, (int)((2 * iter + ph + 1) & 0x3fffffff));
             }
 #ifdef LR_DIAG
             const unsigned long long dq1 = wall_clock64();
@@ -462,13 +493,23 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 #define LR_P4_UNROLL 1
 #endif
 
-#define LR_P4_SCANNERS ((LR_P4_THREADS / LR_WAVE - 2) * LR_WAVE)
-template <int H, bool GENERAL, bool PARAM /* a parametric sampler's chain step (DDRate, trend_rate) instead of the RJ sampler's */>
+// HELP (RJ sampler at unit resolution): waves 2, 3 - the oldest waves of the two SIMDs that carry no stepper - are HELPER
+// waves and twelve waves scan.  A stepper hands the segments of its proposal over through LDS as soon as they stand
+// (lr_propose_rj's HAND, ~1.2 us into a 3.2 us step) and goes on with guard, prior and state; its helper builds the table
+// with its pair planes meanwhile: the serial path of a phase is load + move + staging + table instead of the whole step,
+// and every SIMD carries one wave of the step and three scanners.  Before the hand-over arrives a helper makes the draws
+// of the OTHER pair's next step (the draw duty four scanner waves carry otherwise).
+template <int H, bool GENERAL, bool PARAM /* a parametric sampler's chain step (DDRate, trend_rate) instead of the RJ sampler's */,
+          bool HELP = false>
 __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
                                                                        lr_packed_lineages pk, long long n8,
                                                                        lr_p4_shares sh, long long n_iters) {
+    static_assert(!HELP || (!GENERAL && !PARAM), "helper waves: RJ sampler at unit resolution");
     const lr_step_args& a = *ap;
-    constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners
+    constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners (HELP: 2 + 2 helpers + 12)
+    constexpr int W0 = HELP ? 4 : 2;                      // first scanner wave
+    constexpr int NS = NW - W0;                           // scanner waves
+    constexpr int LR_P4_SCANNERS = NS * LR_WAVE;
     constexpr int ENT = GENERAL ? 2 : 1;                  // double2 per pair-table entry (LR_TAB_PAIRGEN / LR_TAB_UNIT)
     constexpr int ES = GENERAL ? 6 * H : 2;               // the builders' `so`: doubles from a value to its slope in the LDS image
     __shared__ double2 tab[2][LR_UNIT_PLANES * H];        // pair tables: S, E (general times: and their slopes) + the pair planes
@@ -480,6 +521,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     constexpr bool LAST_SUMS = LR_P4_LAST_SUMS != 0 && !GENERAL;
     __shared__ double2 part[LAST_SUMS ? NW - 2 : 1][LR_WAVE];
     __shared__ int arrived;
+    __shared__ lr_table_hand hands[2];
     __shared__ lr_seg_scratch scratch[2];
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
     __shared__ int st_i32[4][LR_ISTATE_ROWS * LR_ROW];
@@ -502,33 +544,45 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     constexpr bool draw_ahead = LR_P4_DRAW_AHEAD && !GENERAL && !PARAM;
     // draw duty of scanner wave 2 + q, q < 4, for the pair `pr` that has just been scanned: part q >> 1 of chain q & 1
     auto draw_duty = [&](int pr) {
-        const int q = wave - 2, k = q & 1, ch = 2 * pr + k;
+        const int q = wave - W0, k = q & 1, ch = 2 * pr + k;      // (the four oldest scanner waves: the first to finish)
         if (!draw_ahead || q < 0 || q >= 4 || (int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
         const int* I = st_i32[ch] + LR_IROW_SCALARS * LR_ROW;
         const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + 1ull;
         lr_spec_draw_part(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, &draws[ch], q >> 1);
     };
-    if (tid == 0) arrived = 0;
+    // a helper wave's table duty of a phase whose steppers advance pair `ph`: once the stepper has handed them over, the
+    // tables of its chain of pair ph
+    auto help_duty = [&](int ph, int epoch) {
+        const int k = wave - 2;
+        const int ch = 2 * ph + k;
+        if ((int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
+        lr_table_hand* hand = &hands[k];
+#ifdef LR_DIAG
+        const unsigned long long dh0 = wall_clock64();
+#endif
+        while (__hip_atomic_load(&hand->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+#ifdef LR_DIAG
+        if (lane == 0 && blockIdx.x < 64) atomicAdd(&lr_diag_step[16384 + (blockIdx.x * 16 + wave) * 4 + 2], wall_clock64() - dh0);
+#endif
+        const lr_seg_scratch* sc = &scratch[k];
+        const int eL = lane <= LR_KMAX ? sc->edge[0][lane] : 0, eM = lane <= LR_KMAX ? sc->edge[1][lane] : 0;
+        double* tabd = reinterpret_cast<double*>(tab[ph]) + k;
+        const double constP = lr_build_tables_segments<(H <= 264 ? lr_bins_per_lane(H) : 1), 2>(
+            sc, eL, eM, hand->KL, hand->KM, br_lds[0], br_lds[1], a_lds.cfg.model, a_lds.cfg.n_bins, a_lds.n_cls, a_lds.H,
+            reinterpret_cast<double2*>(tabd), lane, LR_TAB_UNIT, a_lds.cfg.frac_birth, a_lds.cfg.frac_death, ES, nullptr);
+        LR_WAVE_LDS_ORDER();
+        lr_pair_planes_wave(tabd, H, a_lds.cfg.n_bins, lane, 0);
+        if (lane == 0) st_f64[ch][LR_ROW_SCALARS * LR_ROW + LR_S_CONST_P] = constP;
+    };
+    if (tid == 0) arrived = 0, hands[0].epoch = 0, hands[1].epoch = 0;
     for (int i = tid; i < 2 * NW * 2; i += LR_P4_THREADS) (&red[0][0][0])[i] = 0.0;
     int scans_done = 0;
-    // a scanner wave's end of scan number `scans_done` for pair `pr`: leave the lanes' sums, count in, and reduce if last
+    // a scanning wave's end of scan number `scans_done` for pair `pr` (HELP: the helper waves score a share too - slots NS,
+    // NS + 1)
+    constexpr int NA = NS + (HELP ? 2 : 0);
     auto leave_sums = [&](int pr, double s0, double s1) {
-        part[wave - 2][lane] = make_double2(s0, s1);
-        int prev = 0;
-        if (lane == 0) prev = __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        prev = __builtin_amdgcn_readfirstlane(prev);
-        if (prev == (NW - 2) * (scans_done + 1) - 1) {
-            asm volatile("" ::: "memory");     // the sums are read after the count was seen (a wave's LDS operations execute in order)
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW - 2; ++w) {
-                const double2 v = part[w][lane];
-                a0 += v.x, a1 += v.y;
-            }
-            a0 = lr_wave_sum(a0), a1 = lr_wave_sum(a1);
-            if (lane == 0) red[pr][2][0] = a0, red[pr][2][1] = a1;
-        }
-        ++scans_done;
+        lr_p4_leave_sums<NA>(part, &arrived, &red[pr][2][0], wave >= W0 ? wave - W0 : NS + wave - 2, lane, scans_done, s0, s1);
     };
     const int c0 = blockIdx.x * 4;
     const int C = a.cfg.n_chains;
@@ -554,8 +608,9 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         lr_pair_planes_block(tab[1], H, a.cfg.n_bins, tid, LR_P4_THREADS);
     }
     __syncthreads();
-    const bool scanner = wave >= 2;
-    const int sid = tid - 2 * LR_WAVE;
+    const bool scanner = wave >= W0;
+    const bool helper = HELP && (wave == 2 || wave == 3);
+    const int sid = tid - W0 * LR_WAVE;
     // The SIMD issue arbiter serves its oldest wave first: with equal shares the scanner waves of a SIMD finish one
     // after the other (5.0 / 6.4 / 7.9 / 9.5 us per phase, measured with in-kernel stamps), the youngest runs the tail
     // alone, and SIMDs 0, 1 carry the stepper waves on top.  So the waves get unequal shares (lr_p4_shares) chosen to
@@ -563,17 +618,25 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // this is only a per-wave end of the loop: a fixed partition, the summation order - and with it bitwise
     // reproducibility - stays.
     const int k_tot = (int)((n8 + LR_P4_SCANNERS - 1) / LR_P4_SCANNERS);
-    const int k_mine = k_tot + (scanner ? sh.delta[wave - 2] : 0);
+    const int k_mine = k_tot + (scanner ? sh.delta[wave - W0] : 0);
     // equal shares (short scans): the true end, so that the ragged last trip costs only the lanes that have a group
     bool any_shift = false;
 #pragma unroll
-    for (int q = 0; q < 14; ++q) any_shift |= sh.delta[q] != 0;
-    const long long n8w = any_shift ? (long long)k_mine * LR_P4_SCANNERS : n8;
+    for (int q = 0; q < NS; ++q) any_shift |= sh.delta[q] != 0;
+    // HELP: the first `nh` groups are the helper waves' (equal shares behind them)
+    // ([0, nh): helper waves, the rest: the scanner waves)
+    const long long nh = HELP ? (long long)sh.help_trips * (2 * LR_WAVE) : 0;
+    const long long n8w = HELP ? n8 - nh : (any_shift ? (long long)k_mine * LR_P4_SCANNERS : n8);
+    auto help_scan = [&](int pr) {
+        double s0 = 0.0, s1 = 0.0;
+        if (nh > 0) lr_persist_scan<H, GENERAL, 1, false, false>(reinterpret_cast<const char*>(tab[pr]), pk, 0, nh, tid - 2 * LR_WAVE, 2 * LR_WAVE, &s0, &s1);
+        leave_sums(pr, s0, s1);
+    };
     // prologue: pair 0's pending proposal is scanned so that phase A can step it
     if (scanner) {
         double s0 = 0.0, s1 = 0.0;
         lr_scan_tail tail;
-        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[0]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
+        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[0]), pk, nh, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
         if (LAST_SUMS) {
             leave_sums(0, s0, s1);
         } else {
@@ -583,14 +646,36 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         lr_scan_drain(tail);
         draw_duty(0);
     }
+    if (helper) help_scan(0);
     __syncthreads();
     // phase ph of an iteration: the steppers advance pair `ph`, the scanners score pair `1 - ph`
-    if (!scanner)
-        lr_persist4_steppers<(H <= 264 ? lr_bins_per_lane(H) : 0), ES, NW, PARAM ? 1 : 0>(
+    if (helper) {
+        for (long long iter = 0; iter < n_iters; ++iter) {
+#pragma unroll 1
+            for (int ph = 0; ph < 2; ++ph) {
+#ifdef LR_DIAG
+                const unsigned long long dq0 = wall_clock64();
+#endif
+                help_scan(1 - ph);
+                help_duty(ph, (int)((2 * iter + ph + 1) & 0x3fffffff));
+#ifdef LR_DIAG
+                const unsigned long long dq1 = wall_clock64();
+#endif
+                __syncthreads();
+#ifdef LR_DIAG
+                if (lane == 0 && blockIdx.x < 64) {
+                    atomicAdd(&lr_diag_step[16384 + (blockIdx.x * 16 + wave) * 4 + 0], dq1 - dq0);
+                    atomicAdd(&lr_diag_step[16384 + (blockIdx.x * 16 + wave) * 4 + 1], wall_clock64() - dq1);
+                }
+#endif
+            }
+        }
+    } else if (!scanner)
+        lr_persist4_steppers<(H <= 264 ? lr_bins_per_lane(H) : 0), ES, NW, PARAM ? 1 : 0, HELP>(
             (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c0, C, wave, lane,
             (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave], (lr_lds_f64*)&st_f64[0][0], (lr_lds_i32*)&st_i32[0][0],
             (lr_lds_f64*)&red[0][0][0], (lr_lds_f64*)reinterpret_cast<double*>(tab[0]), 2 * LR_UNIT_PLANES * H,
-            (lr_lds_f64*)&br_lds[0][0], n_iters, &draws[0]);
+            (lr_lds_f64*)&br_lds[0][0], n_iters, &draws[0], &hands[0]);
     else
     for (long long iter = 0; iter < n_iters; ++iter) {
 #pragma unroll
@@ -601,7 +686,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
             {
                 double s0 = 0.0, s1 = 0.0;
                 lr_scan_tail tail;
-                lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[1 - ph]), pk, 0, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
+                lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[1 - ph]), pk, nh, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
                 if (LAST_SUMS) {
                     leave_sums(1 - ph, s0, s1);
                 } else {
@@ -1412,6 +1497,7 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);   \
         else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);      \
         else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);        \
+        else if (lr_p4_help(e)) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n); \
         else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);                  \
     } else if (wide) {                                                                                                        \
         hipLaunchKernelGGL((lr_persist_kernel<HH, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); \
@@ -1506,7 +1592,9 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
         if (e->lay.persistent == 3)
             snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d, %s, %s, %d>", e->plan.H, e->lay.reserved1, e->cfg.sampler == 0 ? "true" : "false", gen,
                      lr_spec_mode(e));
-        else if (e->lay.persistent == 2) snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s, %s>", e->plan.H, gen, e->cfg.sampler != 0 ? "true" : "false");
+        else if (e->lay.persistent == 2)
+            snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s, %s, %s>", e->plan.H, gen, e->cfg.sampler != 0 ? "true" : "false",
+                     lr_p4_help(e) ? "true" : "false");
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
     } else if (e->part[0].pipelined) {
         snprintf(buf, (size_t)n, "lr_fused_iter_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");

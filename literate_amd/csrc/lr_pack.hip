@@ -211,14 +211,24 @@ static void lr_set_shares(lr_engine* e) {
     static const char* env = getenv("LR_P4_SHARES");       // "d2,d4,d6,d8,d10,d12,d14" for 14 trips
     static const int env2 = lr_env_int_pack("LR_P2_SHARE", 0);   // two-chain kernel (no gain measured: off)
     for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
+    e->p4.help_trips = 0;
+    if (e->lay.persistent == 2 && lr_p4_help(e)) {
+        // a helper wave is idle until its stepper's hand-over arrives (~1.2 us into a phase, a scan trip takes ~0.35 us):
+        // it scores the first groups meanwhile (the 128 helper lanes stride over [0, 128 trips), the scanners over the rest)
+        static const int env_t = lr_env_int_pack("LR_P4_HELP_TRIPS", 5);
+        const long long k12 = (e->n8 + 767) / 768;                 // trips of a scanner wave without the helpers' share
+        e->p4.help_trips = k12 >= 6 ? env_t : 0;
+        if (e->p4.help_trips < 0) e->p4.help_trips = 0;
+        if ((long long)e->p4.help_trips * 128 > e->n8) e->p4.help_trips = 0;
+    }
     if (e->lay.persistent == 3) {
         e->p4.n_slots = 8;       // speculative kernel: plain layout, every scanner wave strides over its block's slice
     } else if (e->lay.persistent == 2) {
-        e->p4.n_slots = 14;
+        e->p4.n_slots = lr_p4_help(e) ? 12 : 14;      // (with helper waves: twelve scanners, equal shares)
         // (with 14-lineage groups a scan is ~8 trips of cfg4 and equal shares measure as fast as any: the default is
         // equal; the knob stays for experiments)
         int base[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (env) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
+        if (env && e->p4.n_slots == 14) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
         const int k_tot = (int)((e->n8 + 895) / 896);
         int sum = 0;
         for (int j = 0; j < 7; ++j) {

@@ -15,12 +15,14 @@
 //   a team per PAIR (MODE 0): waves 0..3 are the candidate waves (chain = wave / 2, outcome = wave % 2), each with a column
 //     of its own; behind the barrier the scanner waves lay the two pending columns side by side into the six-plane scan
 //     table (lr_build_scan_table) - every gather then serves two chains;
-//   a team per CHAIN (MODE 1, 2): waves 0, 1 are the candidate waves of the one chain, waves 2, 3 their HELPER waves on
+//   a team per CHAIN (MODE 1, 2, 3): waves 0, 1 are the candidate waves of the one chain, waves 2, 3 their HELPER waves on
 //     the two SIMDs that carry no candidate: a candidate hands its staged segments (RJ) or parameter vector (DDRate /
 //     trend_rate) over through LDS as soon as they stand and goes on with guard, prior and set, its helper builds the
 //     table meanwhile (and makes the draws of the iteration after the next).  Every state owns a whole scan table
-//     ((.x, .y) = (the chain, 0)), so behind the barrier the scanners only switch tables.  MODE 2 (short scans): the
-//     helper stops at the S and E planes and the scanner waves derive the pair planes of the table that becomes pending.
+//     ((.x, .y) = (the chain, 0)), so behind the barrier the scanners only switch tables.  MODE 1 is a team of several
+//     blocks; MODE 2, 3 are one block on its own CU (the exchange between blocks is compiled out of them); in MODE 2
+//     (short scans) the helper stops at the S and E planes and the scanner waves derive the pair planes of the table
+//     that becomes pending.
 //
 // Teams of blocks.  With fewer teams than CUs a team is k blocks (k = 2, 4, 8; one block per CU).  Every block of the
 // team runs the same candidate waves on the same state - a replicated state machine, so no table or state ever crosses a
@@ -347,18 +349,26 @@ __device__ __forceinline__ lr_spec_dec_in lr_spec_dec_fetch(const LDS& sm, const
     return in;
 }
 
+// Blocks per team as the kernel's mode knows it: MODE 2, 3 (a team per chain on its own CU) have none to exchange with,
+// so the exchange, its abort path and the priority games of a team are compiled out of them.
+template <int MODE>
+__device__ __forceinline__ int lr_spec_team_blocks(const lr_spec_args& x) {
+    return (MODE == 2 || MODE == 3) ? 1 : x.team_blocks;
+}
+
 // End of a wave's scan share: its sums to LDS, and - for the wave that arrives LAST among the block's scanning waves (the
 // scanner waves; a team per chain: + the two candidate waves) - the decision of the iteration: the block's sums added in
 // a fixed order (in a team: published and the team's swept), the Metropolis-Hastings tests, the outcome left in LDS.
-template <int H, int T, bool RJ, bool GENERAL, bool SINGLE>
+template <int H, int T, bool RJ, bool GENERAL, int MODE>
 __device__ __forceinline__ void lr_spec_deliver(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_spec_ctx& ctx, long long iter,
                                                 const lr_spec_dec_in& in, double acc0, double acc1, int wave, int lane) {
     constexpr int NW = T / LR_WAVE;
     constexpr bool rj = RJ;
+    constexpr bool SINGLE = MODE != 0;
     // (a team per chain under a parametric sampler: the two candidate waves scan - and count themselves in - when they
     // were given a share; the RJ sampler's never are: lr_launch_spec)
     const int n_arrive = (NW - 4) + ((SINGLE && !RJ && ctx.cand_n > 0) ? 2 : 0);
-    const int k_team = ctx.x.team_blocks;
+    const int k_team = lr_spec_team_blocks<MODE>(ctx.x);
     const unsigned long long it = ctx.it0 + (unsigned long long)iter;
     {
         const double s0 = lr_wave_sum(acc0), s1 = lr_wave_sum(acc1);
@@ -480,17 +490,17 @@ __device__ __forceinline__ void lr_spec_deliver(lr_spec_lds<H, T / LR_WAVE, GENE
 // built.  Behind the barrier every wave reads the outcome, turns the roles of the sets and goes on: the scanners to the
 // pair table of the selected candidates, the candidate waves to the next candidates.  The last two scanner waves also
 // have the draw duty.
-// MODE: 0 = a team per pair, 1 = a team per chain (pair planes by the helper waves), 2 = a team per chain on a short scan
-// (pair planes by the scanner waves) - a template parameter rather than a run-time switch: every path that is compiled in
-// costs instruction-cache room and registers in a kernel of ~9000 instructions (taking a dead path out of the RJ kernels
-// was worth 4 % on cfg2)
+// MODE: 0 = a team per pair; a team per chain: 1 = in a team of several blocks, 2 = on its own CU, short scan (pair planes
+// by the scanner waves), 3 = on its own CU, long scan (pair planes by the helper waves, as in mode 1) - a template
+// parameter rather than a run-time switch: every path that is compiled in costs instruction-cache room and registers in a
+// kernel of ~9000 instructions (taking a dead path out of the RJ kernels was worth 4 % on cfg2)
 template <int H, int T, bool RJ, bool GENERAL, int MODE>
 __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     constexpr int NW = T / LR_WAVE;
     constexpr int NSCAN = (NW - 4) * LR_WAVE;
     const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
-    const int k_team = ctx.x.team_blocks;
+    const int k_team = lr_spec_team_blocks<MODE>(ctx.x);
     constexpr bool rj = RJ;
     const bool act1 = ctx.n_act > 1;
     // Draw duty.  A block on its own is bound by its slowest wave before the barrier, so the duty is split over the last
@@ -547,7 +557,7 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         const char* lbase = reinterpret_cast<const char*>(single ? sm.t.tabs[(role0 >> 2) & 3] : sm.t.pair.scan);
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, part_g0, part_n, sid, n_scan, &acc0, &acc1, &first);
         LR_XSTAMP(dg_a);
-        lr_spec_deliver<H, T, RJ, GENERAL, SINGLE>(sm, ctx, iter, dec_in, acc0, acc1, wave, lane);
+        lr_spec_deliver<H, T, RJ, GENERAL, MODE>(sm, ctx, iter, dec_in, acc0, acc1, wave, lane);
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
         // (a block on its own has made these draws at the top of the iteration, see below)
         if (drawer && !draws_first) draw_duty(it + 2, it & 1);
@@ -605,7 +615,7 @@ template <int H, int T, bool RJ, bool GENERAL, int MODE>
 __device__ __forceinline__ void lr_spec_help_role(lr_spec_lds<H, T / LR_WAVE, GENERAL ? 2 : 1>& sm, const lr_step_args& a,
                                                   const lr_spec_ctx& ctx, int tid) {
     const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
-    const int k_team = ctx.x.team_blocks;
+    const int k_team = lr_spec_team_blocks<MODE>(ctx.x);
     const int k = wave - 2;
     for (long long iter = 0; iter < ctx.n_iters; ++iter) {
         const unsigned long long it = ctx.it0 + (unsigned long long)iter;
@@ -668,7 +678,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
     const int lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int c = wave >> 1, k = wave & 1;
     const int c0 = ctx.c0, C = ctx.C;
-    const int k_team = ctx.x.team_blocks;
+    const int k_team = lr_spec_team_blocks<MODE>(ctx.x);
     constexpr bool rj = RJ;
     const bool act1 = ctx.n_act > 1;
     const bool mine_active = c < ctx.n_act;
@@ -753,7 +763,7 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             double acc0 = 0.0, acc1 = 0.0;
             lr_persist_scan<H, GENERAL, 1, false>(reinterpret_cast<const char*>(sm.t.tabs[(role0 >> 2) & 3]), ctx.pk, ctx.cand_g0, ctx.cand_n,
                                                   k * LR_WAVE + lane, 2 * LR_WAVE, &acc0, &acc1, nullptr);
-            lr_spec_deliver<H, T, RJ, GENERAL, SINGLE>(sm, ctx, iter, dec_in, acc0, acc1, wave, lane);
+            lr_spec_deliver<H, T, RJ, GENERAL, MODE>(sm, ctx, iter, dec_in, acc0, acc1, wave, lane);
         }
         LR_XSTAMP(dg_work);
         __syncthreads();                                                     // the decision and the candidates are in
@@ -813,7 +823,7 @@ __global__ __launch_bounds__(T, (T + 255) / 256) void lr_spec_kernel(lr_step_arg
     static_assert(sizeof(lr_spec_lds<H, NW, ENT>) <= 160 * 1024, "the block's LDS image must fit a CU");
     __shared__ lr_spec_lds<H, NW, ENT> sm;
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
-    const int k_team = x.team_blocks;
+    const int k_team = lr_spec_team_blocks<MODE>(x);
     const int team = blockIdx.x % x.n_teams, rank = blockIdx.x / x.n_teams;   // a team's blocks differ by a multiple of
     const int c0 = team * CPB;                                                 // n_teams: one XCD when 8 | n_teams
     const int C = a.cfg.n_chains;

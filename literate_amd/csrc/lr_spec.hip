@@ -44,11 +44,13 @@ int lr_launch_spec(lr_engine* e, const lr_step_args& a, const lr_packed_lineages
     hipLaunchKernelGGL((lr_spec_kernel<HH, (MM) != 0 ? LR_SPEC_THREADS_SINGLE : LR_SPEC_THREADS, RR, GG, MM>), grid, blk, 0, stream, a, pk, e->n8, x, (long long)n)
 #define LR_SPEC_LAUNCH(HH, GG)                                                         \
     if (e->cfg.sampler == 0) {                                                         \
-        if (mode == 2) LR_SPEC_LAUNCH_M(HH, GG, true, 2);                              \
+        if (mode == 3) LR_SPEC_LAUNCH_M(HH, GG, true, 3);                              \
+        else if (mode == 2) LR_SPEC_LAUNCH_M(HH, GG, true, 2);                         \
         else if (mode == 1) LR_SPEC_LAUNCH_M(HH, GG, true, 1);                         \
         else LR_SPEC_LAUNCH_M(HH, GG, true, 0);                                        \
     } else {                                                                           \
-        if (mode == 2) LR_SPEC_LAUNCH_M(HH, GG, false, 2);                             \
+        if (mode == 3) LR_SPEC_LAUNCH_M(HH, GG, false, 3);                             \
+        else if (mode == 2) LR_SPEC_LAUNCH_M(HH, GG, false, 2);                        \
         else if (mode == 1) LR_SPEC_LAUNCH_M(HH, GG, false, 1);                        \
         else LR_SPEC_LAUNCH_M(HH, GG, false, 0);                                       \
     }

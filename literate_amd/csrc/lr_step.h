@@ -365,6 +365,19 @@ __device__ __forceinline__ void lr_chain_store(const lr_chain_regs& r, double* S
     I[LR_IROW_SCALARS * LR_ROW + lane] = r.isc;
 }
 
+// the same for a step whose proposal's tables are a helper wave's: that wave writes the model constant of the proposal
+// into the state's scalar row itself, at a time of its own - every scalar but that one
+__device__ __forceinline__ void lr_chain_store_handed(const lr_chain_regs& r, double* S, int* I, int lane) {
+    S[LR_ROW_L * LR_ROW + lane] = r.L, S[LR_ROW_M * LR_ROW + lane] = r.M;
+    S[LR_ROW_TL * LR_ROW + lane] = r.tL, S[LR_ROW_TM * LR_ROW + lane] = r.tM;
+    S[LR_ROW_PL * LR_ROW + lane] = r.pL, S[LR_ROW_PM * LR_ROW + lane] = r.pM;
+    S[LR_ROW_PTL * LR_ROW + lane] = r.ptL, S[LR_ROW_PTM * LR_ROW + lane] = r.ptM;
+    if (lane != LR_S_CONST_P) S[LR_ROW_SCALARS * LR_ROW + lane] = r.sc;
+    I[LR_IROW_EL * LR_ROW + lane] = r.eL, I[LR_IROW_EM * LR_ROW + lane] = r.eM;
+    I[LR_IROW_PEL * LR_ROW + lane] = r.peL, I[LR_IROW_PEM * LR_ROW + lane] = r.peM;
+    I[LR_IROW_SCALARS * LR_ROW + lane] = r.isc;
+}
+
 // ---- the two halves of a runMCMC step (LRF:216-373) ---------------------------------------------------------
 // A state "as accepted" in the registers of one wave: per-lane rows plus wave-uniform scalars.
 struct lr_rj_state {
@@ -766,11 +779,14 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
 // (lik_sum, without the model constant), write the trace row, draw the next proposal and build its lookup
 // tables at `table` (global memory or LDS; see lr_chain_table for the addressing).
 // mode: 0 = regular step, 1 = finish init (adopt the evaluated initial state, then propose iteration 0)
-template <bool LDS_CONSTS = false, int PB = 0>
+// HAND (four-chain kernel with helper waves): the proposal's lookup tables, pair planes and model constant are another
+// wave's (lr_propose_rj's HAND) - the scalar LR_S_CONST_P of the state then belongs to that wave, see lr_chain_store_handed
+template <bool LDS_CONSTS = false, int PB = 0, bool HAND = false>
 __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_step_args& a, int mode, int c, int lane,
                                                    lr_seg_scratch* scratch_p, double lik_sum, double2* table,
                                                    int table_es = 2, const double* br_lds = nullptr,
-                                                   const double* logbr_lds = nullptr, const lr_rj_draws* pre = nullptr) {
+                                                   const double* logbr_lds = nullptr, const lr_rj_draws* pre = nullptr,
+                                                   lr_table_hand* hand = nullptr, int hand_epoch = 0) {
     const lr_mcmc_config& cfg = a.cfg;
     const double sc = st.sc;
     const int isc = st.isc;
@@ -828,7 +844,8 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
 
     // ---- propose iteration `it` (LRF:234-304) ----
     lr_rj_prop p;
-    lr_propose_rj<LDS_CONSTS, PB>(a, c, lane, scratch_p, it, s, p, table, table_es, pre, br_lds, logbr_lds);
+    if (HAND) lr_propose_rj<LDS_CONSTS, (PB > 0 ? PB : 1), 2, true, HAND>(a, c, lane, scratch_p, it, s, p, table, table_es, pre, br_lds, logbr_lds, nullptr, 0, 0.0, hand, hand_epoch);
+    else lr_propose_rj<LDS_CONSTS, PB>(a, c, lane, scratch_p, it, s, p, table, table_es, pre, br_lds, logbr_lds);
 
     // ---- back into the state registers ----
     st.pL = s.L, st.pM = s.M, st.ptL = s.tL, st.ptM = s.tM, st.peL = s.eL, st.peM = s.eM;

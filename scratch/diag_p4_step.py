@@ -17,9 +17,10 @@ for rep in range(20):
     lib.lr_diag_dump_seg(seg, 64 * 16, 0)
     sg = np.frombuffer(seg, dtype=np.uint64).reshape(64, 16).astype(np.float64)
     sg = sg[::2]                      # even chains: wave 0 of each block
-    order = [0, 1, 2, 3, 4, 5, 6, 7, 8]
-    names = {1: 'state load + decide', 2: 'Philox call', 3: 'move', 4: 'stage segments (log)', 5: 'prior', 6: 'tables + planes',
-             7: 'bookkeeping', 8: 'state store'}
+    order = [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 6, 7, 8]
+    names = {1: 'state load + decide', 2: 'Philox call', 3: 'move', 4: 'stage segments (log)', 5: 'prior', 9: 'table: entry',
+             10: 'table: bin ranks', 11: 'table: rates of the bins', 12: 'table: prefix sum', 13: 'table: S, E writes',
+             6: 'pair planes', 7: 'bookkeeping', 8: 'state store'}
     for a_, b in zip(order[:-1], order[1:]):
         d = (sg[:, b] - sg[:, a_]) / 2400.0
         d = d[(d > 0) & (d < 20)]

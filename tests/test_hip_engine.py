@@ -41,11 +41,17 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        (3, dict(engine="spec", team=8, cpt=1)), (0, dict(engine="spec", cpt=1, unit_resolution=False)),
                                        (3, dict(engine="launch")), (3, dict(engine="spec", team=2)),
                                        (3, dict(engine="persistent4")), (3, dict(engine="persistent2")),
-                                       (3, dict(engine="spec", unit_resolution=False))])
-def test_engine_follows_oracle_trajectory(G, model, kw):
+                                       (3, dict(engine="spec", unit_resolution=False)),
+                                       # (a chain on its own CU with the pair planes by the helper waves - the kernel mode of
+                                       # long scans - forced on this short one)
+                                       (0, dict(engine="spec", team=1, cpt=1, planes_by_scanners=0)),
+                                       (1, dict(engine="spec", team=1, cpt=1, planes_by_scanners=0, unit_resolution=False))])
+def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
     from literate_amd.engine import ChainEngine, split_trace_row
     name, seed, n_it, C, off = "example_TBP", 2024, 1500, 6, 40
     kw = dict(kw)
+    if "planes_by_scanners" in kw:
+        monkeypatch.setenv("LR_SPEC_PLANES_BY_SCANNERS", str(kw.pop("planes_by_scanners")))
     ekw = dict(const_rates=kw.get("const_rates", 0), const_death_rate=kw.get("const_death_rate", 0),
                use_rate_HP=kw.get("use_rate_HP", 1), poisson_HP=kw.get("Poisson_HP", 0.0),
                unit_resolution=kw.pop("unit_resolution", None), engine=kw.pop("engine", "auto"), team=kw.pop("team", 0),
@@ -55,6 +61,8 @@ def test_engine_follows_oracle_trajectory(G, model, kw):
     if ekw["engine"] == "spec":
         assert eng.layout.persistent == 3 and eng.layout.team_blocks == (ekw["team"] or eng.layout.team_blocks)
         assert eng.layout.spec_chains_per_team == (ekw["chains_per_team"] or eng.layout.spec_chains_per_team)
+        if "LR_SPEC_PLANES_BY_SCANNERS" in os.environ:
+            assert eng.kernel_name().endswith(", 3>")
     if ekw["engine"] == "persistent2":
         assert eng.layout.persistent == 1
     # binning done by the engine's own kernel must equal the reference's
@@ -297,7 +305,8 @@ def test_cfg3_synthetic_10k_lineages_256_chains(G):
     eng.close()
 
 
-@pytest.mark.parametrize("engine,C,kw", [("spec", 12, {}), ("spec", 128, {}), ("persistent2", 24, {}), ("persistent4", 24, {}),
+@pytest.mark.parametrize("engine,C,kw", [("spec", 12, {}), ("spec", 128, {}), ("spec", 128, dict(team=1, cpt=1)),
+                                          ("persistent2", 24, {}), ("persistent4", 24, {}),
                                           ("spec", 6, dict(general=True)), ("persistent4", 24, dict(general=True))])
 def test_long_inputs_and_few_chain_shards_keep_parity(engine, C, kw):
     """1.3 million lineages (the advisor's out-of-bounds case of round 1: more than 136 trips per scanner wave) and the
@@ -318,13 +327,19 @@ def test_long_inputs_and_few_chain_shards_keep_parity(engine, C, kw):
         ts = ts + grid(rng.uniform(0, 0.999, n_lin))
         te = np.maximum(np.ceil(te) - 1.0 + grid(rng.uniform(1e-3, 0.999, n_lin)), ts + 0.0078125)
     n_it, seed = 40, 77
-    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine)
+    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine, team=kw.get("team", 0),
+                      chains_per_team=kw.get("cpt", 0))
     assert eng.layout.persistent == {"spec": 3, "persistent2": 1, "persistent4": 2}[engine]
-    if engine == "spec":
+    if engine == "spec" and "team" in kw:
+        # a chain per CU on a long scan: the kernel mode without the exchange between blocks
+        assert (eng.layout.team_blocks, eng.layout.spec_chains_per_team) == (1, 1)
+    elif engine == "spec":
         # the 128-chain shard: a team of 2 CUs per chain (a team of 4 per pair on general times); few chains: teams of 8
         assert (eng.layout.team_blocks, eng.layout.spec_chains_per_team) == (((4, 2) if general else (2, 1)) if C == 128 else (8, 1))
     assert eng.layout.table_mode == (2 if general else 1)
     eng.init(); eng.steps(25); eng.steps(n_it - 25)
+    if engine == "spec" and "team" in kw:
+        assert eng.kernel_name().endswith(", 3>")        # (the mode follows the packed lineages: known once init() has run)
     tr = eng.trace_rows()
     snap = eng.snapshot()
     assert np.all(snap["it"] == n_it) and np.all(np.isfinite(snap["likA"]))

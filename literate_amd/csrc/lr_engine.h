@@ -61,6 +61,9 @@ static inline long long lr_groups_alloc(long long n_lineages) {
     return (n_lineages + LR_SLOTS - 1) / LR_SLOTS + runs + LR_IDX_SPARE;
 }
 
+// four-chain kernel: bytes per block of the sums a launch leaves for the next ([16 waves][2] doubles + a valid word)
+#define LR_P4_CARRY_BYTES 512
+
 // widest table class of the persistent kernels (the launch-based scans are instantiated up to H = 264)
 #define LR_H_WIDE 520
 

@@ -503,7 +503,7 @@ template <int H, bool GENERAL, bool PARAM /* a parametric sampler's chain step (
           bool HELP = false>
 __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
                                                                        lr_packed_lineages pk, long long n8,
-                                                                       lr_p4_shares sh, long long n_iters) {
+                                                                       lr_p4_shares sh, long long n_iters, char* carry_all) {
     static_assert(!HELP || (!GENERAL && !PARAM), "helper waves: RJ sampler at unit resolution");
     const lr_step_args& a = *ap;
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners (HELP: 2 + 2 helpers + 12)
@@ -632,8 +632,16 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         if (nh > 0) lr_persist_scan<H, GENERAL, 1, false, false>(reinterpret_cast<const char*>(tab[pr]), pk, 0, nh, tid - 2 * LR_WAVE, 2 * LR_WAVE, &s0, &s1);
         leave_sums(pr, s0, s1);
     };
-    // prologue: pair 0's pending proposal is scanned so that phase A can step it
-    if (scanner) {
+    // prologue: pair 0's pending proposal is scanned so that phase A can step it - unless the launch before this one has
+    // left the sums of that very scan (its last phase scored pair 0; lr_prepare_constants clears the flag whenever the
+    // state is set from outside): the same doubles, the scan uses the same partition
+    static_assert(2 * NW * 8 + 4 <= LR_P4_CARRY_BYTES, "");
+    char* carry = carry_all ? carry_all + (size_t)blockIdx.x * LR_P4_CARRY_BYTES : nullptr;
+    const bool carried = carry && *reinterpret_cast<const int*>(carry + 2 * NW * 8) == 1;
+    if (carried) {
+        if (tid < 2 * NW) (&red[0][0][0])[tid] = reinterpret_cast<const double*>(carry)[tid];
+        if (scanner) draw_duty(0);
+    } else if (scanner) {
         double s0 = 0.0, s1 = 0.0;
         lr_scan_tail tail;
         lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[0]), pk, nh, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         lr_scan_drain(tail);
         draw_duty(0);
     }
-    if (helper) help_scan(0);
+    if (helper && !carried) help_scan(0);
     __syncthreads();
     // phase ph of an iteration: the steppers advance pair `ph`, the scanners score pair `1 - ph`
     if (helper) {
@@ -718,6 +726,11 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     for (int i = tid; i < 2 * H * ENT; i += LR_P4_THREADS) {
         const int e = GENERAL ? lr_pairgen_lds_entry(i, H) : i;
         g0[i] = tab[0][e], g1[i] = tab[1][e];
+    }
+    // the last phase has scored pair 0's pending proposal: its sums for the next launch's first phase
+    if (carry) {
+        if (tid < 2 * NW) reinterpret_cast<double*>(carry)[tid] = (&red[0][0][0])[tid];
+        if (tid == 0) *reinterpret_cast<int*>(carry + 2 * NW * 8) = 1;
     }
 }
 
@@ -1134,7 +1147,9 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->table_mode = p.unit;
     out->status = o, o += 256;   // engine status word
     // team exchange granules of the speculative kernel: [2 parities][pairs][LR_TEAM_MAX][LR_SPEC_GRANULES] x 8 bytes
-    out->xchg = o, o += (team_k > 1) ? lr_align_up64(2ll * C * LR_TEAM_MAX * LR_SPEC_GRANULES * 8, 256) : 0;   // (room for a team per chain)
+    // (four-chain kernel: the scan sums a launch leaves for the next one, LR_P4_CARRY_BYTES per block - lr_persist4_kernel)
+    out->xchg = o, o += (team_k > 1) ? lr_align_up64(2ll * C * LR_TEAM_MAX * LR_SPEC_GRANULES * 8, 256)   // (room for a team per chain)
+                                     : (out->persistent == 2 ? lr_align_up64((C + 3) / 4 * LR_P4_CARRY_BYTES, 256) : 0);
     out->total_bytes = o;
     out->table_stride = p.tab_stride;
     out->tiles = p.tiles;
@@ -1288,6 +1303,8 @@ static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipS
     // a fresh or restored run starts with a clear status and warning word (a checkpoint never carries a void run on:
     // ChainEngine.save refuses to write one)
     (void)hipMemsetAsync(e->ws + e->lay.status, 0, 256, stream);
+    // ... and nothing carried over from the launches before it (four-chain kernel)
+    if (e->lay.persistent == 2) (void)hipMemsetAsync(e->ws + e->lay.xchg, 0, (size_t)((e->cfg.n_chains + 3) / 4) * LR_P4_CARRY_BYTES, stream);
     hipLaunchKernelGGL(lr_log_br_kernel, dim3((e->cfg.n_bins + 127) / 128), dim3(128), 0, stream, e->br_length,
                        e->cfg.n_bins, (double*)(e->ws + e->lay.bin_consts));
     if (e->cfg.sampler == 1)
@@ -1491,14 +1508,16 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         if (e->lay.persistent == 3) return lr_launch_spec(e, a, pk, n_iters, stream);
         for (int64_t done = 0; done < n_iters;) {
             const int64_t n = (n_iters - done > 4096) ? 4096 : n_iters - done;   // keep single launches short
+        static const int carry_env = lr_env_int("LR_P4_CARRY", 1);   // 0: every launch scans pair 0 again (A/B runs)
+        char* p4_carry = (p4 && carry_env) ? e->ws + e->lay.xchg : nullptr;
 #define LR_P_LAUNCH(HH)                                                                                                       \
     if (p4) {                                                                                                                 \
         const dim3 g4((e->cfg.n_chains + 3) / 4), b4(LR_P4_THREADS);                                                          \
-        if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);   \
-        else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);      \
-        else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);        \
-        else if (lr_p4_help(e)) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n); \
-        else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n);                  \
+        if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);   \
+        else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);      \
+        else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);        \
+        else if (lr_p4_help(e)) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
+        else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);                  \
     } else if (wide) {                                                                                                        \
         hipLaunchKernelGGL((lr_persist_kernel<HH, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); \
     } else {                                                                                                                  \

@@ -155,6 +155,42 @@ struct lr_seg_cache {
     bool reuse;
 };
 
+// Segment of every bin = number of shifts at or before it, for the P bins of this lane (b0 = lane * P).  The K - 1 shift
+// lanes drop a count on their bin in LDS (birth shifts in the low half-word, death shifts in the high one), every lane
+// reads the counts of its own bins and one integer wave scan turns them into ranks: a fixed ~35 instructions instead of
+// a dependent (K_l + K_m) x P compare-and-add chain (the largest single item of the chain step before).
+template <int P>
+__device__ __forceinline__ void lr_bin_ranks(const lr_seg_scratch* sc, int eL, int eM, int KL, int KM, int n_bins, int lane,
+                                             int (&segL)[P], int (&segM)[P]) {
+    const int b0 = lane * P;
+    int* marks = const_cast<int*>(sc->marks);
+    for (int b = lane; b <= n_bins; b += LR_WAVE) marks[b] = 0;
+    LR_WAVE_LDS_ORDER();
+    if (lane >= 1 && lane < KL) atomicAdd(&marks[eL], 1);
+    if (lane >= 1 && lane < KM) atomicAdd(&marks[eM], 0x10000);
+    LR_WAVE_LDS_ORDER();
+    int cnt[P], tot = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        cnt[p] = (b0 + p <= n_bins) ? marks[b0 + p] : 0;
+        tot += cnt[p];
+    }
+    int run = lr_wave_exclusive_scan_i32(tot);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        run += cnt[p];
+        segL[p] = run & 0xffff, segM[p] = run >> 16;
+    }
+}
+// the ranks of a lane's bins, 8 bits each (at most LR_KMAX = 32 segments, at most 4 bins per lane)
+template <int P>
+__device__ __forceinline__ void lr_pack_ranks(const int (&segL)[P], const int (&segM)[P], int* packL, int* packM) {
+    int pl = 0, pm = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) pl |= segL[p] << (8 * p), pm |= segM[p] << (8 * p);
+    *packL = pl, *packM = pm;
+}
+
 // CS: doubles between consecutive entries of the chain's column (lr_put_S)
 template <int P, int CS = 2>
 __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scratch* sc, int eL, int eM, int KL,
@@ -180,39 +216,14 @@ __device__ __forceinline__ double lr_build_tables_segments_fast(const lr_seg_scr
         k_b[p] = (model < 2) ? br_length[b] : 1.0;
         lk_b[p] = (model < 2) ? log_br[b] : 0.0;
     }
-    // Segment of every bin = number of shifts at or before it.  The K - 1 shift lanes drop a count on their bin in
-    // LDS (birth shifts in the low half-word, death shifts in the high one), every lane reads the counts of its own
-    // bins and one integer wave scan turns them into ranks: a fixed ~35 instructions instead of a dependent
-    // (K_l + K_m) x P compare-and-add chain (the largest single item of the chain step before).
+    // segment of every bin (lr_bin_ranks)
     if (sg && sg->reuse) {
         // same bin edges as the state the proposal was made from: its ranks (8 bits per bin of this lane) still hold
 #pragma unroll
         for (int p = 0; p < P; ++p) segL[p] = (sg->packL >> (8 * p)) & 0xff, segM[p] = (sg->packM >> (8 * p)) & 0xff;
     } else {
-        int* marks = const_cast<int*>(sc->marks);
-        for (int b = lane; b <= n_bins; b += LR_WAVE) marks[b] = 0;
-        LR_WAVE_LDS_ORDER();
-        if (lane >= 1 && lane < KL) atomicAdd(&marks[eL], 1);
-        if (lane >= 1 && lane < KM) atomicAdd(&marks[eM], 0x10000);
-        LR_WAVE_LDS_ORDER();
-        int cnt[P], tot = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            cnt[p] = (b0 + p <= n_bins) ? marks[b0 + p] : 0;
-            tot += cnt[p];
-        }
-        int run = lr_wave_exclusive_scan_i32(tot);
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            run += cnt[p];
-            segL[p] = run & 0xffff, segM[p] = run >> 16;
-        }
-        if (sg) {
-            int pl = 0, pm = 0;
-#pragma unroll
-            for (int p = 0; p < P; ++p) pl |= segL[p] << (8 * p), pm |= segM[p] << (8 * p);
-            sg->packL = pl, sg->packM = pm;
-        }
+        lr_bin_ranks<P>(sc, eL, eM, KL, KM, n_bins, lane, segL, segM);
+        if (sg) lr_pack_ranks<P>(segL, segM, &sg->packL, &sg->packM);
     }
     LR_SSTAMP(10);
     double logB[P], logD[P], R[P];

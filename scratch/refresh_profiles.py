@@ -52,3 +52,33 @@ b = json.loads(open(bench_json).read().strip().splitlines()[-1])
 json.dump(b, open(os.path.join(root, "profiles/%s_bench_cfg4_1gpu.json" % tag), "w"), indent=1)
 print(json.dumps(launch, indent=1)); print(json.dumps(summary, indent=1))
 print("value %.4e  kernel_ms %.3f  cpu %s" % (b["value"], b["roofline"]["kernel_ms"], b.get("cpu_baseline") and b["cpu_baseline"]["value"]))
+
+# optional: the same counters over one launch of the speculative kernel (bash scratch/pmc_spec.sh <dir> 10000 256)
+if len(sys.argv) > 4:
+    sp = sys.argv[4]
+    ps = json.load(open(os.path.join(sp, "pmc_summary.json")))
+    ksp = [x for x in ps if "lr_spec_kernel" in x][0]
+    vs = {a: b["mean"] for a, b in ps[ksp].items()}
+    rows = []
+    for f in glob.glob(os.path.join(sp, "SQ_LDS_IDX_ACTIVE", "*", "*kernel_trace.csv")):
+        rows += [r for r in csv.DictReader(open(f)) if "lr_spec_kernel" in r["Kernel_Name"]]
+    ns = max(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
+    cyc, n_it, blocks = ns * 2.4, 2000, 256
+    spec = {"kernel": ksp.replace("void ", ""),
+            "workload": "cfg3: 256 chains x 10k lineages, a team per chain (256 blocks), one launch of 2000 iterations from the initial state",
+            "counters_mean_per_launch": vs, "profiled_launch_ms": ns / 1e6, "us_per_iteration_in_profiled_launch": ns / 1e3 / n_it,
+            "valu_busy_fraction": vs["SQ_ACTIVE_INST_VALU"] / cyc / blocks, "lds_busy_fraction": vs["SQ_LDS_IDX_ACTIVE"] / cyc / blocks,
+            "vector_issue_fraction": (vs["SQ_INSTS_VALU"] + vs["SQ_INSTS_LDS"]) / (blocks * 4) * 4.18 / cyc,
+            "vector_instructions_per_CU_per_iteration": (vs["SQ_INSTS_VALU"] + vs["SQ_INSTS_LDS"]) / blocks / n_it,
+            "salu_instructions_per_CU_per_iteration": vs["SQ_INSTS_SALU"] / blocks / n_it,
+            "note": "2 candidate + 2 helper + 8 scanner waves per CU; the iteration is the serial chain candidate (to the hand-over) -> "
+                    "helper (table) -> barrier -> scanners (pair planes, scan, decision): the CU issues about half of what it could",
+            "source": "rocprofv3 --pmc <counter group> --kernel-trace (separate passes) -- python3 scratch/prof_spec.py 10000 256 "
+                      "(bash scratch/pmc_spec.sh <dir> 10000 256)"}
+    json.dump(spec, open(os.path.join(root, "profiles/%s_pmc_spec_cfg3.json" % tag), "w"), indent=1)
+    print(json.dumps({k: v for k, v in spec.items() if k != "counters_mean_per_launch"}, indent=1))
+# optional: the bench line at the driver's arguments
+if len(sys.argv) > 5:
+    b20 = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])
+    json.dump(b20, open(os.path.join(root, "profiles/%s_bench_cfg4_1gpu_driver_args.json" % tag), "w"), indent=1)
+    print("driver args: value %.4e  wall/device %.3f" % (b20["value"], b20["ms_per_step"] * b20["steps"] / b20["roofline"]["kernel_ms"]))

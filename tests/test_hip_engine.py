@@ -579,6 +579,34 @@ def test_checkpoint_resume_is_bit_identical(G, tmp_path, engine, C):
         e.close()
 
 
+@pytest.mark.parametrize("general", [False, True])
+def test_four_chain_kernel_does_not_depend_on_how_a_run_is_cut_into_launches(general):
+    """The four-chain kernel leaves the scan sums of its last phase for the next launch instead of scoring pair 0 again: a
+    run cut into launches of 7 + 1 + 32 iterations equals one launch of 40 bit for bit (60k lineages: several trips per
+    scanner lane, the helper waves' share included), and a second init() of the same engine - which sets the state
+    from outside - is not served the sums the run before it left."""
+    import torch
+    from literate_amd import synth
+    from literate_amd.engine import ChainEngine
+    ts, te, _ = synth.make_lineages(60_000, n_bins=128, n_shifts=20, seed=11)
+    if general:
+        rng = np.random.default_rng(3)
+        ts = ts + rng.uniform(0, 0.999, len(ts))
+        te = np.maximum(te + rng.uniform(-0.49, 0.49, len(te)), ts + 1e-3)
+    kw = dict(model=0, seed=5, s_freq=1, n_trace_slots=40, engine="persistent4")
+    one = ChainEngine(ts, te, 22, **kw)
+    one.init(); one.steps(40)
+    cut = ChainEngine(ts, te, 22, **kw)
+    cut.init(); cut.steps(13)                 # a run whose sums must not leak into the next one
+    cut.init(); cut.steps(7); cut.steps(1); cut.steps(32)
+    torch.cuda.synchronize()
+    assert one.layout.persistent == 2 and one.kernel_name().endswith("false>" if general else "true>")
+    bits = lambda t: t.contiguous().view(torch.int64)
+    assert torch.equal(bits(cut.trace), bits(one.trace))
+    assert torch.equal(bits(cut.state_f64), bits(one.state_f64)) and torch.equal(cut.state_i32, one.state_i32)
+    one.close(); cut.close()
+
+
 @pytest.mark.parametrize("mb,md,engine", [(2, 2, "auto"), (2, 2, "launch"), (2, 2, "persistent4"), (1, 1, "auto"),
                                           (0, 0, "auto"), (2, -1, "auto"), (2, 0, "launch"), (1, 2, "auto"),
                                           (2, -2, "auto")])

@@ -956,7 +956,7 @@ static int lr_device_cus() {
 // team (scratch/exp_teams.py, round 3: candidates with a column of their own, no-op moves copying it): with `trips` =
 // groups / k / 512 scanner lanes,
 //                        a team per PAIR                                  a team per CHAIN
-//     unit resolution    k = 1: max(2.95, 2.93 + 0.171 trips)             k = 1: max(2.44, 1.62 + 0.20 trips)
+//     unit resolution    k = 1: max(2.95, 2.93 + 0.180 trips)             k = 1: max(2.44, 1.62 + 0.20 trips)
 //                        k > 1: max(3.40, 3.20 + 0.205 trips)             k > 1: max(2.88, 2.45 + 0.165 trips) + 0.05 log2(k / 2)
 //     general times      k = 1: max(2.90, 2.85 + 0.434 trips)             k = 1: max(2.32, 1.50 + 0.46 trips)
 //                        k > 1: max(3.45, 2.90 + 0.478 trips)             k > 1: max(2.72, 2.10 + 0.46 trips) + 0.05 log2(k / 2)
@@ -998,7 +998,7 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
                 else t = (k == 1) ? fmax(2.30, 1.45 + 0.20 * trips) : fmax(2.90, 2.50 + 0.16 * trips);
                 if (general) t += 0.26 * trips;
             } else if (!general) {
-                if (cpb == 2) t = (k == 1) ? fmax(2.95, 2.93 + 0.171 * trips) : fmax(3.40, 3.20 + 0.205 * trips);
+                if (cpb == 2) t = (k == 1) ? fmax(2.95, 2.93 + 0.180 * trips) : fmax(3.40, 3.20 + 0.205 * trips);
                 else t = (k == 1) ? fmax(2.44, 1.62 + 0.20 * trips) : fmax(2.88, 2.45 + 0.165 * trips) + (k == 4 ? 0.05 : (k == 8 ? 0.10 : 0.0));
             } else {
                 if (cpb == 2) t = (k == 1) ? fmax(2.90, 2.85 + 0.434 * trips) : fmax(3.45, 2.90 + 0.478 * trips);
@@ -1019,20 +1019,22 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
 // engine (2 and 3 still need the prerequisites); auto picks the persistent kernel unless the chains are too few for the lineage count: a block
 // scans ALL lineages for its two chains, so with few chains and very long inputs the tiled launch-based scan,
 // which spreads one chain group over many CUs, is faster.
-// Measured iteration times (us, MI355X, scratch/exp_p2_vs_p4.py: 3k..3M lineages x 768 / 1024 / 1536 chains) of the two
-// persistent kernels that take more than 256 chain pairs, per round of 1024 chains:
-//   two-chain kernel (512-thread blocks, two per CU)   f2 = 5.0 + 0.0395 per 1000 lineages
-//   four-chain kernel                                  f4 = max(7.7, 3.8 + 0.044 per 1000 lineages)   (general times: 0.091)
-// and a remainder of at most 512 chains costs the two-chain kernel 0.77 of a round.
+// Measured iteration times (us, MI355X, scratch/exp_p2_vs_p4.py: 3k..3M lineages x 768 / 1024 / 1536 chains; refitted at
+// the end of round 3, the four-chain kernel with helper waves) of the two persistent kernels that take more than 256
+// chain pairs, per round of 1024 chains:
+//   two-chain kernel (512-thread blocks, two per CU)   f2 = 4.8 + 0.0355 per 1000 lineages
+//   four-chain kernel                                  f4 = max(5.45, 3.13 + 0.0362 per 1000 lineages)
+//                                                      (general times: max(8.0, 3.8 + 0.091 per 1000 lineages), round 2)
+// and a remainder of at most 512 chains costs the two-chain kernel 0.62 of a round.
 static double lr_model_two_chain(const lr_mcmc_config* cfg) {
     const double kn = (double)cfg->n_lineages * 1e-3;
     const int C = cfg->n_chains, rem = C % 1024;
-    const double f2 = 5.0 + 0.0395 * kn;
-    return f2 * ((double)(C / 1024) + (rem == 0 ? 0.0 : (rem <= 512 ? 0.77 : 1.0)));
+    const double f2 = 4.8 + 0.0355 * kn;
+    return f2 * ((double)(C / 1024) + (rem == 0 ? 0.0 : (rem <= 512 ? 0.62 : 1.0)));
 }
 static double lr_model_four_chain(const lr_mcmc_config* cfg, bool general) {
     const double kn = (double)cfg->n_lineages * 1e-3;
-    const double f4 = fmax(general ? 8.0 : 7.7, 3.8 + (general ? 0.091 : 0.044) * kn);
+    const double f4 = general ? fmax(8.0, 3.8 + 0.091 * kn) : fmax(5.45, 3.13 + 0.0362 * kn);
     return f4 * (double)((cfg->n_chains + 1023) / 1024);
 }
 
@@ -1060,8 +1062,8 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
 // Which persistent kernel: 1 = two chains per 512-thread block (lr_persist_kernel), 2 = four chains per 1024-thread
 // block in ping-pong (lr_persist4_kernel), 3 = the speculative team kernel (at most 256 chain pairs).  The four-chain
 // block hides the chain step under the other pair's scan, so beyond 256 pairs it wins while a scan is about as long as a
-// step (~70k..270k lineages, whole rounds of 1024 chains); the two-chain kernel, two blocks per CU, is ahead on short
-// scans (the step is all there is), on long ones (every wave scans) and on remainders of at most 512 chains.
+// step (from ~20k lineages up, whole rounds of 1024 chains); the two-chain kernel, two blocks per CU, is ahead on short
+// scans (the step is all there is) and on remainders of at most 512 chains; on very long scans the two tie.
 static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k, int* team_cpb = nullptr) {
     if (team_k) *team_k = 0;
     if (team_cpb) *team_cpb = 0;
@@ -1073,9 +1075,9 @@ static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, 
     const double t_spec = (p.H > (general ? 136 : 264)) ? 1e30 : lr_spec_model(cfg, &k, general, &cpb);
     if (k > 0 && t_spec < 1e29 && cfg->engine_mode != 3 && cfg->engine_mode != 4 && spec_env != 0) {
         // the two-chain kernel with all 16 waves scanning wins only on long scans without room for a team
-        // (measured at 256 pairs, 10k..1M lineages: 5.1 + 0.26 us per trip of its 1024 scanner lanes, 4.9 at least; the
-        // speculative kernel is ahead up to ~200k lineages)
-        const double t_wide = general ? 1e30 : fmax(4.9, 5.1 + 0.262 * (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP) / 1024.0);
+        // (measured at 256 pairs, 10k..1M lineages, scratch/exp_engines.py: 4.41 + 0.236 us per trip of its 1024 scanner
+        // lanes, 4.1 at least; the speculative kernel is ahead up to ~200k lineages)
+        const double t_wide = general ? 1e30 : fmax(4.1, 4.41 + 0.236 * (double)((cfg->n_lineages + LR_GRP - 1) / LR_GRP) / 1024.0);
         if (cfg->engine_mode == 5 || spec_env == 1 || t_spec <= t_wide) {
             if (team_k) *team_k = k;
             if (team_cpb) *team_cpb = cpb;

@@ -213,11 +213,16 @@ static void lr_set_shares(lr_engine* e) {
     for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
     e->p4.help_trips = 0;
     if (e->lay.persistent == 2 && lr_p4_help(e)) {
-        // a helper wave is idle until its stepper's hand-over arrives (~1.2 us into a phase, a scan trip takes ~0.35 us):
-        // it scores the first groups meanwhile (the 128 helper lanes stride over [0, 128 trips), the scanners over the rest)
-        static const int env_t = lr_env_int_pack("LR_P4_HELP_TRIPS", 5);
-        const long long k12 = (e->n8 + 767) / 768;                 // trips of a scanner wave without the helpers' share
-        e->p4.help_trips = k12 >= 6 ? env_t : 0;
+        // a helper wave is idle until its stepper's hand-over arrives (~1.2 us into a phase, a scan trip takes ~0.3 us):
+        // it scores the first groups meanwhile (the 128 helper lanes stride over [0, 128 trips), the scanners over the rest).
+        // With t trips per scanner lane behind that share (groups = 128 h + 768 t) the two sides end together at about
+        // h = t - 3.5; more than five never paid - the helpers scan with plain loads, one group in flight per lane
+        // (scratch/exp_help_trips.py: 60k lineages 2, cfg4 5, 300k and 1M 5).  LR_P4_HELP_TRIPS overrides it.
+        static const int env_t = lr_env_int_pack("LR_P4_HELP_TRIPS", -1);
+        const double t = ((double)e->n8 + 512.0) / 896.0;
+        int h = (int)lrint(t - 3.5);
+        h = h < 0 ? 0 : (h > 5 ? 5 : h);
+        e->p4.help_trips = env_t >= 0 ? env_t : h;
         if (e->p4.help_trips < 0) e->p4.help_trips = 0;
         if ((long long)e->p4.help_trips * 128 > e->n8) e->p4.help_trips = 0;
     }

@@ -68,6 +68,11 @@ def build_hip(force=False, verbose=False):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps=obj"] + extra
     shutil.rmtree(OBJ_DIR, ignore_errors=True)
     os.makedirs(OBJ_DIR)
+    # a build that fails - a compile error, a hand-placed load the checker objects to - must not leave the library of an
+    # EARLIER build behind: it would travel to the GPU box and be measured as if it were this source
+    for stale in (LIB, BUILD_INFO):
+        if os.path.exists(stale):
+            os.remove(stale)
     objs = [os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o") for s in SOURCES]
 
     def compile_one(pair):

@@ -221,7 +221,9 @@ typedef struct lr_mcmc_layout {
     int32_t reserved1;    /* threads per block of the persistent kernel (512 / 1024), 0 for the launch-based engine */
     int64_t status;       /* engine status word (uint32): 0 ok, 1 = a team exchange of the speculative kernel timed out;
                            * the uint32 behind it is the warning word (lr_mcmc_warnings)                                */
-    int64_t xchg;         /* partial-sum exchange granules of the speculative kernel's teams (team_blocks > 1)        */
+    int64_t xchg;         /* partial-sum exchange granules of the speculative kernel's teams (team_blocks > 1); under the
+                           * four-chain kernel (persistent == 2) the scan sums a launch leaves for the next one, 512 bytes
+                           * per block - engine scratch either way: not part of a run, cleared by init / restore        */
     int32_t team_blocks;  /* blocks (= CUs) that share one chain pair, each scanning 1/team_blocks of the lineages     */
     int32_t table_mode;   /* 0 chain-major general tables, 1 unit-resolution pair tables, 2 pair-general tables (persistent
                            * engines on general lineage times: in-bin fractions packed as 32-bit fixed point)             */
@@ -307,7 +309,9 @@ int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream);
  * the workspace is bit-identical to an uninterrupted one.  The caller copies a workspace saved from an engine
  * with the SAME configuration (hence the same lr_mcmc_layout) into this engine's workspace, then calls this
  * instead of lr_mcmc_init: it rebuilds what holds device addresses or derives from the data (argument blob,
- * log(br_length), packed lineage indices) and leaves the chains alone.                                          */
+ * log(br_length), packed lineage indices), forgets what earlier launches left in the engine's scratch regions (status,
+ * warnings, carried scan sums) and leaves the chains alone.  Chain state written into the workspace from outside
+ * must always be followed by this call.                                                                          */
 int lr_mcmc_restore(lr_engine* e, void* stream);
 /* measurement hook (bench.py roofline): average duration in ms of `reps` back-to-back launches of
  * the engine's lineage-scan kernel on `stream`, timed with HIP events recorded on that stream.

@@ -544,11 +544,13 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     constexpr bool draw_ahead = LR_P4_DRAW_AHEAD && !GENERAL && !PARAM;
     // draw duty of scanner wave 2 + q, q < 4, for the pair `pr` that has just been scanned: part q >> 1 of chain q & 1
     auto draw_duty = [&](int pr) {
-        const int q = wave - W0, k = q & 1, ch = 2 * pr + k;      // (the four oldest scanner waves: the first to finish)
-        if (!draw_ahead || q < 0 || q >= 4 || (int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
+        const int q = wave - W0, k = q & 1, ch = 2 * pr + k;      // (the oldest scanner waves: the first to finish)
+        if (!draw_ahead || q < 0 || q >= (HELP ? 2 : 4) || (int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
         const int* I = st_i32[ch] + LR_IROW_SCALARS * LR_ROW;
         const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + 1ull;
-        lr_spec_draw_part(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, &draws[ch], q >> 1);
+        // (HELP: one wave per chain, one Philox call for both parts)
+        if (HELP) lr_spec_draw_both(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, &draws[ch]);
+        else lr_spec_draw_part(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, &draws[ch], q >> 1);
     };
     // a helper wave's table duty of a phase whose steppers advance pair `ph`: once the stepper has handed them over, the
     // tables of its chain of pair ph

@@ -562,6 +562,37 @@ __device__ __forceinline__ double lr_wave_multiplier_pre(double& R, int K, bool 
     return lr_wave_sum(active ? x : 0.0);
 }
 
+// the same draws by ONE wave in ONE Philox call, addressed as lr_propose_rj addresses them when it draws by itself: lanes
+// 0..31 the multiplier pairs of their rates, lanes LR_UD_LANE + 0..3 the wave-uniform ones (the four-chain kernel with
+// helper waves: the kernel is bound by its vector instruction count, a Philox block is ~100 instructions)
+__device__ __forceinline__ void lr_spec_draw_both(const lr_step_args& a, int c, int lane, unsigned long long it, lr_draw_slot* out) {
+    const lr_mcmc_config& cfg = a.cfg;
+    const lr_stream rng{(uint32_t)cfg.seed, (uint32_t)(cfg.chain_offset + c)};
+    const int ul = lane - LR_UD_LANE;
+    const uint32_t purpose = (ul < 0) ? LR_P_MULT : ((ul == 0) ? LR_P_ACCEPT : (ul == 1 ? LR_P_MOVE : LR_P_RJ));
+    const lr_u2 u = lr_pair(rng, it, purpose, ul < 0 ? (uint32_t)lane : (ul == 3 ? 1u : 0u));
+    const double x = a.mult_l * (u.b - .5);                                // LRF:165-176
+    out->x[lane] = x, out->m[lane] = exp(x), out->da[lane] = u.a;          // (lanes 0..31 are read)
+    const double lu = lr_log(ul == 0 ? u.a : 1.0);
+    const double r_a = lr_bcast(u.a, LR_UD_LANE + 1), q_b = lr_bcast(u.b, LR_UD_LANE + 2);
+    double beta = 0.0;
+    if (!(r_a < 0.8) && r_a < 0.999 && cfg.const_rates == 0 && q_b > 0.5) {
+        double ga, gb;
+        lr_wave_gamma2(rng, it, LR_P_BETA_A, LR_SHAPE_BETA_RJ, LR_P_BETA_B, LR_SHAPE_BETA_RJ, lane, &ga, &gb);
+        beta = ga / (ga + gb);
+    }
+    // slots: log_u, r_a, r_b, q_a, q_b, q2_a, q2_b, beta
+    double so = lr_bcast(lu, LR_UD_LANE);
+    so = (lane == 1) ? r_a : so;
+    so = (lane == 2) ? lr_bcast(u.b, LR_UD_LANE + 1) : so;
+    so = (lane == 3) ? lr_bcast(u.a, LR_UD_LANE + 2) : so;
+    so = (lane == 4) ? q_b : so;
+    so = (lane == 5) ? lr_bcast(u.a, LR_UD_LANE + 3) : so;
+    so = (lane == 6) ? lr_bcast(u.b, LR_UD_LANE + 3) : so;
+    so = (lane == 7) ? beta : so;
+    if (lane < 8) out->sc[lane] = so;
+}
+
 // Propose iteration `it` from the state `s` (LRF:234-304): on return `s` IS the proposal (a Gibbs step changes the
 // hyper-parameters, every other move the rates / times of one process), `p` its bookkeeping, and its lookup tables
 // stand at `table`.  A pure function of (s, it, the chain's Philox stream, the data): the speculative engine calls it

@@ -82,3 +82,32 @@ if len(sys.argv) > 5:
     b20 = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])
     json.dump(b20, open(os.path.join(root, "profiles/%s_bench_cfg4_1gpu_driver_args.json" % tag), "w"), indent=1)
     print("driver args: value %.4e  wall/device %.3f" % (b20["value"], b20["ms_per_step"] * b20["steps"] / b20["roofline"]["kernel_ms"]))
+# optional: the SQ counters over one 4000-iteration launch (bash scratch/pmc_persist_long.sh <dir>)
+if len(sys.argv) > 6:
+    lg = sys.argv[6]
+    pl = json.load(open(os.path.join(lg, "pmc_summary.json")))
+    kl = [x for x in pl if kname.split("<")[0] in x][0]
+    vl = {a_: b_["mean"] for a_, b_ in pl[kl].items()}
+    rows = []
+    for f in glob.glob(os.path.join(lg, "SQ_LDS_IDX_ACTIVE", "*", "*kernel_trace.csv")):
+        rows += [r for r in csv.DictReader(open(f)) if kname.split("<")[0] in r["Kernel_Name"]]
+    ns = max(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
+    n_it, cyc, us_bench = 4000, ns * 2.4, b["ms_per_step"] * 1e3
+    valu, lds = vl["SQ_INSTS_VALU"] / 256 / n_it, vl["SQ_INSTS_LDS"] / 256 / n_it
+    long_ = {"kernel": kl.replace("void ", ""),
+             "workload": "cfg4: 1024 chains x 100k lineages, ONE launch of 4000 iterations from the initial state (the chains reach their "
+                         "working number of shifts after ~500)",
+             "iterations_in_profiled_launch": n_it, "counters_mean_per_launch": vl, "profiled_launch_ms": ns / 1e6,
+             "us_per_iteration_profiled": ns / 1e3 / n_it, "us_per_iteration_unprofiled_bench": us_bench,
+             "per_CU_per_iteration": {"valu": valu, "lds": lds, "salu": vl["SQ_INSTS_SALU"] / 256 / n_it, "vmem_rd": vl["SQ_INSTS_VMEM_RD"] / 256 / n_it},
+             "valu_busy_fraction_profiled": vl["SQ_ACTIVE_INST_VALU"] / cyc / 256, "lds_busy_fraction_profiled": vl["SQ_LDS_IDX_ACTIVE"] / cyc / 256,
+             "lds_bank_conflict_fraction": vl["SQ_LDS_BANK_CONFLICT"] / vl["SQ_LDS_IDX_ACTIVE"],
+             "valu_issue_fraction_at_bench_speed": valu * 4.18 / 4 / (us_bench * 2400),
+             "valu_plus_lds_issue_fraction_at_bench_speed": (valu + lds) * 4.18 / 4 / (us_bench * 2400),
+             "note": "the counter passes slow the launch (us_per_iteration_profiled against the unprofiled bench line); the *_at_bench_speed "
+                     "fractions put the instruction counts of this launch over the unprofiled iteration time: a SIMD issues one wave64 VALU "
+                     "instruction per 4.18 cycles (scratch/ubench/valu_rate.hip)",
+             "source": "bash scratch/pmc_persist_long.sh <dir>: rocprofv3 --pmc <group> --kernel-trace (separate passes) -- python3 "
+                       "scratch/prof_persist.py with LR_PROF_ITERS=4000"}
+    json.dump(long_, open(os.path.join(root, "profiles/%s_pmc_4000it.json" % tag), "w"), indent=1)
+    print(json.dumps({k_: v_ for k_, v_ in long_.items() if k_ != "counters_mean_per_launch"}, indent=1))

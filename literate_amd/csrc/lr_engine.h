@@ -90,7 +90,7 @@ static inline long long lr_groups_alloc(long long n_lineages) {
 // Four-chain kernel: helper waves (lr_persist4_kernel's HELP) under the RJ sampler at unit resolution; LR_P4_HELP = 0: the
 // form with fourteen scanner waves (A/B runs)
 static inline bool lr_p4_help(const lr_engine* e) {
-    static const char* env = getenv("LR_P4_HELP");
+    const char* env = getenv("LR_P4_HELP");      // (read per call: a test process runs both forms)
     if (e->lay.persistent != 2 || e->plan.unit == LR_TAB_PAIRGEN || e->cfg.sampler != 0 || e->plan.H > 264) return false;
     return env ? atoi(env) != 0 : true;
 }

@@ -45,6 +45,8 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        # (a chain on its own CU with the pair planes by the helper waves - the kernel mode of
                                        # long scans - forced on this short one)
                                        (0, dict(engine="spec", team=1, cpt=1, planes_by_scanners=0)),
+                                       # (the four-chain kernel's form without helper waves: fourteen scanner waves)
+                                       (0, dict(engine="persistent4", p4_help=0)), (3, dict(engine="persistent4", p4_help=0)),
                                        (1, dict(engine="spec", team=1, cpt=1, planes_by_scanners=0, unit_resolution=False))])
 def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
     from literate_amd.engine import ChainEngine, split_trace_row
@@ -52,6 +54,8 @@ def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
     kw = dict(kw)
     if "planes_by_scanners" in kw:
         monkeypatch.setenv("LR_SPEC_PLANES_BY_SCANNERS", str(kw.pop("planes_by_scanners")))
+    if "p4_help" in kw:
+        monkeypatch.setenv("LR_P4_HELP", str(kw.pop("p4_help")))
     ekw = dict(const_rates=kw.get("const_rates", 0), const_death_rate=kw.get("const_death_rate", 0),
                use_rate_HP=kw.get("use_rate_HP", 1), poisson_HP=kw.get("Poisson_HP", 0.0),
                unit_resolution=kw.pop("unit_resolution", None), engine=kw.pop("engine", "auto"), team=kw.pop("team", 0),
@@ -65,6 +69,8 @@ def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
             assert eng.kernel_name().endswith(", 3>")
     if ekw["engine"] == "persistent2":
         assert eng.layout.persistent == 1
+    if ekw["engine"] == "persistent4" and ekw["unit_resolution"] is not False:
+        assert eng.kernel_name().endswith("false>" if "LR_P4_HELP" in os.environ else "true>")
     # binning done by the engine's own kernel must equal the reference's
     assert np.array_equal(eng.sp_events.cpu().numpy(), G[name + "/sp"])
     assert np.array_equal(eng.br_length.cpu().numpy(), G[name + "/br"])

@@ -440,6 +440,15 @@ def test_cfg4_full_size_1024_chains_100k_lineages():
     # the same through the oracle's binned form for a sample of chains
     for c in range(0, C, 97):
         assert lo.calc_likelihood(0, lam[c], mu[c], stats) == pytest.approx(snap["likA"][c], rel=1e-9)
+    # (iv) 20,000 iterations on (the chains grow to ~10 rates per process: add / remove moves at every size, several
+    # launches, the sums carried from one to the next): the property of (ii) again
+    eng.steps(20_000)
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it + 20_000) and float(np.mean(snap["K_l"])) > 4.0 and eng.warnings() == 0
+    lam = np.stack([snap["L"][c][lo.get_rate_index(np.floor(snap["tL"][c]), n_bins)] for c in range(C)])
+    mu = np.stack([snap["M"][c][lo.get_rate_index(np.floor(snap["tM"][c]), n_bins)] for c in range(C)])
+    lik = ops.bd_loglik_batch(eng.ts, eng.te, eng.t0, lam, mu, 0, br_length=br).cpu().numpy()
+    assert np.allclose(lik, snap["likA"], rtol=1e-9)
     eng.close()
 
 

@@ -497,8 +497,9 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 // waves and twelve waves scan.  A stepper hands the segments of its proposal over through LDS as soon as they stand
 // (lr_propose_rj's HAND, ~1.2 us into a 3.2 us step) and goes on with guard, prior and state; its helper builds the table
 // with its pair planes meanwhile: the serial path of a phase is load + move + staging + table instead of the whole step,
-// and every SIMD carries one wave of the step and three scanners.  Before the hand-over arrives a helper makes the draws
-// of the OTHER pair's next step (the draw duty four scanner waves carry otherwise).
+// and every SIMD carries one wave of the step and three scanners.  Before the hand-over arrives a helper scores the first
+// groups of the scan (sh.help_trips trips of the 128 helper lanes; the scanners stride over the rest), and the draws of the
+// OTHER pair's next step are one Philox call on each of the two oldest scanner waves (four waves, a call each, otherwise).
 template <int H, bool GENERAL, bool PARAM /* a parametric sampler's chain step (DDRate, trend_rate) instead of the RJ sampler's */,
           bool HELP = false>
 __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,

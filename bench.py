@@ -293,6 +293,257 @@ def measure_traffic(workload, chains, steps, kname, engine, sample_every):
                        % (steps, kname, vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
 
 
+# ---- the ABI-level streaming kernels against the HBM roofline ----------------------------------------------------
+# lr_bin_unit_events (precompute_events / get_br for every unit window: lib:74-85, loop LRF:519-523) and lr_bd_loglik_batch
+# (per-lineage get_BDlik, BDIx:124-146 = the calc_likelihood seam INTEGRATION.md binds) are the kernels that stream
+# ts / te from HBM: 16 B per lineage and pass.  The engines never re-read ts / te, so these two are where
+# the north star's HBM roofline is testable - at lineage counts where HBM matters (1e7, 3e7: 160 / 480 MB per pass).
+ABI_SIZES = (10_000_000, 30_000_000)
+ABI_BINS = 128
+
+
+def abi_lineages(n, general, order="sorted"):
+    """n synthetic lineages in HBM: cfg4's generator output tiled to n; `general` moves every time off the year grid
+    (own in-bin fractions); order = 'sorted' by birth time (how the reference's input files are written) or 'shuffled'."""
+    import torch
+    from literate_amd import synth
+    ts0, te0, _ = synth.make_lineages(100_000, n_bins=ABI_BINS, n_shifts=20, seed=0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    reps = -(-n // len(ts0))
+    ts = torch.as_tensor(ts0, device="cuda").repeat(reps)[:n].contiguous()
+    te = torch.as_tensor(te0, device="cuda").repeat(reps)[:n].contiguous()
+    if general:
+        ts = ts + torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 0.999
+        te = torch.maximum(torch.ceil(te) - 1.0 + 1e-3 + 0.998 * torch.rand(n, generator=g, device="cuda", dtype=torch.float64),
+                           ts + 1e-3)
+    if order == "sorted":
+        ts, perm = torch.sort(ts, stable=True)
+        te = te[perm].contiguous()
+    else:
+        perm = torch.randperm(n, generator=g, device="cuda")
+        ts, te = ts[perm].contiguous(), te[perm].contiguous()
+    return ts, te
+
+
+def abi_calls(kernel, ts, te, n_chains, model=2):
+    """-> (closure that enqueues ONE ABI call on torch's current stream with everything pre-marshalled, outputs, info)"""
+    import torch
+    from literate_amd import _hip
+    lib = _hip.load()
+    n = ts.numel()
+    dev = ts.device
+    stream = _hip.stream_ptr(dev)
+    if kernel == "lr_bin_events":
+        lo = torch.arange(ABI_BINS, dtype=torch.float64, device=dev)
+        hi = lo + 1.0
+        sp = torch.empty(ABI_BINS, dtype=torch.int64, device=dev)
+        ex = torch.empty_like(sp)
+        br = torch.empty(ABI_BINS, dtype=torch.float64, device=dev)
+        ws = torch.empty(int(lib.lr_bin_events_workspace_bytes(n, ABI_BINS)), dtype=torch.uint8, device=dev)
+        args = (_hip.ptr(ts), _hip.ptr(te), n, _hip.ptr(lo), _hip.ptr(hi), ABI_BINS, _hip.ptr(sp), _hip.ptr(ex),
+                _hip.ptr(br), _hip.ptr(ws), ws.numel(), stream)
+        keep = (lo, hi, sp, ex, br, ws)
+
+        def call():
+            rc = lib.lr_bin_events(*args)
+            assert rc == 0, rc
+        return call, (sp, ex, br), dict(passes=1, windows=ABI_BINS), keep
+    if kernel == "lr_bin_unit_events":
+        sp = torch.empty(ABI_BINS, dtype=torch.int64, device=dev)
+        ex = torch.empty_like(sp)
+        br = torch.empty(ABI_BINS, dtype=torch.float64, device=dev)
+        ws = torch.empty(int(lib.lr_bin_unit_events_workspace_bytes(n, ABI_BINS)), dtype=torch.uint8, device=dev)
+        args = (_hip.ptr(ts), _hip.ptr(te), n, 0.0, ABI_BINS, _hip.ptr(sp), _hip.ptr(ex), _hip.ptr(br), _hip.ptr(ws),
+                ws.numel(), stream)
+        keep = (sp, ex, br, ws)
+
+        def call():
+            rc = lib.lr_bin_unit_events(*args)
+            assert rc == 0, rc
+        return call, (sp, ex, br), dict(passes=1, windows=ABI_BINS), keep
+    rng = np.random.default_rng(5)
+    lam = torch.as_tensor(np.exp(rng.uniform(np.log(.05), np.log(.6), (n_chains, ABI_BINS))), device=dev)
+    mu = torch.as_tensor(np.exp(rng.uniform(np.log(.02), np.log(.3), (n_chains, ABI_BINS))), device=dev)
+    out = torch.empty(n_chains, dtype=torch.float64, device=dev)
+    ws = torch.empty(int(lib.lr_bd_loglik_workspace_bytes(n, ABI_BINS, n_chains, model)), dtype=torch.uint8, device=dev)
+    plan = (_hip.c_i32 * 4)()
+    rc = lib.lr_bd_loglik_plan(n, ABI_BINS, n_chains, model, plan)
+    assert rc == 0, rc
+    cb, tiles, H = int(plan[0]), int(plan[1]), int(plan[2])
+    args = (_hip.ptr(ts), _hip.ptr(te), n, 0.0, ABI_BINS, _hip.ptr(lam), _hip.ptr(mu), n_chains, model, None, 0.0,
+            _hip.ptr(out), _hip.ptr(ws), ws.numel(), stream)
+    keep = (lam, mu, out, ws)
+
+    def call():
+        rc = lib.lr_bd_loglik_batch(*args)
+        assert rc == 0, rc
+    return call, (out, lam, mu), dict(passes=-(-n_chains // cb), Cb=cb, tiles=tiles, H=H), keep
+
+
+def abi_time(call, reps):
+    """average device time in ms of one ABI call: HIP events on the stream the call enqueues on, `reps` calls back to back"""
+    import torch
+    call()
+    call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def abi_child(args):
+    """--abi-child: `kernel` on n lineages, three calls, nothing else (the rocprofv3 --pmc / --kernel-trace target)."""
+    import torch
+    ts, te = abi_lineages(args.abi_n, args.abi_general, args.abi_order)
+    call, _, _, keep = abi_calls(args.abi_kernel, ts, te, args.chains or 8)
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+
+
+def abi_fetch_bytes(kernel, n, chains, general, order):
+    """HBM bytes read by ONE call (all its kernels): rocprofv3 --pmc FETCH_SIZE child pass, doubled (gfx950 correction,
+    MI355X_MICROARCH.md HBM); the largest dispatch of three identical calls' kernels, summed per call."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="lr_abi_pmc_", dir="/tmp")
+    cmd = [rocprof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--abi-child", "--abi-kernel", kernel, "--abi-n", str(n),
+           "--chains", str(chains), "--abi-order", order] + (["--abi-general"] if general else [])
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=240)
+    except (subprocess.TimeoutExpired, OSError) as ex:
+        shutil.rmtree(d, ignore_errors=True)
+        return None, "rocprofv3 --pmc FETCH_SIZE: %s" % type(ex).__name__
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            rows += [x for x in csv.DictReader(fh) if x.get("Counter_Name") == "FETCH_SIZE" and "lr_" in x.get("Kernel_Name", "")]
+    shutil.rmtree(d, ignore_errors=True)
+    if r.returncode != 0 or not rows:
+        return None, "rocprofv3 --pmc FETCH_SIZE: rc %d, %d rows" % (r.returncode, len(rows))
+    total_kib = sum(float(x["Counter_Value"]) for x in rows)
+    return 2.0 * total_kib * 1024.0 / 3.0, "FETCH_SIZE x 2 (gfx950), all lr_* kernels of three calls / 3"
+
+
+def abi_section(pmc=True, sizes=ABI_SIZES):
+    """`abi`: the two HBM-streaming entry points at 1e7 / 3e7 lineages, and the cost of the calc_likelihood seam."""
+    import torch
+    out = {"peak_GBs": HBM_PEAK_GBS, "bytes_per_lineage_pass": 16,
+           "note": "achieved = 16 B x N x ceil(C / Cb) / device time of one ABI call (all its kernels; HIP events on the "
+                   "call's stream, back-to-back calls); lineages = cfg4's synthetic generator tiled to N, sorted by birth "
+                   "time as input files are (shuffled order beside it); general = continuous times"}
+    src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    copy_ms = abi_time(lambda: dst.copy_(src), 10)
+    out["copy_GBs_measured"] = 2.0 * src.numel() / (copy_ms * 1e-3) / 1e9
+    read_ms = abi_time(lambda: src.view(torch.int64).sum(), 10)
+    out["read_GBs_measured_torch_sum"] = src.numel() / (read_ms * 1e-3) / 1e9
+    del src, dst
+    rows = []
+    for n in sizes:
+        for general in (False, True):
+            for order in ("sorted", "shuffled"):
+                if order == "shuffled" and (general or n != sizes[0]):
+                    continue
+                ts, te = abi_lineages(n, general, order)
+                cases = [("lr_bin_unit_events", 0), ("lr_bin_events", 0)] + [("lr_bd_loglik_batch", c) for c in (1, 8, 16, 256)]
+                for kernel, c in cases:
+                    if kernel == "lr_bin_events" and (general or order != "sorted" or n != sizes[0]):
+                        continue            # arbitrary windows, 8 per pass over the lineages: one row for comparison
+                    call, _, info, keep = abi_calls(kernel, ts, te, c)
+                    reps = 20 if c <= 16 else 3
+                    ms = abi_time(call, reps)
+                    if kernel == "lr_bin_events":
+                        info["passes"] = -(-ABI_BINS // 8)      # LR_BW = 8 windows per block (csrc/lr_stats.hip)
+                    gbs = 16.0 * n * info["passes"] / (ms * 1e-3) / 1e9
+                    row = dict(kernel=kernel, lineages=n, general_times=general, order=order, chains=c, ms=ms,
+                               achieved_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS, frac_of_copy=gbs / out["copy_GBs_measured"],
+                               lineages_per_s=n / (ms * 1e-3), **info)
+                    if kernel == "lr_bd_loglik_batch":
+                        row["evals_per_s"] = float(n) * c / (ms * 1e-3)
+                    rows.append(row)
+                    del call, keep
+                del ts, te
+                torch.cuda.empty_cache()
+    out["rows"] = rows
+
+    def best(kernel, pred):
+        r = [x for x in rows if x["kernel"] == kernel and pred(x)]
+        return max(r, key=lambda x: x["hbm_frac"]) if r else None
+    for kernel, key, pred in (("lr_bin_unit_events", "lr_bin_unit_events", lambda x: x["order"] == "sorted" and not x["general_times"]),
+                              ("lr_bd_loglik_batch", "lr_bd_loglik_batch", lambda x: x["order"] == "sorted" and x["chains"] <= x["Cb"])):
+        b = best(kernel, pred)
+        if b:
+            out[key] = dict(hbm_frac=b["hbm_frac"], achieved_GBs=b["achieved_GBs"], lineages=b["lineages"], chains=b["chains"],
+                            general_times=b["general_times"], ms=b["ms"], traffic=None)
+            if pmc:
+                traffic, note = abi_fetch_bytes(kernel, b["lineages"], b["chains"], b["general_times"], "sorted")
+                out[key]["traffic"], out[key]["traffic_note"] = traffic, note
+                if traffic:
+                    out[key]["traffic_over_algorithmic"] = traffic / (16.0 * b["lineages"])
+    out["seam"] = abi_seam()
+    return out
+
+
+def abi_seam():
+    """What the drop-in seam costs: literate_library.BDI_partial_lik / BD_lik_Keiding (the calc_likelihood operator,
+    LRF:137-162, 305-308) on the shipped metal_bands lineages - wall time per call with ONE state (what a maintainer who
+    only swaps the operator pays per iteration: launch + sync + 8-byte read-back) and with 1024 states per call - beside
+    the reference's binned numpy expression timed in this process (cpu leg: oracle/)."""
+    import literate_library as ll
+    G = np.load(os.path.join(ROOT, "tests", "golden", "binning_lik.npz"))
+    ts, te = G["metal_bands/ts"], G["metal_bands/te"]
+    ll.bind_lineages(ts, te, model=0)
+    nb = ll.n_bins
+    rng = np.random.default_rng(3)
+    L1, M1 = np.exp(rng.uniform(-3, -1, nb)), np.exp(rng.uniform(-3, -1, nb))
+    LC, MC = np.exp(rng.uniform(-3, -1, (1024, nb))), np.exp(rng.uniform(-3, -1, (1024, nb)))
+    out = {"dataset": "metal_bands_1.tsv, %d lineages, %d bins" % (len(ts), nb)}
+    for name, fn in (("BDI_partial_lik", ll.BDI_partial_lik), ("BD_lik_Keiding", ll.BD_lik_Keiding)):
+        for _ in range(20):
+            fn(L1, M1)
+        t = time.perf_counter()
+        for _ in range(300):
+            fn(L1, M1)
+        us1 = (time.perf_counter() - t) / 300 * 1e6
+        for _ in range(3):
+            fn(LC, MC)
+        t = time.perf_counter()
+        for _ in range(30):
+            fn(LC, MC)
+        usC = (time.perf_counter() - t) / 30 * 1e6
+        out[name] = {"us_per_call_1_state": us1, "us_per_call_1024_states": usC,
+                     "states_per_s_at_1024": 1024 / (usC * 1e-6), "evals_per_s_at_1024": 1024.0 * len(ts) / (usC * 1e-6)}
+    # cpu leg: the reference's own operator is an n_bins-long numpy expression on binned statistics (oracle restatement)
+    from oracle import literate_oracle as lo
+    stats = dict(sp=ll.sp_events_bin, ex=ll.ex_events_bin, br=ll.br_length_bin)
+    for name, model in (("BDI_partial_lik", 0), ("BD_lik_Keiding", 2)):
+        with np.errstate(all="ignore"):
+            for _ in range(200):
+                lo.calc_likelihood(model, L1, M1, stats)
+            t = time.perf_counter()
+            for _ in range(5000):
+                lo.calc_likelihood(model, L1, M1, stats)
+        out[name]["numpy_binned_us_per_call"] = (time.perf_counter() - t) / 5000 * 1e6
+        out[name]["seam_over_numpy_at_1_state"] = out[name]["us_per_call_1_state"] / out[name]["numpy_binned_us_per_call"]
+        out[name]["states_per_call_to_break_even"] = None
+    out["note"] = ("one state per call is launch-latency bound (3 kernels + sync + read-back) and slower than the reference's "
+                   "24..32-element numpy expression; the seam pays off when states are batched per call (chains, or the "
+                   "fused engine lr_mcmc_steps, which keeps the whole loop on the device)")
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher's environment: start the N ranks ourselves - one process per GPU
     under torch.distributed.run - BEFORE this process has touched the GPU (it never does), pass their output through and
@@ -351,9 +602,21 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (cfg2, cfg3, cfg5, ...)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-abi", action="store_true", help="skip the `abi` section (HBM-streaming entry points at 1e7 / 3e7 lineages)")
+    ap.add_argument("--abi-only", action="store_true", help="print only the `abi` section")
+    ap.add_argument("--abi-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--abi-kernel", default="lr_bd_loglik_batch", help=argparse.SUPPRESS)
+    ap.add_argument("--abi-n", type=int, default=ABI_SIZES[0], help=argparse.SUPPRESS)
+    ap.add_argument("--abi-general", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--abi-order", default="sorted", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
+    if args.abi_child:
+        return abi_child(args)
+    if args.abi_only:
+        print(json.dumps({"abi": abi_section(pmc=not args.no_pmc)}))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))           # nothing above has imported torch or touched the GPU
 
@@ -586,6 +849,8 @@ def main():
                 out["configs"]["cfg5"]["cpu_baseline"] = cpu_baseline_dd(ts5, te5)
         else:
             out["cpu_baseline"] = None
+        if not args.no_abi:
+            out["abi"] = abi_section(pmc=not args.no_pmc)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -59,6 +59,16 @@ int lr_bin_events(const double* ts, const double* te, int64_t n,
                   int64_t* sp_events, int64_t* ex_events, double* br_length,
                   void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same statistics for the n_bins UNIT windows [t0 + w, t0 + w + 1] the reference always bins into (LRF:519-523:
+ * `for i in range(int(min(ts)), int(max(te)))`; lib create_bins:231-245), t0 integer valued: ONE pass over ts / te,
+ * 16 bytes per lineage - SURVEY 8(b)'s lr_bin_events(ts, te, n, t0, n_bins, ...).  Counts are exact; br_length[w] is the
+ * EXACT sum of the per-lineage overlaps get_br forms (lib:74-79), rounded to fp64 once (integer accumulation: order
+ * free, bitwise reproducible); on year-resolution input it equals the reference's value bit for bit.              */
+int64_t lr_bin_unit_events_workspace_bytes(int64_t n, int32_t n_bins);
+int lr_bin_unit_events(const double* ts, const double* te, int64_t n, double t0, int32_t n_bins,
+                       int64_t* sp_events, int64_t* ex_events, double* br_length,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- A3: rate index -----------------------------------------------------------------------
  * Replaces get_rate_index + fancy indexing L[indL] (LRF:125-135, 262, 306): expands K segment
  * rates to one rate per unit bin.  rates [C,kmax], times [C,kmax+1] ascending, K [C].
@@ -77,6 +87,10 @@ int lr_expand_rates(const double* rates, const double* times, const int32_t* K, 
  * L_acc_vec/M_acc_vec arguments).  br_length [n_bins] is required for models 0/1 (it is the
  * k = br_length_bin of LRF:154), end_time for model 3.  out_loglik [C].                     */
 int64_t lr_bd_loglik_workspace_bytes(int64_t n, int32_t n_bins, int32_t n_chains, int32_t model);
+/* measurement hook: the launch shape lr_bd_loglik_batch uses for these sizes - out[0] = Cb, the chains one pass over
+ * ts / te scores (the call makes ceil(n_chains / Cb) passes = 16 B x n x passes of algorithmic HBM reads), out[1] =
+ * lineage tiles per pass, out[2] = table entries reserved per chain and side, out[3] = passes.  out: host int32[4]. */
+int lr_bd_loglik_plan(int64_t n, int32_t n_bins, int32_t n_chains, int32_t model, int32_t* out /* host */);
 int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n, double t0, int32_t n_bins,
                        const double* lam_bins, const double* mu_bins, int32_t n_chains,
                        int32_t model, const double* br_length, double end_time,

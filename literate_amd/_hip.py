@@ -48,8 +48,11 @@ SIGNATURES = {
     "lr_version": (c_i32, []),
     "lr_bin_events_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "lr_bin_events": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "lr_bin_unit_events_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "lr_bin_unit_events": (c_i32, [c_vp, c_vp, c_i64, c_f64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "lr_expand_rates": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "lr_bd_loglik_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i32]),
+    "lr_bd_loglik_plan": (c_i32, [c_i64, c_i32, c_i32, c_i32, C.POINTER(c_i32)]),
     "lr_bd_loglik_batch": (c_i32, [c_vp, c_vp, c_i64, c_f64, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_f64, c_vp,
                                    c_vp, c_i64, c_vp]),
     "lr_rj_propose_score": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_vp, c_vp,

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(LR_BIN_THREADS) void lr_bin_partial_kernel(
         for (int w = 0; w < LR_BW; ++w) {
             csp[w] += (s >= lo[w]) & (s < hi[w]);
             cex[w] += (e > lo[w]) & (e <= hi[w]);
-            const double d = fmin(e, hi[w]) - fmax(s, lo[w]);
+            // the reference's own clipping (lib:74-79: `te[te > t1] = t1`, `ts[ts < t0] = t0`): a NaN stays a NaN and
+            // drops out at `br > 0` - fmin / fmax would replace it by the window edge
+            const double d = (e > hi[w] ? hi[w] : e) - (s < lo[w] ? lo[w] : s);
             br[w] += (d > 0.0) ? d : 0.0;
         }
     }
@@ -112,6 +114,273 @@ extern "C" int lr_bin_events(const double* ts, const double* te, int64_t n, cons
     if (rc) return rc;
     hipLaunchKernelGGL(lr_bin_final_kernel, dim3((n_windows + 127) / 128), dim3(128), 0, stream, p_sp, p_ex, p_br,
                        tiles, n_windows, (long long*)sp_events, (long long*)ex_events, br_length);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// A1/A2 for UNIT windows [t0 + w, t0 + w + 1], w < n_bins (the loop LRF:519-523, create_bins lib:231-245): ONE pass over
+// ts / te, 16 bytes per lineage - the HBM-bound form.  Per lineage: birth bin bs = floor(ts) - t0, death bin
+// be = ceil(te) - 1 - t0, two histogram increments (the events) and, for the lineage-time, only the PARTIAL bins:
+//     bs == be : te - ts in that bin;      else : (floor(ts) + 1) - ts in bin bs, te - (ceil(te) - 1) in bin be
+// - the very differences get_br forms for those windows (lib:74-79) - while the bins a lineage spans completely count 1
+// each: A[b] = #{bs < b} - #{be <= b} + #{bs == be == b}, prefix sums of the two event histograms.  Lineages with
+// te <= ts (or a NaN) count as events but carry no time, as in the reference (`br > 0`), through a correction histogram.
+// Everything is accumulated in INTEGERS, so the result does not depend on the order of the atomics: a partial term t in
+// (0, 1] enters as the 52-bit integer  bits(1.0 + t) - bits(1.0)  (exact whenever t is a multiple of 2^-52: every time
+// >= 1, hence every dataset; otherwise rounded to nearest once), split into a 32-bit and a 20-bit limb so that 64-bit
+// counters cannot overflow, and br_length[b] = the exact integer sum A[b] * 2^52 + sum of terms, rounded to fp64 ONCE -
+// the correctly rounded sum where the reference's pairwise numpy sum carries ~1e-16 * log N.
+// LDS: every histogram exists in R copies, lane l using copy l % R (entry = bin * R + copy: the copies of one bin lie in
+// different banks), so 64 lanes that hit the same bin - the normal case on input sorted by birth - do not serialise.
+// ------------------------------------------------------------------------------------------
+#define LR_UB_THREADS 1024
+#define LR_UB_MAX_BLOCKS 1024
+
+struct lr_ub_shape {
+    int W;          // windows
+    int rshift;     // log2 of the copies per histogram
+    int n32;        // 32-bit histogram entries per copy: bs [W+2] | be [W+2] | adj [W]
+    int cols;       // 64-bit partial columns per block: n32 + hi [W] + lo [W]
+    size_t lds_bytes;
+};
+
+static lr_ub_shape lr_ub_plan(int W) {
+    lr_ub_shape p;
+    p.W = W;
+    p.n32 = 3 * W + 4;
+    p.cols = p.n32 + 2 * W;
+    p.rshift = 5;
+    for (;;) {
+        p.lds_bytes = ((size_t)p.n32 * 4 + (size_t)2 * W * 8) << p.rshift;
+        if (p.lds_bytes <= 144 * 1024 || p.rshift == 0) break;
+        --p.rshift;
+    }
+    if (p.lds_bytes < (size_t)p.cols * 8) p.lds_bytes = (size_t)p.cols * 8;   // the last block's column totals
+    return p;
+}
+
+__device__ __forceinline__ unsigned long long lr_ub_term(double t) {
+    return (unsigned long long)(__double_as_longlong(1.0 + t) - 0x3ff0000000000000ll);
+}
+
+__device__ __forceinline__ void lr_ub_add_term(unsigned long long* hi, unsigned long long* lo, int idx, double t) {
+    const unsigned long long u = lr_ub_term(t);
+    atomicAdd(hi + idx, u >> 20);
+    const unsigned long long l = u & 0xfffffull;
+    if (l) atomicAdd(lo + idx, l);          // year-resolution data: every term is a multiple of 2^-32, no low limb
+}
+
+__device__ __forceinline__ void lr_ub_lineage(double s, double e, double t0, int W, int rshift, int copy,
+                                              unsigned int* h_bs, unsigned int* h_be, int* h_adj,
+                                              unsigned long long* h_hi, unsigned long long* h_lo) {
+    const double fl = floor(s), ce = ceil(e);
+    // entry index = bin + 1; 0 = before the first window, W + 1 = past the last (v_cvt_i32_f64 saturates)
+    int ia = min(max(__double2int_rz(fl - t0), -1), W) + 1;
+    int ib = min(max(__double2int_rz(ce - t0), 0), W + 1);
+    if (s != s) ia = W + 1;                 // a NaN is in no window (every comparison of LRF:119-120 is false)
+    if (e != e) ib = W + 1;
+    atomicAdd(h_bs + ((ia << rshift) | copy), 1u);
+    atomicAdd(h_be + ((ib << rshift) | copy), 1u);
+    if (s < e) {
+        if (ia == ib) {
+            if (ia >= 1 && ia <= W) {
+                atomicAdd(h_adj + (((ia - 1) << rshift) | copy), 1);
+                lr_ub_add_term(h_hi, h_lo, ((ia - 1) << rshift) | copy, e - s);
+            }
+        } else {
+            if (ia >= 1 && ia <= W) lr_ub_add_term(h_hi, h_lo, ((ia - 1) << rshift) | copy, (fl + 1.0) - s);
+            if (ib >= 1 && ib <= W) lr_ub_add_term(h_hi, h_lo, ((ib - 1) << rshift) | copy, e - (ce - 1.0));
+        }
+    } else {
+        // no lineage-time: cancel what the prefix sums of the two histograms would count for it
+        const int bs = ia - 1, be = ib - 1;
+        const int b_lo = max(min(bs, be), 0), b_hi = min(max(bs, be), W - 1);
+        for (int b = b_lo; b <= b_hi; ++b) {
+            const int d = (int)(be <= b) - (int)(bs < b);
+            if (d) atomicAdd(h_adj + ((b << rshift) | copy), d);
+        }
+    }
+}
+
+__global__ __launch_bounds__(LR_UB_THREADS) void lr_bin_unit_kernel(const double* __restrict__ ts,
+                                                                   const double* __restrict__ te, long long n, double t0,
+                                                                   lr_ub_shape p, long long chunk,
+                                                                   long long* __restrict__ acc,
+                                                                   unsigned int* __restrict__ ticket,
+                                                                   long long* __restrict__ sp, long long* __restrict__ ex,
+                                                                   double* __restrict__ br) {
+    extern __shared__ unsigned long long ub_lds[];
+    const int tid = threadIdx.x, W = p.W, rshift = p.rshift, R = 1 << rshift;
+    unsigned long long* h_hi = ub_lds;
+    unsigned long long* h_lo = h_hi + ((size_t)W << rshift);
+    unsigned int* h_bs = reinterpret_cast<unsigned int*>(h_lo + ((size_t)W << rshift));
+    unsigned int* h_be = h_bs + ((size_t)(W + 2) << rshift);
+    int* h_adj = reinterpret_cast<int*>(h_be + ((size_t)(W + 2) << rshift));
+    const long long start = (long long)blockIdx.x * chunk, end = min(start + chunk, n);
+    const bool aligned = ((((uintptr_t)ts) | ((uintptr_t)te)) & 15) == 0;     // chunk is even, so start is
+    long long i = start + 2 * tid;
+    // two pairs of lineages per thread in flight (64 B): 64 KB per CU at one block of 16 waves per CU
+    double2 s2 = make_double2(0.0, 0.0), e2 = s2, s3 = s2, e3 = s2;
+    if (aligned && i + 1 < end) {
+        s2 = *reinterpret_cast<const double2*>(ts + i);
+        e2 = *reinterpret_cast<const double2*>(te + i);
+        if (i + 2 * LR_UB_THREADS + 1 < end) {
+            s3 = *reinterpret_cast<const double2*>(ts + i + 2 * LR_UB_THREADS);
+            e3 = *reinterpret_cast<const double2*>(te + i + 2 * LR_UB_THREADS);
+        }
+    }
+    {
+        uint4* z = reinterpret_cast<uint4*>(ub_lds);
+        const int n16 = (int)(p.lds_bytes >> 4);
+        for (int k = tid; k < n16; k += LR_UB_THREADS) z[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    const int copy = tid & (R - 1);
+    if (aligned) {
+        while (i + 1 < end) {
+            const double2 sc = s2, ec = e2;
+            s2 = s3, e2 = e3;
+            const long long nx2 = i + 4 * LR_UB_THREADS;
+            if (nx2 + 1 < end) {
+                s3 = *reinterpret_cast<const double2*>(ts + nx2);
+                e3 = *reinterpret_cast<const double2*>(te + nx2);
+            }
+            lr_ub_lineage(sc.x, ec.x, t0, W, rshift, copy, h_bs, h_be, h_adj, h_hi, h_lo);
+            lr_ub_lineage(sc.y, ec.y, t0, W, rshift, copy, h_bs, h_be, h_adj, h_hi, h_lo);
+            i += 2 * LR_UB_THREADS;
+        }
+        if (i < end) lr_ub_lineage(ts[i], te[i], t0, W, rshift, copy, h_bs, h_be, h_adj, h_hi, h_lo);
+    } else {
+        for (; i < end; i += 2 * LR_UB_THREADS) {
+            lr_ub_lineage(ts[i], te[i], t0, W, rshift, copy, h_bs, h_be, h_adj, h_hi, h_lo);
+            if (i + 1 < end) lr_ub_lineage(ts[i + 1], te[i + 1], t0, W, rshift, copy, h_bs, h_be, h_adj, h_hi, h_lo);
+        }
+    }
+    __syncthreads();
+    // fold the R copies of every histogram entry and add the block's column sums into the call's 64-bit accumulators
+    // (agent-scope integer atomics at the memory side: coherent across the XCDs' L2s, and order-free).  Thread j starts
+    // at copy j % R, so the threads of a wave read different banks.
+    for (int j = tid; j < p.cols; j += LR_UB_THREADS) {
+        long long v = 0;
+        if (j < p.n32) {
+            const int* h = reinterpret_cast<const int*>(h_bs) + ((size_t)j << rshift);
+            for (int r = 0; r < R; ++r) v += h[(r + j) & (R - 1)];
+        } else {
+            const unsigned long long* h = h_hi + ((size_t)(j - p.n32) << rshift);
+            for (int r = 0; r < R; ++r) v += (long long)h[(r + j) & (R - 1)];
+        }
+        if (v) __hip_atomic_fetch_add(acc + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // The block that takes the last ticket turns the accumulators into the outputs.  No release / acquire fences (an
+    // agent-scope fence writes back and invalidates the XCD's whole L2: ~1.3 us each, serialised per XCD): a wave's
+    // atomics have been performed once its vmcnt reaches 0, the barrier orders the block's waves before its ticket, and
+    // the last block reads the accumulators with agent-scope (sc1) loads that do not hit in its own L2.
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    long long* tot = reinterpret_cast<long long*>(ub_lds);          // [cols], the histograms are dead
+    for (int j = tid; j < p.cols; j += LR_UB_THREADS)
+        tot[j] = __hip_atomic_load(acc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const long long* t_bs = tot;                 // [W + 2]
+    const long long* t_be = tot + (W + 2);       // [W + 2]
+    const long long* t_adj = tot + 2 * (W + 2);  // [W]
+    const long long* t_hi = tot + p.n32;         // [W]
+    const long long* t_lo = t_hi + W;            // [W]
+    if (tid < LR_WAVE) {
+        // A[b] = sum_{j <= b} (bs[j] - be[j + 1]) - be[0] + adj[b]: lane l owns the bins [l * per, (l + 1) * per)
+        const int per = (W + LR_WAVE - 1) / LR_WAVE;
+        const int b0 = tid * per, b1 = min(b0 + per, W);
+        long long local = 0;
+        for (int b = b0; b < b1; ++b) local += t_bs[b] - t_be[b + 1];
+        long long incl = local;
+        for (int d = 1; d < LR_WAVE; d <<= 1) {
+            const long long up = __shfl_up(incl, d);
+            if (tid >= d) incl += up;
+        }
+        long long run = incl - local - t_be[0];
+        for (int b = b0; b < b1; ++b) {
+            run += t_bs[b] - t_be[b + 1];
+            const long long A = run + t_adj[b];
+            sp[b] = t_bs[b + 1];
+            ex[b] = t_be[b + 1];
+            // exact total in units of 2^-52: A * 2^52 + hi * 2^20 + lo, as a 128-bit integer (q1:q0), rounded to fp64 once
+            const unsigned long long hi = (unsigned long long)t_hi[b], lo = (unsigned long long)t_lo[b];
+            unsigned long long q0 = (unsigned long long)A << 52, q1 = (unsigned long long)A >> 12;
+            unsigned long long add = hi << 20;
+            q0 += add, q1 += (hi >> 44) + (q0 < add);
+            q0 += lo, q1 += (q0 < lo);
+            double v;
+            if (q1 == 0 && q0 < (1ull << 53)) {
+                v = (double)(long long)q0;
+            } else {
+                const int top = q1 ? 127 - __clzll((long long)q1) : 63 - __clzll((long long)q0);   // index of the leading bit
+                const int sh = top - 52;                                                    // bits to drop (>= 1)
+                unsigned long long m, rem_hi, rem_lo;      // mantissa (53 bits), dropped bits left-aligned in rem_hi:rem_lo
+                if (sh >= 64) {
+                    m = q1 >> (sh - 64);
+                    rem_hi = (sh == 64) ? q0 : ((q1 << (128 - sh)) | (q0 >> (sh - 64)));
+                    rem_lo = (sh == 64) ? 0ull : (q0 << (128 - sh));
+                } else {
+                    m = (q1 << (64 - sh)) | (q0 >> sh);
+                    rem_hi = q0 << (64 - sh);
+                    rem_lo = 0ull;
+                }
+                const unsigned long long half = 1ull << 63;
+                if (rem_hi > half || (rem_hi == half && (rem_lo != 0ull || (m & 1ull)))) ++m;   // to nearest, ties to even
+                v = ldexp((double)(long long)m, sh);
+            }
+            br[b] = ldexp(v, -52);
+        }
+    }
+}
+
+extern "C" int64_t lr_bin_unit_events_workspace_bytes(int64_t n, int32_t n_bins) {
+    if (n < 1 || n_bins < 1 || n_bins > LR_MAX_BINS) return LR_ERR_SIZE;
+    const lr_ub_shape p = lr_ub_plan(n_bins);
+    return 256 + (int64_t)p.cols * 8;
+}
+
+extern "C" int lr_bin_unit_events(const double* ts, const double* te, int64_t n, double t0, int32_t n_bins,
+                                  int64_t* sp_events, int64_t* ex_events, double* br_length, void* workspace,
+                                  int64_t workspace_bytes, void* stream_) {
+    if (!ts || !te || !sp_events || !ex_events || !br_length || !workspace) return LR_ERR_NULL;
+    if (n < 1 || n_bins < 1 || n_bins > LR_MAX_BINS) return LR_ERR_SIZE;
+    if (t0 != floor(t0) || fabs(t0) > 1e9) return LR_ERR_T0;
+    const lr_ub_shape p = lr_ub_plan(n_bins);
+    const size_t ws_bytes = 256 + (size_t)p.cols * 8;      // the ticket, then one 64-bit accumulator per column
+    if ((int64_t)ws_bytes > workspace_bytes) return LR_ERR_WORKSPACE;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    static size_t configured = 64 * 1024;
+    if (p.lds_bytes > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_bin_unit_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        configured = p.lds_bytes;
+    }
+    // one block of 16 waves per CU (the histograms fill most of its LDS); short inputs: >= 8 lineages per thread
+    const long long unit = 2 * LR_UB_THREADS;
+    long long blocks = min((long long)min(n_cu, LR_UB_MAX_BLOCKS), (n + 4 * unit - 1) / (4 * unit));
+    if (blocks < 1) blocks = 1;
+    const long long chunk = lr_align_up64((n + blocks - 1) / blocks, unit);
+    blocks = (n + chunk - 1) / chunk;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    // ticket and accumulators start at zero: the workspace is the caller's, uninitialised memory
+    hipError_t e = hipMemsetAsync(ws, 0, ws_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(lr_bin_unit_kernel, dim3((unsigned)blocks), dim3(LR_UB_THREADS), p.lds_bytes, stream, ts, te,
+                       (long long)n, t0, p, chunk, (long long*)(ws + 256), (unsigned int*)ws, (long long*)sp_events,
+                       (long long*)ex_events, br_length);
     return (int)hipGetLastError();
 }
 

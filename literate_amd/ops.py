@@ -35,11 +35,56 @@ def _workspace(nbytes, device):
     return ws
 
 
-def bin_events(ts, te, win_lo, win_hi):
-    """(sp_events int64[W], ex_events int64[W], br_length f64[W]) for windows [lo_w, hi_w]
-    (precompute_events / get_br, lib:74-85, for all windows in one launch)."""
+def _unit_windows(win_lo, win_hi):
+    """(t0, n_bins) when the windows are the unit bins [t0 + w, t0 + w + 1] with t0 integer valued - what the reference
+    always bins into (LRF:519-523, lib create_bins) - else None.  Decided on host arrays only (no device read-back)."""
+    torch = _torch()
+    if isinstance(win_lo, torch.Tensor) or isinstance(win_hi, torch.Tensor):
+        return None
+    lo, hi = np.asarray(win_lo, dtype=float).ravel(), np.asarray(win_hi, dtype=float).ravel()
+    if lo.size < 1 or hi.size != lo.size or lo.size > _hip.LR_MAX_BINS:
+        return None
+    t0 = float(lo[0])
+    if not (np.isfinite(t0) and t0 == np.floor(t0) and abs(t0) < 1e9):
+        return None
+    grid = t0 + np.arange(lo.size, dtype=float)
+    if np.array_equal(lo, grid) and np.array_equal(hi, grid + 1.0):
+        return t0, int(lo.size)
+    return None
+
+
+def bin_unit_events(ts, te, t0, n_bins):
+    """(sp_events int64[n_bins], ex_events, br_length f64) of the unit windows [t0 + w, t0 + w + 1]: one pass over the
+    lineages (lr_bin_unit_events; the loop LRF:519-523 / lib create_bins:231-245)."""
     torch = _torch()
     lib = _hip.load()
+    ts = _dev(ts, torch.float64)
+    te = _dev(te, torch.float64, ts.device)
+    n = ts.numel()
+    if te.numel() != n:
+        raise ValueError("ts and te differ in length")
+    sp = torch.empty(n_bins, dtype=torch.int64, device=ts.device)
+    ex = torch.empty(n_bins, dtype=torch.int64, device=ts.device)
+    br = torch.empty(n_bins, dtype=torch.float64, device=ts.device)
+    nbytes = lib.lr_bin_unit_events_workspace_bytes(n, n_bins)
+    if nbytes < 0:
+        _hip.check(int(nbytes), "lr_bin_unit_events_workspace_bytes")
+    ws = _workspace(nbytes, ts.device)
+    rc = _hip.launch(lib.lr_bin_unit_events, ts.device, _hip.ptr(ts), _hip.ptr(te), n, float(t0), int(n_bins), _hip.ptr(sp),
+                     _hip.ptr(ex), _hip.ptr(br), _hip.ptr(ws), ws.numel())
+    _hip.check(rc, "lr_bin_unit_events")
+    return sp, ex, br
+
+
+def bin_events(ts, te, win_lo, win_hi):
+    """(sp_events int64[W], ex_events int64[W], br_length f64[W]) for windows [lo_w, hi_w]
+    (precompute_events / get_br, lib:74-85, for all windows in one launch).  Unit windows on an integer origin - every
+    binning call of the reference's CLIs - take the one-pass kernel (bin_unit_events)."""
+    torch = _torch()
+    lib = _hip.load()
+    unit = _unit_windows(win_lo, win_hi)
+    if unit is not None:
+        return bin_unit_events(ts, te, unit[0], unit[1])
     ts = _dev(ts, torch.float64)
     te = _dev(te, torch.float64, ts.device)
     lo, hi = _dev(win_lo, torch.float64, ts.device), _dev(win_hi, torch.float64, ts.device)

@@ -75,6 +75,144 @@ def test_bin_events_edge_cases(ops):
             assert float(br[k]) == pytest.approx(c, rel=1e-12, abs=1e-12)
 
 
+def _general_bin_events(ops, ts, te, lo, hi):
+    """lr_bin_events proper (arbitrary windows): device tensors are never routed to the unit-window kernel"""
+    import torch
+    return ops.bin_events(ts, te, torch.as_tensor(np.asarray(lo, float)).cuda(), torch.as_tensor(np.asarray(hi, float)).cuda())
+
+
+def _fsum_br(ts, te, lo, hi):
+    """the reference's per-lineage overlap terms of one window (get_br, lib:74-79), added EXACTLY (math.fsum)"""
+    import math
+    with np.errstate(invalid="ignore"):
+        d = np.minimum(te, hi) - np.maximum(ts, lo)
+        d = d[d > 0]
+    return math.fsum(d.tolist())
+
+
+def test_bin_unit_events_against_oracle_and_general_kernel(ops):
+    """lr_bin_unit_events (one pass, integer accumulation) on float times: counts exact against the oracle's
+    precompute_events, br_length = the EXACT sum of the reference's per-lineage terms rounded once (bit for bit against
+    math.fsum when every time is >= 1, where each term is a multiple of 2^-52), and against lr_bin_events on the same
+    windows.  Ragged sizes, lineages outside the window, exact bin edges, te <= ts, NaN / inf, unaligned pointers, bin
+    counts on both sides of the replication steps of the LDS histograms."""
+    import torch
+    from oracle import literate_oracle as lo
+    rng = np.random.default_rng(11)
+    for n, W, t0 in [(1, 1, 5.0), (2, 3, 2.0), (63, 24, 1.0), (1000, 24, 10.0), (4097, 128, 3.0), (20001, 300, 7.0),
+                     (30000, 1300, 100.0), (5000, 4000, 1.0), (70000, 33, -20.0)]:
+        ts = rng.uniform(t0 - 3, t0 + W + 2, n)
+        te = ts + rng.exponential(max(W / 6.0, 0.7), n)
+        te[rng.random(n) < 0.15] = t0 + W + 0.5                    # extant, past the last window
+        k = rng.integers(0, n, max(1, n // 10))
+        ts[k], te[k] = np.floor(ts[k]), np.ceil(te[k])              # exact bin edges
+        k = rng.integers(0, n, max(1, n // 25))
+        te[k] = ts[k] - rng.integers(0, 3, len(k)) * rng.random(len(k))     # te <= ts: events, no lineage-time
+        if n > 100:
+            ts[5], te[7], ts[9], te[11], te[13] = np.nan, np.nan, -np.inf, np.inf, -np.inf
+            te[15] = ts[15] = t0 + 4.0                              # born and dead on one edge
+        sp, ex, br = [_np(x) for x in ops.bin_unit_events(ts, te, t0, W)]
+        lo_e = t0 + np.arange(W, dtype=float)
+        gsp, gex, gbr = [_np(x) for x in _general_bin_events(ops, ts, te, lo_e, lo_e + 1.0)]
+        assert np.array_equal(sp, gsp) and np.array_equal(ex, gex), (n, W)
+        assert np.allclose(br, gbr, rtol=1e-13, atol=1e-13), (n, W)
+        exact_terms = t0 >= 1.0
+        for w in (range(W) if W <= 130 else rng.integers(0, W, 40)):
+            with np.errstate(invalid="ignore"):
+                a, b, c = lo.precompute_events(ts, te, lo_e[w], lo_e[w] + 1.0)
+            assert (int(sp[w]), int(ex[w])) == (a, b), (n, W, w)
+            ref = _fsum_br(ts, te, lo_e[w], lo_e[w] + 1.0)
+            if exact_terms:
+                assert br[w] == ref, (n, W, w, br[w], ref)
+            else:
+                assert br[w] == pytest.approx(ref, rel=1e-15, abs=n * 2.0 ** -53)
+        # the routing of ops.bin_events: host unit windows take this kernel (identical bits)
+        r = [_np(x) for x in ops.bin_events(ts, te, lo_e, lo_e + 1.0)]
+        assert np.array_equal(r[0], sp) and np.array_equal(r[1], ex) and np.array_equal(r[2], br, equal_nan=True)
+        if n > 8:
+            tsd = torch.as_tensor(np.concatenate([[0.0], ts])).cuda()[1:]
+            ted = torch.as_tensor(np.concatenate([[0.0], te])).cuda()[1:]
+            u = [_np(x) for x in ops.bin_unit_events(tsd, ted, t0, W)]
+            assert np.array_equal(u[0], sp) and np.array_equal(u[1], ex) and np.array_equal(u[2], br)
+    with pytest.raises(ValueError, match="LR_ERR_T0"):
+        ops.bin_unit_events(np.array([1.0, 2.0]), np.array([2.5, 3.5]), 0.5, 4)
+    with pytest.raises(ValueError, match="LR_ERR_SIZE"):
+        ops.bin_unit_events(np.array([1.0, 2.0]), np.array([2.5, 3.5]), 0.0, 5000)
+
+
+def _big_lineages(n, general, seed):
+    """n synthetic lineages on the device: cfg4's generator tiled (bench.py's abi workload), unsorted"""
+    import torch
+    from literate_amd import synth
+    ts0, te0, _ = synth.make_lineages(100_000, n_bins=128, n_shifts=20, seed=0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    reps = -(-n // len(ts0))
+    ts = torch.as_tensor(ts0, device="cuda").repeat(reps)[:n].contiguous()
+    te = torch.as_tensor(te0, device="cuda").repeat(reps)[:n].contiguous()
+    if general:
+        ts = ts + torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 0.999
+        te = torch.maximum(torch.ceil(te) - 1.0 + 1e-3 + 0.998 * torch.rand(n, generator=g, device="cuda", dtype=torch.float64),
+                           ts + 1e-3)
+    return ts, te
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_streaming_kernels_at_1e7_lineages(ops, general):
+    """The two entry points that stream ts / te from HBM, at the size bench.py's `abi` section times them (1e7 lineages,
+    160 MB per pass), through size-independent properties: additivity over a split, permutation invariance (BIT-exact
+    for the binning: integer accumulation), agreement of the two binning kernels, conservation of lineage-time,
+    likelihood == binned Keiding on the binned statistics, closed form at constant rates, bitwise reproducibility."""
+    import torch
+    n, W, t0 = 10_000_000, 128, 0.0
+    ts, te = _big_lineages(n, general, 99)
+    sp, ex, br = ops.bin_unit_events(ts, te, t0, W)
+    lo_e = torch.arange(W, dtype=torch.float64, device="cuda")
+    gsp, gex, gbr = ops.bin_events(ts, te, lo_e, lo_e + 1.0)
+    assert torch.equal(sp, gsp) and torch.equal(ex, gex)
+    assert torch.allclose(br, gbr, rtol=1e-12, atol=0)
+    # counts against torch's own histogram of the bins
+    assert torch.equal(sp, torch.bincount(torch.floor(ts).long(), minlength=W)[:W])
+    be = (torch.ceil(te) - 1).long()
+    assert torch.equal(ex, torch.bincount(be[be < W], minlength=W)[:W])
+    # lineage-time is conserved: sum over the windows = sum of the clipped durations
+    total = (torch.clamp(te, max=float(W)) - torch.clamp(ts, min=0.0)).clamp(min=0.0).sum()
+    assert float(br.sum()) == pytest.approx(float(total), rel=1e-12)
+    # a split, and a permutation: bit-identical (the accumulation is integer)
+    cut = 3_333_333
+    a = ops.bin_unit_events(ts[:cut], te[:cut], t0, W)
+    b = ops.bin_unit_events(ts[cut:].clone(), te[cut:].clone(), t0, W)
+    assert torch.equal(a[0] + b[0], sp) and torch.equal(a[1] + b[1], ex)
+    assert torch.allclose(a[2] + b[2], br, rtol=1e-15, atol=0)
+    perm = torch.randperm(n, device="cuda")
+    tsp, tep = ts[perm].contiguous(), te[perm].contiguous()
+    p = ops.bin_unit_events(tsp, tep, t0, W)
+    assert torch.equal(p[0], sp) and torch.equal(p[1], ex) and torch.equal(p[2], br)
+    # ---- lr_bd_loglik_batch on the same lineages ----
+    rng = np.random.default_rng(2)
+    C = 12                                                  # two passes: a full group of 8 and a ragged one
+    lam = np.exp(rng.uniform(np.log(.05), np.log(.6), (C, W)))
+    mu = np.exp(rng.uniform(np.log(.02), np.log(.3), (C, W)))
+    full = _np(ops.bd_loglik_batch(ts, te, t0, lam, mu, 2))
+    sp_, ex_, br_ = _np(sp), _np(ex), _np(br)
+    keiding = (np.log(lam) * sp_ - lam * br_).sum(1) + (np.log(mu) * ex_ - mu * br_).sum(1)
+    assert np.allclose(full, keiding, rtol=REL)
+    a = _np(ops.bd_loglik_batch(ts[:cut], te[:cut], t0, lam, mu, 2))
+    b = _np(ops.bd_loglik_batch(ts[cut:].clone(), te[cut:].clone(), t0, lam, mu, 2))
+    assert np.allclose(a + b, full, rtol=1e-11)
+    assert np.allclose(_np(ops.bd_loglik_batch(tsp, tep, t0, lam, mu, 2)), full, rtol=1e-11)
+    assert np.array_equal(_np(ops.bd_loglik_batch(ts, te, t0, lam, mu, 2)), full)
+    solo = _np(ops.bd_loglik_batch(ts, te, t0, lam[5:6], mu[5:6], 2))
+    assert solo[0] == pytest.approx(full[5], rel=1e-11)
+    one = _np(ops.bd_loglik_batch(ts, te, t0, np.full((1, W), .3), np.full((1, W), .2), 2))
+    assert one[0] == pytest.approx(np.log(.3) * sp_.sum() + np.log(.2) * ex_.sum() - .5 * br_.sum(), rel=1e-11)
+    # model 0 carries the data constant sum (U + D) log k (LRF:150-162)
+    m0 = _np(ops.bd_loglik_batch(ts, te, t0, lam[:2], mu[:2], 0, br_))
+    ok = br_ > 0                                            # bins without lineage-time are dropped (LRF:156-160)
+    const = ((sp_ + ex_)[ok] * np.log(br_[ok])).sum()
+    assert np.allclose(m0, keiding[:2] + const, rtol=REL)
+
+
 def _states(G, name):
     KL, KM = G[name + "/state_KL"], G[name + "/state_KM"]
     return (G[name + "/state_L"], G[name + "/state_tL"], KL, G[name + "/state_M"], G[name + "/state_tM"], KM)

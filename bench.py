@@ -93,8 +93,9 @@ def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
     if eng.layout.persistent:
         # persistent engines: groups of up to 14 lineages of one birth bin in 7 slots (lr_pack.hip; a slot = one lineage or a
         # pair through a pair-sum plane): per group and chain PAIR one gather of the birth entry + 7 of the slots' entries,
-        # 16 B each (unit resolution); value and slope entry each on general times
-        lds_bytes_per_eval = (1 + 7) * (16 if unit else 32) / (14 * 2.0)
+        # 16 B each (unit resolution); value and slope entry each on general times.  The speculative kernel with a team
+        # per CHAIN scores ONE chain per gather (the entry's second half is unused): twice the bytes per eval
+        lds_bytes_per_eval = (1 + 7) * (16 if unit else 32) / (14.0 * chains_per_gather(eng))
     else:
         lds_bytes_per_eval = 16 if unit else 32      # launch-based scan: two 8-byte / two 16-byte entries per (lineage, chain)
     evals = float(n_iters) * n_lin * chains
@@ -112,11 +113,17 @@ def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
         # 51 + 16 + 4 (general times) - counted in the ISA of lr_persist4_kernel<136, .> - and a SIMD issues one wave64
         # vector instruction per 4.18 cycles whatever its kind (measured).  The chain steps share the same SIMDs, so the
         # fraction below is the share of the chip's issue rate spent on SCAN-LOOP instructions.
-        instr_per_eval = (38 if unit else 71) / 28.0
+        instr_per_eval = (38 if unit else 71) / (14.0 * chains_per_gather(eng))
         peak = ISSUE_PEAK_LANE_INSTR_PER_S / instr_per_eval
         out["issue"] = dict(vector_instr_per_eval=instr_per_eval, cycles_per_wave_instr=ISSUE_CYCLES, peak_evals_per_s=peak,
                             frac=out["evals_per_s"] / peak)
     return out
+
+
+def chains_per_gather(eng):
+    """chains one 16-byte table gather of the persistent scans serves: a pair - except under the speculative kernel with
+    a team per chain (lr_spec_kernel<..., MODE 1|2|3>), whose table entries are (chain, unused)"""
+    return 1 if (int(eng.layout.persistent) == 3 and int(eng.layout.spec_chains_per_team) == 1) else 2
 
 
 def eval_cost(eng):
@@ -129,6 +136,12 @@ def eval_cost(eng):
     if not eng.layout.persistent:
         return dict(gathers_per_eval=2.0, fp64_ops_per_eval=3.0 if unit else 4.0, aggregation="none: launch-based scan, "
                     "two table gathers per (lineage, chain)")
+    cpg = chains_per_gather(eng)
+    if cpg == 1:
+        # a team per chain: the same 8 gathers serve 14 lineages of ONE chain; half the adds
+        return dict(gathers_per_eval=(8 if unit else 16) / 14.0, fp64_ops_per_eval=(10 if unit else 22) / 14.0,
+                    aggregation="as the pair form (run-length on the birth side, pairs on the death side), one chain per "
+                                "gather: a team of blocks per chain, table entries (chain, unused)")
     if unit:
         # 8 ds_read_b128 serve 14 lineages x 2 chains; 6 + 6 adds, 2 fma, 2 accumulates, 1 conversion of the count
         return dict(gathers_per_eval=8 / 28.0, fp64_ops_per_eval=17 / 28.0,
@@ -157,6 +170,7 @@ def side_config(name, steps, warmup):
                                                     "DDRate sampler -m_birth 2 -m_death 2" if model == "dd" else "model_BDI %d" % model),
                lineages=len(ts), chains=chains, steps=steps, iters_per_s_per_chain=steps / (ms * 1e-3))
     out.update(kernel_figures(eng, len(ts), chains, steps, ms))
+    out["chains_per_gather"] = chains_per_gather(eng)
     eng.close()
     return out
 
@@ -733,8 +747,8 @@ def main():
             launches = -(-args.steps // 4096)
             n_ev = args.steps / launches                            # iterations per launch (average)
             kernel_ms = region_kernel_ms / launches
-            passes = n_ev * ((chains + 1) // 2)                     # lineage passes: one per chain pair per iteration
-            cb_pass = 2
+            cb_pass = chains_per_gather(eng)                        # chains one pass over the packed lineages scores
+            passes = n_ev * (-(-chains // cb_pass))                 # lineage passes per launch
         else:
             # launch-based engine: the lineage scan runs as the scan blocks of lr_fused_iter_kernel, which HIP
             # events cannot bracket launch by launch under graph replay; the SAME block body is timed live as the
@@ -761,7 +775,7 @@ def main():
         roof["hbm"]["copy_GBs_measured"] = 10 * 2.0 * src.numel() / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
         del src, dst
         roof["engine"] = {"persistent": fig["persistent"], "threads_per_block": fig["threads_per_block"],
-                          "chains_per_block": {1: 2, 2: 4, 3: 2}[int(eng.layout.persistent)] if persistent else cb,
+                          "chains_per_block": {1: 2, 2: 4, 3: chains_per_gather(eng)}[int(eng.layout.persistent)] if persistent else cb,
                           "team_blocks": int(eng.layout.team_blocks), "table_mode": int(eng.layout.table_mode),
                           "unit_resolution_tables": unit, "us_per_iter_device": fig["us_per_iter"]}
         out = {
@@ -834,7 +848,7 @@ def main():
                     "workload": g["workload"], "value": g["evals_per_s"], "unit": out["unit"], "steps": g["steps"],
                     "us_per_iter_device": g["us_per_iter"], "timing": "HIP events around one 2000-iteration launch",
                     "roofline": roofline_object(g, g["kernel"], ms, g["steps"], g["lineages"], g["chains"],
-                                                g["steps"] * ((g["chains"] + 1) // 2), 2)}
+                                                g["steps"] * (-(-g["chains"] // g["chains_per_gather"])), g["chains_per_gather"])}
         if not args.no_cpu_baseline:
             if model == "dd":
                 out["cpu_baseline"] = cpu_baseline_dd(ts, te, budget_s=15.0)

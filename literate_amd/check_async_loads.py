@@ -13,8 +13,13 @@ The walk is a depth-first search over (instruction, loads issued since) states a
 import re
 import sys
 
-# instructions that increment vmcnt on gfx9 (loads, and stores / atomics without return count in vmcnt as well)
-_VMEM = re.compile(r"^(global_|flat_|buffer_|scratch_|tbuffer_|image_)")
+# Instructions that increment vmcnt on gfx9 AND complete in issue order with the tracked global load (loads, and stores /
+# atomics without return, of the global / buffer / scratch paths).  FLAT operations also use vmcnt but may be served by
+# LDS and then complete out of order with global ones (which is why LLVM forces vmcnt(0) while one is pending): they are
+# NOT counted as "behind" the tracked load.  That is the safe side: with `behind` in-order operations issued after the
+# load, a wait that leaves at most N <= behind operations outstanding cannot leave the load outstanding, whatever else
+# (a flat operation) is in the counter as well.
+_VMEM = re.compile(r"^(global_|buffer_|scratch_|tbuffer_|image_)")
 _LOAD = re.compile(r"\s+global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[\d+:\d+\]")
 
 

@@ -41,6 +41,8 @@ struct lr_engine {
     long long n8;             // 16-byte groups of packed lineage indices
     long long n8_alloc;       // ... allocated (zero-filled behind the data)
     lr_p4_shares p4;          // per scanner wave: trips more (+) or fewer (-) than the equal share (four-chain kernel)
+    bool p4_help;             // four-chain kernel: the form with helper waves - latched by lr_set_shares (init / restore), so
+                              // that the form, its shares and the sums carried between launches belong together for a whole run
     hipEvent_t fork;
     hipEvent_t ev0, ev1;      // timing events of lr_mcmc_time_steps / lr_mcmc_time_scan, created once
 };
@@ -88,9 +90,10 @@ static inline long long lr_groups_alloc(long long n_lineages) {
 #define LR_SPEC_TIMEOUT_TICKS 200000000ull   /* 2 s of the 100 MHz wall clock */
 
 // Four-chain kernel: helper waves (lr_persist4_kernel's HELP) under the RJ sampler at unit resolution; LR_P4_HELP = 0: the
-// form with fourteen scanner waves (A/B runs)
-static inline bool lr_p4_help(const lr_engine* e) {
-    const char* env = getenv("LR_P4_HELP");      // (read per call: a test process runs both forms)
+// form with fourteen scanner waves (A/B runs).  Evaluated ONLY by lr_set_shares, i.e. at lr_mcmc_init / lr_mcmc_restore
+// (a test process that runs both forms re-initialises between them); everything else reads e->p4_help.
+static inline bool lr_p4_help_choice(const lr_engine* e) {
+    const char* env = getenv("LR_P4_HELP");
     if (e->lay.persistent != 2 || e->plan.unit == LR_TAB_PAIRGEN || e->cfg.sampler != 0 || e->plan.H > 264) return false;
     return env ? atoi(env) != 0 : true;
 }

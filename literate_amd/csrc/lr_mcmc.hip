@@ -1198,6 +1198,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->n8_alloc = lr_groups_alloc(cfg->n_lineages);
     for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
     e->p4.n_slots = 8;
+    e->p4_help = lr_p4_help_choice(e);                  // (lr_mcmc_describe before init; latched again by lr_set_shares)
     e->fork = nullptr;
     e->ev0 = e->ev1 = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
@@ -1521,7 +1522,7 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);   \
         else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);      \
         else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);        \
-        else if (lr_p4_help(e)) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
+        else if (e->p4_help) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
         else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);                  \
     } else if (wide) {                                                                                                        \
         hipLaunchKernelGGL((lr_persist_kernel<HH, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); \
@@ -1618,7 +1619,7 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
                      lr_spec_mode(e));
         else if (e->lay.persistent == 2)
             snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s, %s, %s>", e->plan.H, gen, e->cfg.sampler != 0 ? "true" : "false",
-                     lr_p4_help(e) ? "true" : "false");
+                     e->p4_help ? "true" : "false");
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
     } else if (e->part[0].pipelined) {
         snprintf(buf, (size_t)n, "lr_fused_iter_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");

@@ -212,7 +212,8 @@ static void lr_set_shares(lr_engine* e) {
     static const int env2 = lr_env_int_pack("LR_P2_SHARE", 0);   // two-chain kernel (no gain measured: off)
     for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
     e->p4.help_trips = 0;
-    if (e->lay.persistent == 2 && lr_p4_help(e)) {
+    e->p4_help = lr_p4_help_choice(e);
+    if (e->lay.persistent == 2 && e->p4_help) {
         // a helper wave is idle until its stepper's hand-over arrives (~1.2 us into a phase, a scan trip takes ~0.3 us):
         // it scores the first groups meanwhile (the 128 helper lanes stride over [0, 128 trips), the scanners over the rest).
         // With t trips per scanner lane behind that share (groups = 128 h + 768 t) the two sides end together at about
@@ -229,7 +230,7 @@ static void lr_set_shares(lr_engine* e) {
     if (e->lay.persistent == 3) {
         e->p4.n_slots = 8;       // speculative kernel: plain layout, every scanner wave strides over its block's slice
     } else if (e->lay.persistent == 2) {
-        e->p4.n_slots = lr_p4_help(e) ? 12 : 14;      // (with helper waves: twelve scanners, equal shares)
+        e->p4.n_slots = e->p4_help ? 12 : 14;      // (with helper waves: twelve scanners, equal shares)
         // (with 14-lineage groups a scan is ~8 trips of cfg4 and equal shares measure as fast as any: the default is
         // equal; the knob stays for experiments)
         int base[7] = {0, 0, 0, 0, 0, 0, 0};

@@ -463,6 +463,7 @@ __device__ __forceinline__ void lr_spec_deliver(lr_spec_lds<H, T / LR_WAVE, GENE
                     if (rj) {
                         ok = lr_mh_accept(gibbs, invalid, lik_sum, lr_bcast(v, LR_SET_CONST), likA, priorP, priorA, hasting, log_u, &lik[cc]);
                         lik_p[cc] = invalid ? -INFINITY : lik[cc];
+                        lr_warn_kcap((unsigned int*)ctx.x.status + 1, invalid, lane);   // (the warning word sits behind the status word) P is the chain's own pending proposal, decided here
                     } else {
                         lik[cc] = lik_sum;
                         ok = lr_dd_accept(lik[cc], likA, priorP, priorA, hasting, log_u, it);

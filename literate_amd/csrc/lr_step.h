@@ -408,6 +408,15 @@ struct lr_rj_prop {
 };
 
 // The Metropolis-Hastings rule of LRF:305-313 for a pending proposal whose lineage scan returned lik_sum.
+// values of a proposal's `invalid` flag (any non-zero value rejects it, LRF:290-292)
+#define LR_INVALID_GUARD 1   /* fails the LRF:290 guard                                                 */
+#define LR_INVALID_KCAP 3    /* an add-shift from K = LR_KMAX rates: the device cap, not the reference's */
+// called where a proposal is decided: the chain really proposed an add-shift at the cap and loses it for that reason
+__device__ __forceinline__ void lr_warn_kcap(unsigned int* warn, int invalid, int lane) {
+    if (invalid == LR_INVALID_KCAP && lane == 0)
+        __hip_atomic_fetch_or(warn, (unsigned int)LR_WARN_KCAP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ bool lr_mh_accept(int gibbs, int invalid, double lik_sum, double constP, double likA,
                                              double priorP, double priorA, double hasting, double log_u, double* lik) {
     *lik = gibbs ? likA : lik_sum + constP;
@@ -695,11 +704,11 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
         const lr_u2 q2 = pre ? lr_u2{pre->q2_a, pre->q2_b} : lr_u2{lr_bcast(ud.a, LR_UD_LANE + 3), lr_bcast(ud.b, LR_UD_LANE + 3)};
         if (q.b > 0.5) {
             if (K >= LR_KMAX) {
-                // device cap on the number of rates; the reference has none (LRF:29-47): the proposal is rejected and
-                // the engine's warning word says so (the speculative kernel also raises it for a candidate that is
-                // built from a K = LR_KMAX proposal and never selected: the chain is at the cap either way)
-                invalid = 1;
-                if (lane == 0) __hip_atomic_fetch_or(a.warn, (unsigned int)LR_WARN_KCAP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // device cap on the number of rates; the reference has none (LRF:29-47): the proposal is invalid FOR THAT
+                // REASON (LR_INVALID_KCAP) and the engine's warning word is raised when it is DECIDED (lr_warn_kcap at the
+                // Metropolis-Hastings test) - not here, where the speculative kernel also builds candidates from
+                // proposals that are then rejected and never become the chain's pending proposal
+                invalid = LR_INVALID_KCAP;
             } else {
                 const int ind = min((int)(q2.a * K), K - 1);
                 const double delta = q2.b * (lr_bcast(T, ind + 1) - lr_bcast(T, ind));
@@ -771,7 +780,7 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
         const double nL = lr_dpp_zero<0x130 /* wave_shl:1 */, 0xf, 0xf>(ptL);   // lane l <- element l+1
         const double nM = lr_dpp_zero<0x130, 0xf, 0xf>(ptM);
         const double dmin = fmin(lane < PKL ? fabs(nL - ptL) : 1e300, lane < PKM ? fabs(nM - ptM) : 1e300);
-        if (__ballot(dmin <= LR_MIN_ALLOWED_T)) invalid = 1;       // min <= 1  <=>  any <= 1: one compare, no reduction
+        if (__ballot(dmin <= LR_MIN_ALLOWED_T)) invalid |= LR_INVALID_GUARD;      // min <= 1  <=>  any <= 1: one compare, no reduction
     }
     if (!invalid) {
         // Gamma(2, g) log-densities of all rates of both processes in one reduction (LRF:296)
@@ -864,6 +873,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
         const bool ok = lr_mh_accept(gibbs, invalid, lik_sum, constP, likA, priorP, priorA, lr_bcast(sc, LR_S_HASTING),
                                      lr_bcast(sc, LR_S_LOG_U), &lik);
         lik_p = invalid ? -INFINITY : lik;
+        lr_warn_kcap(a.warn, invalid, lane);
         if (ok) {
             s.L = st.pL, s.M = st.pM, s.tL = st.ptL, s.tM = st.ptM, s.eL = st.peL, s.eM = st.peM;
             s.KL = lr_bcast_i(isc, LR_I_PKL), s.KM = lr_bcast_i(isc, LR_I_PKM);

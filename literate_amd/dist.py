@@ -41,3 +41,13 @@ def gather_traces(local, total_chains=None, dst=0, group=None):
         return None
     parts = [bufs[r][:, :shard_chains(total_chains, world, r)[1]].to(device) for r in range(world)]
     return torch.cat(parts, 1)
+
+
+def agree_status(status, device, group=None):
+    """The largest engine status word over the ranks (0 = every rank is fine).  A rank whose team exchange timed out must
+    not leave the others blocked in the next collective: every rank learns of it here and raises alike."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(status)
+    t = torch.tensor([int(status)], dtype=torch.int32, device="cpu" if dist.get_backend(group) == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())

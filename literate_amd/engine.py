@@ -351,7 +351,14 @@ class TraceStreamer:
 
     The trace keeps every sampled row resident (slot = sample number), so a window's rows are not touched by later
     windows; the state blocks are copied device-to-device at the window's end on the main stream (a later launch
-    rewrites them)."""
+    rewrites them).
+
+    Co-residency: the copies and the RCCL gather of window k run on the side stream WHILE window k + 1's kernel is
+    resident.  The speculative kernel's teams of blocks exchange partial sums and need every block of the launch
+    resident at once (the planner never plans more blocks than the device has CUs; an exchange that stalls for 2 s
+    raises the status word): RCCL's kernels take a few CUs' worth of workgroup slots beside it, not whole CUs, and the
+    planner's blocks leave room for them (one 512-thread block per CU).  A device shared with OTHER processes gives no
+    such guarantee: set LR_SHARED_DEVICE=1 there (no teams)."""
 
     def __init__(self, eng, total_chains=None, n_local=None, gather=True):
         """gather=False: every rank keeps (and writes) the rows of its own chains (the DDRate / trend_rate CLIs)."""
@@ -385,9 +392,14 @@ class TraceStreamer:
         s0, s1, its, S, I, st, ev = self.pending.pop(0)
         with torch.cuda.device(eng.device), torch.cuda.stream(self.side):
             self.side.wait_event(ev)
-            status = st.view(torch.int32).cpu()
-            if int(status[0]) != 0:
-                raise _hip.HipLibraryError("engine status %d: a team exchange timed out, the run is void" % int(status[0]))
+            status = int(st.view(torch.int32).cpu()[0])
+            if self.gather:
+                # a collective of its own BEFORE the gather: every rank sees the worst status and raises alike - a rank
+                # that raised alone would leave the others blocked in dist.gather for good
+                status = lrd.agree_status(status, eng.device)
+            if status != 0:
+                raise _hip.HipLibraryError("engine status %d on at least one rank: a team exchange timed out, the run "
+                                           "is void" % status)
             local = eng.trace[s0:s1][:, :self.n_local].contiguous()
             # (a window without a sample is empty on every rank alike: no collective for it)
             rows = lrd.gather_traces(local, self.total) if (self.gather and s1 > s0) else local

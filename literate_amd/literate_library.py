@@ -35,6 +35,7 @@ only_dead = 0
 start_time = end_time = 0.0
 _t0 = 0.0
 _ts_dev = _te_dev = None
+_sessions = {}          # (states per call, model) -> ops.LoglikSession on the bound lineages
 
 
 def _host(x):
@@ -47,6 +48,7 @@ def bind_lineages(ts_, te_, model=0):
     global ts, te, sp_events_bin, ex_events_bin, br_length_bin, ex_events_bin_dead, br_length_bin_dead
     global n_bins, model_BDI, only_dead, start_time, end_time, _t0, _ts_dev, _te_dev
     torch = ops._torch()
+    _sessions.clear()
     ts, te = np.asarray(ts_, dtype=float), np.asarray(te_, dtype=float)
     _ts_dev, _te_dev = ops._dev(ts, torch.float64), ops._dev(te, torch.float64)
     start_time, end_time = float(np.min(ts)), float(np.max(te))
@@ -116,9 +118,17 @@ def _loglik(L_acc_vec, M_acc_vec, model):
     if L.shape[-1] != n_bins or M.shape[-1] != n_bins:
         print(L.shape[-1], M.shape[-1], len(sp_events_bin))     # the reference's diagnostic (LRF:145-147)
         raise SystemExit
-    out = ops.bd_loglik_batch(_ts_dev, _te_dev, _t0, L, M, model, br_length_bin, end_time)
-    out = _host(out)
-    return np.float64(out[0]) if L.ndim == 1 else out
+    # one prepared session per (states per call, model): the per-iteration call of runMCMC (LRF:305-308) then costs one
+    # upload of the rates, the launches, one read-back and one synchronisation - nothing is allocated or re-uploaded
+    C = 1 if L.ndim == 1 else L.shape[0]
+    key = (C, model, id(br_length_bin), float(end_time))
+    ses = _sessions.get(key)
+    if ses is None:
+        if len(_sessions) >= 8:
+            _sessions.clear()
+        ses = _sessions[key] = ops.LoglikSession(_ts_dev, _te_dev, _t0, n_bins, C, model, br_length_bin, end_time)
+    out = ses(L, M)
+    return np.float64(out[0]) if L.ndim == 1 else out.copy()
 
 
 def BD_lik_Keiding(L_acc_vec, M_acc_vec):

@@ -146,6 +146,51 @@ def bd_loglik_batch(ts, te, t0, lam_bins, mu_bins, model=2, br_length=None, end_
     return out
 
 
+class LoglikSession:
+    """The calc_likelihood seam (LRF:305-308: one call per MCMC iteration) with everything that does not change
+    between calls prepared once: lineages, br_length and workspace resident in HBM, a pinned staging buffer for the
+    per-bin rates of `n_states` states and one for the result.  A call is then one host-to-device copy, the three
+    launches of lr_bd_loglik_batch, one device-to-host copy and one stream synchronisation."""
+
+    def __init__(self, ts, te, t0, n_bins, n_states, model=2, br_length=None, end_time=0.0):
+        torch = _torch()
+        self.lib = _hip.load()
+        self.ts = _dev(ts, torch.float64)
+        self.te = _dev(te, torch.float64, self.ts.device)
+        dev = self.ts.device
+        self.n, self.n_bins, self.C, self.model = self.ts.numel(), int(n_bins), int(n_states), int(model)
+        self.br = None if br_length is None else _dev(br_length, torch.float64, dev)
+        self.rates_host = torch.empty((2, self.C, self.n_bins), dtype=torch.float64).pin_memory()
+        self.rates_np = self.rates_host.numpy()
+        self.rates = torch.empty_like(self.rates_host, device=dev)
+        self.out = torch.empty(self.C, dtype=torch.float64, device=dev)
+        self.out_host = torch.empty(self.C, dtype=torch.float64).pin_memory()
+        self.out_np = self.out_host.numpy()
+        nbytes = self.lib.lr_bd_loglik_workspace_bytes(self.n, self.n_bins, self.C, self.model)
+        if nbytes < 0:
+            _hip.check(int(nbytes), "lr_bd_loglik_workspace_bytes")
+        self.ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)   # the session's own: nothing else scribbles on it
+        self.stream = torch.cuda.current_stream(dev)
+        lam, mu = self.rates[0], self.rates[1]
+        self.args = (_hip.ptr(self.ts), _hip.ptr(self.te), self.n, float(t0), self.n_bins, _hip.ptr(lam), _hip.ptr(mu),
+                     self.C, self.model, _hip.ptr(self.br), float(end_time), _hip.ptr(self.out), _hip.ptr(self.ws),
+                     self.ws.numel(), _hip.c_vp(self.stream.cuda_stream))
+
+    def __call__(self, L, M):
+        """L, M: [n_states, n_bins] (or [n_bins] when n_states == 1) host arrays -> numpy [n_states] (a view of the
+        session's pinned result buffer: valid until the next call)."""
+        torch = _torch()
+        self.rates_np[0] = L
+        self.rates_np[1] = M
+        with torch.cuda.stream(self.stream):
+            self.rates.copy_(self.rates_host, non_blocking=True)
+            rc = self.lib.lr_bd_loglik_batch(*self.args)
+            _hip.check(rc, "lr_bd_loglik_batch")
+            self.out_host.copy_(self.out, non_blocking=True)
+        self.stream.synchronize()
+        return self.out_np
+
+
 def rj_propose_score(rates, times, K, move, index, draws, mult_d=1.1):
     """Batched explicit-draw proposal scorer (LRF:29-69, 165-176).  Returns
     (rates'[C,kmax], times'[C,kmax+1], K'[C], score[C])."""

@@ -57,8 +57,11 @@ def test_the_checker_sees_a_violation(tmp_path):
     bad3 = good.replace("	v_add_f64 v[10:11], v[12:13], v[14:15]\n", "	s_waitcnt vmcnt(1)\n	v_mov_b32_e32 v21, v7\n")
     good2 = good.replace("	v_add_f64 v[10:11], v[12:13], v[14:15]\n",
                          "	global_load_dwordx4 v[30:33], v8, s[4:5]\n	s_waitcnt vmcnt(1)\n	v_mov_b32_e32 v21, v7\n")
+    # a FLAT operation behind the load may complete out of order with it (it can be served by LDS): it must not count as
+    # an operation "behind" the load, so vmcnt(1) does not land the load here - the same lines with a global load do
+    bad4 = good2.replace("global_load_dwordx4 v[30:33], v8, s[4:5]", "flat_load_dwordx4 v[30:33], v[40:41]")
     for name, text, want, n_want in (("good", good, 0, 1), ("bad", bad, 1, 1), ("bad2", bad2, 1, 1), ("bad3", bad3, 1, 1),
-                                     ("good2", good2, 0, 2)):
+                                     ("good2", good2, 0, 2), ("bad4", bad4, 1, 1)):
         p = tmp_path / (name + ".s")
         p.write_text(text)
         n, v = check_async_loads.check([str(p)], verbose=False)

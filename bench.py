@@ -138,8 +138,9 @@ def eval_cost(eng):
                     "two table gathers per (lineage, chain)")
     cpg = chains_per_gather(eng)
     if cpg == 1:
-        # a team per chain: the same 8 gathers serve 14 lineages of ONE chain; half the adds
-        return dict(gathers_per_eval=(8 if unit else 16) / 14.0, fp64_ops_per_eval=(10 if unit else 22) / 14.0,
+        # a team per chain: the same 8 gathers - and the same pair arithmetic, its second half on zeros - serve 14
+        # lineages of ONE chain
+        return dict(gathers_per_eval=(8 if unit else 16) / 14.0, fp64_ops_per_eval=(17 if unit else 40) / 14.0,
                     aggregation="as the pair form (run-length on the birth side, pairs on the death side), one chain per "
                                 "gather: a team of blocks per chain, table entries (chain, unused)")
     if unit:

@@ -45,8 +45,8 @@ class ChainEngine:
         self.end_time = float(self.te.max().item())
         if stats is None:
             t0, n_bins = int(self.start_time), int(self.end_time) - int(self.start_time)
-            lo = torch.arange(t0, t0 + n_bins, dtype=torch.float64, device=self.device)
-            self.sp_events, self.ex_events, self.br_length = ops.bin_events(self.ts, self.te, lo, lo + 1.0)
+            # the unit windows [i, i + 1], i in range(int(min ts), int(max te)) (LRF:519-523): one pass over the lineages
+            self.sp_events, self.ex_events, self.br_length = ops.bin_unit_events(self.ts, self.te, float(t0), n_bins)
         else:
             t0, n_bins, br = stats
             self.br_length = ops._dev(br, torch.float64, self.device)

@@ -369,7 +369,9 @@ def test_long_inputs_and_few_chain_shards_keep_parity(engine, C, kw):
 
 @pytest.mark.parametrize("engine,model,general", [("spec", 0, False), ("persistent4", 0, False), ("persistent2", 2, False),
                                                   ("spec", 3, False), ("persistent4", 3, False), ("spec", 0, True),
-                                                  ("persistent4", 0, True), ("spec", 3, True)])
+                                                  ("persistent4", 0, True), ("spec", 3, True),
+                                                  ("persistent4", 1, True), ("persistent4", 2, True),
+                                                  ("persistent4", 3, True), ("spec", 1, True)])
 def test_packing_of_unsorted_sparse_and_extant_lineages(engine, model, general):
     """The pair-slot packing (csrc/lr_pack.hip) on input it was not designed for: lineages in RANDOM order (runs of one or
     two lineages of a birth bin, death bins far apart or decreasing: singles, short stretches, groups of one slot), many
@@ -968,3 +970,123 @@ def test_kmax_cap_raises_the_warning_word():
         eng.steps(50)
         assert eng.warnings() == 0
         eng.close()
+
+
+def _off_year_grid(ts, te, rng, exact=True):
+    """Continuous times from year-resolution ones: births anywhere inside their year, deaths later in theirs; the first
+    births and the extant lineages stay where they are, so ORIGIN / PRESENT (lib:196-229) stay integer / unchanged.
+    exact: jitter on the 2^-32 grid, where the persistent engines' fixed-point fractions are exact."""
+    grid = (lambda x: np.round(x * 2.0 ** 32) / 2.0 ** 32) if exact else (lambda x: x)
+    n = len(ts)
+    ts2 = ts + grid(rng.uniform(0, 0.999, n))
+    ts2[ts == ts.min()] = ts.min()
+    te2 = np.maximum(te + grid(rng.uniform(0, 0.4, n)), ts2 + 0.0078125)
+    te2[te >= te.max()] = te.max()
+    return ts2, te2
+
+
+@pytest.mark.parametrize("kind,engine", [("dd", "auto"), ("dd", "persistent4"), ("dd", "spec"), ("trend", "auto"),
+                                         ("trend", "persistent4"), ("trend", "spec")])
+def test_parametric_samplers_on_continuous_times(G, golden_dir, kind, engine):
+    """`DDRate.py -d <continuous times>` / trend_rate.py select the PARAM x GENERAL instantiations - lr_persist4_kernel<H,
+    true, true, .>, lr_spec_kernel<H, T, false, true, .> - which no unit-resolution test reaches (pair-general table
+    layout under a parametric sampler).  metal_bands moved off the year grid: every sampled log row against the oracle loop
+    run on statistics binned from the SAME jittered data, and every chain's accepted parameter vector re-evaluated by
+    lr_dd_rates / lr_trend_rates + lr_bd_loglik_batch (other kernels, fp64 fractions from the raw times)."""
+    from literate_amd import ops
+    from literate_amd.ddrate import DDRateEngine
+    from literate_amd.trendrate import TrendRateEngine
+    from oracle import dd_mcmc_oracle as ddo
+    from oracle import literate_oracle as lo
+    from oracle import trend_mcmc_oracle as tro
+    R = np.load(os.path.join(golden_dir, "ratemaps.npz"))
+    rng = np.random.default_rng(17)
+    ts, te = _off_year_grid(G["metal_bands/lib_ts"], G["metal_bands/lib_te"], rng)
+    origin, present = float(ts.min()), float(te.max())
+    o, p, nsp, nex, dt, nb, t_range = lo.create_bins(origin, present, ts, te, 0)
+    n_it, s, seed, C, off = 450, 3, 77, 9, 2
+    kw = dict(seed=seed, s_freq=s, n_trace_slots=n_it // s, chain_offset=off, engine=engine)
+    if kind == "dd":
+        eng = DDRateEngine(ts, te, origin, present, C, m_birth=2, m_death=2, **kw)
+    else:
+        assert len(R["TREND"]) == nb
+        eng = TrendRateEngine(ts, te, origin, present, R["TREND"], C, **kw)
+    assert not eng.unit_resolution
+    name = eng.kernel_name()
+    if engine == "persistent4":
+        assert eng.layout.persistent == 2 and name.startswith("lr_persist4_kernel<") and ", true, true, " in name, name
+    elif engine == "spec":
+        assert eng.layout.persistent == 3 and name.startswith("lr_spec_kernel<") and ", false, true, " in name, name
+    if eng.layout.persistent:
+        assert eng.layout.table_mode == 2
+    assert np.array_equal(eng.n_spec, nsp) and np.array_equal(eng.n_exti, nex) and np.allclose(eng.DT, dt, rtol=1e-13)
+    eng.init(); eng.steps(200); eng.steps(n_it - 200)
+    with np.errstate(all="ignore"):
+        emp = (nsp / dt, nex / dt)
+    moved = 0
+    for c in (0, 4, 8):
+        if kind == "dd":
+            ref = ddo.run_dd_mcmc(nsp, nex, dt, t_range, o, p, 2, 2, ddo.PhiloxDraws(seed, off + c), n_it, s, emp=emp)
+        else:
+            ref = tro.run_trend_mcmc(nsp, nex, dt, R["TREND"], tro.PhiloxDraws(seed, off + c), n_it, s, False, False, emp=emp)
+        got = eng.log_rows(c, emp=emp)
+        assert len(got) == len(ref) == n_it // s
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert g[0] == r[0]
+            assert np.allclose(g[1:-3], r[1:-3], rtol=1e-9, atol=1e-9, equal_nan=True), (c, i, g[:14], r[:14])
+            assert np.allclose(g[-3:], r[-3:], rtol=1e-7, atol=1e-9, equal_nan=True)
+        moved += len(set(np.round(np.array(ref)[:, 2], 6)))
+    assert moved > 3 * 20
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it)
+    n_par = 8 if kind == "dd" else 6
+    args = np.stack([snap["L"][c][:n_par] for c in range(C)])
+    if kind == "dd":
+        b, d, _, _ = ops.dd_rates(args, dt, 2, 2)
+    else:
+        b, d = ops.trend_rates(args, R["TREND"], False, False)
+    lik = ops.bd_loglik_batch(ts, te, o, b, d, 2).cpu().numpy()
+    assert np.allclose(lik, snap["likA"], rtol=1e-9), (lik, snap["likA"])
+    eng.close()
+
+
+@pytest.mark.parametrize("model", [1, 2, 3])
+def test_cfg4_general_times_other_models_under_the_four_chain_kernel(model):
+    """lr_persist4_kernel<136, true, false, false> (pair-general layout) under models 1, 2 and 3 at the bench size - 1024
+    chains x 100k lineages on ARBITRARY fp64 times (bench.py's cfg4_general; model 0 is
+    test_general_times_off_grid_against_the_oracle_at_size): the log-likelihood EVERY chain carries for its accepted state
+    against (i) the oracle's fp64 per-lineage evaluation of that state on the raw times (models 1, 2; BDIx:124-146 form),
+    (ii) the oracle's binned calc_likelihood on statistics binned from the same times - model 3 with its te < end_time
+    death half (LRF:141-142, 529-546) -, (iii) lr_bd_loglik_batch (another kernel, fp64 fractions)."""
+    from literate_amd import ops, synth
+    from literate_amd.engine import ChainEngine
+    from oracle import literate_oracle as lo
+    rng = np.random.default_rng(7)
+    n_lin, C, n_it = 100_000, 1024, 120
+    ts, te, _ = synth.make_lineages(n_lin, n_bins=128, n_shifts=20, seed=0)
+    ts = ts + rng.uniform(0.0, 1.0, n_lin) * 0.999
+    te = np.maximum(np.ceil(te) - 1.0 + rng.uniform(1e-3, 0.999, n_lin), ts + 1e-3)
+    eng = ChainEngine(ts, te, C, model=model, seed=2026, s_freq=10, n_trace_slots=n_it // 10, engine="persistent4")
+    assert not eng.unit_resolution and eng.layout.table_mode == 2 and eng.layout.persistent == 2
+    assert eng.kernel_name().startswith("lr_persist4_kernel<") and ", true, false, " in eng.kernel_name()
+    eng.init(); eng.steps(n_it // 2); eng.steps(n_it - n_it // 2)
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it) and np.all(snap["accepted"] > 0) and np.all(np.isfinite(snap["likA"]))
+    t0, sp, ex, br = lo.bin_events_cli(ts, te)
+    stats = dict(sp=sp, ex=ex, br=br)
+    if model == 3:
+        stats["ex_dead"], stats["br_dead"] = lo.bin_events_dead(ts, te, te.max())
+    lam, mu = _accepted_rates(snap, eng.n_bins, C)
+    lik = ops.bd_loglik_batch(eng.ts, eng.te, eng.t0, lam, mu, model, br_length=br, end_time=eng.end_time).cpu().numpy()
+    assert np.allclose(lik, snap["likA"], rtol=1e-9)
+    pre = lo.lineage_bins(ts, te, float(t0), eng.n_bins)
+    worst = 0.0
+    for c in range(C):
+        with np.errstate(all="ignore"):
+            ref = lo.calc_likelihood(model, lam[c], mu[c], stats)
+        worst = max(worst, abs(snap["likA"][c] - ref) / abs(ref))
+        if model != 3 and c % 8 == 0:
+            ref = lo.per_lineage_loglik(ts, te, float(t0), lam[c], mu[c], model, br, pre=pre)
+            worst = max(worst, abs(snap["likA"][c] - ref) / abs(ref))
+    assert worst < 1e-9, worst
+    eng.close()

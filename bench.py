@@ -552,10 +552,15 @@ def abi_seam():
                 lo.calc_likelihood(model, L1, M1, stats)
         out[name]["numpy_binned_us_per_call"] = (time.perf_counter() - t) / 5000 * 1e6
         out[name]["seam_over_numpy_at_1_state"] = out[name]["us_per_call_1_state"] / out[name]["numpy_binned_us_per_call"]
-        out[name]["states_per_call_to_break_even"] = None
-    out["note"] = ("one state per call is launch-latency bound (3 kernels + sync + read-back) and slower than the reference's "
-                   "24..32-element numpy expression; the seam pays off when states are batched per call (chains, or the "
-                   "fused engine lr_mcmc_steps, which keeps the whole loop on the device)")
+        # cost(C states per call) ~ a + b (C - 1) from the two measured points, numpy = n C: equal at C = (a - b) / (n - b)
+        a, n_us = out[name]["us_per_call_1_state"], out[name]["numpy_binned_us_per_call"]
+        b = (out[name]["us_per_call_1024_states"] - a) / 1023.0
+        out[name]["states_per_call_to_break_even"] = (a - b) / (n_us - b) if n_us > b else None
+    out["note"] = ("one state per call is latency bound (one upload, 3 launches, one read-back, one synchronisation: "
+                   "literate_amd.ops.LoglikSession) and several times slower than the reference's 24..32-element numpy "
+                   "expression on binned statistics; swapping only the operator pays off from states_per_call_to_break_even "
+                   "states per call (chains evaluated together) - a maintainer who wants the speed binds lr_mcmc_steps, "
+                   "which keeps the whole loop on the device")
     return out
 
 
@@ -653,7 +658,11 @@ def main():
         if world > 1:
             os.environ.setdefault("LR_SHARED_DEVICE", "1")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # a process group whenever a launcher started us (RANK set) - also for ONE rank: `torch.distributed.run
+    # --nproc-per-node 1 bench.py --gpus 1` then runs the whole RCCL path (communicator, barrier, the gather of the
+    # sampled rows on the device) on the one GPU; plain `python bench.py` has no group and no collective
+    dist_on = world > 1 or "RANK" in os.environ
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -666,7 +675,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -705,11 +714,11 @@ def main():
             # the log-posterior rows sampled in iterations [a, b) gathered to rank 0 over RCCL / xGMI
             # (literate_amd/dist.py; the same function runs under gloo in tests/test_host_cpu.py).  A region that
             # samples nothing gathers nothing - on every rank alike
-            if b > a and world > 1:
+            if b > a and dist_on:
                 gather_rows(eng.trace[a:b, :, :13].contiguous(), total_chains=total)
             return b - a
 
-        if world > 1:       # untimed: sets up the RCCL communicator and loads the copy kernels (one-off costs)
+        if dist_on:         # untimed: sets up the RCCL communicator and loads the copy kernels (one-off costs)
             gather_rows(eng.trace[0:1, :, :13].contiguous(), total_chains=total)
         timed_call = eng.prepared_timed_steps(args.steps)      # (arguments marshalled outside the region)
         sync, clock = torch.cuda.synchronize, time.perf_counter
@@ -721,7 +730,7 @@ def main():
         rows = gather_traces(s0, s1)
         sync()
         elapsed = clock() - t_begin
-        if world > 1:
+        if dist_on:
             dist.barrier()
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -791,6 +800,7 @@ def main():
                        "lineages": n_lin, "chains_per_gpu": chains, "chains_total": total_chains,
                        "n_bins": eng.n_bins, "sample_every": args.sample_every,
                        "trace_rows_gathered_in_region": rows_gathered,
+                       "process_group": (dist.get_backend() if dist_on else None),
                        "iters_per_s_per_chain": args.steps / elapsed,
                        "wall_over_device": elapsed * 1e3 / region_kernel_ms,
                        "eval_note": "one eval = one lineage scored under one chain's rates in one iteration.  The scan does NOT "
@@ -871,7 +881,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -342,6 +342,44 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert s["value"] == pytest.approx(300 * b["config"]["lineages"] * 64 / (s["ms_per_step"] * 1e-3 * 300))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
+def test_rccl_on_the_one_gpu():
+    """RCCL on hardware (every other multi-rank test here runs under gloo): a world-size-1 "nccl" process group on the one
+    leased GPU.  (i) a child started by torch.distributed.run creates the communicator on cuda:0 and runs the engine's
+    sharded path - TraceStreamer(gather=True) over two windows: status all-reduce + dist.gather on the side stream - with
+    librccl mapped into the process; (ii) `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`, the driver's
+    multi-GPU command at N = 1: bench.py then keeps its process group, barriers and the device-side gather of the sampled
+    rows, and says so in config.process_group."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LR_DIST_BACKEND", "LR_SHARED_DEVICE"):
+        env.pop(k, None)
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
+    r = subprocess.run(launcher + ["--master-port", _free_port(), os.path.join(ROOT, "tests", "helpers", "rccl_child.py")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_CHILD ")]
+    assert len(line) == 1, r.stdout[-2000:]
+    c = json.loads(line[0][len("RCCL_CHILD "):])
+    assert c["rccl_loaded"] and c["backend"] == "nccl" and c["rows"] == 40 and c["all_reduce"] == [0.0, 1.0, 2.0, 3.0]
+    r = subprocess.run(launcher + ["--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "300",
+                                   "--warmup", "50", "--workload", "cfg3", "--chains", "64", "--sample-every", "10",
+                                   "--no-cpu-baseline", "--no-configs", "--no-pmc", "--no-abi"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 1 and b["config"]["process_group"] == "nccl" and b["config"]["trace_rows_gathered_in_region"] == 30
+    assert b["value"] == pytest.approx(300 * b["config"]["lineages"] * 64 / (b["ms_per_step"] * 1e-3 * 300))
+
+
 def test_cli_cfg1_fixed_two_shifts(G, tmp_path):
     """BASELINE.json configs[0]: example_dataTBP, 1 chain, fixed 2 rate shifts (-const_rates 1 with a
     3-rate initial state, SURVEY 8c 'config-1 note').  K stays (3, 3), shift times never move (A9), the

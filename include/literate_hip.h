@@ -218,7 +218,7 @@ typedef struct lr_mcmc_layout {
     int64_t bin_consts;   /* [n_bins] doubles: log(br_length) (models 0/1)                    */
     int64_t lineage_idx;  /* [groups] 16 bytes: packed table entries of the lineages (persistent engines): a group = up to
                            * 14 consecutive lineages of one birth bin in 7 slots of one or two lineages: byte 0 birth
-                           * index, byte 1 count, then seven 16-bit entry indices (csrc/lr_pack.hip)                  */
+                           * index, byte 1 count, then seven 16-bit entry byte offsets (csrc/lr_pack.hip)                  */
     int64_t args_blob;    /* 1 KiB: kernel arguments of the persistent engine, kept in device memory          */
     int64_t tables;       /* [C, table_stride] double2                                        */
     int64_t partials;     /* [tiles, C] doubles                                               */

@@ -6,7 +6,7 @@
 // neighbouring bin.  The packing makes both explicit:
 //
 //   group = up to 14 CONSECUTIVE lineages of ONE birth bin in LR_SLOTS = 7 slots, 16 bytes:
-//           a 16-bit header (birth index a << 4 | number of lineages), then seven 16-bit ENTRY indices into the block's
+//           a 16-bit header (birth index a << 4 | number of lineages), then seven 16-bit entry BYTE OFFSETS (index << 4) into the block's
 //           pair table
 //   slot  = ONE lineage (entry H + j: its death entry E[j]) or TWO consecutive lineages of the run with death entries
 //           j and j + d, 0 <= d <= 3 at unit resolution (entry (2 + d) H + j: the pair-sum plane E[j] + E[j + d]) /
@@ -144,7 +144,7 @@ __global__ void lr_pack_slots_kernel(const double* __restrict__ ts, const double
         const int d1 = lr_pack_death_entry(ts, te, i + 1, t0, n_bins, extant_block, end_time, &x1);
         entry = (2 + (d1 - d0)) * H + d0;                              // pair: plane 2 + d (general times: d = 0 only)
     }
-    grp[1 + slot] = (unsigned short)entry;
+    grp[1 + slot] = (unsigned short)(entry << 4);                     // the BYTE offset of the 16-byte entry (lr_word_off16)
     // general times: fs = ts - floor ts and fe' = ceil te - te (both in [0, 1)) as 32-bit fixed point, rounded to nearest
     auto fix = [](double f) { return fmin(rint(f * 4294967296.0), 4294967295.0); };
     if (frac) {
@@ -171,7 +171,7 @@ __global__ void lr_pack_slots_kernel(const double* __restrict__ ts, const double
             cnt += pr ? 2 : 1, k += pr ? 2 : 1, ++slots;
         }
         grp[0] = (unsigned short)((a << 4) | cnt);                         // masked with 0xfff0: the byte offset of S[a]
-        for (int q = slots; q < LR_SLOTS; ++q) grp[1 + q] = (unsigned short)H;
+        for (int q = slots; q < LR_SLOTS; ++q) grp[1 + q] = (unsigned short)(H << 4);
         if (frac) {
             // the sum of the group's fs (an exact integer below 2^36) as a double: array 2, (.x, .y)
             double sum = 0.0;

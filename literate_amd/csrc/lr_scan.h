@@ -323,7 +323,7 @@ __device__ __forceinline__ unsigned int lr_grp_off(const uint4& w, int k) {
 
 // ---- unit resolution: pair slots ------------------------------------------------------------------------------------
 // Group format (lr_pack.hip, unit-resolution data): uint4 = a 16-bit header (birth index a << 4 | number of lineages:
-// masked with 0xfff0 it IS the byte offset of the birth entry), then LR_SLOTS = 7 sixteen-bit ENTRY indices into the
+// masked with 0xfff0 it IS the byte offset of the birth entry), then LR_SLOTS = 7 sixteen-bit entry BYTE OFFSETS (entry index << 4) into the
 // block's pair table.  A slot holds ONE lineage (entry H + j, its death
 // entry E[j]) or TWO consecutive lineages of the run whose death entries are j and j + d, 0 <= d <= 3 (entry
 // (2 + d) H + j, the pair sum E[j] + E[j + d]); padding slots point at E[0] = 0.  The pair table in LDS therefore has six
@@ -335,21 +335,13 @@ __device__ __forceinline__ unsigned int lr_grp_off(const uint4& w, int k) {
 #define LR_PAIR_DMAX 3
 #define LR_UNIT_PLANES 6                /* S, E, E2[0..3] */
 
-// byte offset (entry * 16) of 16-bit field `hi` of a word: one word-select shift (the loop is bound by vector instruction
-// issue: scratch/ubench/README.md).  `four` = a register holding 4 (lr_shift_four: kept out of the loop by hand)
-__device__ __forceinline__ unsigned int lr_word_off16(unsigned int v, int hi, unsigned int four) {
-    unsigned int r;
-    if (hi) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(four), "v"(v));
-    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(four), "v"(v));
-    return r;
-}
-// the shift amount of lr_word_off16 in a register of its own for a whole scan (an SDWA operand cannot be a constant;
-// volatile: not rematerialised inside the loop when the translation unit is built without machine LICM)
-__device__ __forceinline__ unsigned int lr_shift_four() {
-    unsigned int r;
-    asm volatile("v_mov_b32 %0, 4" : "=v"(r));
-    return r;
-}
+// byte offset of the table entry a slot points at = 16-bit field `hi` of a word: lr_pack.hip stores the slots as BYTE
+// offsets (entry index << 4; six planes of at most 520 entries stay below 2^16), so a field is used as it is.  What the
+// extraction costs (scratch/ubench/issue_rate.hip, profiles/r04_ubench.txt; cycles per wave64 instruction per SIMD at
+// >= 2 waves per SIMD): v_and_b32 with a literal 2.4, v_lshrrev_b32 2.3 - against 4.2 for any SDWA form (the word-select
+// shift that used to turn an entry INDEX into an offset), for v_lshlrev_b32, v_bfe_u32, v_and_or_b32, v_perm_b32 and for
+// every fp64 instruction.  The scan loop is bound by vector instruction issue.
+__device__ __forceinline__ unsigned int lr_word_off16(unsigned int v, int hi) { return hi ? (v >> 16) : (v & 0xffffu); }
 
 // A 16-byte global load the compiler does not see (base: uniform pointer, off: 32-bit byte offset of the lane), and the
 // wait that makes its result - and every load issued before it - usable.  The scan loops issue the NEXT group's load
@@ -415,7 +407,6 @@ __device__ __forceinline__ void lr_persist_scan_pair_slice(const char* __restric
     // 32-bit loop arithmetic (fewer than 2^31 groups): a 64-bit compare and add per trip are two instructions each
     const int n = (int)n8;
     int i = (int)sid;
-    const unsigned int four = lr_shift_four();
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     if (first) w = first->w;
     else if (i < n) w = idx8[i];
@@ -427,13 +418,13 @@ __device__ __forceinline__ void lr_persist_scan_pair_slice(const char* __restric
         const double2 S = *reinterpret_cast<const double2*>(lbase + (cur.x & 0xfff0u));
         const double cnt = (double)(cur.x & 0xfu);
         double2 E[LR_SLOTS];
-        E[0] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.x, 1, four));
-        E[1] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 0, four));
-        E[2] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 1, four));
-        E[3] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 0, four));
-        E[4] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 1, four));
-        E[5] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 0, four));
-        E[6] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 1, four));
+        E[0] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.x, 1));
+        E[1] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 0));
+        E[2] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.y, 1));
+        E[3] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 0));
+        E[4] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.z, 1));
+        E[5] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 0));
+        E[6] = *reinterpret_cast<const double2*>(lbase + lr_word_off16(cur.w, 1));
         // fixed pairwise tree over the slots, then the birth entry `count` times
         const double u0 = ((E[0].x + E[1].x) + (E[2].x + E[3].x)) + ((E[4].x + E[5].x) + E[6].x);
         const double u1 = ((E[0].y + E[1].y) + (E[2].y + E[3].y)) + ((E[4].y + E[5].y) + E[6].y);
@@ -458,7 +449,9 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
     double acc0 = *acc0_, acc1 = *acc1_;
     // 32-bit loop arithmetic (fewer than 2^27 groups)
     const int n = ZERO_TAIL ? __builtin_amdgcn_readfirstlane((int)n8) : (int)n8;
-    const unsigned int four = lr_shift_four();
+    // The group address of a trip = a wave-uniform base (scalar registers, advanced by scalar instructions) + the lane's
+    // constant byte offset: ZERO_TAIL keeps the whole loop control off the vector ALU (a v_add_u32 with a scalar operand
+    // costs 4.2 cycles of the SIMD's issue, as much as an fp64 add).
     const char* gbase = lr_uniform_ptr(idx8);
     const unsigned int stride_b = (unsigned int)n_scan * 16u;
     const unsigned int end_b = (unsigned int)n * 16u;
@@ -473,10 +466,10 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
         lr_gload_wait<0>(w);
         const unsigned int oS = w.x & 0xfff0u;
         const double cnt = (double)(w.x & 0xfu);
-        const unsigned int o0 = lr_word_off16(w.x, 1, four), o1 = lr_word_off16(w.y, 0, four), o2 = lr_word_off16(w.y, 1, four),
-                           o3 = lr_word_off16(w.z, 0, four), o4 = lr_word_off16(w.z, 1, four), o5 = lr_word_off16(w.w, 0, four),
-                           o6 = lr_word_off16(w.w, 1, four);
-        if (ZERO_TAIL) i0 += n_scan, has = i0 < n, off += has ? stride_b : 0u;
+        const unsigned int o0 = lr_word_off16(w.x, 1), o1 = lr_word_off16(w.y, 0), o2 = lr_word_off16(w.y, 1),
+                           o3 = lr_word_off16(w.z, 0), o4 = lr_word_off16(w.z, 1), o5 = lr_word_off16(w.w, 0),
+                           o6 = lr_word_off16(w.w, 1);
+        if (ZERO_TAIL) i0 += n_scan, has = i0 < n, gbase += has ? stride_b : 0u;
         else off += stride_b, has = off < end_b;
         // Unconditionally: a lane's last trip loads a group it will not score (behind a tile or slice the next one's,
         // behind the data zeros: lr_groups_alloc keeps more spare groups than any stride).  Under a condition `w` becomes
@@ -556,7 +549,6 @@ __device__ __forceinline__ void lr_persist_scan_pair_general_slice(const char* _
     double acc0 = *acc0_, acc1 = *acc1_;
     const int n = (int)n8;
     int i = (int)sid;
-    const unsigned int four = lr_shift_four();
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     uint4 fw[LR_FRAC_ARRAYS];
 #pragma unroll
@@ -593,8 +585,8 @@ __device__ __forceinline__ void lr_persist_scan_pair_general_slice(const char* _
         const double2 Ss = *reinterpret_cast<const double2*>(pS + SLOPES);
         const double cnt = (double)(cur.x & 0xfu);
         const double sfs = __hiloint2double((int)fr[2].y, (int)fr[2].x);
-        const unsigned int off[LR_SLOTS] = {lr_word_off16(cur.x, 1, four), lr_word_off16(cur.y, 0, four), lr_word_off16(cur.y, 1, four), lr_word_off16(cur.z, 0, four),
-                                            lr_word_off16(cur.z, 1, four), lr_word_off16(cur.w, 0, four), lr_word_off16(cur.w, 1, four)};
+        const unsigned int off[LR_SLOTS] = {lr_word_off16(cur.x, 1), lr_word_off16(cur.y, 0), lr_word_off16(cur.y, 1), lr_word_off16(cur.z, 0),
+                                            lr_word_off16(cur.z, 1), lr_word_off16(cur.w, 0), lr_word_off16(cur.w, 1)};
         const unsigned int fq[LR_SLOTS] = {fr[0].x, fr[0].y, fr[0].z, fr[0].w, fr[1].x, fr[1].y, fr[1].z};
         double p0[LR_SLOTS], p1[LR_SLOTS];
 #pragma unroll
@@ -629,7 +621,6 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
     }
     double acc0 = *acc0_, acc1 = *acc1_;
     const int n = ZERO_TAIL ? __builtin_amdgcn_readfirstlane((int)n8) : (int)n8;
-    const unsigned int four = lr_shift_four();
     const char* gbase = lr_uniform_ptr(idx8);
     const char* fb0 = lr_uniform_ptr(frac);
     const char* fb1 = lr_uniform_ptr(frac + fstride);
@@ -658,9 +649,9 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
         else lr_gload_wait<0>(w);
         const unsigned int oS = w.x & 0xfff0u;
         const double cnt = (double)(w.x & 0xfu);
-        const unsigned int o[LR_SLOTS] = {lr_word_off16(w.x, 1, four), lr_word_off16(w.y, 0, four), lr_word_off16(w.y, 1, four),
-                                          lr_word_off16(w.z, 0, four), lr_word_off16(w.z, 1, four), lr_word_off16(w.w, 0, four),
-                                          lr_word_off16(w.w, 1, four)};
+        const unsigned int o[LR_SLOTS] = {lr_word_off16(w.x, 1), lr_word_off16(w.y, 0), lr_word_off16(w.y, 1),
+                                          lr_word_off16(w.z, 0), lr_word_off16(w.z, 1), lr_word_off16(w.w, 0),
+                                          lr_word_off16(w.w, 1)};
         double fe[LR_SLOTS], sfs = 0.0;
         if (PREFETCH) {
             // the fractions came with the group: turn them into doubles before their registers are refilled

@@ -55,8 +55,18 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 LDS_PEAK_GBS = 256 * 256 * 2.4e9 / 1e9     # 256 B/clk/CU x 256 CUs x 2.4 GHz = 157,286 GB/s (MI355X_MICROARCH.md, LDS)
-ISSUE_CYCLES = 4.18                       # cycles per wave64 vector instruction per SIMD (scratch/ubench/valu_rate.hip)
-ISSUE_PEAK_LANE_INSTR_PER_S = 256 * 4 * 2.4e9 / ISSUE_CYCLES * 64
+# Vector-instruction ISSUE cost, cycles per wave64 instruction per SIMD at >= 2 waves per SIMD (ONE table for every class:
+# scratch/ubench/issue_rate.hip -> profiles/r04_ubench.txt).  Two classes: 2.3-2.4 for the plain 32-bit VOP1 / VOP2 forms
+# (v_and_b32 - also with a literal -, v_lshrrev_b32, v_add_u32, v_xor_b32, v_mov_b32, v_add_f32, v_fma_f32); 4.2 for every
+# fp64 instruction (add, mul, fma, max, compare, v_cvt_f64_u32), every SDWA and DPP form, v_lshlrev_b32, the three-operand
+# integer forms (v_bfe_u32, v_and_or_b32, v_perm_b32, v_lshl_add_u32, v_mad_u32_u24, v_med3_i32), v_mul_lo_u32, v_cndmask
+# under an SGPR mask, and any VALU instruction with an SGPR source operand.
+ISSUE_CYC_FULL = 2.35
+ISSUE_CYC_HALF = 4.2
+# the compiled scan loops (ISA of lr_persist4_kernel<136, .>): (half-rate instructions, full-rate instructions) per trip
+# of one 16-byte group = 14 lineages x 2 chains
+SCAN_LOOP_MIX = {True: (16 + 1, 9),        # unit resolution: 14 v_add_f64 + 2 v_fmac_f64, v_cvt_f64_u32; 4 v_and + 5 v_lshrrev / v_and
+                 False: (32 + 8, 9)}       # general times: 18 v_fmac_f64 + 14 v_add_f64, 8 v_cvt_f64_u32; 9 v_and / v_lshrrev
 
 
 def make_workload(name):
@@ -108,15 +118,19 @@ def kernel_figures(eng, n_lin, chains, n_iters, kernel_ms):
     # SURVEY 8(d)'s un-amortised "effective GB/s": 16 B (fp64 ts + te) per (lineage, chain) evaluation
     out["effective_GBs_16B_per_eval"] = 16.0 * evals / (kernel_ms * 1e-3) / 1e9
     if eng.layout.persistent:
-        # What the scan loop is really bound by (scratch/ubench/README.md): vector instruction issue.  Per group of 14
-        # lineages and chain pair the compiled loop issues 29 VALU + 8 LDS + 1 global instruction (unit resolution) or
-        # 51 + 16 + 4 (general times) - counted in the ISA of lr_persist4_kernel<136, .> - and a SIMD issues one wave64
-        # vector instruction per 4.18 cycles whatever its kind (measured).  The chain steps share the same SIMDs, so the
-        # fraction below is the share of the chip's issue rate spent on SCAN-LOOP instructions.
-        instr_per_eval = (38 if unit else 71) / (14.0 * chains_per_gather(eng))
-        peak = ISSUE_PEAK_LANE_INSTR_PER_S / instr_per_eval
-        out["issue"] = dict(vector_instr_per_eval=instr_per_eval, cycles_per_wave_instr=ISSUE_CYCLES, peak_evals_per_s=peak,
-                            frac=out["evals_per_s"] / peak)
+        # What the scan loop is really bound by (profiles/r04_ubench.txt): vector instruction ISSUE.  The SIMD-cycles one
+        # trip (14 lineages x chains_per_gather chains x 64 lanes) costs = its half-rate instructions x 4.2 + its full-rate
+        # ones x 2.35; the LDS gathers (8 / 16 ds_read_b128 per trip) and the group load issue beside them.  The chain
+        # steps share the same SIMDs, so the fraction below is the share of the chip's issue CYCLES spent on SCAN-LOOP
+        # vector instructions.
+        n_half, n_full = SCAN_LOOP_MIX[unit]
+        cyc_trip = n_half * ISSUE_CYC_HALF + n_full * ISSUE_CYC_FULL
+        evals_trip = 14.0 * chains_per_gather(eng) * 64
+        peak = 256 * 4 * 2.4e9 / cyc_trip * evals_trip
+        out["issue"] = dict(half_rate_instr_per_trip=n_half, full_rate_instr_per_trip=n_full, cycles_half=ISSUE_CYC_HALF,
+                            cycles_full=ISSUE_CYC_FULL, simd_cycles_per_trip=cyc_trip, evals_per_trip=evals_trip,
+                            vector_instr_per_eval=(n_half + n_full) / (14.0 * chains_per_gather(eng)),
+                            peak_evals_per_s=peak, frac=out["evals_per_s"] / peak)
     return out
 
 

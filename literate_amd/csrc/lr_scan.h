@@ -399,10 +399,41 @@ struct lr_first_group {
 
 // the same scan with plain loads and a test per lane: for a tile or a team member's slice (short scans, often a single
 // trip that starts from the first group kept in registers: an idle prefetch behind it would cost a memory round trip)
-template <int H, int UNROLL = 1>
+// ONE: the table holds ONE chain (the speculative kernel with a team per chain: entries (chain, unused)) - the gathers
+// read the 8-byte half they need (ds_read_b64: half the LDS bytes of a ds_read_b128) and the second chain's eight fp64
+// instructions per group are not issued; acc0 is formed by the same operations in the same order as in the pair form.
+template <int H, int UNROLL = 1, bool ONE = false>
 __device__ __forceinline__ void lr_persist_scan_pair_slice(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                      long long n8, long long sid, int n_scan, double* acc0_,
                                                      double* acc1_, const lr_first_group* first = nullptr) {
+    if (ONE) {
+        double acc0 = *acc0_;
+        const int n = (int)n8;
+        int i = (int)sid;
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if (first) w = first->w;
+        else if (i < n) w = idx8[i];
+#pragma unroll UNROLL
+        while (i < n) {
+            const uint4 cur = w;
+            const int nx = i + n_scan;
+            if (nx < n) w = idx8[nx];
+            const double S = *reinterpret_cast<const double*>(lbase + (cur.x & 0xfff0u));
+            const double cnt = (double)(cur.x & 0xfu);
+            const double E0 = *reinterpret_cast<const double*>(lbase + lr_word_off16(cur.x, 1));
+            const double E1 = *reinterpret_cast<const double*>(lbase + lr_word_off16(cur.y, 0));
+            const double E2 = *reinterpret_cast<const double*>(lbase + lr_word_off16(cur.y, 1));
+            const double E3 = *reinterpret_cast<const double*>(lbase + lr_word_off16(cur.z, 0));
+            const double E4 = *reinterpret_cast<const double*>(lbase + lr_word_off16(cur.z, 1));
+            const double E5 = *reinterpret_cast<const double*>(lbase + lr_word_off16(cur.w, 0));
+            const double E6 = *reinterpret_cast<const double*>(lbase + lr_word_off16(cur.w, 1));
+            const double u0 = ((E0 + E1) + (E2 + E3)) + ((E4 + E5) + E6);
+            acc0 += fma(cnt, S, u0);
+            i = nx;
+        }
+        *acc0_ = acc0;
+        return;
+    }
     double acc0 = *acc0_, acc1 = *acc1_;
     // 32-bit loop arithmetic (fewer than 2^31 groups): a 64-bit compare and add per trip are two instructions each
     const int n = (int)n8;
@@ -435,14 +466,15 @@ __device__ __forceinline__ void lr_persist_scan_pair_slice(const char* __restric
     *acc0_ = acc0, *acc1_ = acc1;
 }
 
-template <int H, int UNROLL = 1, bool ZERO_TAIL = false, bool ASYNC = ZERO_TAIL>
+template <int H, int UNROLL = 1, bool ZERO_TAIL = false, bool ASYNC = ZERO_TAIL, bool ONE = false>
 __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                      long long n8, long long sid, int n_scan, double* acc0_,
                                                      double* acc1_, const lr_first_group* first = nullptr,
                                                      lr_scan_tail* tail = nullptr) {
     static_assert(ASYNC || !ZERO_TAIL, "the wave-uniform trip count comes with the hand-placed loads");
+    static_assert(!(ONE && ASYNC), "the one-chain form exists for the plain-load slices only");
     if (!ASYNC) {
-        lr_persist_scan_pair_slice<H, UNROLL>(lbase, idx8, n8, sid, n_scan, acc0_, acc1_, first);
+        lr_persist_scan_pair_slice<H, UNROLL, ONE>(lbase, idx8, n8, sid, n_scan, acc0_, acc1_, first);
         if (tail) tail->w = lr_u32x4{0u, 0u, 0u, 0u};
         return;
     }
@@ -541,7 +573,7 @@ __device__ __forceinline__ void lr_pair_planes_block(double2* tab, int H, int n_
 // Per group: 2 + 14 ds_read_b128; per slot and chain pair one conversion and four fp64 operations.
 #define LR_FRAC_ARRAYS 3
 // (plain loads, a test per lane: see lr_persist_scan_pair_slice)
-template <int H, int UNROLL = 1, bool PREFETCH = false>
+template <int H, int UNROLL = 1, bool PREFETCH = false, bool ONE = false>
 __device__ __forceinline__ void lr_persist_scan_pair_general_slice(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                              const uint4* __restrict__ frac, long long fstride,
                                                              long long n8, long long sid, int n_scan, double* acc0_,
@@ -581,13 +613,28 @@ __device__ __forceinline__ void lr_persist_scan_pair_general_slice(const char* _
             }
         }
         const char* pS = lbase + (cur.x & 0xfff0u);
-        const double2 Sv = *reinterpret_cast<const double2*>(pS);
-        const double2 Ss = *reinterpret_cast<const double2*>(pS + SLOPES);
         const double cnt = (double)(cur.x & 0xfu);
         const double sfs = __hiloint2double((int)fr[2].y, (int)fr[2].x);
         const unsigned int off[LR_SLOTS] = {lr_word_off16(cur.x, 1), lr_word_off16(cur.y, 0), lr_word_off16(cur.y, 1), lr_word_off16(cur.z, 0),
                                             lr_word_off16(cur.z, 1), lr_word_off16(cur.w, 0), lr_word_off16(cur.w, 1)};
         const unsigned int fq[LR_SLOTS] = {fr[0].x, fr[0].y, fr[0].z, fr[0].w, fr[1].x, fr[1].y, fr[1].z};
+        if (ONE) {
+            // one chain per table: 8-byte reads of the halves in use, the same operations on them in the same order
+            const double Sv1 = *reinterpret_cast<const double*>(pS), Ss1 = *reinterpret_cast<const double*>(pS + SLOPES);
+            double q0[LR_SLOTS];
+#pragma unroll
+            for (int k = 0; k < LR_SLOTS; ++k) {
+                const double Ev = *reinterpret_cast<const double*>(lbase + off[k]);
+                const double Es = *reinterpret_cast<const double*>(lbase + off[k] + SLOPES);
+                q0[k] = fma((double)fq[k], Es, Ev);
+            }
+            const double u0 = ((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q0[4] + q0[5]) + q0[6]);
+            acc0 += fma(sfs, Ss1, fma(cnt, Sv1, u0));
+            i = nx;
+            continue;
+        }
+        const double2 Sv = *reinterpret_cast<const double2*>(pS);
+        const double2 Ss = *reinterpret_cast<const double2*>(pS + SLOPES);
         double p0[LR_SLOTS], p1[LR_SLOTS];
 #pragma unroll
         for (int k = 0; k < LR_SLOTS; ++k) {
@@ -607,15 +654,16 @@ __device__ __forceinline__ void lr_persist_scan_pair_general_slice(const char* _
     *acc0_ = acc0, *acc1_ = acc1;
 }
 
-template <int H, int UNROLL = 1, bool PREFETCH = false, bool ZERO_TAIL = false, bool ASYNC = ZERO_TAIL>
+template <int H, int UNROLL = 1, bool PREFETCH = false, bool ZERO_TAIL = false, bool ASYNC = ZERO_TAIL, bool ONE = false>
 __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restrict__ lbase, const uint4* __restrict__ idx8,
                                                              const uint4* __restrict__ frac, long long fstride,
                                                              long long n8, long long sid, int n_scan, double* acc0_,
                                                              double* acc1_, const lr_first_group* first = nullptr,
                                                              lr_scan_tail* tail = nullptr) {
     static_assert(ASYNC || !ZERO_TAIL, "the wave-uniform trip count comes with the hand-placed loads");
+    static_assert(!(ONE && ASYNC), "the one-chain form exists for the plain-load slices only");
     if (!ASYNC) {
-        lr_persist_scan_pair_general_slice<H, UNROLL, PREFETCH>(lbase, idx8, frac, fstride, n8, sid, n_scan, acc0_, acc1_, first);
+        lr_persist_scan_pair_general_slice<H, UNROLL, PREFETCH, ONE>(lbase, idx8, frac, fstride, n8, sid, n_scan, acc0_, acc1_, first);
         if (tail) tail->w = tail->f0 = tail->f1 = tail->f2 = lr_u32x4{0u, 0u, 0u, 0u};
         return;
     }
@@ -666,8 +714,14 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
         } else {
             lr_gload16_async(f0, fb0, off), lr_gload16_async(f1, fb1, off), lr_gload16_async(f2, fb2, off);
         }
-        if (ZERO_TAIL) i0 += n_scan, has = i0 < n, off += has ? stride_b : 0u;
-        else off += stride_b, has = off < end_b;
+        if (ZERO_TAIL) {
+            // (the four wave-uniform bases advance in scalar registers; the lane's byte offset stays what it is)
+            i0 += n_scan, has = i0 < n;
+            const unsigned int adv = has ? stride_b : 0u;
+            gbase += adv, fb0 += adv, fb1 += adv, fb2 += adv;
+        } else {
+            off += stride_b, has = off < end_b;
+        }
         // unconditionally (see lr_persist_scan_pair): a lane's last trip loads a group it will not score
         lr_gload16_async(w, gbase, off);
         if (PREFETCH) lr_gload16_async(f0, fb0, off), lr_gload16_async(f1, fb1, off), lr_gload16_async(f2, fb2, off);
@@ -764,12 +818,12 @@ struct lr_packed_lineages {
     long long fstride;
 };
 
-template <int H, bool GENERAL, int UNROLL = 1, bool PREFETCH = false, bool ZERO_TAIL = false, bool ASYNC = ZERO_TAIL>
+template <int H, bool GENERAL, int UNROLL = 1, bool PREFETCH = false, bool ZERO_TAIL = false, bool ASYNC = ZERO_TAIL, bool ONE = false>
 __device__ __forceinline__ void lr_persist_scan(const char* __restrict__ lbase, const lr_packed_lineages& pk, long long g0,
                                                 long long n8, long long sid, int n_scan, double* acc0, double* acc1,
                                                 const lr_first_group* first = nullptr, lr_scan_tail* tail = nullptr) {
-    if (GENERAL) lr_persist_scan_pair_general<H, UNROLL, PREFETCH, ZERO_TAIL, ASYNC>(lbase, pk.idx8 + g0, pk.frac + g0, pk.fstride, n8, sid, n_scan, acc0, acc1, first, tail);
-    else lr_persist_scan_pair<H, UNROLL, ZERO_TAIL, ASYNC>(lbase, pk.idx8 + g0, n8, sid, n_scan, acc0, acc1, first, tail);
+    if (GENERAL) lr_persist_scan_pair_general<H, UNROLL, PREFETCH, ZERO_TAIL, ASYNC, ONE>(lbase, pk.idx8 + g0, pk.frac + g0, pk.fstride, n8, sid, n_scan, acc0, acc1, first, tail);
+    else lr_persist_scan_pair<H, UNROLL, ZERO_TAIL, ASYNC, ONE>(lbase, pk.idx8 + g0, n8, sid, n_scan, acc0, acc1, first, tail);
 }
 
 // the first group of lane `sid` (zeros when the lane has none)

@@ -556,7 +556,8 @@ __device__ __forceinline__ void lr_spec_scan_role(lr_spec_lds<H, T / LR_WAVE, GE
         const lr_spec_dec_in dec_in = lr_spec_dec_fetch(sm, ctx, role0, role1, lane);
         double acc0 = 0.0, acc1 = 0.0;
         const char* lbase = reinterpret_cast<const char*>(single ? sm.t.tabs[(role0 >> 2) & 3] : sm.t.pair.scan);
-        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true>(lbase, ctx.pk, part_g0, part_n, sid, n_scan, &acc0, &acc1, &first);
+        // (a team per chain: the one-chain form of the scan - 8-byte gathers, half the fp64 instructions)
+        lr_persist_scan<H, GENERAL, GENERAL ? 1 : LR_SPEC_SCAN_UNROLL, true, false, false, SINGLE>(lbase, ctx.pk, part_g0, part_n, sid, n_scan, &acc0, &acc1, &first);
         LR_XSTAMP(dg_a);
         lr_spec_deliver<H, T, RJ, GENERAL, MODE>(sm, ctx, iter, dec_in, acc0, acc1, wave, lane);
         // draw duty after the sums are delivered: the (state independent) draws of iteration it + 2 for chain dch
@@ -762,8 +763,8 @@ __device__ __forceinline__ void lr_spec_cand_role(lr_spec_lds<H, T / LR_WAVE, GE
             // may be the wave that arrives last and decides
             const lr_spec_dec_in dec_in = lr_spec_dec_fetch(sm, ctx, role0, role1, lane);
             double acc0 = 0.0, acc1 = 0.0;
-            lr_persist_scan<H, GENERAL, 1, false>(reinterpret_cast<const char*>(sm.t.tabs[(role0 >> 2) & 3]), ctx.pk, ctx.cand_g0, ctx.cand_n,
-                                                  k * LR_WAVE + lane, 2 * LR_WAVE, &acc0, &acc1, nullptr);
+            lr_persist_scan<H, GENERAL, 1, false, false, false, true>(reinterpret_cast<const char*>(sm.t.tabs[(role0 >> 2) & 3]), ctx.pk, ctx.cand_g0, ctx.cand_n,
+                                                                      k * LR_WAVE + lane, 2 * LR_WAVE, &acc0, &acc1, nullptr);
             lr_spec_deliver<H, T, RJ, GENERAL, MODE>(sm, ctx, iter, dec_in, acc0, acc1, wave, lane);
         }
         LR_XSTAMP(dg_work);

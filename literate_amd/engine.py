@@ -91,6 +91,53 @@ class ChainEngine:
         self.n_chains = int(n_chains)
         self.iterations = 0
         self._hash = None
+        self._plan_args = dict(model=model, const_rates=const_rates, const_death_rate=const_death_rate, use_rate_HP=use_rate_HP,
+                               poisson_HP=poisson_HP, update_fraction=update_fraction, unit_resolution=self.unit_resolution, dd=dd,
+                               stats=(self.t0, self.n_bins, self.br_length))
+        self.plan_report = None
+        if engine == "auto" and os.environ.get("LR_PLAN_CHECK", "0") == "1" and not ChainEngine._in_plan_check:
+            self.plan_report = self.plan_check()
+
+    _in_plan_check = False
+
+    def plan_check(self, n_iters=200, tolerance=0.10):
+        """LR_PLAN_CHECK=1: the planner's choice against a measurement ON THIS DEVICE.  lr_persist_variant picks the engine
+        from cost models fitted to sweeps on the build pool's boxes (csrc/lr_mcmc.hip); here every engine that accepts
+        this configuration runs n_iters iterations after as many of warm-up, from the CLI's initial state, and a warning
+        names any engine that beats the planner's choice by more than `tolerance`.  Returns {"auto": kernel name,
+        "us_per_iter": {engine: us or None when the engine refuses the configuration}, "best": engine, "ok": bool}."""
+        import warnings
+        torch = _hip.require_gpu()
+        ChainEngine._in_plan_check = True
+        times = {}
+        try:
+            for name in ("auto", "persistent4", "persistent2", "spec", "launch"):
+                try:
+                    e = ChainEngine(self.ts, self.te, self.n_chains, seed=int(self.cfg.seed), s_freq=1 << 30, n_trace_slots=2,
+                                    chain_offset=int(self.cfg.chain_offset), device=self.device, sort_lineages=False,
+                                    engine=name, **self._plan_args)
+                except (ValueError, _hip.HipLibraryError):
+                    times[name] = None
+                    continue
+                try:
+                    e.init()
+                    e.steps(n_iters)
+                    torch.cuda.synchronize(self.device)
+                    times[name] = e.timed_steps(n_iters) / n_iters * 1e3
+                    if name == "auto":
+                        auto_kernel = e.kernel_name()
+                finally:
+                    e.close()
+        finally:
+            ChainEngine._in_plan_check = False
+        valid = {k: v for k, v in times.items() if v is not None and k != "auto"}
+        best = min(valid, key=valid.get)
+        ok = times["auto"] <= (1.0 + tolerance) * valid[best]
+        if not ok:
+            warnings.warn("LR_PLAN_CHECK: the planner chose %s (%.2f us per iteration) but engine=%r runs this configuration "
+                          "in %.2f us on this device: pass engine=%r, and refit the planner's model (csrc/lr_mcmc.hip)"
+                          % (auto_kernel, times["auto"], best, valid[best], best), RuntimeWarning)
+        return dict(auto=auto_kernel, us_per_iter=times, best=best, ok=bool(ok))
 
     @property
     def _data_hash(self):

@@ -316,31 +316,39 @@ def print_R_vec(name, v):
 
 # ---- set-up (lib:196-229, 260-308) ----
 def parse_ts_te(input_file, TBP, first_year, last_year, death_jitter):
-    import pandas as pd
-    t_file = pd.read_csv(input_file, delimiter='\t').to_numpy()
-    if t_file.shape[1] == 4:
+    """lib:196-229.  The file's time columns -> (ts, te, PRESENT, ORIGIN) on a forward time axis, te with the jitter.
+
+    The window [first_year, last_year] is given in the FILE's years: on a time-before-present axis the first year is the
+    larger number.  Lineages born before the window are dropped, lineages born after its last year too, and deaths
+    beyond the last year are cut to it.  One reference quirk is kept on purpose, because callers see it: on a TBP axis
+    the reference filters the births by -last_year first and then indexes the deaths with a mask built from the
+    ALREADY FILTERED births (lib:211-212) - as soon as that filter removes a lineage the mask no longer fits the
+    deaths and numpy raises IndexError (tests/golden/parse_paths.npz holds the reference's own outcomes)."""
+    table = pd.read_csv(input_file, delimiter='\t').to_numpy()
+    if table.shape[1] == 4:
         warn('Four column (with clade) LiteRate input is deprecated. Use three columns.', FutureWarning)
-        ts_years, te_years = t_file[:, 2], t_file[:, 3]
+        born, died = table[:, 2], table[:, 3]
     else:
-        ts_years, te_years = t_file[:, 1], t_file[:, 2]
+        born, died = table[:, 1], table[:, 2]
+    # "year a is not later than year b" on the file's axis: ages count down towards the present, calendar years up
+    not_later = (lambda a, b: a >= b) if TBP else (lambda a, b: a <= b)
+    if first_year != -1:
+        inside = not_later(first_year, born)
+        born, died = born[inside], died[inside]
+    if last_year != -1:
+        inside = not_later(born, last_year)
+        if TBP:
+            born = born[inside]
+            died = died[not_later(born, last_year)]      # the quirk: a mask of the filtered births on the unfiltered deaths
+        else:
+            born, died = born[inside], died[inside]
+        died = np.array(died)
+        died[~not_later(died, last_year)] = last_year    # still alive at the end of the window
     if TBP:
-        if first_year != -1:
-            te_years = te_years[ts_years <= first_year]
-            ts_years = ts_years[ts_years <= first_year]
-        if last_year != -1:
-            ts_years = ts_years[ts_years >= last_year]
-            te_years = te_years[ts_years >= last_year]
-            te_years[te_years < last_year] = last_year
-        ts_, te_ = max(ts_years) - ts_years, max(ts_years) - te_years
+        oldest = max(born)
+        ts_, te_ = oldest - born, oldest - died
     else:
-        if first_year != -1:
-            te_years = te_years[ts_years >= first_year]
-            ts_years = ts_years[ts_years >= first_year]
-        if last_year != -1:
-            te_years = te_years[ts_years <= last_year]
-            ts_years = ts_years[ts_years <= last_year]
-            te_years[te_years > last_year] = last_year
-        ts_, te_ = ts_years, te_years
+        ts_, te_ = born, died
     te_ = te_ + death_jitter
     return ts_, te_, max(te_), min(ts_)
 

@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,shipped,cfg1,trendtraj,traj,library,flags,marginal]
+    python tests/golden/make_golden.py [--only binning,proposals,ddrate,ratemaps,ddtraj,shipped,cfg1,trendtraj,traj,library,flags,marginal,parse]
     python tests/golden/make_chains.py <dataset> <model> <n> <s> <chains>   # long reference chains
 
 The reference is executed unmodified: LiteRateForward.py / DDRate.py through
@@ -651,13 +651,59 @@ def make_marginal_rates(work):
     np.savez_compressed(os.path.join(HERE, "marginal_rates.npz"), **out)
 
 
+def make_parse_paths(work):
+    """lib parse_ts_te (lib:196-229: the DDRate / trend_rate CLIs' reader) on the shipped example files and on a
+    four-column variant, for every filter path: no filter, -first_year, -last_year (TBP: the reference indexes the deaths
+    with a mask built from the already filtered births - as soon as the filter removes a lineage numpy raises), both.
+    Inputs: the file tables; outputs: (ts, te, present, origin) or the name of the exception the reference dies with."""
+    sys.path.insert(0, REF)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            import literate_library as ref
+    finally:
+        sys.path.pop(0)
+    out = {}
+    cases = []
+    for name, tbp, filters in (("example_TBP", True, [(-1, -1), (20, -1), (-1, 0), (-1, 5), (18, 3), (30, -1)]),
+                               ("example_TAD", False, [(-1, -1), (1998, -1), (-1, 2030), (-1, 2012), (1999, 2011)]),
+                               ("metal_bands", False, [(-1, -1), (1985, 2005)])):
+        rel = DATASETS[name][0]
+        src = os.path.join(REF, rel)
+        for fy, ly in filters:
+            for jitter in (0.5, 0.0):
+                tag = "%s/fy%d_ly%d_j%g" % (name, fy, ly, jitter)
+                try:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        ts, te, present, origin = ref.parse_ts_te(src, tbp, fy, ly, jitter)
+                    out[tag + "/ts"], out[tag + "/te"] = np.asarray(ts, float), np.asarray(te, float)
+                    out[tag + "/present_origin"] = np.array([present, origin], float)
+                    err = ""
+                except Exception as ex:
+                    err = type(ex).__name__
+                out[tag + "/error"] = np.array(err)
+                cases.append([name, str(int(tbp)), str(fy), str(ly), repr(jitter), tag])
+                print(tag, err or "ok")
+    out["cases"] = np.array(cases)
+    # the tables themselves (numeric columns of the shipped files), so that the test can write them back as TSV files
+    for name in ("example_TBP", "example_TAD", "metal_bands"):
+        rel = DATASETS[name][0]
+        import pandas as pd
+        t = pd.read_csv(os.path.join(REF, rel), delimiter="\t")
+        out[name + "/table"] = t.to_numpy().astype(float)            # (the TAD file carries two empty trailing columns: NaN)
+        out[name + "/header"] = np.array([str(c) for c in t.columns])
+    np.savez_compressed(os.path.join(HERE, "parse_paths.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="lr_golden_")
     steps = dict(binning=make_binning_and_lik, proposals=make_proposals, ddrate=make_ddrate, ratemaps=make_ratemaps, ddtraj=make_dd_trajectories, shipped=make_shipped, cfg1=make_cfg1, trendtraj=make_trend_trajectories,
-                 traj=make_trajectories, library=make_library_surface, flags=make_flag_paths, marginal=make_marginal_rates)
+                 traj=make_trajectories, library=make_library_surface, flags=make_flag_paths, marginal=make_marginal_rates,
+                 parse=make_parse_paths)
     for name, fn in steps.items():
         if args.only and name not in args.only.split(","):
             continue

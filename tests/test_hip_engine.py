@@ -1090,3 +1090,26 @@ def test_cfg4_general_times_other_models_under_the_four_chain_kernel(model):
             worst = max(worst, abs(snap["likA"][c] - ref) / abs(ref))
     assert worst < 1e-9, worst
     eng.close()
+
+
+@pytest.mark.parametrize("n_lin,C", [(10_000, 256), (100_000, 1024), (30_000, 128)])
+def test_planner_self_check_against_a_measurement(monkeypatch, n_lin, C):
+    """LR_PLAN_CHECK=1 (ChainEngine.plan_check): the engine the planner picks from its fitted cost models, timed on THIS
+    device against every other engine that accepts the configuration - cfg3, cfg4 and a cfg2-sized shape.  The report
+    names the planner's kernel and every engine's time; the planner's choice must not lose to the best one by more than
+    the check's own tolerance plus what boxes of the pool differ by."""
+    from literate_amd import synth
+    from literate_amd.engine import ChainEngine
+    ts, te, _ = synth.make_lineages(n_lin, n_bins=128 if n_lin != 30_000 else 32, n_shifts=20 if n_lin != 30_000 else 4, seed=0)
+    monkeypatch.setenv("LR_PLAN_CHECK", "1")
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        eng = ChainEngine(ts, te, C, model=0, seed=3, s_freq=100, n_trace_slots=4)
+    r = eng.plan_report
+    eng.close()
+    assert r is not None and r["auto"].startswith("lr_") and set(r["us_per_iter"]) == {"auto", "persistent4", "persistent2", "spec", "launch"}
+    t = r["us_per_iter"]
+    assert t["auto"] is not None and t["launch"] is not None and t[r["best"]] == min(v for k, v in t.items() if v is not None and k != "auto")
+    assert t["auto"] <= 1.25 * t[r["best"]], r
+    assert r["ok"] == (not any("LR_PLAN_CHECK" in str(w.message) for w in caught))

@@ -297,3 +297,41 @@ def test_bench_gpus_n_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch_loaded_before:
         assert "torch" not in sys.modules          # the parent never got as far as importing torch
+
+
+def test_parse_ts_te_against_the_reference_outcomes(tmp_path, golden_dir):
+    """literate_library.parse_ts_te (the DDRate / trend_rate reader, lib:196-229) on every filter path against what the
+    REFERENCE's function returned - or died with - on the same files (tests/golden/parse_paths.npz, generated by
+    make_golden.py --only parse): arrays bit for bit, PRESENT / ORIGIN, and the exception type where the reference
+    raises (the TBP -last_year mask quirk: IndexError; an empty selection: ValueError)."""
+    import warnings
+    import pandas as pd
+    from literate_amd import literate_library as ll
+    P = np.load(os.path.join(golden_dir, "parse_paths.npz"))
+    files = {}
+    for name in ("example_TBP", "example_TAD", "metal_bands"):
+        t = pd.DataFrame(P[name + "/table"], columns=[str(c) for c in P[name + "/header"]])
+        for c in t.columns:
+            if not t[c].isna().any():
+                t[c] = t[c].astype(np.int64)             # the shipped files hold integers
+        path = tmp_path / (name + ".tsv")
+        t.to_csv(path, sep="\t", index=False, na_rep="")
+        files[name] = str(path)
+    n_ok = n_err = 0
+    for name, tbp, fy, ly, jitter, tag in P["cases"]:
+        want_err = str(P[tag + "/error"])
+        args = (files[name], bool(int(tbp)), int(fy), int(ly), float(jitter))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if want_err:
+                with pytest.raises(Exception) as ei:
+                    ll.parse_ts_te(*args)
+                assert type(ei.value).__name__ == want_err, (tag, type(ei.value).__name__, want_err)
+                n_err += 1
+                continue
+            ts, te, present, origin = ll.parse_ts_te(*args)
+        assert np.array_equal(np.asarray(ts, float), P[tag + "/ts"]), tag
+        assert np.array_equal(np.asarray(te, float), P[tag + "/te"]), tag
+        assert [float(present), float(origin)] == list(P[tag + "/present_origin"]), tag
+        n_ok += 1
+    assert n_ok >= 16 and n_err >= 8

@@ -714,14 +714,8 @@ __device__ __forceinline__ void lr_persist_scan_pair_general(const char* __restr
         } else {
             lr_gload16_async(f0, fb0, off), lr_gload16_async(f1, fb1, off), lr_gload16_async(f2, fb2, off);
         }
-        if (ZERO_TAIL) {
-            // (the four wave-uniform bases advance in scalar registers; the lane's byte offset stays what it is)
-            i0 += n_scan, has = i0 < n;
-            const unsigned int adv = has ? stride_b : 0u;
-            gbase += adv, fb0 += adv, fb1 += adv, fb2 += adv;
-        } else {
-            off += stride_b, has = off < end_b;
-        }
+        if (ZERO_TAIL) i0 += n_scan, has = i0 < n, off += has ? stride_b : 0u;
+        else off += stride_b, has = off < end_b;
         // unconditionally (see lr_persist_scan_pair): a lane's last trip loads a group it will not score
         lr_gload16_async(w, gbase, off);
         if (PREFETCH) lr_gload16_async(f0, fb0, off), lr_gload16_async(f1, fb1, off), lr_gload16_async(f2, fb2, off);

@@ -14,13 +14,15 @@
 
 enum { ADD_F32, ADD_F64, FMA_F64, AND_B32, LSHL_B32, BFE_U32, AND_OR_B32, PERM_B32, LSHL_SDWA, AND_SDWA, CVT_F64_U32, ADD_U32, MOV_B32,
        LSHL_ADD_U32, MAD_U32_U24, DS_READ_B128, DS_READ_B64, MUL_F64, CNDMASK, ADD_F64_DEP,
-       LSHR_B32, AND_LIT, AND_SGPR, CNDMASK_E64, MOV_DPP, CMP_F64, MAX_F64, MED3_I32, XOR_B32, MAD_U64_U32, FMA_F32, MUL_LO_U32, N_OPS };
+       LSHR_B32, AND_LIT, AND_SGPR, CNDMASK_E64, MOV_DPP, CMP_F64, MAX_F64, MED3_I32, XOR_B32, MAD_U64_U32, FMA_F32, MUL_LO_U32, CMP_CND_VCC, CND_VCC_SET, CMP_U32_VCC, READLANE, CMP_2CND_VCC, CMP_2CND_SGPR, CMP_4CND_VCC, CND_VCC_NOP, N_OPS };
 static const char* NAMES[N_OPS] = {"v_add_f32", "v_add_f64", "v_fma_f64", "v_and_b32", "v_lshlrev_b32", "v_bfe_u32", "v_and_or_b32", "v_perm_b32",
                                    "v_lshlrev_b32_sdwa WORD_1", "v_and_b32_sdwa WORD_0", "v_cvt_f64_u32", "v_add_u32", "v_mov_b32",
                                    "v_lshl_add_u32", "v_mad_u32_u24", "ds_read_b128 (conflict-free)", "ds_read_b64 (conflict-free)", "v_mul_f64",
                                    "v_cndmask_b32 vcc", "v_add_f64 one dependent chain", "v_lshrrev_b32", "v_and_b32 literal", "v_and_b32 sgpr mask",
                                    "v_cndmask_b32 e64 sgpr mask", "v_mov_b32_dpp row_shr:1", "v_cmp_lt_f64 -> sgpr pair", "v_max_f64", "v_med3_i32", "v_xor_b32",
-                                   "v_mad_u64_u32", "v_fma_f32", "v_mul_lo_u32"};
+                                   "v_mad_u64_u32", "v_fma_f32", "v_mul_lo_u32", "v_cmp_lt_u32 vcc + v_cndmask vcc (per PAIR)", "v_cndmask_b32 vcc (vcc set before the loop)",
+                                   "v_cmp_lt_u32 -> vcc", "v_readlane_b32", "v_cmp vcc + 2 v_cndmask vcc (per TRIPLE)", "v_cmp s[20:21] + 2 v_cndmask e64 (per TRIPLE)",
+                                   "v_cmp vcc + 4 v_cndmask vcc (per FIVE)", "v_cndmask vcc + v_add_u32 alternating (per PAIR)"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void k(unsigned long long* out, double seed) {
@@ -155,6 +157,56 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, double seed) 
 #define F(n) "v_mul_lo_u32 %" #n ", %" #n ", %8\n"
             asm volatile(S8(F) : OPS8 : "v"(b));
 #undef F
+        } else if (OP == CMP_CND_VCC) {
+#define F(n) "v_cmp_lt_u32 vcc, %" #n ", %8\n v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+            asm volatile(S8(F) : OPS8 : "v"(b) : "vcc");
+#undef F
+        } else if (OP == CND_VCC_SET) {
+#define F(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+            asm volatile("s_mov_b64 vcc, 0x5555\n" S8(F) : OPS8 : "v"(b) : "vcc");
+#undef F
+        } else if (OP == CMP_U32_VCC) {
+#define F(n) "v_cmp_lt_u32 vcc, %" #n ", %8\n"
+            asm volatile(S8(F) : OPS8 : "v"(b) : "vcc");
+#undef F
+        } else if (OP == READLANE) {
+            asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 3\n v_readlane_b32 s22, %2, 3\n v_readlane_b32 s23, %3, 3\n"
+                         "v_readlane_b32 s24, %4, 3\n v_readlane_b32 s25, %5, 3\n v_readlane_b32 s26, %6, 3\n v_readlane_b32 s27, %7, 3\n"
+                         : OPS8 : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        } else if (OP == CMP_2CND_VCC) {
+            asm volatile("v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %6, %8\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %6, %8\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                         : OPS8 : "v"(b) : "vcc");
+        } else if (OP == CMP_2CND_SGPR) {
+            asm volatile("v_cmp_lt_u32 s[20:21], %0, %8\n v_cndmask_b32 %0, %0, %8, s[20:21]\n v_cndmask_b32 %1, %1, %8, s[20:21]\n"
+                         "v_cmp_lt_u32 s[22:23], %2, %8\n v_cndmask_b32 %2, %2, %8, s[22:23]\n v_cndmask_b32 %3, %3, %8, s[22:23]\n"
+                         "v_cmp_lt_u32 s[24:25], %4, %8\n v_cndmask_b32 %4, %4, %8, s[24:25]\n v_cndmask_b32 %5, %5, %8, s[24:25]\n"
+                         "v_cmp_lt_u32 s[26:27], %6, %8\n v_cndmask_b32 %6, %6, %8, s[26:27]\n v_cndmask_b32 %7, %7, %8, s[26:27]\n"
+                         "v_cmp_lt_u32 s[20:21], %0, %8\n v_cndmask_b32 %0, %0, %8, s[20:21]\n v_cndmask_b32 %1, %1, %8, s[20:21]\n"
+                         "v_cmp_lt_u32 s[22:23], %2, %8\n v_cndmask_b32 %2, %2, %8, s[22:23]\n v_cndmask_b32 %3, %3, %8, s[22:23]\n"
+                         "v_cmp_lt_u32 s[24:25], %4, %8\n v_cndmask_b32 %4, %4, %8, s[24:25]\n v_cndmask_b32 %5, %5, %8, s[24:25]\n"
+                         "v_cmp_lt_u32 s[26:27], %6, %8\n v_cndmask_b32 %6, %6, %8, s[26:27]\n v_cndmask_b32 %7, %7, %8, s[26:27]\n"
+                         : OPS8 : "v"(b) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        } else if (OP == CMP_4CND_VCC) {
+            asm volatile("v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                         : OPS8 : "v"(b) : "vcc");
+        } else if (OP == CND_VCC_NOP) {
+#define F(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n v_add_u32 %" #n ", %" #n ", %8\n"
+            asm volatile(S8(F) : OPS8 : "v"(b) : "vcc");
+#undef F
         } else if (OP == DS_READ_B128) {
             asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:1024\n ds_read_b128 %2, %4 offset:2048\n ds_read_b128 %3, %4 offset:3072\n"
                          "ds_read_b128 %0, %4 offset:4096\n ds_read_b128 %1, %4 offset:5120\n ds_read_b128 %2, %4 offset:6144\n ds_read_b128 %3, %4 offset:7168\n"
@@ -214,6 +266,8 @@ int main() {
     all<AND_B32>(f); all<LSHL_B32>(f); all<BFE_U32>(f); all<AND_OR_B32>(f); all<PERM_B32>(f); all<LSHL_SDWA>(f); all<AND_SDWA>(f);
     all<ADD_U32>(f); all<MOV_B32>(f); all<LSHL_ADD_U32>(f); all<MAD_U32_U24>(f); all<CNDMASK>(f);
     all<LSHR_B32>(f); all<AND_LIT>(f); all<AND_SGPR>(f); all<XOR_B32>(f); all<MED3_I32>(f); all<MUL_LO_U32>(f); all<MAD_U64_U32>(f); all<FMA_F32>(f);
+    all<CMP_2CND_VCC>(f); all<CMP_2CND_SGPR>(f); all<CMP_4CND_VCC>(f); all<CND_VCC_NOP>(f);
+    all<CMP_CND_VCC>(f); all<CND_VCC_SET>(f); all<CMP_U32_VCC>(f); all<READLANE>(f);
     all<CNDMASK_E64>(f); all<MOV_DPP>(f); all<CMP_F64>(f); all<MAX_F64>(f);
     all<DS_READ_B128>(f); all<DS_READ_B64>(f);
     return 0;

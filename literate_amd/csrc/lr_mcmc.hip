@@ -959,12 +959,14 @@ static int lr_device_cus() {
 // team (scratch/exp_teams.py, round 3: candidates with a column of their own, no-op moves copying it): with `trips` =
 // groups / k / 512 scanner lanes,
 //                        a team per PAIR                                  a team per CHAIN
-//     unit resolution    k = 1: max(2.95, 2.93 + 0.180 trips)             k = 1: max(2.44, 1.62 + 0.20 trips)
-//                        k > 1: max(3.40, 3.20 + 0.205 trips)             k > 1: max(2.88, 2.45 + 0.165 trips) + 0.05 log2(k / 2)
-//     general times      k = 1: max(2.90, 2.85 + 0.434 trips)             k = 1: max(2.32, 1.50 + 0.46 trips)
-//                        k > 1: max(3.45, 2.90 + 0.478 trips)             k > 1: max(2.72, 2.10 + 0.46 trips) + 0.05 log2(k / 2)
-//     DDRate / trend     k = 1: max(2.60, 2.70 + 0.18 trips)              k = 1: max(2.30, 1.45 + 0.20 trips)
-//                        k > 1: max(3.05, 2.70 + 0.21 trips)              k > 1: max(2.90, 2.50 + 0.16 trips)
+//     unit resolution    k = 1: max(2.95, 2.93 + 0.180 trips)             k = 1: max(2.02, 1.68 + 0.135 trips)
+//                        k > 1: max(3.40, 3.20 + 0.205 trips)             k > 1: max(2.78, 2.32 + 0.125 trips) + 0.05 log2(k / 2)
+//     general times      k = 1: max(2.90, 2.85 + 0.434 trips)             k = 1: max(2.05, 1.53 + 0.30 trips)
+//                        k > 1: max(3.45, 2.90 + 0.478 trips)             k > 1: max(2.63, 2.15 + 0.33 trips) + 0.05 log2(k / 2)
+//     DDRate / trend     k = 1: max(2.60, 2.70 + 0.18 trips)              k = 1: max(2.05, 1.55 + 0.125 trips)
+//                        k > 1: max(3.05, 2.70 + 0.21 trips)              k > 1: max(2.90, 2.25 + 0.112 trips)
+// (a team per chain: refitted in round 4 to the one-chain form of the scan - 8-byte gathers, half the fp64 instructions -,
+// scratch/exp_teams.py 1 unit | dd | general on 32 chains; LR_PLAN_CHECK=1 checks the choice on the device in use)
 // (the floor is the candidate build - shorter with one chain per CU: the table is built by a helper wave on a SIMD of its
 // own, a no-op move copies its table, and the scanners need no table build behind the barrier -; a team pays the exchange
 // behind its last scanner; a team per chain scans for one chain what a team per pair scans for two, so it needs the CUs:
@@ -993,19 +995,26 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
             if (k_env > 0 && k != k_env) continue;
             // (groups beyond an XCD's 4 MB of L2 stream from HBM with one group of prefetch per lane: measured 0.32 instead of
             // 0.205 us per trip at 10M lineages; round-2 sweep)
-            const double slow = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) > 4.0e6 ? 1.55 : 1.0;
+            const bool streaming = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) > 4.0e6;
+            const double slow = streaming ? 1.55 : 1.0;
             const double trips = slow * n8 / k / (double)((cpb == 1 ? LR_SPEC_THREADS_SINGLE : LR_SPEC_THREADS) - 256);
+            // (a trip that waits for its group to arrive from HBM costs what the memory round trip costs: the one-chain form
+            // of the scan, which made the L2-resident trips of a team per chain cheaper in round 4, does not shorten it -
+            // the round-3 slopes stay for that regime)
+            const double s1 = streaming ? 0.20 : 0.135, sk = streaming ? 0.165 : 0.125;          // unit resolution, a team per chain
+            const double d1 = streaming ? 0.20 : 0.125, dk = streaming ? 0.16 : 0.112;           // parametric samplers
+            const double g1 = streaming ? 0.46 : 0.30, gk = streaming ? 0.46 : 0.33;             // general times
             double t;
             if (cfg->sampler != 0) {
                 if (cpb == 2) t = (k == 1) ? fmax(2.60, 2.70 + 0.18 * trips) : fmax(3.05, 2.70 + 0.21 * trips);
-                else t = (k == 1) ? fmax(2.30, 1.45 + 0.20 * trips) : fmax(2.90, 2.50 + 0.16 * trips);
-                if (general) t += 0.26 * trips;
+                else t = (k == 1) ? fmax(2.05, 1.55 + d1 * trips) : fmax(2.90, 2.25 + dk * trips);
+                if (general) t += ((cpb == 1 && !streaming) ? 0.17 : 0.26) * trips;
             } else if (!general) {
                 if (cpb == 2) t = (k == 1) ? fmax(2.95, 2.93 + 0.180 * trips) : fmax(3.40, 3.20 + 0.205 * trips);
-                else t = (k == 1) ? fmax(2.44, 1.62 + 0.20 * trips) : fmax(2.88, 2.45 + 0.165 * trips) + (k == 4 ? 0.05 : (k == 8 ? 0.10 : 0.0));
+                else t = (k == 1) ? fmax(2.02, 1.68 + s1 * trips) : fmax(2.78, 2.32 + sk * trips) + (k == 4 ? 0.05 : (k == 8 ? 0.10 : 0.0));
             } else {
                 if (cpb == 2) t = (k == 1) ? fmax(2.90, 2.85 + 0.434 * trips) : fmax(3.45, 2.90 + 0.478 * trips);
-                else t = (k == 1) ? fmax(2.32, 1.50 + 0.46 * trips) : fmax(2.72, 2.10 + 0.46 * trips) + (k == 4 ? 0.05 : (k == 8 ? 0.10 : 0.0));
+                else t = (k == 1) ? fmax(2.05, 1.53 + g1 * trips) : fmax(2.63, 2.15 + gk * trips) + (k == 4 ? 0.05 : (k == 8 ? 0.10 : 0.0));
             }
             if (t < best_c - 0.05) best_c = t, k_c = k;
         }

@@ -243,13 +243,15 @@ def test_engine_chain_streams_do_not_depend_on_sharding(G):
                                                        ("metal_bands", 2, 128, 600_000, 600, 0.8)])
 def test_engine_posterior_matches_reference_chains(G, golden_dir, name, model, C, n_it, s, k_tol):
     """Posterior rate marginals within Monte-Carlo error of long runs of the reference CLI
-    (tests/golden/make_chains.py: 4 chains x 2M iterations): per-bin marginal means, mean K.
+    (tests/golden/make_chains.py: 16 chains x 2M iterations each, so that the reference side no longer dominates the
+    standard error): per-bin marginal means at |z| < 4 and 8 % relative, mean K.
     metal_bands / 128 chains / RJ prior is BASELINE.json configs[1]."""
     path = os.path.join(golden_dir, "posterior_%s_m%d.npz" % (name, model))
     from literate_amd.engine import ChainEngine, split_trace_row
     from oracle import literate_oracle as lo
     R = np.load(path)
     n_ref = int(R["meta"][3])
+    assert n_ref >= 16
     eng = ChainEngine(G[name + "/ts"], G[name + "/te"], C, model=model, seed=77, s_freq=s, n_trace_slots=n_it // s)
     eng.init(); eng.steps(n_it)
     tr = eng.trace_rows()
@@ -269,8 +271,8 @@ def test_engine_posterior_matches_reference_chains(G, golden_dir, name, model, C
     for mine, ref in ((sp, ref_sp), (ex, ref_ex)):
         se = np.sqrt(mine.var(0, ddof=1) / len(mine) + ref.var(0, ddof=1) / len(ref))
         z = (mine.mean(0) - ref.mean(0)) / se
-        assert np.max(np.abs(z)) < 6.0, z
-        assert np.allclose(mine.mean(0), ref.mean(0), rtol=0.15)
+        assert np.max(np.abs(z)) < 4.0, z
+        assert np.allclose(mine.mean(0), ref.mean(0), rtol=0.08), np.max(np.abs(mine.mean(0) / ref.mean(0) - 1.0))
     ref_kl = [np.dot(R["c%d/K_l_hist" % c], np.arange(40)) / R["c%d/K_l_hist" % c].sum() for c in range(n_ref)]
     assert abs(np.mean(kl) - np.mean(ref_kl)) < k_tol
     if name == "metal_bands":

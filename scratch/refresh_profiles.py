@@ -40,9 +40,9 @@ summary = {"kernel": kname, "workload": "cfg4: 1024 chains x 100k lineages", "it
            "lds_busy_fraction": v["SQ_LDS_IDX_ACTIVE"] / cycles / 256,
            "valu_busy_fraction": v["SQ_ACTIVE_INST_VALU"] / cycles / 256,
            "lds_bank_conflict_fraction": v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"],
-           # wave64 vector instructions (VALU + LDS) per SIMD x 4.18 cycles each (scratch/ubench/valu_rate.hip) over the
-           # cycles of the launch: how full the SIMDs' issue ports are
-           "vector_issue_fraction": (v["SQ_INSTS_VALU"] + v["SQ_INSTS_LDS"]) / (256 * 4) * 4.18 / cycles,
+           # VALU issue cycles over the cycles of the launch, bracketed by the two issue classes of profiles/r04_ubench.txt
+           # (every instruction full rate: 2.35 cycles; every instruction half rate: 4.2)
+           "valu_issue_fraction_bounds": [v["SQ_INSTS_VALU"] / (256 * 4) * 2.35 / cycles, v["SQ_INSTS_VALU"] / (256 * 4) * 4.2 / cycles],
            "vector_instructions_per_CU_per_iteration": (v["SQ_INSTS_VALU"] + v["SQ_INSTS_LDS"]) / 256 / 1000,
            "wave_cycles_split": {x: v[x] / v["SQ_WAVE_CYCLES"] for x in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS") if x in v},
            "source": "rocprofv3 --pmc <counter group> --kernel-trace (separate passes) -- python3 scratch/prof_persist.py (one launch of "
@@ -68,7 +68,7 @@ if len(sys.argv) > 4:
             "workload": "cfg3: 256 chains x 10k lineages, a team per chain (256 blocks), one launch of 2000 iterations from the initial state",
             "counters_mean_per_launch": vs, "profiled_launch_ms": ns / 1e6, "us_per_iteration_in_profiled_launch": ns / 1e3 / n_it,
             "valu_busy_fraction": vs["SQ_ACTIVE_INST_VALU"] / cyc / blocks, "lds_busy_fraction": vs["SQ_LDS_IDX_ACTIVE"] / cyc / blocks,
-            "vector_issue_fraction": (vs["SQ_INSTS_VALU"] + vs["SQ_INSTS_LDS"]) / (blocks * 4) * 4.18 / cyc,
+            "valu_issue_fraction_bounds": [vs["SQ_INSTS_VALU"] / (blocks * 4) * 2.35 / cyc, vs["SQ_INSTS_VALU"] / (blocks * 4) * 4.2 / cyc],
             "vector_instructions_per_CU_per_iteration": (vs["SQ_INSTS_VALU"] + vs["SQ_INSTS_LDS"]) / blocks / n_it,
             "salu_instructions_per_CU_per_iteration": vs["SQ_INSTS_SALU"] / blocks / n_it,
             "note": "2 candidate + 2 helper + 8 scanner waves per CU; the iteration is the serial chain candidate (to the hand-over) -> "
@@ -102,11 +102,14 @@ if len(sys.argv) > 6:
              "per_CU_per_iteration": {"valu": valu, "lds": lds, "salu": vl["SQ_INSTS_SALU"] / 256 / n_it, "vmem_rd": vl["SQ_INSTS_VMEM_RD"] / 256 / n_it},
              "valu_busy_fraction_profiled": vl["SQ_ACTIVE_INST_VALU"] / cyc / 256, "lds_busy_fraction_profiled": vl["SQ_LDS_IDX_ACTIVE"] / cyc / 256,
              "lds_bank_conflict_fraction": vl["SQ_LDS_BANK_CONFLICT"] / vl["SQ_LDS_IDX_ACTIVE"],
-             "valu_issue_fraction_at_bench_speed": valu * 4.18 / 4 / (us_bench * 2400),
-             "valu_plus_lds_issue_fraction_at_bench_speed": (valu + lds) * 4.18 / 4 / (us_bench * 2400),
+             "valu_issue_fraction_at_bench_speed_bounds": [valu * 2.35 / 4 / (us_bench * 2400), valu * 4.2 / 4 / (us_bench * 2400)],
+             "scan_loop_valu_issue_fraction_at_bench_speed": 4 * 7143 / 64.0 * 92.55 / 4 / (us_bench * 2400),
+             "lds_data_cycles_fraction_at_bench_speed": vl["SQ_LDS_IDX_ACTIVE"] / 256 / n_it / (us_bench * 2400),
              "note": "the counter passes slow the launch (us_per_iteration_profiled against the unprofiled bench line); the *_at_bench_speed "
-                     "fractions put the instruction counts of this launch over the unprofiled iteration time: a SIMD issues one wave64 VALU "
-                     "instruction per 4.18 cycles (scratch/ubench/valu_rate.hip)",
+                     "fractions put the counts of this launch over the unprofiled iteration time.  VALU issue: a wave64 instruction costs "
+                     "2.35 (plain 32-bit) or 4.2 cycles (fp64, SDWA / DPP, three-operand integer, compares) of its SIMD (profiles/r04_ubench.txt) - "
+                     "the bounds take all instructions as one class; the scan loop's own share is exact (4 chains = 2 pairs x 7143 groups / 64 lanes "
+                     "x 92.55 cycles per trip over 4 SIMDs).  SQ_LDS_IDX_ACTIVE = cycles the LDS data path is busy, per CU",
              "source": "bash scratch/pmc_persist_long.sh <dir>: rocprofv3 --pmc <group> --kernel-trace (separate passes) -- python3 "
                        "scratch/prof_persist.py with LR_PROF_ITERS=4000"}
     json.dump(long_, open(os.path.join(root, "profiles/%s_pmc_4000it.json" % tag), "w"), indent=1)

@@ -1,5 +1,6 @@
-"""The committed bench line (profiles/r03_bench_cfg4_1gpu.json = `python bench.py` on an MI355X) carries every field the
-driver's contract names, and the numbers in it are mutually consistent and agree with the committed rocprofv3 summary."""
+"""The committed bench line (profiles/r04_bench_cfg4_1gpu.json = `python bench.py` on an MI355X) carries every field the
+driver's contract names, and the numbers in it are mutually consistent and agree with the committed rocprofv3 summaries
+(engine kernel: r04_launch_durations.json / r04_pmc_*.json; the HBM-streaming entry points: r04_abi_kernel_stats.json)."""
 import json
 import os
 
@@ -9,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    b = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_cfg4_1gpu.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg4_1gpu.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "configs"):
         assert k in b, k
@@ -39,6 +40,12 @@ def test_committed_bench_line_has_the_contract_fields():
         s = b["configs"][name]
         assert s["evals_per_s"] > 0 and s["us_per_iter"] > 0 and 0 < s["lds_frac"] < 1 and s["kernel"].startswith("lr_")
     assert b["configs"]["cfg5"]["cpu_baseline"]["kind"] == "port"
+    # a team per CHAIN scores one chain per gather (8-byte reads of the one-chain scan): its LDS bytes per eval follow that
+    for name in ("cfg2", "cfg3", "cfg5", "cfg4_shard128"):
+        s = b["configs"][name]
+        assert s["chains_per_gather"] == 1 and s["gathers_per_eval"] == pytest.approx(8 / 14) and "lr_spec_kernel" in s["kernel"]
+        assert s["lds_bytes_per_eval"] == pytest.approx(8 * 16 / 14.0)
+    assert b["configs"]["cfg4_general"]["chains_per_gather"] == 2
     # the unit is stated for what it is: gathers and fp64 operations per counted eval, the un-amortised 16-B figure, the
     # aggregation in words; every host core in the CPU leg; the co-headline on continuous times with its own roofline
     assert r["gathers_per_eval"] == pytest.approx(8 / 28) and r["fp64_ops_per_eval"] == pytest.approx(17 / 28)
@@ -50,13 +57,51 @@ def test_committed_bench_line_has_the_contract_fields():
     assert "continuous times" in co["workload"] and co["value"] == pytest.approx(b["configs"]["cfg4_general"]["evals_per_s"])
     assert co["roofline"]["gathers_per_eval"] == pytest.approx(16 / 28) and 0 < co["roofline"]["frac"] < 1
     assert cfg["wall_over_device"] == pytest.approx(b["ms_per_step"] * b["steps"] / r["kernel_ms"], rel=1e-6)
+    # the issue-rate view follows the per-class costs of profiles/r04_ubench.txt
+    i = r["issue"]
+    assert i["simd_cycles_per_trip"] == pytest.approx(i["half_rate_instr_per_trip"] * 4.2 + i["full_rate_instr_per_trip"] * 2.35)
+    assert i["frac"] == pytest.approx(r["kernel_evals_per_s"] / i["peak_evals_per_s"]) and 0 < i["frac"] < 1
+
+
+def test_abi_section_prices_the_hbm_streaming_entry_points():
+    """`abi`: lr_bin_unit_events and lr_bd_loglik_batch at 1e7 / 3e7 lineages against the 8 TB/s HBM peak - the kernels for
+    which HBM IS the bound (16 B per lineage and pass) - with the FETCH_SIZE traffic of the same call, and the
+    cost of the calc_likelihood seam."""
+    b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg4_1gpu.json")))
+    a = b["abi"]
+    assert a["peak_GBs"] == 8000.0 and a["bytes_per_lineage_pass"] == 16
+    sizes = {r["lineages"] for r in a["rows"]}
+    assert sizes == {10_000_000, 30_000_000}
+    for r in a["rows"]:
+        assert r["achieved_GBs"] == pytest.approx(16.0 * r["lineages"] * r["passes"] / (r["ms"] * 1e-3) / 1e9)
+        assert r["hbm_frac"] == pytest.approx(r["achieved_GBs"] / 8000.0)
+        if r["kernel"] == "lr_bd_loglik_batch":
+            assert r["passes"] == -(-r["chains"] // r["Cb"]) and r["Cb"] in (1, 2, 4, 8)
+    for k in ("lr_bin_unit_events", "lr_bd_loglik_batch"):
+        h = a[k]
+        assert h["hbm_frac"] >= 0.40, (k, h)                     # the north star's bar, on the kernel HBM bounds
+        assert h["traffic"] is not None and 0.9 < h["traffic_over_algorithmic"] < 1.3      # no wasted re-reads
+    # every sorted-input row with C <= Cb chains (one pass) is above the bar too
+    one_pass = [r for r in a["rows"] if r["kernel"] == "lr_bd_loglik_batch" and r["passes"] == 1 and r["order"] == "sorted"]
+    assert len(one_pass) >= 8 and min(r["hbm_frac"] for r in one_pass) >= 0.40
+    # the kernel trace of the same child command agrees with the HIP-event time of the call (three cold calls against
+    # back-to-back warm ones: within 15 %)
+    st = json.load(open(os.path.join(ROOT, "profiles", "r04_abi_kernel_stats.json")))["rows"]
+    for run, kern, rows_key in (("abi_lr_bd_loglik_batch_c1_n30000000", "lr_scan_fast_kernel<1, 136>", dict(kernel="lr_bd_loglik_batch", chains=1)),
+                                ("abi_lr_bin_unit_events_c0_n30000000", "lr_bin_unit_kernel", dict(kernel="lr_bin_unit_events", chains=0))):
+        k_ns = [x["avg_ns"] for x in st if x["run"] == run and kern in x["kernel"]][0]
+        call_ms = [r["ms"] for r in a["rows"] if r["lineages"] == 30_000_000 and not r["general_times"] and r["order"] == "sorted"
+                   and all(r[k] == v for k, v in rows_key.items())][0]
+        assert k_ns * 1e-6 == pytest.approx(call_ms, rel=0.15)
+    seam = a["seam"]["BDI_partial_lik"]
+    assert seam["us_per_call_1_state"] > seam["numpy_binned_us_per_call"] and seam["states_per_call_to_break_even"] < 64
 
 
 def test_driver_args_bench_line_measures_the_kernel():
-    """profiles/r03_bench_cfg4_1gpu_driver_args.json = `python bench.py --steps 20 --warmup 5` (the driver's command): the
+    """profiles/r04_bench_cfg4_1gpu_driver_args.json = `python bench.py --steps 20 --warmup 5` (the driver's command): the
     wall-clock figure stays within 35 % of the event-bracketed device time of the same region (round 2: 66 %; what is left
-    is one launch, two event markers and the completion wake-up of a ~150-us region: 1.22-1.29 by box of the pool)."""
-    b = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_cfg4_1gpu_driver_args.json")))
+    is one launch, two event markers and the completion wake-up of a ~140-us region: 1.18-1.22 by box of the pool)."""
+    b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg4_1gpu_driver_args.json")))
     assert b["steps"] == 20 and b["warmup"] == 5 and b["n_gpus"] == 1
     r = b["roofline"]
     assert b["ms_per_step"] * 1e3 <= 1.35 * r["engine"]["us_per_iter_device"]
@@ -65,12 +110,12 @@ def test_driver_args_bench_line_measures_the_kernel():
 
 
 def test_profile_summary_agrees_with_the_bench_line():
-    """profiles/r03_launch_durations.json: the timed launch in rocprofv3's kernel trace against bench.py's HIP events of
-    the same (profiled) run; profiles/r03_pmc_1000it.json names the same kernel."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_launch_durations.json")))
+    """profiles/r04_launch_durations.json: the timed launch in rocprofv3's kernel trace against bench.py's HIP events of
+    the same (profiled) run; profiles/r04_pmc_1000it.json names the same kernel."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_launch_durations.json")))
     assert d["timed_2000_iteration_launch_ms_kernel_trace"] == pytest.approx(
         d["bench_hip_event_ms_for_the_timed_2000_iteration_launch"], rel=0.01)
-    p = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_1000it.json")))
-    b = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_cfg4_1gpu.json")))
+    p = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_1000it.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg4_1gpu.json")))
     assert p["kernel"].split("<")[0] == b["roofline"]["kernel"].split("<")[0] == d["kernel"].split("<")[0]
     assert 0 < p["lds_busy_fraction"] < 1 and 0 < p["valu_busy_fraction"] < 1

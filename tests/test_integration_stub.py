@@ -1,5 +1,6 @@
-"""The ctypes stub INTEGRATION.md section 2 shows a LiteRate maintainer, exercised as written: raw ctypes on
-libliterate_hip.so (no literate_amd import), torch only for device memory, replacing calc_likelihood (LRF:430-431)."""
+"""The ctypes stubs INTEGRATION.md section 2 shows a LiteRate maintainer, exercised as written: raw ctypes on
+libliterate_hip.so (no literate_amd import), torch only for device memory, replacing calc_likelihood (LRF:430-431) and
+the binning loop (LRF:519-523)."""
 import ctypes
 import os
 
@@ -51,3 +52,26 @@ def test_integration_md_stub_matches_reference_likelihoods(G):
         M = np.where(np.arange(n_bins) < 16, .15, .19)
         want = 15.824528451812753 if model_BDI == 0 else -352.6785362157869
         assert calc_likelihood(L, M) == pytest.approx(want, rel=1e-9)
+
+
+def test_integration_md_binning_stub_matches_reference_statistics(G):
+    """The one-pass binning call of INTEGRATION.md section 2, as written, against the statistics the reference's own loop
+    (LRF:519-523) produced for the shipped datasets (tests/golden/binning_lik.npz): bit for bit."""
+    import torch
+    _lr = ctypes.CDLL(os.path.join(ROOT, "literate_amd", "csrc", "libliterate_hip.so"))
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    for name in ("example_TBP", "example_TAD", "metal_bands", "simulated"):
+        ts, te = G[name + "/ts"], G[name + "/te"]
+        _ts = torch.as_tensor(ts, dtype=torch.float64, device="cuda")
+        _te = torch.as_tensor(te, dtype=torch.float64, device="cuda")
+        _lr.lr_bin_unit_events_workspace_bytes.restype = ctypes.c_int64
+        t0 = int(min(ts)); n_bins = int(max(te)) - t0                      # the windows [i, i + 1], i in range(int(min ts), int(max te))
+        _sp = torch.empty(n_bins, dtype=torch.int64, device="cuda"); _ex = torch.empty_like(_sp)
+        _brl = torch.empty(n_bins, dtype=torch.float64, device="cuda")
+        _wsb = torch.empty(_lr.lr_bin_unit_events_workspace_bytes(ctypes.c_int64(len(ts)), n_bins), dtype=torch.uint8, device="cuda")
+        rc = _lr.lr_bin_unit_events(P(_ts), P(_te), ctypes.c_int64(len(ts)), ctypes.c_double(t0), n_bins, P(_sp), P(_ex), P(_brl),
+                                    P(_wsb), ctypes.c_int64(_wsb.numel()), None)
+        sp_events_bin, ex_events_bin, br_length_bin = _sp.cpu().numpy(), _ex.cpu().numpy(), _brl.cpu().numpy()
+        assert rc == 0 and n_bins == len(G[name + "/sp"])
+        assert np.array_equal(sp_events_bin, G[name + "/sp"]) and np.array_equal(ex_events_bin, G[name + "/ex"])
+        assert np.array_equal(br_length_bin, G[name + "/br"])

@@ -269,12 +269,18 @@ __global__ __launch_bounds__(LR_UB_THREADS) void lr_bin_unit_kernel(const double
             const unsigned long long* h = h_hi + ((size_t)(j - p.n32) << rshift);
             for (int r = 0; r < R; ++r) v += (long long)h[(r + j) & (R - 1)];
         }
-        if (v) __hip_atomic_fetch_add(acc + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v) {
+            // a RETURNING atomic, its old value consumed: the value comes back from where the add was performed (the
+            // memory side, agent scope), so once it is here the add is visible to every XCD - whatever a no-return
+            // atomic's completion count may mean on the way there
+            const long long old = __hip_atomic_fetch_add(acc + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(old));
+        }
     }
     // The block that takes the last ticket turns the accumulators into the outputs.  No release / acquire fences (an
-    // agent-scope fence writes back and invalidates the XCD's whole L2: ~1.3 us each, serialised per XCD): a wave's
-    // atomics have been performed once its vmcnt reaches 0, the barrier orders the block's waves before its ticket, and
-    // the last block reads the accumulators with agent-scope (sc1) loads that do not hit in its own L2.
+    // agent-scope fence writes back and invalidates the XCD's whole L2: ~1.3 us each, serialised per XCD): every add of
+    // this block has returned its old value (above), the barrier orders the block's waves before its ticket, and the
+    // last block reads the accumulators with agent-scope (sc1) loads that do not hit in its own L2.
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

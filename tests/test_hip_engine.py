@@ -243,8 +243,10 @@ def test_engine_chain_streams_do_not_depend_on_sharding(G):
                                                        ("metal_bands", 2, 128, 600_000, 600, 0.8)])
 def test_engine_posterior_matches_reference_chains(G, golden_dir, name, model, C, n_it, s, k_tol):
     """Posterior rate marginals within Monte-Carlo error of long runs of the reference CLI
-    (tests/golden/make_chains.py: 16 chains x 2M iterations each, so that the reference side no longer dominates the
-    standard error): per-bin marginal means at |z| < 4 and 8 % relative, mean K.
+    (tests/golden/make_chains.py: 32 chains x 2M iterations for example_TBP, 16 for metal_bands, so that the reference side
+    no longer dominates the standard error): per-bin marginal means at |z| < 4 and 8 % relative, mean K.  (With 16
+    example_TBP chains the reference's own grand mean of the recent death rates sat 0.5 % = 2.7 of its standard errors
+    below that of the next 16 - scratch/posterior_check.py; the device agrees with all 32 at |z| < 2.)
     metal_bands / 128 chains / RJ prior is BASELINE.json configs[1]."""
     path = os.path.join(golden_dir, "posterior_%s_m%d.npz" % (name, model))
     from literate_amd.engine import ChainEngine, split_trace_row

@@ -156,6 +156,7 @@ static lr_ub_shape lr_ub_plan(int W) {
         --p.rshift;
     }
     if (p.lds_bytes < (size_t)p.cols * 8) p.lds_bytes = (size_t)p.cols * 8;   // the last block's column totals
+    p.lds_bytes = (p.lds_bytes + 15) & ~(size_t)15;                           // zeroed in 16-byte stores, all of it
     return p;
 }
 
@@ -366,12 +367,11 @@ extern "C" int lr_bin_unit_events(const double* ts, const double* te, int64_t n,
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    static size_t configured = 64 * 1024;
-    if (p.lds_bytes > configured) {
+    if (p.lds_bytes > 64 * 1024) {
+        // (per call: the attribute belongs to the function on the CURRENT device, and a process may drive several)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_bin_unit_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return (int)e;
-        configured = p.lds_bytes;
     }
     // one block of 16 waves per CU (the histograms fill most of its LDS); short inputs: >= 8 lineages per thread
     const long long unit = 2 * LR_UB_THREADS;

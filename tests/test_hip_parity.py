@@ -100,7 +100,8 @@ def test_bin_unit_events_against_oracle_and_general_kernel(ops):
     from oracle import literate_oracle as lo
     rng = np.random.default_rng(11)
     for n, W, t0 in [(1, 1, 5.0), (2, 3, 2.0), (63, 24, 1.0), (1000, 24, 10.0), (4097, 128, 3.0), (20001, 300, 7.0),
-                     (30000, 1300, 100.0), (5000, 4000, 1.0), (70000, 33, -20.0)]:
+                     (30000, 1300, 100.0), (5000, 4000, 1.0), (70000, 33, -20.0), (9000, 2001, 4.0), (9000, 3003, 2.0),
+                     (6000, 4094, 1.0)]:
         ts = rng.uniform(t0 - 3, t0 + W + 2, n)
         te = ts + rng.exponential(max(W / 6.0, 0.7), n)
         te[rng.random(n) < 0.15] = t0 + W + 0.5                    # extant, past the last window

@@ -521,8 +521,43 @@ def abi_section(pmc=True, sizes=ABI_SIZES):
                 out[key]["traffic"], out[key]["traffic_note"] = traffic, note
                 if traffic:
                     out[key]["traffic_over_algorithmic"] = traffic / (16.0 * b["lineages"])
+    out["engine_streaming"] = abi_engine_rows(sizes)
     out["seam"] = abi_seam()
     return out
+
+
+def abi_engine_rows(sizes=ABI_SIZES, chains=16):
+    """The RJMCMC loop itself where HBM bounds it: few chains x very many lineages.  The planner then runs the
+    launch-based engine, whose scan kernel streams ts / te from HBM in EVERY iteration (16 B per lineage and pass of Cb
+    chains), followed by the chain-step kernel: us per iteration of the whole loop, evals/s, and 16 B x N x ceil(C / Cb) /
+    t against the 8 TB/s peak - for the whole iteration and for the scan kernel alone (lr_mcmc_time_scan)."""
+    import torch
+    from literate_amd.engine import ChainEngine
+    rows = []
+    for n in sizes:
+        ts, te = abi_lineages(n, False, "sorted")
+        eng = ChainEngine(ts, te, chains, model=0, seed=2026, s_freq=100, n_trace_slots=8, sort_lineages=False)
+        eng.init()
+        eng.steps(40)
+        torch.cuda.synchronize()
+        n_it = 100
+        ms = eng.timed_steps(n_it)
+        us = ms / n_it * 1e3
+        row = dict(lineages=n, chains=chains, kernel=eng.kernel_name(), persistent=int(eng.layout.persistent), us_per_iter=us,
+                   evals_per_s=float(n) * chains / (us * 1e-6))
+        if not eng.layout.persistent:
+            cb = int(eng.layout.chains_per_block)
+            passes = -(-chains // cb)
+            scan_us = eng.time_scan(20) * 1e3
+            row.update(Cb=cb, passes=passes, hbm_GBs=16.0 * n * passes / (us * 1e-6) / 1e9, scan_kernel_us=scan_us,
+                       scan_hbm_GBs=16.0 * n * passes / (scan_us * 1e-6) / 1e9)
+            row["hbm_frac"] = row["hbm_GBs"] / HBM_PEAK_GBS
+            row["scan_hbm_frac"] = row["scan_hbm_GBs"] / HBM_PEAK_GBS
+        rows.append(row)
+        eng.close()
+        del eng, ts, te
+        torch.cuda.empty_cache()
+    return rows
 
 
 def abi_seam():

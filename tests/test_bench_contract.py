@@ -93,6 +93,15 @@ def test_abi_section_prices_the_hbm_streaming_entry_points():
         call_ms = [r["ms"] for r in a["rows"] if r["lineages"] == 30_000_000 and not r["general_times"] and r["order"] == "sorted"
                    and all(r[k] == v for k, v in rows_key.items())][0]
         assert k_ns * 1e-6 == pytest.approx(call_ms, rel=0.15)
+    # the RJMCMC loop itself where HBM bounds it (few chains x 1e7 / 3e7 lineages: the launch-based engine streams ts / te in
+    # every iteration): the WHOLE iteration against the HBM peak, and its scan kernel alone
+    es = a["engine_streaming"]
+    assert [r["lineages"] for r in es] == [10_000_000, 30_000_000] and all(r["persistent"] == 0 and r["passes"] == 1 for r in es)
+    for r in es:
+        assert r["hbm_GBs"] == pytest.approx(16.0 * r["lineages"] * r["passes"] / (r["us_per_iter"] * 1e-6) / 1e9)
+        assert r["evals_per_s"] == pytest.approx(r["lineages"] * r["chains"] / (r["us_per_iter"] * 1e-6)) and r["evals_per_s"] > 1e12
+        assert r["hbm_frac"] >= 0.35 and r["scan_hbm_frac"] >= 0.55 and "lr_scan_unit_kernel" in r["kernel"]
+    assert es[1]["hbm_frac"] >= 0.50
     seam = a["seam"]["BDI_partial_lik"]
     assert seam["us_per_call_1_state"] > seam["numpy_binned_us_per_call"] and seam["states_per_call_to_break_even"] < 64
 

@@ -1117,3 +1117,42 @@ def test_planner_self_check_against_a_measurement(monkeypatch, n_lin, C):
     assert t["auto"] is not None and t["launch"] is not None and t[r["best"]] == min(v for k, v in t.items() if v is not None and k != "auto")
     assert t["auto"] <= 1.25 * t[r["best"]], r
     assert r["ok"] == (not any("LR_PLAN_CHECK" in str(w.message) for w in caught))
+
+
+def test_launch_engine_streams_1e7_lineages_from_hbm():
+    """Few chains x very many lineages - 16 chains x 1e7 lineages, the regime where the ENGINE is HBM-bound: the planner
+    picks the launch-based engine, whose scan kernel reads ts / te (160 MB) in every iteration.  Two chains row by row
+    against the oracle loop on statistics binned from the same lineages, and every chain's accepted state re-evaluated by
+    lr_bd_loglik_batch and by the oracle's binned calc_likelihood."""
+    import torch
+    from literate_amd import ops, synth
+    from literate_amd.engine import ChainEngine, split_trace_row
+    from oracle import literate_oracle as lo
+    from oracle import mcmc_oracle as mo
+    ts0, te0, _ = synth.make_lineages(100_000, n_bins=128, n_shifts=20, seed=0)
+    reps, C, n_it, seed = 100, 16, 60, 2026
+    ts, te = np.tile(ts0, reps), np.tile(te0, reps)
+    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it)
+    assert eng.layout.persistent == 0 and eng.unit_resolution and eng.kernel_name().startswith("lr_scan_unit_kernel<16,")
+    eng.init(); eng.steps(25); eng.steps(n_it - 25)
+    tr = eng.trace_rows()
+    snap = eng.snapshot()
+    assert np.all(snap["it"] == n_it) and np.all(np.isfinite(snap["likA"]))
+    # the statistics of the tiled data are `reps` times those of one copy (exact: integer counts, half-integer lineage-time)
+    t0, sp, ex, br = lo.bin_events_cli(ts0, te0)
+    stats = dict(sp=sp * reps, ex=ex * reps, br=br * reps)
+    assert np.array_equal(eng.sp_events.cpu().numpy(), stats["sp"]) and np.array_equal(eng.br_length.cpu().numpy(), stats["br"])
+    lam, mu = _accepted_rates(snap, eng.n_bins, C)
+    lik = ops.bd_loglik_batch(eng.ts, eng.te, eng.t0, lam, mu, 0, br_length=stats["br"]).cpu().numpy()
+    assert np.allclose(lik, snap["likA"], rtol=1e-9)
+    for c in range(C):
+        with np.errstate(all="ignore"):
+            assert lo.calc_likelihood(0, lam[c], mu[c], stats) == pytest.approx(snap["likA"][c], rel=1e-9)
+    for c in (0, 15):
+        with np.errstate(all="ignore"):
+            ref = mo.run_mcmc(stats, ts.min(), te.max(), mo.Settings(model_BDI=0), mo.PhiloxDraws(seed, c), n_it, 1, k_max=32)
+        for i in range(n_it):
+            head, s_row, e_row = split_trace_row(tr[i, c])
+            assert np.allclose(head[:13], ref["mcmc"][i][:13], rtol=1e-9, atol=1e-9), (c, i, head[:6], ref["mcmc"][i][:6])
+    eng.close()
+    torch.cuda.empty_cache()

@@ -1182,18 +1182,24 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
     int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
     lr_chain_load(st, S, I, lane);
-    // the lane's tile partials, added in tile order - eight independent loads in flight at a time: with ~2000 tiles (few
-    // chains x very many lineages) a load-add-load chain of 32 round trips cost this kernel 16 us, half the scan it follows
+    // the lane's tile partials, added in tile order - sixteen independent loads in flight at a time: with ~2000 tiles (few
+    // chains x very many lineages) a load-add-load chain of 32 memory round trips cost this kernel 16 us, half the scan it
+    // follows (the partials come from blocks on every XCD: each round trip goes to memory)
     double part = 0.0;
     const double* col = a.partials + c;
     const size_t stride = (size_t)a.cfg.n_chains;
     int t = lane;
-    for (; t + 7 * LR_WAVE < a.tiles; t += 8 * LR_WAVE) {
+    for (; t + 15 * LR_WAVE < a.tiles; t += 16 * LR_WAVE) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = col[(size_t)(t + q * LR_WAVE) * stride];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part += v[q];
+    }
+    for (; t + 3 * LR_WAVE < a.tiles; t += 4 * LR_WAVE) {
         const double a0 = col[(size_t)t * stride], a1 = col[(size_t)(t + LR_WAVE) * stride];
         const double a2 = col[(size_t)(t + 2 * LR_WAVE) * stride], a3 = col[(size_t)(t + 3 * LR_WAVE) * stride];
-        const double a4 = col[(size_t)(t + 4 * LR_WAVE) * stride], a5 = col[(size_t)(t + 5 * LR_WAVE) * stride];
-        const double a6 = col[(size_t)(t + 6 * LR_WAVE) * stride], a7 = col[(size_t)(t + 7 * LR_WAVE) * stride];
-        part += a0, part += a1, part += a2, part += a3, part += a4, part += a5, part += a6, part += a7;
+        part += a0, part += a1, part += a2, part += a3;
     }
     for (; t < a.tiles; t += LR_WAVE) part += col[(size_t)t * stride];
     const double lik_sum = lr_wave_sum(part);

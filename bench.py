@@ -563,7 +563,8 @@ def abi_engine_rows(sizes=ABI_SIZES, chains=16):
 def abi_seam():
     """What the drop-in seam costs: literate_library.BDI_partial_lik / BD_lik_Keiding (the calc_likelihood operator,
     LRF:137-162, 305-308) on the shipped metal_bands lineages - wall time per call with ONE state (what a maintainer who
-    only swaps the operator pays per iteration: launch + sync + 8-byte read-back) and with 1024 states per call - beside
+    only swaps the operator pays per iteration: one launch + the result polled in pinned host memory) and with 1024 states
+    per call (upload, three launches, read-back, synchronisation) - beside
     the reference's binned numpy expression timed in this process (cpu leg: oracle/)."""
     import literate_library as ll
     G = np.load(os.path.join(ROOT, "tests", "golden", "binning_lik.npz"))
@@ -605,11 +606,13 @@ def abi_seam():
         a, n_us = out[name]["us_per_call_1_state"], out[name]["numpy_binned_us_per_call"]
         b = (out[name]["us_per_call_1024_states"] - a) / 1023.0
         out[name]["states_per_call_to_break_even"] = (a - b) / (n_us - b) if n_us > b else None
-    out["note"] = ("one state per call is latency bound (one upload, 3 launches, one read-back, one synchronisation: "
-                   "literate_amd.ops.LoglikSession) and several times slower than the reference's 24..32-element numpy "
-                   "expression on binned statistics; swapping only the operator pays off from states_per_call_to_break_even "
-                   "states per call (chains evaluated together) - a maintainer who wants the speed binds lr_mcmc_steps, "
-                   "which keeps the whole loop on the device")
+    out["note"] = ("one state per call is latency bound - for few states on few lineages lr_bd_loglik_batch is ONE launch "
+                   "(lr_loglik_small_kernel) and literate_amd.ops.LoglikSession lets the kernel read the rates from pinned host "
+                   "memory and write its result there, polled by the host: no copy, no stream synchronisation - and still "
+                   "slower than the reference's 24..32-element numpy expression on binned statistics; swapping only the "
+                   "operator pays off from states_per_call_to_break_even states per call (chains evaluated together; beyond 16 "
+                   "states per call: one upload, three launches, one read-back) - a maintainer who wants the speed binds "
+                   "lr_mcmc_steps, which keeps the whole loop on the device")
     return out
 
 

@@ -127,6 +127,44 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_kernel(const double* 
     }
 }
 
+// Small inputs (the calc_likelihood seam: LRF:305-308 evaluates ONE state per MCMC iteration on a few thousand lineages):
+// one launch instead of three.  A 1024-thread block per chain: wave 0 builds the chain's table in LDS, every thread scores
+// lineages tid, tid + 1024, ..., the wave sums (fixed order inside a wave) are added in wave order, out[c] = sum + constant.
+#define LR_SMALL_THREADS 1024
+__global__ __launch_bounds__(LR_SMALL_THREADS) void lr_loglik_small_kernel(
+    const double* __restrict__ ts, const double* __restrict__ te, long long n, double t0, int n_bins, int n_cls, int H,
+    double end_time, const double* __restrict__ lam_bins, const double* __restrict__ mu_bins,
+    const double* __restrict__ br_length, int model, double* __restrict__ out) {
+    extern __shared__ double2 lds[];
+    __shared__ double red[LR_SMALL_THREADS / LR_WAVE];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
+    double cst = 0.0;
+    if (wave == 0)
+        cst = lr_build_tables_wave(lam_bins + (size_t)c * n_bins, mu_bins + (size_t)c * n_bins, br_length, model, n_bins, n_cls,
+                                   H, lds, lane);
+    __syncthreads();
+    double acc[1] = {0.0};
+    const double nb1 = (double)(n_bins + 1);
+    const int tab_stride = n_cls * 2 * H;
+    for (long long i = tid; i < n; i += LR_SMALL_THREADS)
+        lr_score_lineage<1>(ts[i], te[i], t0, nb1, H, n_cls, end_time, lds, tab_stride, acc);
+    const double w = lr_wave_sum(acc[0]);
+    if (lane == 0) red[wave] = w;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < LR_SMALL_THREADS / LR_WAVE; ++k) t += red[k];
+        out[c] = t + cst;
+    }
+}
+
+// the inputs the one-launch form takes: few states on few lineages (a block walks ALL lineages for its chain)
+static inline bool lr_loglik_small(long long n, int n_chains) {
+    static const int off = getenv("LR_LOGLIK_SMALL") ? atoi(getenv("LR_LOGLIK_SMALL")) == 0 : 0;
+    return !off && n <= (1ll << 18) && n_chains <= 64 && n * (long long)n_chains <= (1ll << 21);
+}
+
 // out[c] = consts[c] + the sum of chain c's tile partials, in a FIXED order: one 256-thread block per chain, thread j adds
 // tiles j, j + 256, ... in ascending order (four independent loads in flight), 16 threads then add 16 of those sums each,
 // thread 0 the 16.  (One thread per chain walking ~2000 tiles serially took 145 us - five times the scan of 1e7 lineages.)
@@ -359,6 +397,14 @@ extern "C" int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n,
     lr_loglik_ws(p, n_chains, &o_tab, &o_cst, &o_par, &total);
     if ((int64_t)total > workspace_bytes) return LR_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
+    if (lr_loglik_small(n, n_chains)) {
+        const size_t lds = (size_t)p.n_cls * 2 * (n_bins + 2) * sizeof(double2);
+        if (lds <= 60 * 1024) {
+            hipLaunchKernelGGL(lr_loglik_small_kernel, dim3(n_chains), dim3(LR_SMALL_THREADS), lds, stream, ts, te, (long long)n, t0,
+                               n_bins, p.n_cls, n_bins + 2, end_time, lam_bins, mu_bins, br_length, model, out_loglik);
+            return (int)hipGetLastError();
+        }
+    }
     char* ws = (char*)workspace;
     double2* tables = (double2*)(ws + o_tab);
     double* consts = (double*)(ws + o_cst);

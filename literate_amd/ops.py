@@ -3,6 +3,8 @@
 Every function enqueues on torch's current HIP stream and raises if the HIP library or a GPU is
 missing (no CPU path).  Shapes follow include/literate_hip.h.
 """
+import os
+
 import numpy as np
 
 from . import _hip
@@ -171,10 +173,22 @@ class LoglikSession:
             _hip.check(int(nbytes), "lr_bd_loglik_workspace_bytes")
         self.ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)   # the session's own: nothing else scribbles on it
         self.stream = torch.cuda.current_stream(dev)
-        lam, mu = self.rates[0], self.rates[1]
+        # Few states on few lineages (the reference's own use: one state per iteration): lr_bd_loglik_batch is then ONE
+        # launch (lr_loglik_small_kernel), and the call can do without copies and without a stream synchronisation - the
+        # kernel reads the rates from the pinned host buffer and writes its result into pinned host memory, which the host
+        # polls (pinned host memory is device-accessible under its own address).
+        self.zero_copy = (self.C <= 16 and self.n <= (1 << 18) and self.n * self.C <= (1 << 21) and self.n_bins <= 900
+                          and os.environ.get("LR_LOGLIK_SMALL", "1") != "0")
+        if self.zero_copy:
+            lam, mu, out = self.rates_host[0], self.rates_host[1], self.out_host
+            self.out_bits = self.out_np.view(np.uint64)
+        else:
+            lam, mu, out = self.rates[0], self.rates[1], self.out
         self.args = (_hip.ptr(self.ts), _hip.ptr(self.te), self.n, float(t0), self.n_bins, _hip.ptr(lam), _hip.ptr(mu),
-                     self.C, self.model, _hip.ptr(self.br), float(end_time), _hip.ptr(self.out), _hip.ptr(self.ws),
+                     self.C, self.model, _hip.ptr(self.br), float(end_time), _hip.ptr(out), _hip.ptr(self.ws),
                      self.ws.numel(), _hip.c_vp(self.stream.cuda_stream))
+
+    _SENTINEL = np.uint64(0x7FF8DEAD0000BEEF)      # a NaN payload no arithmetic produces: "not written yet"
 
     def __call__(self, L, M):
         """L, M: [n_states, n_bins] (or [n_bins] when n_states == 1) host arrays -> numpy [n_states] (a view of the
@@ -182,6 +196,18 @@ class LoglikSession:
         torch = _torch()
         self.rates_np[0] = L
         self.rates_np[1] = M
+        if self.zero_copy:
+            self.out_bits[:] = self._SENTINEL
+            rc = self.lib.lr_bd_loglik_batch(*self.args)
+            _hip.check(rc, "lr_bd_loglik_batch")
+            bits, sent = self.out_bits, self._SENTINEL
+            for _ in range(200000):                       # ~0.2 s of polling at most, then the ordinary wait
+                if not (bits == sent).any():
+                    return self.out_np
+            self.stream.synchronize()
+            if (bits == sent).any():
+                raise _hip.HipLibraryError("lr_bd_loglik_batch: the result never arrived in host memory")
+            return self.out_np
         with torch.cuda.stream(self.stream):
             self.rates.copy_(self.rates_host, non_blocking=True)
             rc = self.lib.lr_bd_loglik_batch(*self.args)

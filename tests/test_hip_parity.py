@@ -288,6 +288,39 @@ def test_loglik_random_float_data_vs_oracle(ops):
             assert np.array_equal(a, b)
 
 
+def test_loglik_session_zero_copy_and_small_kernel(ops, G, monkeypatch):
+    """The calc_likelihood seam's prepared session (ops.LoglikSession): with few states on few lineages lr_bd_loglik_batch is
+    the one-launch kernel and the session runs it on pinned host buffers (rates read, result polled: no copy, no
+    synchronisation); beyond 16 states per call, or with LR_LOGLIK_SMALL=0, the tiled three-launch path with copies.  All
+    of them against the reference's calc_likelihood values and against each other, models 0-3, repeated calls."""
+    name = "metal_bands"
+    ts, te = G[name + "/ts"], G[name + "/te"]
+    start, end = G[name + "/start_end"]
+    L, tL, KL, M, tM, KM = _states(G, name)
+    n_bins = len(G[name + "/sp"])
+    lam = _np(ops.expand_rates(L, tL, KL, n_bins))
+    mu = _np(ops.expand_rates(M, tM, KM, n_bins))
+    for model in (0, 1, 2, 3):
+        ref = G["%s/lik_model%d" % (name, model)]
+        ok = np.isfinite(ref)
+        one = ops.LoglikSession(ts, te, float(int(start)), n_bins, 1, model, G[name + "/br"], end)
+        four = ops.LoglikSession(ts, te, float(int(start)), n_bins, 4, model, G[name + "/br"], end)
+        many = ops.LoglikSession(ts, te, float(int(start)), n_bins, len(ref), model, G[name + "/br"], end)
+        assert one.zero_copy and four.zero_copy and not many.zero_copy
+        got_many = many(lam, mu).copy()
+        assert np.allclose(got_many[ok], ref[ok], rtol=REL, atol=1e-9)
+        for rep in range(2):
+            for i in range(len(ref)):
+                v = one(lam[i], mu[i])[0]
+                assert (np.isfinite(v) and v == pytest.approx(ref[i], rel=REL, abs=1e-9)) or not ok[i], (model, i, v, ref[i])
+        got4 = four(lam[:4], mu[:4]).copy()
+        assert np.allclose(got4[ok[:4]], ref[:4][ok[:4]], rtol=REL, atol=1e-9)
+    monkeypatch.setenv("LR_LOGLIK_SMALL", "0")
+    plain = ops.LoglikSession(ts, te, float(int(start)), n_bins, 1, 2, G[name + "/br"], end)
+    assert not plain.zero_copy
+    assert plain(lam[0], mu[0])[0] == pytest.approx(G[name + "/lik_model2"][0], rel=REL)
+
+
 def test_loglik_bad_arguments(ops):
     ts, te = np.array([0.0, 1.0]), np.array([2.5, 3.5])
     lam = np.full((1, 3), .1)

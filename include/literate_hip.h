@@ -85,7 +85,11 @@ int lr_expand_rates(const double* rates, const double* times, const int32_t* K, 
  * ts/te per group of chains, unit bins [t0+b, t0+b+1), b < n_bins, t0 integer valued
  * (= int(min ts), LRF:519).  lam_bins/mu_bins [C,n_bins] are the per-bin rates (the
  * L_acc_vec/M_acc_vec arguments).  br_length [n_bins] is required for models 0/1 (it is the
- * k = br_length_bin of LRF:154), end_time for model 3.  out_loglik [C].                     */
+ * k = br_length_bin of LRF:154), end_time for model 3.  out_loglik [C].
+ * Few states on few lineages (n <= 2^18, C <= 64, n * C <= 2^21: the reference's own use, one state per iteration) take
+ * ONE launch - a block per state builds its table in LDS and walks all lineages (LR_LOGLIK_SMALL=0: never); lam_bins,
+ * mu_bins and out_loglik may then as well be pinned HOST memory (device-accessible), which saves the caller two copies
+ * and the synchronisation (literate_amd/ops.py LoglikSession).                                  */
 int64_t lr_bd_loglik_workspace_bytes(int64_t n, int32_t n_bins, int32_t n_chains, int32_t model);
 /* measurement hook: the launch shape lr_bd_loglik_batch uses for these sizes - out[0] = Cb, the chains one pass over
  * ts / te scores (the call makes ceil(n_chains / Cb) passes = 16 B x n x passes of algorithmic HBM reads), out[1] =

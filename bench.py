@@ -21,7 +21,11 @@ Beside the headline the line carries
   configs       - the other BASELINE configurations (cfg2, cfg3, cfg5), cfg4 on general (non-integer) lineage times,
                   and cfg4 exactly as BASELINE.json words it (1024 chains over 8 GPUs = a 128-chain shard);
   strong_scaling- for N > 1: the same 1024 chains in total, sharded over the N ranks, timed the same way;
-  cpu_baseline  - the numpy port (oracle/) on the host cores of the same box.
+  cpu_baseline  - the numpy port (oracle/) on the host cores of the same box;
+  abi           - the kernels HBM bounds, at sizes where it does (1e7 / 3e7 lineages): lr_bin_unit_events and
+                  lr_bd_loglik_batch against the 8 TB/s peak with the FETCH_SIZE traffic of the same call, the
+                  launch-based ENGINE on 16 chains x 1e7 / 3e7 lineages (the RJMCMC loop streaming ts / te every
+                  iteration), and the cost of the calc_likelihood seam per call.
 """
 import argparse
 import csv

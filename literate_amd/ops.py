@@ -40,8 +40,7 @@ def _workspace(nbytes, device):
 def _unit_windows(win_lo, win_hi):
     """(t0, n_bins) when the windows are the unit bins [t0 + w, t0 + w + 1] with t0 integer valued - what the reference
     always bins into (LRF:519-523, lib create_bins) - else None.  Decided on host arrays only (no device read-back)."""
-    torch = _torch()
-    if isinstance(win_lo, torch.Tensor) or isinstance(win_hi, torch.Tensor):
+    if hasattr(win_lo, "data_ptr") or hasattr(win_hi, "data_ptr"):     # torch tensors: possibly on the device, not inspected
         return None
     lo, hi = np.asarray(win_lo, dtype=float).ravel(), np.asarray(win_hi, dtype=float).ravel()
     if lo.size < 1 or hi.size != lo.size or lo.size > _hip.LR_MAX_BINS:

@@ -335,3 +335,28 @@ def test_parse_ts_te_against_the_reference_outcomes(tmp_path, golden_dir):
         assert [float(present), float(origin)] == list(P[tag + "/present_origin"]), tag
         n_ok += 1
     assert n_ok >= 16 and n_err >= 8
+
+
+def test_unit_window_routing_is_decided_on_the_host():
+    """ops.bin_events sends the windows the reference always bins into - [t0 + w, t0 + w + 1] on an integer origin (LRF:519-523,
+    lib create_bins:231-245) - to the one-pass kernel and everything else to lr_bin_events; the decision reads host arrays
+    only (no device read-back, no GPU needed to make it)."""
+    from literate_amd import ops
+    lo = 7.0 + np.arange(24)
+    assert ops._unit_windows(lo, lo + 1) == (7.0, 24)
+    assert ops._unit_windows([3.0], [4.0]) == (3.0, 1)
+    assert ops._unit_windows(list(lo), list(lo + 1)) == (7.0, 24)
+    assert ops._unit_windows(-5.0 + np.arange(4), -4.0 + np.arange(4)) == (-5.0, 4)
+    for bad_lo, bad_hi in ((lo + 0.5, lo + 1.5),                 # not on an integer origin
+                           (lo, lo + 2),                         # two units wide
+                           (lo[::-1], lo[::-1] + 1),             # descending
+                           (np.r_[lo[:5], lo[6:]], np.r_[lo[:5], lo[6:]] + 1),   # a gap
+                           ([0.0, 3.3], [1.0, 9.9]),             # arbitrary windows (precompute_events / get_BDlik segments)
+                           ([np.nan], [1.0]), ([1e12], [1e12 + 1]), ([], [])):
+        assert ops._unit_windows(bad_lo, bad_hi) is None
+    assert ops._unit_windows(np.arange(5000.0), np.arange(5000.0) + 1) is None      # more windows than LR_MAX_BINS
+
+    class FakeTensor:                                            # anything with a data_ptr is left alone
+        def data_ptr(self):
+            return 0
+    assert ops._unit_windows(FakeTensor(), FakeTensor()) is None

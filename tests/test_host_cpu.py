@@ -210,11 +210,15 @@ def _gloo_worker(rank, world, port, total, ret):
     for c in range(n):
         local[:, c, :] = float(off + c) + torch.arange(4, dtype=torch.float64)[:, None] * 100
     out = gather_traces(local, total)
+    # the engine status word agreed over the ranks before a window's gather (TraceStreamer.collect): a rank whose team
+    # exchange timed out (status 1) is seen by every rank, so that all raise alike and none is left waiting in the gather
+    from literate_amd.dist import agree_status
+    agreed = [agree_status(0, "cpu"), agree_status(1 if rank == 1 else 0, "cpu"), agree_status(0, "cpu")]
     if rank == 0:
         ok = out.shape == (4, total, 5) and all(float(out[s, c, 0]) == c + 100 * s for s in range(4) for c in range(total))
-        ret.put(bool(ok))
+        ret.put(bool(ok) and agreed == [0, 1, 0])
     else:
-        assert out is None
+        assert out is None and agreed == [0, 1, 0]
     dist.destroy_process_group()
 
 

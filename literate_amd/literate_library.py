@@ -77,8 +77,9 @@ def calcHPD(data, level=0.95):
 
 
 def random_choice(vector):
-    ind = np.random.choice(range(len(vector)))
-    return [vector[ind], ind]
+    """lib:69-72: [a uniformly chosen element, its position] - one np.random.choice draw, as the reference makes it."""
+    where = np.random.choice(len(vector))
+    return [vector[where], where]
 
 
 # ---- sufficient statistics (lib:74-85, 231-257) ----
@@ -211,22 +212,28 @@ def remove_shift_RJ_weighted_mean(rates, times):
 
 
 # ---- proposals on scalars / vectors that never touch the lineages: host numpy, the reference's draw order (lib:124-154) ----
+def _slide(value, width):
+    """the window move both sliding proposals share (lib:124-134): one uniform draw, centred, `width` wide"""
+    return value + (np.random.random() - .5) * width
+
+
 def update_sliding_win(i, m=0, M=1, d=0.05):
-    ii = i + (np.random.random() - .5) * d
-    if ii > M:
-        ii = M - (ii - M)
-    if m == 0:
-        ii = abs(ii)
-    return ii
+    """lib:124-128: reflected at the upper bound M; a lower bound of 0 reflects by sign."""
+    moved = _slide(i, d)
+    over = moved - M
+    if over > 0:
+        moved = M - over
+    return abs(moved) if m == 0 else moved
 
 
 def update_sliding_win_log(i, m=1, M=np.e, d=0.05):
-    ii = i + (np.random.random() - .5) * d
-    if ii > M:
-        ii = M - (ii - M)
-    elif ii < m:
-        ii = m + (m - ii)
-    return ii
+    """lib:130-134: reflected at either bound."""
+    moved = _slide(i, d)
+    if moved > M:
+        return M - (moved - M)
+    if moved < m:
+        return m + (m - moved)
+    return moved
 
 
 def update_normal_nobound(i, d=0.05):
@@ -234,11 +241,12 @@ def update_normal_nobound(i, d=0.05):
 
 
 def update_normal_nobound_vec(i, d=0.05, f=.75):
-    S = np.shape(i)
-    ff = np.random.binomial(1, f, S)
-    m = np.random.normal(0, d, S)
-    m[ff == 0] = 0.
-    return i + m, 0
+    """lib:140-145: every element moves by a normal step with probability f (the draws in the reference's order: the
+    Bernoulli mask, then the steps); symmetric, so the Hastings term is 0."""
+    shape = np.shape(i)
+    moves = np.random.binomial(1, f, shape) != 0
+    steps = np.random.normal(0, d, shape)
+    return i + np.where(moves, steps, 0.), 0
 
 
 def approx_log_fact(n):
@@ -354,11 +362,12 @@ def parse_ts_te(input_file, TBP, first_year, last_year, death_jitter):
 
 
 def print_empirical_rates(n_spec, n_exti, Dt):
-    print("EMPIRICAL BIRTH RATES:")
-    print(n_spec / Dt)
-    print("EMPIRICAL DEATH RATES:")
-    print(n_exti / Dt)
-    return (n_spec / Dt, n_exti / Dt)
+    """lib:259-264: events per unit of lineage-time in every bin, printed under the reference's two headings."""
+    rates = tuple(events / Dt for events in (n_spec, n_exti))
+    for heading, r in zip(("EMPIRICAL BIRTH RATES:", "EMPIRICAL DEATH RATES:"), rates):
+        print(heading)
+        print(r)
+    return rates
 
 
 def calculate_r_squared(emp_birth, emp_death, est_birth, est_death):

@@ -1,4 +1,6 @@
 // lr_stats.hip - sufficient statistics (A1/A2), rate-index expansion (A3) and DDRate rates (A12).
+#include <cstdlib>
+
 #include "lr_device.h"
 #include "lr_dd.h"
 #include "lr_internal.h"
@@ -149,7 +151,8 @@ static lr_ub_shape lr_ub_plan(int W) {
     p.W = W;
     p.n32 = 3 * W + 4;
     p.cols = p.n32 + 2 * W;
-    p.rshift = 5;
+    static const int rs_env = getenv("LR_UB_RSHIFT") ? atoi(getenv("LR_UB_RSHIFT")) : 5;     // (A/B runs: copies = 1 << rshift)
+    p.rshift = rs_env < 0 ? 0 : (rs_env > 5 ? 5 : rs_env);
     for (;;) {
         p.lds_bytes = ((size_t)p.n32 * 4 + (size_t)2 * W * 8) << p.rshift;
         if (p.lds_bytes <= 144 * 1024 || p.rshift == 0) break;
@@ -375,7 +378,10 @@ extern "C" int lr_bin_unit_events(const double* ts, const double* te, int64_t n,
     }
     // one block of 16 waves per CU (the histograms fill most of its LDS); short inputs: >= 8 lineages per thread
     const long long unit = 2 * LR_UB_THREADS;
-    long long blocks = min((long long)min(n_cu, LR_UB_MAX_BLOCKS), (n + 4 * unit - 1) / (4 * unit));
+    // (as many blocks as fit a CU's LDS side by side: two when the histograms take less than half of it)
+    static const int bpc_env = getenv("LR_UB_BLOCKS_PER_CU") ? atoi(getenv("LR_UB_BLOCKS_PER_CU")) : 0;
+    const int per_cu = bpc_env > 0 ? bpc_env : (p.lds_bytes <= 76 * 1024 ? 2 : 1);
+    long long blocks = min((long long)min(n_cu * per_cu, LR_UB_MAX_BLOCKS), (n + 4 * unit - 1) / (4 * unit));
     if (blocks < 1) blocks = 1;
     const long long chunk = lr_align_up64((n + blocks - 1) / blocks, unit);
     blocks = (n + chunk - 1) / chunk;

@@ -166,8 +166,8 @@ static inline bool lr_loglik_small(long long n, int n_chains) {
 }
 
 // out[c] = consts[c] + the sum of chain c's tile partials, in a FIXED order: one 256-thread block per chain, thread j adds
-// tiles j, j + 256, ... in ascending order (four independent loads in flight), 16 threads then add 16 of those sums each,
-// thread 0 the 16.  (One thread per chain walking ~2000 tiles serially took 145 us - five times the scan of 1e7 lineages.)
+// tiles j, j + 256, ... in ascending order (eight loads in flight, absent tiles entering as + 0.0: every round of loads is
+// a round trip to memory), 16 threads then add 16 of those sums each, thread 0 the 16.  (One thread per chain walking ~2000 tiles serially took 145 us - five times the scan of 1e7 lineages.)
 __global__ __launch_bounds__(256) void lr_reduce_partials_kernel(const double* __restrict__ partials,
                                                                  const double* __restrict__ consts, int tiles,
                                                                  int n_chains, double* __restrict__ out) {
@@ -175,13 +175,16 @@ __global__ __launch_bounds__(256) void lr_reduce_partials_kernel(const double* _
     const int c = blockIdx.x, j = threadIdx.x;
     const double* col = partials + c;
     double s = 0.0;
-    int k = j;
-    for (; k + 3 * 256 < tiles; k += 4 * 256) {
-        const double a0 = col[(size_t)k * n_chains], a1 = col[(size_t)(k + 256) * n_chains];
-        const double a2 = col[(size_t)(k + 512) * n_chains], a3 = col[(size_t)(k + 768) * n_chains];
-        s += a0, s += a1, s += a2, s += a3;
+    for (int k0 = 0; k0 < tiles; k0 += 8 * 256) {     // (the planner's <= 2048 tiles: ONE round of loads)
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q * 256 + j;
+            v[q] = k < tiles ? col[(size_t)k * n_chains] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
     }
-    for (; k < tiles; k += 256) s += col[(size_t)k * n_chains];
     red[j] = s;
     __syncthreads();
     if (j < 16) {

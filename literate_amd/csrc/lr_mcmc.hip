@@ -119,7 +119,7 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_chain_step_kernel(lr_step_
     __shared__ lr_seg_scratch scratch[LR_STEP_WAVES];
     const int wave = threadIdx.x / LR_WAVE, lane = threadIdx.x & (LR_WAVE - 1);
     const int j = blockIdx.x * LR_STEP_WAVES + wave;
-    if (j < n_sub) lr_chain_step_body(a, mode, chain_base + j, lane, &scratch[wave]);
+    if (j < n_sub) lr_chain_step_body<32>(a, mode, chain_base + j, lane, &scratch[wave]);
 }
 
 // Fused launch of the software-pipelined engine: the first `step_blocks` blocks run the chain step of the

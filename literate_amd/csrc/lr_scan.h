@@ -96,17 +96,12 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
     const long long end = min(start + chunk, n);
     const bool aligned = ((((uintptr_t)ts) | ((uintptr_t)te)) & 15) == 0;
     long long i = start + 2 * tid;
-    // the first TWO pairs of lineages of this thread: in flight while the tables are staged (64 B per thread: at four
-    // 256-thread blocks per CU that is 64 KB of HBM reads in flight per CU, what a stream at the HBM rate needs)
+    // first pair of lineages: in flight while the tables are staged.  (One pair - 32 B - per thread in flight is enough:
+    // with four to eight 256-thread blocks per CU a second pair measured the same at 1e7 - 3e7 lineages, round 4.)
     double2 s2 = make_double2(0.0, 0.0), e2 = make_double2(0.0, 0.0);
-    double2 s3 = make_double2(0.0, 0.0), e3 = make_double2(0.0, 0.0);
     if (aligned && i + 1 < end) {
         s2 = *reinterpret_cast<const double2*>(ts + i);
         e2 = *reinterpret_cast<const double2*>(te + i);
-        if (i + 2 * LR_SCAN_THREADS + 1 < end) {
-            s3 = *reinterpret_cast<const double2*>(ts + i + 2 * LR_SCAN_THREADS);
-            e3 = *reinterpret_cast<const double2*>(te + i + 2 * LR_SCAN_THREADS);
-        }
     }
     {
         // stage the CB tables: all 16-byte global loads are issued back to back (one latency), then written
@@ -134,12 +129,10 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
     if (aligned) {
         while (i + 1 < end) {
             const double2 sc = s2, ec = e2;
-            s2 = s3, e2 = e3;
             const long long nx = i + 2 * LR_SCAN_THREADS;
-            const long long nx2 = nx + 2 * LR_SCAN_THREADS;
-            if (nx2 + 1 < end) {  // prefetch the pair after the next
-                s3 = *reinterpret_cast<const double2*>(ts + nx2);
-                e3 = *reinterpret_cast<const double2*>(te + nx2);
+            if (nx + 1 < end) {  // prefetch the next pair
+                s2 = *reinterpret_cast<const double2*>(ts + nx);
+                e2 = *reinterpret_cast<const double2*>(te + nx);
             }
             lr_score_lineage_fast<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
             lr_score_lineage_fast<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);

@@ -1175,33 +1175,43 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
     }
 }
 
+template <int Q>
+__device__ __forceinline__ double lr_partials_round(const double* col, size_t stride, int tiles, int t0, double part) {
+    double v[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int t = t0 + q * LR_WAVE;
+        v[q] = t < tiles ? col[(size_t)t * stride] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) part += v[q];
+    return part;
+}
+
+// sum over the tiles lane, lane + 64, ... of one chain's column of partials, in ascending order
+template <int Q>
+__device__ __forceinline__ double lr_sum_tile_partials(const double* col, size_t stride, int tiles, int lane) {
+    double part = 0.0;
+    int t = lane;
+    for (; t - lane + 8 * LR_WAVE < tiles; t += Q * LR_WAVE) part = lr_partials_round<Q>(col, stride, tiles, t, part);
+    if (t - lane < tiles) part = lr_partials_round<8>(col, stride, tiles, t, part);
+    return part;
+}
+
+template <int Q = 16>
 __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mode, int c, int lane,
                                                    lr_seg_scratch* scratch_p) {
     LR_SSTAMP(0);
-    lr_chain_regs st;
+    // the lane's tile partials, added in tile order.  Every round of loads is a round trip to memory (the partials come from
+    // blocks on every XCD), so the rounds are made as few as possible: Q loads in flight per lane (32 in the step kernel; 16
+    // in the fused kernel, whose scan blocks 32 would cost a resident wave per SIMD), absent tiles entering as + 0.0 (a no-op
+    // in the sum) - one or two rounds for the scan's <= 2048 tiles.  (A load-add-load chain cost
+    // this kernel 16 us at ~2000 tiles, half the scan it follows; rounds of 16, 4 and 1 loads - seven round trips - 12 us.)
+    const double part = lr_sum_tile_partials<Q>(a.partials + c, (size_t)a.cfg.n_chains, a.tiles, lane);
+    lr_chain_regs st;   // (loaded behind the partials: their registers are free again by then)
     double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
     int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
     lr_chain_load(st, S, I, lane);
-    // the lane's tile partials, added in tile order - sixteen independent loads in flight at a time: with ~2000 tiles (few
-    // chains x very many lineages) a load-add-load chain of 32 memory round trips cost this kernel 16 us, half the scan it
-    // follows (the partials come from blocks on every XCD: each round trip goes to memory)
-    double part = 0.0;
-    const double* col = a.partials + c;
-    const size_t stride = (size_t)a.cfg.n_chains;
-    int t = lane;
-    for (; t + 15 * LR_WAVE < a.tiles; t += 16 * LR_WAVE) {
-        double v[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = col[(size_t)(t + q * LR_WAVE) * stride];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) part += v[q];
-    }
-    for (; t + 3 * LR_WAVE < a.tiles; t += 4 * LR_WAVE) {
-        const double a0 = col[(size_t)t * stride], a1 = col[(size_t)(t + LR_WAVE) * stride];
-        const double a2 = col[(size_t)(t + 2 * LR_WAVE) * stride], a3 = col[(size_t)(t + 3 * LR_WAVE) * stride];
-        part += a0, part += a1, part += a2, part += a3;
-    }
-    for (; t < a.tiles; t += LR_WAVE) part += col[(size_t)t * stride];
     const double lik_sum = lr_wave_sum(part);
     if (a.cfg.sampler != 0) lr_dd_step_core(st, a, mode, c, lane, lik_sum, lr_chain_table(a, c), lr_tab_es(a.unit, a.H));
     else lr_chain_step_core(st, a, mode, c, lane, scratch_p, lik_sum, lr_chain_table(a, c), lr_tab_es(a.unit, a.H));

@@ -288,6 +288,39 @@ def test_loglik_random_float_data_vs_oracle(ops):
             assert np.array_equal(a, b)
 
 
+def test_loglik_tiled_path_ragged_sizes_vs_oracle(ops):
+    """Beyond the one-launch kernel's window (more than 2^18 lineages) lr_bd_loglik_batch runs tiled: table kernel +
+    lr_scan_fast_kernel<1 / 2 / 4 / 8, H> + reduction of the tile partials.  Ragged sizes, ragged chain groups, non-integer
+    times, models 0 - 2, against the oracle's per-lineage evaluation; unaligned pointers give identical bits; a chain scores
+    the same alone, in a group of two or four and in a group of eight."""
+    import torch
+    from oracle import literate_oracle as lo
+    rng = np.random.default_rng(7)
+    for n, n_bins in ((262_145, 24), (300_001, 130), (270_003, 257)):
+        t0 = 3.0
+        ts = rng.uniform(t0 - 2, t0 + n_bins + 1, n)
+        te = ts + rng.exponential(n_bins / 6.0, n)
+        te[rng.random(n) < 0.2] = t0 + n_bins + 0.5
+        k = rng.integers(0, n, n // 20)
+        ts[k] = np.floor(ts[k])
+        te[k] = np.ceil(te[k])
+        lam = np.exp(rng.uniform(np.log(.02), np.log(1.5), (9, n_bins)))
+        mu = np.exp(rng.uniform(np.log(.02), np.log(1.5), (9, n_bins)))
+        br = _np(ops.bin_events(ts, te, t0 + np.arange(n_bins), t0 + np.arange(n_bins) + 1.0)[2])
+        tsd, ted = torch.as_tensor(ts).cuda(), torch.as_tensor(te).cuda()
+        for model in (0, 1, 2):
+            ref = np.array([lo.per_lineage_loglik(ts, te, t0, lam[c], mu[c], model, br) for c in range(9)])
+            got = {C: _np(ops.bd_loglik_batch(tsd, ted, t0, lam[:C], mu[:C], model, br)) for C in (1, 2, 3, 4, 9)}
+            for C, g in got.items():
+                assert np.allclose(g, ref[:C], rtol=REL, atol=1e-9), (n, n_bins, model, C)
+                assert np.allclose(g, got[9][:C], rtol=1e-11, atol=0)
+        tsu = torch.as_tensor(np.concatenate([[0.0], ts])).cuda()[1:]
+        teu = torch.as_tensor(np.concatenate([[0.0], te])).cuda()[1:]
+        for C in (1, 3, 9):
+            assert np.array_equal(_np(ops.bd_loglik_batch(tsu, teu, t0, lam[:C], mu[:C], 2)),
+                                  _np(ops.bd_loglik_batch(tsd, ted, t0, lam[:C], mu[:C], 2)))
+
+
 def test_loglik_session_zero_copy_and_small_kernel(ops, G, monkeypatch):
     """The calc_likelihood seam's prepared session (ops.LoglikSession): with few states on few lineages lr_bd_loglik_batch is
     the one-launch kernel and the session runs it on pinned host buffers (rates read, result polled: no copy, no

@@ -225,7 +225,7 @@ typedef struct lr_mcmc_layout {
                            * index, byte 1 count, then seven 16-bit entry byte offsets (csrc/lr_pack.hip)                  */
     int64_t args_blob;    /* 1 KiB: kernel arguments of the persistent engine, kept in device memory          */
     int64_t tables;       /* [C, table_stride] double2                                        */
-    int64_t partials;     /* [tiles, C] doubles                                               */
+    int64_t partials;     /* [C, tiles rounded up to 16] doubles: a chain's tile partials are one row    */
     int64_t trace;        /* [n_trace_slots, C, LR_TRACE_W] doubles                           */
     int64_t total_bytes;
     int32_t table_stride; /* double2 entries per chain                                         */

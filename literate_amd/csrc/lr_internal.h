@@ -27,8 +27,13 @@ struct lr_scan_plan {
 // choose the launch shape of the lineage scan for (n lineages, n_chains, n_bins, model)
 int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit, lr_scan_plan* plan);
 
-// enqueue the scan of `n_chains` chains whose tables start at `tables`:
-// partials[tile * partial_stride + chain] = sum over the tile's lineages
+// The tile partials are laid out CHAIN-major: partials[chain * lr_tile_stride(tiles) + tile] - whoever adds a chain's tiles
+// up reads one contiguous row (16 tiles to a 128-byte line), not one line per tile.  (Tile-major, a chain's ~2000 partials
+// were ~2000 lines: the chain-step kernel of the launch-based engine waited 6 us for them.)
+static inline __host__ __device__ int lr_tile_stride(int tiles) { return (tiles + 15) & ~15; }
+
+// enqueue the scan of `n_chains` chains whose tables start at `tables` and whose rows of partials start at `partials`:
+// partials[chain * partial_stride + tile] = sum over the tile's lineages, partial_stride = lr_tile_stride(plan.tiles)
 int lr_launch_scan(const lr_scan_plan& plan, const double* ts, const double* te, long long n, double t0, int n_bins,
                    double end_time, const double2* tables, int n_chains, double* partials, int partial_stride,
                    hipStream_t stream);

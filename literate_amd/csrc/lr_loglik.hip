@@ -123,7 +123,7 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_kernel(const double* 
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < LR_SCAN_THREADS / LR_WAVE; ++w) t += red[w * CB + tid];
-        partials[(size_t)tile * partial_stride + chain0 + tid] = t;
+        partials[(size_t)(chain0 + tid) * partial_stride + tile] = t;
     }
 }
 
@@ -170,17 +170,17 @@ static inline bool lr_loglik_small(long long n, int n_chains) {
 // a round trip to memory), 16 threads then add 16 of those sums each, thread 0 the 16.  (One thread per chain walking ~2000 tiles serially took 145 us - five times the scan of 1e7 lineages.)
 __global__ __launch_bounds__(256) void lr_reduce_partials_kernel(const double* __restrict__ partials,
                                                                  const double* __restrict__ consts, int tiles,
-                                                                 int n_chains, double* __restrict__ out) {
+                                                                 int tile_stride, double* __restrict__ out) {
     __shared__ double red[256 + 16];
     const int c = blockIdx.x, j = threadIdx.x;
-    const double* col = partials + c;
+    const double* row = partials + (size_t)c * tile_stride;
     double s = 0.0;
     for (int k0 = 0; k0 < tiles; k0 += 8 * 256) {     // (the planner's <= 2048 tiles: ONE round of loads)
         double v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = k0 + q * 256 + j;
-            v[q] = k < tiles ? col[(size_t)k * n_chains] : 0.0;
+            v[q] = k < tiles ? row[k] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) s += v[q];
@@ -364,7 +364,7 @@ static void lr_loglik_ws(const lr_scan_plan& p, int n_chains, size_t* off_tables
     size_t o = 0;
     *off_tables = o, o += lr_align_up64((long long)n_chains * p.tab_stride * sizeof(double2), 256);
     *off_consts = o, o += lr_align_up64((long long)n_chains * sizeof(double), 256);
-    *off_partials = o, o += lr_align_up64((long long)p.tiles * n_chains * sizeof(double), 256);
+    *off_partials = o, o += lr_align_up64((long long)lr_tile_stride(p.tiles) * n_chains * sizeof(double), 256);
     *total = o;
 }
 
@@ -416,10 +416,10 @@ extern "C" int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n,
                        model, n_bins, p.n_cls, p.H, p.tab_stride, tables, consts);
     rc = (int)hipGetLastError();
     if (rc) return rc;
-    rc = lr_launch_scan(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, n_chains, stream);
+    rc = lr_launch_scan(p, ts, te, n, t0, n_bins, end_time, tables, n_chains, partials, lr_tile_stride(p.tiles), stream);
     if (rc) return rc;
     hipLaunchKernelGGL(lr_reduce_partials_kernel, dim3(n_chains), dim3(256), 0, stream, partials, consts, p.tiles,
-                       n_chains, out_loglik);
+                       lr_tile_stride(p.tiles), out_loglik);
     return (int)hipGetLastError();
 }
 

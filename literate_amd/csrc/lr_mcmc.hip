@@ -157,13 +157,14 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
         tile = sb % f.tiles, group = sb / f.tiles;
     }
     const double2* tables = a.tables + (size_t)f.scan_base * a.tab_stride;
-    double* partials = const_cast<double*>(a.partials) + f.scan_base;
+    const int tile_stride = lr_tile_stride(a.tiles);
+    double* partials = const_cast<double*>(a.partials) + (size_t)f.scan_base * tile_stride;
     if (UNIT)
         lr_scan_unit_body<CB, H>(lds, tile, group * CB, f.ts, f.te, f.n, f.t0, f.n_bins, tables, f.scan_n, f.chunk,
-                                 partials, a.cfg.n_chains);
+                                 partials, tile_stride);
     else
         lr_scan_fast_body<CB, H>(lds, tile, group * CB, f.ts, f.te, f.n, f.t0, f.n_bins, tables, f.scan_n, f.chunk,
-                                 partials, a.cfg.n_chains);
+                                 partials, tile_stride);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_fused_iter_kernel(lr_step_
 
 // One pass of the packed lineages against the pair tables in global memory: the launch-based twin of the persistent
 // scan, used where the engines need the sums outside their kernels (the initial state's likelihood, LRF:224-226, and
-// the lr_mcmc_time_scan hook).  Block (tile, pair): partials[tile][2 pair .. 2 pair + 1].
+// the lr_mcmc_time_scan hook).  Block (tile, pair): partials[2 pair .. 2 pair + 1][tile].
 template <int H, bool GENERAL>
 __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk, long long n8, const double2* __restrict__ tables,
                                                           int n_chains, int n_bins, int tiles, double* __restrict__ partials) {
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk,
     if (lane == 0) red[wave][0] = s0, red[wave][1] = s1;
     __syncthreads();
     if (tid < 2 && 2 * pair + tid < n_chains)
-        partials[(size_t)tile * n_chains + 2 * pair + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        partials[(size_t)(2 * pair + tid) * lr_tile_stride(tiles) + tile] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
 // The chain step of the persistent kernels lives in functions of its own (lr_persist4_steppers, lr_persist2_steppers:
@@ -1151,7 +1152,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->pack_tmp = o, o += lr_align_up64(lr_pack_tmp_bytes(cfg->n_lineages), 256);
     out->args_blob = o, o += 1024;   // lr_step_args of the persistent kernel
     out->tables = o, o += lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256);
-    out->partials = o, o += lr_align_up64((long long)p.tiles * C * 8, 256);
+    out->partials = o, o += lr_align_up64((long long)lr_tile_stride(p.tiles) * C * 8, 256);
     out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
     int team_k = 0, team_cpb = 0;
     out->persistent = lr_persist_variant(cfg, p, &team_k, &team_cpb);
@@ -1292,7 +1293,7 @@ static int lr_enqueue_scan_range(const lr_engine* e, int base, int count, hipStr
     }
     return lr_launch_scan(e->plan, e->ts, e->te, e->cfg.n_lineages, e->cfg.t0, e->cfg.n_bins, e->cfg.end_time,
                           (const double2*)(e->ws + e->lay.tables) + (size_t)base * e->plan.tab_stride, count,
-                          (double*)(e->ws + e->lay.partials) + base, e->cfg.n_chains, stream);
+                          (double*)(e->ws + e->lay.partials) + (size_t)base * lr_tile_stride(e->plan.tiles), lr_tile_stride(e->plan.tiles), stream);
 }
 static int lr_enqueue_scan(const lr_engine* e, hipStream_t stream) {
     return lr_enqueue_scan_range(e, 0, e->cfg.n_chains, stream);

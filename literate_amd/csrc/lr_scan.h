@@ -63,7 +63,8 @@ __device__ __forceinline__ void lr_xcd_remap(int sb, int tiles, int groups, int*
 // adds those.  Needs CB*THREADS + THREADS doubles of LDS (the staged tables are dead by then).
 template <int CB>
 __device__ __forceinline__ void lr_block_reduce_chains(const double (&acc)[CB], double* red, int tid, int nvalid,
-                                                       double* __restrict__ out /* partials + chain0 */) {
+                                                       double* __restrict__ out /* chain0's row of partials + tile */,
+                                                       size_t chain_stride) {
     constexpr int T = LR_SCAN_THREADS;
     constexpr int TPC = T / CB;            // threads per chain in stage 1
 #pragma unroll
@@ -78,12 +79,12 @@ __device__ __forceinline__ void lr_block_reduce_chains(const double (&acc)[CB], 
     if (tid < nvalid) {
         double t = 0.0;
         for (int k = 0; k < TPC; ++k) t += red[CB * T + tid * TPC + k];
-        out[tid] = t;
+        out[(size_t)tid * chain_stride] = t;
     }
 }
 
 // One block: tile `tile` of the lineages x chains [chain0, chain0+CB) of the `n_chains` whose tables start at
-// `tables`; partial sums go to partials[tile * partial_stride + chain].
+// `tables`; partial sums go to partials[chain * partial_stride + tile].
 template <int CB, int H>
 __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int chain0, const double* __restrict__ ts,
                                                   const double* __restrict__ te, long long n, double t0, int n_bins,
@@ -148,7 +149,7 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
 
     __syncthreads();
     lr_block_reduce_chains<CB>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
-                               partials + (size_t)tile * partial_stride + chain0);
+                               partials + (size_t)chain0 * partial_stride + tile, (size_t)partial_stride);
 }
 
 
@@ -262,7 +263,7 @@ __device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int ch
     __syncthreads();
     LR_STAMP(diag_blk, 3);
     lr_block_reduce_chains<CB>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
-                               partials + (size_t)tile * partial_stride + chain0);
+                               partials + (size_t)chain0 * partial_stride + tile, (size_t)partial_stride);
     LR_STAMP(diag_blk, 4);
 #ifdef LR_DIAG
     if (threadIdx.x == 0 && diag_blk < 8192) {

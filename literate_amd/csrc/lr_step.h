@@ -1176,25 +1176,25 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
 }
 
 template <int Q>
-__device__ __forceinline__ double lr_partials_round(const double* col, size_t stride, int tiles, int t0, double part) {
+__device__ __forceinline__ double lr_partials_round(const double* row, int tiles, int t0, double part) {
     double v[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int t = t0 + q * LR_WAVE;
-        v[q] = t < tiles ? col[(size_t)t * stride] : 0.0;
+        v[q] = t < tiles ? row[t] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) part += v[q];
     return part;
 }
 
-// sum over the tiles lane, lane + 64, ... of one chain's column of partials, in ascending order
+// sum over the tiles lane, lane + 64, ... of one chain's row of partials, in ascending order
 template <int Q>
-__device__ __forceinline__ double lr_sum_tile_partials(const double* col, size_t stride, int tiles, int lane) {
+__device__ __forceinline__ double lr_sum_tile_partials(const double* row, int tiles, int lane) {
     double part = 0.0;
     int t = lane;
-    for (; t - lane + 8 * LR_WAVE < tiles; t += Q * LR_WAVE) part = lr_partials_round<Q>(col, stride, tiles, t, part);
-    if (t - lane < tiles) part = lr_partials_round<8>(col, stride, tiles, t, part);
+    for (; t - lane + 8 * LR_WAVE < tiles; t += Q * LR_WAVE) part = lr_partials_round<Q>(row, tiles, t, part);
+    if (t - lane < tiles) part = lr_partials_round<8>(row, tiles, t, part);
     return part;
 }
 
@@ -1205,9 +1205,11 @@ __device__ __forceinline__ void lr_chain_step_body(const lr_step_args& a, int mo
     // the lane's tile partials, added in tile order.  Every round of loads is a round trip to memory (the partials come from
     // blocks on every XCD), so the rounds are made as few as possible: Q loads in flight per lane (32 in the step kernel; 16
     // in the fused kernel, whose scan blocks 32 would cost a resident wave per SIMD), absent tiles entering as + 0.0 (a no-op
-    // in the sum) - one or two rounds for the scan's <= 2048 tiles.  (A load-add-load chain cost
-    // this kernel 16 us at ~2000 tiles, half the scan it follows; rounds of 16, 4 and 1 loads - seven round trips - 12 us.)
-    const double part = lr_sum_tile_partials<Q>(a.partials + c, (size_t)a.cfg.n_chains, a.tiles, lane);
+    // in the sum) - one or two rounds for the scan's <= 2048 tiles - and the chain's partials are ONE ROW (lr_tile_stride):
+    // a wave's load is 512 contiguous bytes.  (History, 16 chains x ~2000 tiles, in-kernel stamps: a load-add-load chain 16 us,
+    // half the scan it follows; rounds of 16, 4 and 1 loads 12; one round of 32, but tile-major - every lane's load a line
+    // of its own, 2048 lines per wave - 6.3; as it is now 2.1.)
+    const double part = lr_sum_tile_partials<Q>(a.partials + (size_t)c * lr_tile_stride(a.tiles), a.tiles, lane);
     lr_chain_regs st;   // (loaded behind the partials: their registers are free again by then)
     double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
     int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;

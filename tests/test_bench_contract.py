@@ -109,7 +109,7 @@ def test_abi_section_prices_the_hbm_streaming_entry_points():
 def test_driver_args_bench_line_measures_the_kernel():
     """profiles/r04_bench_cfg4_1gpu_driver_args.json = `python bench.py --steps 20 --warmup 5` (the driver's command): the
     wall-clock figure stays within 35 % of the event-bracketed device time of the same region (round 2: 66 %; what is left
-    is one launch, two event markers and the completion wake-up of a ~140-us region: 1.18-1.22 by box of the pool)."""
+    is one launch, two event markers and the completion wake-up of a ~140-us region: 1.16-1.24 by box of the pool)."""
     b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg4_1gpu_driver_args.json")))
     assert b["steps"] == 20 and b["warmup"] == 5 and b["n_gpus"] == 1
     r = b["roofline"]

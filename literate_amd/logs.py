@@ -62,31 +62,102 @@ def write_div_log(path, sp_events, ex_events, br_length):
             w.writerow(row)
 
 
-def _chain_lines(rows, emp, n_bins, pyrate_output, true_root_age):
-    """rows of ONE chain -> three lists of text lines (mcmc, sp_rates, ex_rates) in the reference's format (LRF:321-359)."""
+def _compact_rows(rows):
+    """[..., LR_TRACE_W] trace rows -> (array holding only the columns in use, kl_max, km_max):
+    head[13] | birth rates[kl_max] | birth shift times[kl_max - 1] | death rates[km_max] | death shift times[km_max - 1].
+    (A row reserves 2 x 63 slots; the runs hold a handful of rates: converting the padding would cost more than the data.)"""
+    R = np.asarray(rows, dtype=np.float64)
+    H, K = LR_TRACE_HEAD, LR_KMAX
+    M0 = H + 2 * K - 1                       # first death-process slot of a row
+    if R.size == 0:
+        return R[..., :H], 1, 1
+    kl, km = int(R[..., 6].max()), int(R[..., 7].max())
+    parts = [R[..., :H], R[..., H:H + kl], R[..., H + K:H + K + kl - 1], R[..., M0:M0 + km], R[..., M0 + K:M0 + K + km - 1]]
+    return np.concatenate(parts, axis=-1), kl, km
+
+
+def _rates_per_bin_rows(rates, shifts, K, start, n_bins):
+    """rates_per_bin for many rows at once: rates [R, kmax], shifts [R, kmax - 1] (row r holds K[r] rates), start [R]
+    -> [R, n_bins], or None when a row's shift times do not ascend (searchsorted's answer is then its own)."""
+    k = np.arange(shifts.shape[1])
+    valid = k[None, :] < (K[:, None] - 1)
+    edges = np.where(valid, np.floor(shifts) - np.floor(start)[:, None], np.inf)
+    if edges.shape[1] > 1 and not np.all(edges[:, 1:] >= edges[:, :-1]):
+        return None
+    seg = (edges[:, :, None] <= np.arange(n_bins, dtype=np.float64)[None, None, :]).sum(axis=1)     # = searchsorted(side="right")
+    return np.take_along_axis(rates, seg, axis=1)
+
+
+def _adequacy_rows(compact, kl_max, km_max, emp, n_bins):
+    """The three adequacy columns (calculate_r_squared, lib:268-279) of many compact rows at once: [R, 3], the very
+    numbers `adequacy` gives row by row (reductions run along the contiguous axis: the same summation per row) - a call
+    per row costs 26 us of small-array numpy, more than the device needs for the 1000 iterations between two samples."""
+    A = compact.reshape(-1, compact.shape[-1])
+    H = LR_TRACE_HEAD
+    o_st, o_er = H + kl_max, H + 2 * kl_max - 1
+    o_et = o_er + km_max
+    KL, KM, start = A[:, 6].astype(np.int64), A[:, 7].astype(np.int64), A[:, 8]
+    lam = _rates_per_bin_rows(A[:, H:H + kl_max], A[:, o_st:o_st + kl_max - 1], KL, start, n_bins)
+    mu = _rates_per_bin_rows(A[:, o_er:o_er + km_max], A[:, o_et:o_et + km_max - 1], KM, start, n_bins)
+    if lam is None or mu is None:
+        return None
+    x = np.concatenate([emp[0], emp[1]])
+    y = np.ascontiguousarray(np.concatenate([lam, mu], axis=1))
+    with np.errstate(all="ignore"):
+        coeff = np.sum(x * y, axis=1) / np.sum(x * x)
+        fitted = coeff[:, None] * x
+        resid = y - fitted
+        r2 = 1 - np.sum(resid ** 2, axis=1) / np.sum(y ** 2, axis=1)
+        vf = np.var(fitted, axis=1, ddof=1)
+        g = vf / (vf + np.var(resid, axis=1, ddof=1))
+    return np.stack([coeff, r2, g], axis=1).reshape(compact.shape[:-1] + (3,))
+
+
+def _lines(compact, kl_max, km_max, emp, n_bins, pyrate_output, true_root_age, adeq=None):
+    """compact rows of ONE chain (_compact_rows(...).tolist()) -> three lists of text lines (mcmc, sp_rates, ex_rates) in
+    the reference's format (LRF:321-359).  Numbers are Python floats formatted with `str`: the shortest round-trip form
+    the reference's `csv` writer produces.  adeq: the rows' adequacy columns (_adequacy_rows(...).tolist()); without
+    them they are computed row by row."""
     lm, ls, le = [], [], []
-    for row in rows:
-        head, sp, ex = split_row(row)
-        kl, km = int(head[6]), int(head[7])
-        start, end = head[8], head[9]
-        vals = [str(int(head[0]))] + [str(float(v)) for v in head[1:6]] + [str(kl), str(km)]
+    H = LR_TRACE_HEAD
+    o_st, o_er = H + kl_max, H + 2 * kl_max - 1
+    o_et = o_er + km_max
+    root = float(true_root_age)
+    for i, r in enumerate(compact):
+        kl, km = int(r[6]), int(r[7])
+        start, end = r[8], r[9]
+        vals = [str(int(r[0])), str(r[1]), str(r[2]), str(r[3]), str(r[4]), str(r[5]), str(kl), str(km)]
         if pyrate_output:
-            vals += [str(float(true_root_age)), str(float(true_root_age - end))]
+            vals += [str(root), str(root - end)]
         else:
-            vals += [str(float(start)), str(float(end))]
-        vals += [str(float(v)) for v in head[10:13]]
+            vals += [str(start), str(end)]
+        vals += [str(r[10]), str(r[11]), str(r[12])]
+        sp_r, sp_t = r[H:H + kl], r[o_st:o_st + kl - 1]
+        ex_r, ex_t = r[o_er:o_er + km], r[o_et:o_et + km - 1]
         if emp is not None:
-            lam = rates_per_bin(sp[:kl], sp[kl:], start, n_bins)
-            mu = rates_per_bin(ex[:km], ex[km:], start, n_bins)
-            with np.errstate(all="ignore"):
-                vals += [str(float(v)) for v in adequacy(emp[0], emp[1], lam, mu)]
+            if adeq is not None:
+                a = adeq[i]
+                vals += [str(a[0]), str(a[1]), str(a[2])]
+            else:
+                lam = rates_per_bin(sp_r, sp_t, start, n_bins)
+                mu = rates_per_bin(ex_r, ex_t, start, n_bins)
+                with np.errstate(all="ignore"):
+                    vals += [str(float(v)) for v in adequacy(emp[0], emp[1], lam, mu)]
         lm.append('\t'.join(vals) + '\n')
         if pyrate_output:
-            sp = np.concatenate([sp[:kl], true_root_age - sp[kl:]])
-            ex = np.concatenate([ex[:km], true_root_age - ex[km:]])
-        ls.append('\t'.join(str(float(v)) for v in sp) + '\n')
-        le.append('\t'.join(str(float(v)) for v in ex) + '\n')
+            sp_t = [root - t for t in sp_t]
+            ex_t = [root - t for t in ex_t]
+        ls.append('\t'.join(map(str, sp_r + sp_t)) + '\n')
+        le.append('\t'.join(map(str, ex_r + ex_t)) + '\n')
     return lm, ls, le
+
+
+def _chain_lines(rows, emp, n_bins, pyrate_output, true_root_age):
+    """rows [samples, LR_TRACE_W] of ONE chain -> the three lists of text lines."""
+    compact, kl, km = _compact_rows(rows)
+    adeq = _adequacy_rows(compact, kl, km, emp, n_bins) if (emp is not None and compact.size) else None
+    return _lines(compact.tolist(), kl, km, emp, n_bins, pyrate_output, true_root_age,
+                  None if adeq is None else adeq.tolist())
 
 
 class ChainLogWriter:
@@ -109,8 +180,13 @@ class ChainLogWriter:
         """rows: [samples, chains, LR_TRACE_W] of one window."""
         if rows is None or len(rows) == 0:
             return
+        # the whole window becomes Python floats in one go (only the columns in use), chain-major
+        compact, kl, km = _compact_rows(np.asarray(rows).transpose(1, 0, 2))
+        adeq = _adequacy_rows(compact, kl, km, self.emp, self.n_bins) if self.emp is not None else None
+        compact, adeq = compact.tolist(), (None if adeq is None else adeq.tolist())
         for c, p in enumerate(self.paths):
-            lm, ls, le = _chain_lines(rows[:, c], self.emp, self.n_bins, self.pyrate, self.root)
+            lm, ls, le = _lines(compact[c], kl, km, self.emp, self.n_bins, self.pyrate, self.root,
+                                None if adeq is None else adeq[c])
             for key, lines in (("mcmc", lm), ("sp_rates", ls), ("ex_rates", le)):
                 with open(p[key], "a") as f:
                     f.writelines(lines)

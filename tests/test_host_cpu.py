@@ -135,6 +135,63 @@ def _trace_row(it, L, tL, M, tM, start, end):
     return row
 
 
+def test_window_log_writer_is_byte_identical_to_a_row_by_row_formatter(tmp_path):
+    """ChainLogWriter.append formats a whole window at once (one tolist(), the adequacy columns of all rows in one set of
+    array operations): its files are byte for byte what a plain per-row formatter in the reference's style writes -
+    csv-style `str(float)` numbers, calculate_r_squared (lib:268-279) per row -, with and without -pyrate_output, with
+    NaN / inf in the empirical rates, and when a row's shift times do not ascend (the per-row fallback)."""
+    from literate_amd import logs, _hip
+    rng = np.random.default_rng(5)
+    start, end, n_bins, S, C = 0.0, 24.5, 24, 40, 5
+    rows = np.empty((S, C, _hip.LR_TRACE_W))
+    for s_ in range(S):
+        for c in range(C):
+            kl, km = int(rng.integers(1, 7)), int(rng.integers(1, 4))
+            tL = np.concatenate([[start], np.sort(rng.uniform(0.2, 24.2, kl - 1)), [end]])
+            tM = np.concatenate([[start], np.sort(rng.uniform(0.2, 24.2, km - 1)), [end]])
+            rows[s_, c] = _trace_row(s_ * 1000, rng.gamma(2, .1, kl) * 10.0 ** rng.integers(-6, 3), tL, rng.gamma(2, .1, km), tM, start, end)
+            rows[s_, c, 1:4] = rng.normal(0, 1, 3) * 10.0 ** rng.integers(-8, 18)      # both notations of str(float)
+    emp = (rng.gamma(2, .1, n_bins), rng.gamma(2, .1, n_bins))
+    emp[0][3], emp[1][7] = np.nan, np.inf
+
+    def reference_lines(chain_rows, emp_, pyrate, root):
+        lm, ls, le = [], [], []
+        for row in chain_rows:
+            head, sp, ex = logs.split_row(row)
+            kl, km = int(head[6]), int(head[7])
+            v = [str(int(head[0]))] + [str(float(x)) for x in head[1:6]] + [str(kl), str(km)]
+            v += [str(float(root)), str(float(root - head[9]))] if pyrate else [str(float(head[8])), str(float(head[9]))]
+            v += [str(float(x)) for x in head[10:13]]
+            if emp_ is not None:
+                with np.errstate(all="ignore"):
+                    v += [str(float(x)) for x in logs.adequacy(emp_[0], emp_[1], logs.rates_per_bin(sp[:kl], sp[kl:], head[8], n_bins),
+                                                              logs.rates_per_bin(ex[:km], ex[km:], head[8], n_bins))]
+            lm.append("\t".join(v) + "\n")
+            if pyrate:
+                sp, ex = np.concatenate([sp[:kl], root - sp[kl:]]), np.concatenate([ex[:km], root - ex[km:]])
+            ls.append("\t".join(str(float(x)) for x in sp) + "\n")
+            le.append("\t".join(str(float(x)) for x in ex) + "\n")
+        return {"mcmc": lm, "sp_rates": ls, "ex_rates": le}
+
+    os.mkdir(tmp_path / "literate_mcmc_logs")
+    unsorted = rows.copy()
+    unsorted[7, 2, 13 + _hip.LR_KMAX:13 + _hip.LR_KMAX + 2] = [20.0, 3.0]        # a row whose shift times descend
+    unsorted[7, 2, 6] = 3
+    unsorted[7, 2, 13:16] = [.1, .2, .3]
+    for tag, R, emp_, pyrate in (("a", rows, emp, False), ("b", rows, emp, True), ("c", rows, None, False), ("d", unsorted, emp, False)):
+        w = logs.ChainLogWriter(str(tmp_path / "toy.tsv"), 0, tag, C, emp_, n_bins, pyrate, 30.25)
+        w.append(R[:25]), w.append(R[25:]), w.append(R[:0])                  # two windows and an empty one
+        for c in range(C):
+            want = reference_lines(R[:, c], emp_, pyrate, 30.25)
+            for key in ("mcmc", "sp_rates", "ex_rates"):
+                got = open(w.paths[c][key]).read().splitlines(keepends=True)
+                assert got[1 if key == "mcmc" else 0:] == want[key], (tag, c, key)
+        # one chain's rows through write_chain_logs: the same lines
+        p1 = logs.log_paths(str(tmp_path / "toy.tsv"), 0, tag + "_one")[1]
+        logs.write_chain_logs(p1, R[:, 1], emp_, n_bins, pyrate, 30.25)
+        assert open(p1["mcmc"]).read().splitlines(keepends=True)[1:] == reference_lines(R[:, 1], emp_, pyrate, 30.25)["mcmc"]
+
+
 def test_log_writers_and_marginal_rates(tmp_path):
     from literate_amd import logs
     from oracle import literate_oracle as lo

@@ -92,7 +92,8 @@ class TrendRateEngine(ChainEngine):
             return
         with open(path, "a") as f:
             w = csv.writer(f, delimiter='\t')
-            for row in rows:
-                w.writerow([int(row[0])] + [float(v) for v in row[1:]])
+            # (one tolist() per window: Python floats, which csv writes in their shortest round-trip form - per-element
+            # numpy scalars cost several times the formatting itself)
+            w.writerows([[int(r[0])] + r[1:] for r in np.asarray(rows, dtype=np.float64).tolist()])
             f.flush()
             os.fsync(f.fileno())

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libliterate_hip.so")
 BUILD_INFO = os.path.join(CSRC, "libliterate_hip.build.json")
 OBJ_DIR = os.path.join(CSRC, "_build")
-SOURCES = ["lr_stats.hip", "lr_loglik.hip", "lr_mcmc.hip", "lr_spec.hip", "lr_pack.hip", "lr_sim.hip"]
+SOURCES = ["lr_stats.hip", "lr_loglik.hip", "lr_mcmc.hip", "lr_spec.hip", "lr_pack.hip", "lr_sim.hip", "lr_format.hip"]
 HEADERS = ["lr_device.h", "lr_math.h", "lr_chain.h", "lr_dd.h", "lr_scan.h", "lr_step.h", "lr_spec.h", "lr_engine.h", "lr_internal.h",
            os.path.join("..", "..", "include", "literate_hip.h")]
 # Per translation unit.  The speculative kernel's loop body is ~8000 instructions at a 168-VGPR budget: machine LICM

@@ -96,21 +96,38 @@ def _adequacy_rows(compact, kl_max, km_max, emp, n_bins):
     H = LR_TRACE_HEAD
     o_st, o_er = H + kl_max, H + 2 * kl_max - 1
     o_et = o_er + km_max
-    KL, KM, start = A[:, 6].astype(np.int64), A[:, 7].astype(np.int64), A[:, 8]
-    lam = _rates_per_bin_rows(A[:, H:H + kl_max], A[:, o_st:o_st + kl_max - 1], KL, start, n_bins)
-    mu = _rates_per_bin_rows(A[:, o_er:o_er + km_max], A[:, o_et:o_et + km_max - 1], KM, start, n_bins)
-    if lam is None or mu is None:
-        return None
     x = np.concatenate([emp[0], emp[1]])
-    y = np.ascontiguousarray(np.concatenate([lam, mu], axis=1))
-    with np.errstate(all="ignore"):
-        coeff = np.sum(x * y, axis=1) / np.sum(x * x)
-        fitted = coeff[:, None] * x
-        resid = y - fitted
-        r2 = 1 - np.sum(resid ** 2, axis=1) / np.sum(y ** 2, axis=1)
-        vf = np.var(fitted, axis=1, ddof=1)
-        g = vf / (vf + np.var(resid, axis=1, ddof=1))
-    return np.stack([coeff, r2, g], axis=1).reshape(compact.shape[:-1] + (3,))
+    out = np.empty((A.shape[0], 3))
+    step = max(1, (1 << 19) // max(1, 2 * n_bins))          # ~4 MB of per-bin rates at a time: the temporaries stay in cache
+
+    def block(a):
+        B = A[a:a + step]
+        KL, KM, start = B[:, 6].astype(np.int64), B[:, 7].astype(np.int64), B[:, 8]
+        lam = _rates_per_bin_rows(B[:, H:H + kl_max], B[:, o_st:o_st + kl_max - 1], KL, start, n_bins)
+        mu = _rates_per_bin_rows(B[:, o_er:o_er + km_max], B[:, o_et:o_et + km_max - 1], KM, start, n_bins)
+        if lam is None or mu is None:
+            return False
+        y = np.ascontiguousarray(np.concatenate([lam, mu], axis=1))
+        with np.errstate(all="ignore"):
+            coeff = np.sum(x * y, axis=1) / np.sum(x * x)
+            fitted = coeff[:, None] * x
+            resid = y - fitted
+            r2 = 1 - np.sum(resid ** 2, axis=1) / np.sum(y ** 2, axis=1)
+            vf = np.var(fitted, axis=1, ddof=1)
+            out[a:a + step, 0], out[a:a + step, 1] = coeff, r2
+            out[a:a + step, 2] = vf / (vf + np.var(resid, axis=1, ddof=1))
+        return True
+
+    starts = range(0, A.shape[0], step)
+    if len(starts) > 1:
+        # blocks of rows are independent and numpy's loops release the interpreter lock: a few threads (a thousand chains
+        # x 128 bins cost 11 us a row on one core - more than the device needs for a sample's 1000 iterations)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max(1, min(8, len(starts), (os.cpu_count() or 2) // 2))) as pool:
+            ok = list(pool.map(block, starts))
+    else:
+        ok = [block(a) for a in starts]
+    return out.reshape(compact.shape[:-1] + (3,)) if all(ok) else None
 
 
 def _lines(compact, kl_max, km_max, emp, n_bins, pyrate_output, true_root_age, adeq=None):
@@ -180,9 +197,11 @@ class ChainLogWriter:
         """rows: [samples, chains, LR_TRACE_W] of one window."""
         if rows is None or len(rows) == 0:
             return
-        # the whole window becomes Python floats in one go (only the columns in use), chain-major
+        # the whole window at once (only the columns in use), chain-major
         compact, kl, km = _compact_rows(np.asarray(rows).transpose(1, 0, 2))
         adeq = _adequacy_rows(compact, kl, km, self.emp, self.n_bins) if self.emp is not None else None
+        if _native() is not None and (self.emp is None or adeq is not None):
+            return self._append_native(compact, kl, km, adeq)
         compact, adeq = compact.tolist(), (None if adeq is None else adeq.tolist())
         for c, p in enumerate(self.paths):
             lm, ls, le = _lines(compact[c], kl, km, self.emp, self.n_bins, self.pyrate, self.root,
@@ -191,6 +210,74 @@ class ChainLogWriter:
                 with open(p[key], "a") as f:
                     f.writelines(lines)
                     f.flush()
+
+    def _append_native(self, A, kl_max, km_max, adeq):
+        """The same bytes through lr_format_rows (csrc/lr_format.hip: Python's str(float) in C++, ~60 ns a number where
+        CPython needs ~400): A = compact rows [chains, samples, columns]."""
+        H = LR_TRACE_HEAD
+        o_st, o_er = H + kl_max, H + 2 * kl_max - 1
+        o_et = o_er + km_max
+        root = float(self.root)
+        S = A.shape[1]
+        KL, KM = A[..., 6].astype(np.int64), A[..., 7].astype(np.int64)
+        head = A[..., :H]
+        if self.pyrate:
+            head = head.copy()
+            head[..., 8], head[..., 9] = root, root - A[..., 9]
+        if adeq is not None:
+            head = np.concatenate([head, adeq], axis=-1)
+        head = np.ascontiguousarray(head)
+        rs_head = np.arange(S + 1, dtype=np.int64) * head.shape[-1]
+
+        def ragged(o_r, o_t, kmax, K):
+            j = np.arange(kmax)
+            T = A[..., o_t:o_t + kmax - 1]
+            vals = np.concatenate([A[..., o_r:o_r + kmax], root - T if self.pyrate else T], axis=-1)
+            mask = np.concatenate([j < K[..., None], j[:kmax - 1] < (K[..., None] - 1)], axis=-1)
+            return vals, mask
+
+        (sp_v, sp_m), (ex_v, ex_m) = ragged(H, o_st, kl_max, KL), ragged(o_er, o_et, km_max, KM)
+        zero = np.zeros(1, dtype=np.int64)
+        for c, p in enumerate(self.paths):
+            parts = (("mcmc", head[c].reshape(-1), rs_head, _MCMC_INT_COLS),
+                     ("sp_rates", sp_v[c][sp_m[c]], np.concatenate([zero, np.cumsum(2 * KL[c] - 1)]), 0),
+                     ("ex_rates", ex_v[c][ex_m[c]], np.concatenate([zero, np.cumsum(2 * KM[c] - 1)]), 0))
+            for key, vals, row_start, int_cols in parts:
+                with open(p[key], "ab") as f:
+                    f.write(_native_format(vals, row_start, int_cols))
+                    f.flush()
+
+
+_MCMC_INT_COLS = (1 << 0) | (1 << 6) | (1 << 7)        # it, K_l, K_m are written as integers (LRF:321-323)
+_NATIVE = []
+
+
+def _native():
+    """libliterate_hip.so's lr_format_rows, or None (LR_LOG_FORMAT=python, or no library: the Python formatter writes the
+    same bytes, tests/test_host_cpu.py)."""
+    if not _NATIVE:
+        lib = None
+        if os.environ.get("LR_LOG_FORMAT", "native") != "python":
+            try:
+                from . import _hip
+                lib = _hip.load()
+                lib.lr_format_rows
+            except Exception:
+                lib = None
+        _NATIVE.append(lib)
+    return _NATIVE[0]
+
+
+def _native_format(vals, row_start, int_cols=0):
+    """Tab-separated lines of `vals` (row i = vals[row_start[i]:row_start[i + 1]]) in the reference's csv form -> bytes."""
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    row_start = np.ascontiguousarray(row_start, dtype=np.int64)
+    cap = 26 * int(vals.size) + int(row_start.size)
+    out = np.empty(cap, dtype=np.uint8)
+    n = _native().lr_format_rows(vals.ctypes.data, row_start.ctypes.data, int(row_start.size) - 1, int(int_cols), out.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError("lr_format_rows: %d" % n)
+    return out[:n].tobytes()
 
 
 def write_chain_logs(paths, rows, emp=None, n_bins=None, pyrate_output=False, true_root_age=0.0):

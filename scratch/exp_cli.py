@@ -8,13 +8,21 @@ n_iter = sys.argv[1] if len(sys.argv) > 1 else "10000000"
 chains = sys.argv[2] if len(sys.argv) > 2 else "128"
 extra = sys.argv[3:]
 tmp = tempfile.mkdtemp()
-ts, te = G["example_TBP/ts"], G["example_TBP/te"] - 0.5
 data = os.path.join(tmp, "example.tsv")
-with open(data, "w") as f:
-    f.write("id\tts\tte\n")
-    for i, (a, b) in enumerate(zip(ts, te)):
-        f.write("%d\t%g\t%g\n" % (i, 24.0 - a, 24.0 - b))
-cmd = [sys.executable, os.path.join(ROOT, "LiteRateForward.py"), "-d", data, "-TBP", "-n", n_iter, "-s", "1000", "-p", "1000000",
+tbp = ["-TBP"]
+if extra and extra[0] == "synth":            # cfg4's synthetic lineages (years since the origin: no -TBP)
+    sys.path.insert(0, ROOT)
+    from literate_amd import synth
+    ts, te, _ = synth.make_lineages(int(extra[1]), 128, 20, 0)
+    extra, tbp = extra[2:], []
+    np.savetxt(data, np.column_stack([np.arange(len(ts)), ts, te - 0.5]), fmt="%d\t%g\t%g", header="id\tts\tte", comments="")
+else:
+    ts, te = G["example_TBP/ts"], G["example_TBP/te"] - 0.5
+    with open(data, "w") as f:
+        f.write("id\tts\tte\n")
+        for i, (a, b) in enumerate(zip(ts, te)):
+            f.write("%d\t%g\t%g\n" % (i, 24.0 - a, 24.0 - b))
+cmd = [sys.executable, os.path.join(ROOT, "LiteRateForward.py"), "-d", data] + tbp + ["-n", n_iter, "-s", "1000", "-p", "1000000",
        "-seed", "31", "--chains", chains] + extra
 t0 = time.perf_counter()
 out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, cwd=tmp, text=True).stdout

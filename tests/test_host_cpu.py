@@ -135,12 +135,37 @@ def _trace_row(it, L, tL, M, tM, start, end):
     return row
 
 
-def test_window_log_writer_is_byte_identical_to_a_row_by_row_formatter(tmp_path):
-    """ChainLogWriter.append formats a whole window at once (one tolist(), the adequacy columns of all rows in one set of
-    array operations): its files are byte for byte what a plain per-row formatter in the reference's style writes -
-    csv-style `str(float)` numbers, calculate_r_squared (lib:268-279) per row -, with and without -pyrate_output, with
-    NaN / inf in the empirical rates, and when a row's shift times do not ascend (the per-row fallback)."""
+def test_native_number_format_is_python_str_of_float():
+    """lr_format_rows (csrc/lr_format.hip, host only) writes every double exactly as Python's str(float) does - what the
+    reference's csv writer emits (LRF:334-359): random bit patterns, log-uniform magnitudes, the notation switches at 1e-4 and
+    1e16, subnormals, the largest double, whole numbers, zeros, nan and inf; integer columns; ragged and empty rows."""
+    from literate_amd import logs
+    if logs._native() is None:
+        pytest.fail("libliterate_hip.so does not load or lacks lr_format_rows")
+    rng = np.random.default_rng(0)
+    y = rng.integers(0, 2 ** 63, 300_000, dtype=np.int64).view(np.float64)
+    y = y[np.isfinite(y)]
+    y = np.concatenate([y, -y, np.exp(rng.uniform(np.log(1e-12), np.log(1e20), 300_000)), rng.normal(-300, 20, 100_000),
+                        rng.integers(-10 ** 6, 10 ** 6, 50_000).astype(float), 10.0 ** np.arange(-30, 31), 9.999999999999999 * 10.0 ** np.arange(-8, 20),
+                        [0.0, -0.0, 1e16, 1e15, 9999999999999998.0, 1e-4, 9.999e-5, 1e-5, 123456789012345680.0, 5e-324, 2.2250738585072014e-308,
+                         1.7976931348623157e308, 24.0, 0.5, 1 / 3, np.nan, np.inf, -np.inf, 1e22, 1e23, 2.5e-5, -2.5e-5, 12345678.9]])
+    got = logs._native_format(y, np.arange(len(y) + 1))
+    assert got == "".join(str(v) + "\n" for v in y.tolist()).encode()
+    assert logs._native_format([3000.0, -1.5, 2.0, 7.0, 1e-5, -12.0], [0, 3, 3, 6], 0b101) == b"3000\t-1.5\t2\n\n7\t1e-05\t-12\n"
+    assert logs._native_format([], [0]) == b"" and logs._native_format([], [0, 0]) == b"\n"
+
+
+@pytest.mark.parametrize("fmt", ["native", "python"])
+def test_window_log_writer_is_byte_identical_to_a_row_by_row_formatter(tmp_path, monkeypatch, fmt):
+    """ChainLogWriter.append formats a whole window at once (the adequacy columns of all rows in one set of array operations;
+    the numbers by lr_format_rows, or - LR_LOG_FORMAT=python, or without the library - by str on one tolist()): its files
+    are byte for byte what a plain per-row formatter in the reference's style writes - csv-style `str(float)` numbers,
+    calculate_r_squared (lib:268-279) per row -, with and without -pyrate_output, with NaN / inf in the empirical rates, and
+    when a row's shift times do not ascend (the per-row fallback)."""
     from literate_amd import logs, _hip
+    monkeypatch.setenv("LR_LOG_FORMAT", fmt)
+    monkeypatch.setattr(logs, "_NATIVE", [])
+    assert (logs._native() is not None) == (fmt == "native")
     rng = np.random.default_rng(5)
     start, end, n_bins, S, C = 0.0, 24.5, 24, 40, 5
     rows = np.empty((S, C, _hip.LR_TRACE_W))

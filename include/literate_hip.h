@@ -170,11 +170,13 @@ int lr_simulate_bd(const double* lam_steps, const double* mu_steps, int32_t n_st
 /* ---- the text form of the logs (host only, no GPU) ---------------------------------
  * The reference writes every number through Python's csv module (LRF:334-359, DD:236-238): str(float), the shortest
  * decimal string that reads back to the same double, "24.0" / "1e-05" / "1.5e+16" by Python's rules.  lr_format_rows
- * writes n_rows tab-separated, newline-terminated lines into `out`: row i = vals[row_start[i] .. row_start[i + 1]);
- * a value in column c < 64 of its row whose bit is set in int_cols is written as an integer.  cap must be at least
- * 26 * (number of values) + n_rows.  Returns the number of bytes written (>= 0) or LR_ERR_*.                       */
-int64_t lr_format_rows(const double* vals, const int64_t* row_start, int64_t n_rows, uint64_t int_cols, char* out,
-                       int64_t cap);
+ * writes n_rows tab-separated lines into `out`: row i = vals[row_start[i] .. row_start[i + 1]); a value in column
+ * c < 64 of its row whose bit is set in int_cols is written as an integer; lines end "\n", or "\r\n" with
+ * LR_FORMAT_CRLF in flags (csv.writer's default, which DDRate.py and trend_rate.py write).  cap must be at least
+ * 26 * (number of values) + 2 * n_rows.  Returns the number of bytes written (>= 0) or LR_ERR_*.  Thread-safe.       */
+#define LR_FORMAT_CRLF 1
+int64_t lr_format_rows(const double* vals, const int64_t* row_start, int64_t n_rows, uint64_t int_cols, int32_t flags,
+                       char* out, int64_t cap);
 
 /* ---- A11: fused multi-chain RJMCMC --------------------------------------------------------
  * Replaces runMCMC (LRF:216-373) for n_chains independent chains.  Per iteration: one scan of

@@ -64,7 +64,7 @@ SIGNATURES = {
     "lr_simulate_bd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_f64, c_f64, c_f64, c_f64, c_i64, c_i64, C.c_uint64, c_vp, c_vp,
                              c_vp, c_vp, c_vp, c_i64, c_vp]),
     "lr_trend_rates": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
-    "lr_format_rows": (c_i64, [c_vp, c_vp, c_i64, C.c_uint64, c_vp, c_i64]),
+    "lr_format_rows": (c_i64, [c_vp, c_vp, c_i64, C.c_uint64, c_i32, c_vp, c_i64]),
     "lr_mcmc_query_layout": (c_i32, [C.POINTER(McmcConfig), C.POINTER(McmcLayout)]),
     "lr_mcmc_create": (c_i32, [C.POINTER(McmcConfig), c_vp, c_vp, c_vp, c_vp, c_i64, C.POINTER(c_vp)]),
     "lr_mcmc_init": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),

@@ -94,11 +94,12 @@ inline char* lr_py_int(char* p, double v) {
 }  // namespace
 
 extern "C" int64_t lr_format_rows(const double* vals, const int64_t* row_start, int64_t n_rows, uint64_t int_cols,
-                                  char* out, int64_t cap) {
+                                  int32_t flags, char* out, int64_t cap) {
     if (!vals || !row_start || !out) return LR_ERR_NULL;
     if (n_rows < 0) return LR_ERR_SIZE;
     const int64_t n_vals = n_rows > 0 ? row_start[n_rows] - row_start[0] : 0;
-    if (n_vals < 0 || cap < 26 * n_vals + n_rows) return LR_ERR_WORKSPACE;   // 24 characters at most per number + a separator
+    const bool crlf = (flags & LR_FORMAT_CRLF) != 0;     // csv.writer's default line end (DD:236, trend_rate.py:189)
+    if (n_vals < 0 || cap < 26 * n_vals + 2 * n_rows) return LR_ERR_WORKSPACE;   // 24 characters at most per number + a separator
     char* p = out;
     for (int64_t i = 0; i < n_rows; ++i) {
         const int64_t a = row_start[i], b = row_start[i + 1];
@@ -108,6 +109,7 @@ extern "C" int64_t lr_format_rows(const double* vals, const int64_t* row_start, 
             if (c < 64 && ((int_cols >> c) & 1)) p = lr_py_int(p, vals[j]);
             else p = lr_py_float(p, vals[j]);
         }
+        if (crlf) *p++ = '\r';
         *p++ = '\n';
     }
     return (int64_t)(p - out);

@@ -42,24 +42,31 @@ class DDRateEngine(ChainEngine):
 
     def log_rows_from(self, tr, emp=None):
         """The same from given trace rows [samples, LR_TRACE_W] of one chain (a window of a streamed run)."""
+        return list(self.log_table_from(tr, emp))
+
+    def log_table_from(self, tr, emp=None):
+        """Trace rows [..., LR_TRACE_W] (any leading shape: a chain's rows, or a whole window [chains, samples]) -> the log
+        rows [..., columns] as one float64 array: the per-bin columns of ALL rows from one lr_dd_rates / lr_binned_keiding
+        launch per 64k rows, the adequacy columns as array operations (logs.adequacy_rows)."""
+        from . import logs
         tr = np.asarray(tr, dtype=float)
-        if len(tr) == 0:
-            return []
-        args = tr[:, 4:12]
-        b, d, ni, nf = [x.cpu().numpy() for x in ops.dd_rates(args, self.DT, self.m_birth, self.m_death)]
-        lb, ld = [x.cpu().numpy() for x in ops.binned_keiding(b, d, self.n_spec, self.n_exti, self.DT)]
-        logged = args.copy()
-        logged[:, 2] += self.origin          # DD:224
-        logged[:, 4] += logged[:, 3]         # DD:225
-        rows = []
-        for i in range(len(tr)):
-            row = [tr[i, 0], tr[i, 1], tr[i, 2], lb[i], ld[i], tr[i, 3]] + list(logged[i]) + list(b[i]) + list(d[i]) \
-                + list(ni[i]) + list(nf[i])
+        lead, R = tr.shape[:-1], tr.reshape(-1, tr.shape[-1])
+        n = len(self.DT)
+        out = np.empty((len(R), 14 + 4 * n + (3 if emp is not None else 0)))
+        for a in range(0, len(R), 1 << 16):
+            T = R[a:a + (1 << 16)]
+            args = T[:, 4:12]
+            b, d, ni, nf = [x.cpu().numpy() for x in ops.dd_rates(args, self.DT, self.m_birth, self.m_death)]
+            lb, ld = [x.cpu().numpy() for x in ops.binned_keiding(b, d, self.n_spec, self.n_exti, self.DT)]
+            O = out[a:a + (1 << 16)]
+            O[:, 0], O[:, 1], O[:, 2], O[:, 3], O[:, 4], O[:, 5] = T[:, 0], T[:, 1], T[:, 2], lb, ld, T[:, 3]
+            O[:, 6:14] = args
+            O[:, 8] += self.origin           # DD:224
+            O[:, 10] += O[:, 9]              # DD:225
+            O[:, 14:14 + n], O[:, 14 + n:14 + 2 * n], O[:, 14 + 2 * n:14 + 3 * n], O[:, 14 + 3 * n:14 + 4 * n] = b, d, ni, nf
             if emp is not None:
-                with np.errstate(all="ignore"):
-                    row += list(calculate_r_squared(emp[0], emp[1], b[i], d[i]))
-            rows.append(np.array(row, dtype=float))
-        return rows
+                O[:, 14 + 4 * n:] = logs.adequacy_rows(emp[0], emp[1], b, d)
+        return out.reshape(lead + (out.shape[1],))
 
     def log_head(self):
         n = len(self.DT)
@@ -79,14 +86,13 @@ class DDRateEngine(ChainEngine):
     def append_log(self, path, tr, emp=None):
         """Append the rows of one window and push them to disk (the reference flushes and fsyncs every sample,
         DD:236-238)."""
-        import os
-        rows = self.log_rows_from(tr, emp)
-        if not rows:
+        self.append_logs([path], np.asarray(tr, dtype=float)[:, None, :], emp)
+
+    def append_logs(self, paths, rows, emp=None):
+        """A window of all local chains at once: rows [samples, chains, LR_TRACE_W] -> paths[c] (one device launch for the
+        per-bin columns of the whole window, the numbers formatted natively on a few threads: literate_amd.logs)."""
+        from . import logs
+        rows = np.asarray(rows, dtype=float)
+        if rows.shape[0] == 0:
             return
-        with open(path, "a") as f:
-            w = csv.writer(f, delimiter='\t')
-            # (one tolist() per window: Python floats, which csv writes in their shortest round-trip form - per-element
-            # numpy scalars cost several times the formatting itself)
-            w.writerows([[int(r[0])] + r[1:] for r in np.asarray(rows, dtype=np.float64).tolist()])
-            f.flush()
-            os.fsync(f.fileno())
+        logs.append_table_logs(paths, self.log_table_from(rows.transpose(1, 0, 2), emp))

@@ -88,46 +88,70 @@ def _rates_per_bin_rows(rates, shifts, K, start, n_bins):
     return np.take_along_axis(rates, seg, axis=1)
 
 
+def _r_squared_block(x, y):
+    """calculate_r_squared (lib:268-279) of every row of y [rows, 2 n_bins] against x [2 n_bins] -> (coeff, r2, gelman)."""
+    with np.errstate(all="ignore"):
+        coeff = np.sum(x * y, axis=1) / np.sum(x * x)
+        fitted = coeff[:, None] * x
+        resid = y - fitted
+        r2 = 1 - np.sum(resid ** 2, axis=1) / np.sum(y ** 2, axis=1)
+        vf = np.var(fitted, axis=1, ddof=1)
+        return coeff, r2, vf / (vf + np.var(resid, axis=1, ddof=1))
+
+
+def _in_row_blocks(n_rows, n_cols, block):
+    """block(a, b) -> bool over the row ranges [a, b) of a table of n_rows x n_cols doubles, ~4 MB of it at a time (the
+    temporaries stay in cache), on a few threads when there are several blocks: they are independent and numpy's loops
+    release the interpreter lock (a thousand chains x 128 bins cost 11 us a row on one core - more than the device needs
+    for a sample's 1000 iterations).  -> all(block results)."""
+    step = max(1, (1 << 19) // max(1, n_cols))
+    spans = [(a, min(a + step, n_rows)) for a in range(0, n_rows, step)]
+    if len(spans) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max(1, min(8, len(spans), (os.cpu_count() or 2) // 2))) as pool:
+            return all(list(pool.map(lambda ab: block(*ab), spans)))
+    return all([block(a, b) for a, b in spans])
+
+
+def adequacy_rows(emp_birth, emp_death, est_birth, est_death):
+    """`adequacy` for many rows at once: est_birth, est_death [rows, n_bins] -> [rows, 3], the very numbers the per-row
+    function gives (reductions run along the contiguous axis: the same summation per row)."""
+    x = np.concatenate([emp_birth, emp_death])
+    est_birth, est_death = np.asarray(est_birth, dtype=np.float64), np.asarray(est_death, dtype=np.float64)
+    out = np.empty((est_birth.shape[0], 3))
+
+    def block(a, b):
+        y = np.ascontiguousarray(np.concatenate([est_birth[a:b], est_death[a:b]], axis=1))
+        out[a:b, 0], out[a:b, 1], out[a:b, 2] = _r_squared_block(x, y)
+        return True
+
+    _in_row_blocks(out.shape[0], x.size, block)
+    return out
+
+
 def _adequacy_rows(compact, kl_max, km_max, emp, n_bins):
     """The three adequacy columns (calculate_r_squared, lib:268-279) of many compact rows at once: [R, 3], the very
-    numbers `adequacy` gives row by row (reductions run along the contiguous axis: the same summation per row) - a call
-    per row costs 26 us of small-array numpy, more than the device needs for the 1000 iterations between two samples."""
+    numbers `adequacy` gives row by row - a call per row costs 26 us of small-array numpy, more than the device needs for
+    the 1000 iterations between two samples.  None when a row's shift times do not ascend (rates_per_bin then decides)."""
     A = compact.reshape(-1, compact.shape[-1])
     H = LR_TRACE_HEAD
     o_st, o_er = H + kl_max, H + 2 * kl_max - 1
     o_et = o_er + km_max
     x = np.concatenate([emp[0], emp[1]])
     out = np.empty((A.shape[0], 3))
-    step = max(1, (1 << 19) // max(1, 2 * n_bins))          # ~4 MB of per-bin rates at a time: the temporaries stay in cache
 
-    def block(a):
-        B = A[a:a + step]
+    def block(a, b):
+        B = A[a:b]
         KL, KM, start = B[:, 6].astype(np.int64), B[:, 7].astype(np.int64), B[:, 8]
         lam = _rates_per_bin_rows(B[:, H:H + kl_max], B[:, o_st:o_st + kl_max - 1], KL, start, n_bins)
         mu = _rates_per_bin_rows(B[:, o_er:o_er + km_max], B[:, o_et:o_et + km_max - 1], KM, start, n_bins)
         if lam is None or mu is None:
             return False
-        y = np.ascontiguousarray(np.concatenate([lam, mu], axis=1))
-        with np.errstate(all="ignore"):
-            coeff = np.sum(x * y, axis=1) / np.sum(x * x)
-            fitted = coeff[:, None] * x
-            resid = y - fitted
-            r2 = 1 - np.sum(resid ** 2, axis=1) / np.sum(y ** 2, axis=1)
-            vf = np.var(fitted, axis=1, ddof=1)
-            out[a:a + step, 0], out[a:a + step, 1] = coeff, r2
-            out[a:a + step, 2] = vf / (vf + np.var(resid, axis=1, ddof=1))
+        out[a:b, 0], out[a:b, 1], out[a:b, 2] = _r_squared_block(x, np.ascontiguousarray(np.concatenate([lam, mu], axis=1)))
         return True
 
-    starts = range(0, A.shape[0], step)
-    if len(starts) > 1:
-        # blocks of rows are independent and numpy's loops release the interpreter lock: a few threads (a thousand chains
-        # x 128 bins cost 11 us a row on one core - more than the device needs for a sample's 1000 iterations)
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max(1, min(8, len(starts), (os.cpu_count() or 2) // 2))) as pool:
-            ok = list(pool.map(block, starts))
-    else:
-        ok = [block(a) for a in starts]
-    return out.reshape(compact.shape[:-1] + (3,)) if all(ok) else None
+    ok = _in_row_blocks(A.shape[0], 2 * n_bins, block)
+    return out.reshape(compact.shape[:-1] + (3,)) if ok else None
 
 
 def _lines(compact, kl_max, km_max, emp, n_bins, pyrate_output, true_root_age, adeq=None):
@@ -248,6 +272,34 @@ class ChainLogWriter:
                     f.flush()
 
 
+def append_table_logs(paths, tables):
+    """paths[c] <- the rows of tables[c] ([rows, columns] float64; column 0 an integer), appended as csv.writer(delimiter
+    '\\t') writes them (DD:236-238, trend_rate.py:183-195: '\\r\\n' line ends), flushed and fsynced per file; the
+    chains on a few threads (formatting and writing both release the interpreter lock)."""
+    def one(c):
+        M = np.ascontiguousarray(tables[c], dtype=np.float64)
+        if M.shape[0] == 0:
+            return
+        if _native() is not None:
+            with open(paths[c], "ab") as f:
+                f.write(_native_format(M.reshape(-1), np.arange(M.shape[0] + 1, dtype=np.int64) * M.shape[1], 1, crlf=True))
+                f.flush()
+                os.fsync(f.fileno())
+        else:
+            with open(paths[c], "a", newline="") as f:
+                csv.writer(f, delimiter='\t').writerows([[int(r[0])] + r[1:] for r in M.tolist()])
+                f.flush()
+                os.fsync(f.fileno())
+
+    if len(paths) > 1 and _native() is not None:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max(1, min(8, len(paths), (os.cpu_count() or 2) // 2))) as pool:
+            list(pool.map(one, range(len(paths))))
+    else:
+        for c in range(len(paths)):
+            one(c)
+
+
 _MCMC_INT_COLS = (1 << 0) | (1 << 6) | (1 << 7)        # it, K_l, K_m are written as integers (LRF:321-323)
 _NATIVE = []
 
@@ -268,13 +320,15 @@ def _native():
     return _NATIVE[0]
 
 
-def _native_format(vals, row_start, int_cols=0):
-    """Tab-separated lines of `vals` (row i = vals[row_start[i]:row_start[i + 1]]) in the reference's csv form -> bytes."""
+def _native_format(vals, row_start, int_cols=0, crlf=False):
+    """Tab-separated lines of `vals` (row i = vals[row_start[i]:row_start[i + 1]]) in the reference's csv form -> bytes
+    (crlf: csv.writer's default line end).  The call releases the interpreter lock: chains can be formatted on threads."""
     vals = np.ascontiguousarray(vals, dtype=np.float64)
     row_start = np.ascontiguousarray(row_start, dtype=np.int64)
-    cap = 26 * int(vals.size) + int(row_start.size)
+    cap = 26 * int(vals.size) + 2 * int(row_start.size)
     out = np.empty(cap, dtype=np.uint8)
-    n = _native().lr_format_rows(vals.ctypes.data, row_start.ctypes.data, int(row_start.size) - 1, int(int_cols), out.ctypes.data, cap)
+    n = _native().lr_format_rows(vals.ctypes.data, row_start.ctypes.data, int(row_start.size) - 1, int(int_cols), 1 if crlf else 0,
+                                 out.ctypes.data, cap)
     if n < 0:
         raise RuntimeError("lr_format_rows: %d" % n)
     return out[:n].tobytes()

@@ -55,20 +55,28 @@ class TrendRateEngine(ChainEngine):
 
     def log_rows_from(self, tr, emp=None):
         """The same from given trace rows [samples, LR_TRACE_W] of one chain (a window of a streamed run)."""
+        return list(self.log_table_from(tr, emp))
+
+    def log_table_from(self, tr, emp=None):
+        """Trace rows [..., LR_TRACE_W] (a chain's rows, or a whole window [chains, samples]) -> the log rows [..., columns]
+        as one float64 array (one lr_trend_rates / lr_binned_keiding launch per 64k rows, adequacy as array operations)."""
+        from . import logs
         tr = np.asarray(tr, dtype=float)
-        if len(tr) == 0:
-            return []
-        args = tr[:, 4:10]
-        b, d = [x.cpu().numpy() for x in ops.trend_rates(args, self.trend, self.const_birth, self.const_death)]
-        lb, ld = [x.cpu().numpy() for x in ops.binned_keiding(b, d, self.n_spec, self.n_exti, self.DT)]
-        rows = []
-        for i in range(len(tr)):
-            row = [tr[i, 0], tr[i, 1], tr[i, 2], lb[i], ld[i], tr[i, 3]] + list(args[i]) + list(b[i]) + list(d[i])
+        lead, R = tr.shape[:-1], tr.reshape(-1, tr.shape[-1])
+        n = len(self.DT)
+        out = np.empty((len(R), 12 + 2 * n + (3 if emp is not None else 0)))
+        for a in range(0, len(R), 1 << 16):
+            T = R[a:a + (1 << 16)]
+            args = T[:, 4:10]
+            b, d = [x.cpu().numpy() for x in ops.trend_rates(args, self.trend, self.const_birth, self.const_death)]
+            lb, ld = [x.cpu().numpy() for x in ops.binned_keiding(b, d, self.n_spec, self.n_exti, self.DT)]
+            O = out[a:a + (1 << 16)]
+            O[:, 0], O[:, 1], O[:, 2], O[:, 3], O[:, 4], O[:, 5] = T[:, 0], T[:, 1], T[:, 2], lb, ld, T[:, 3]
+            O[:, 6:12] = args
+            O[:, 12:12 + n], O[:, 12 + n:12 + 2 * n] = b, d
             if emp is not None:
-                with np.errstate(all="ignore"):
-                    row += list(calculate_r_squared(emp[0], emp[1], b[i], d[i]))
-            rows.append(np.array(row, dtype=float))
-        return rows
+                O[:, 12 + 2 * n:] = logs.adequacy_rows(emp[0], emp[1], b, d)
+        return out.reshape(lead + (out.shape[1],))
 
     def log_head(self):
         n = len(self.DT)
@@ -85,15 +93,13 @@ class TrendRateEngine(ChainEngine):
 
     def append_log(self, path, tr, emp=None):
         """Append the rows of one window and push them to disk (the reference flushes and fsyncs every sample,
-        DD:236-238)."""
-        import os
-        rows = self.log_rows_from(tr, emp)
-        if not rows:
+        trend_rate.py:190-195)."""
+        self.append_logs([path], np.asarray(tr, dtype=float)[:, None, :], emp)
+
+    def append_logs(self, paths, rows, emp=None):
+        """A window of all local chains at once: rows [samples, chains, LR_TRACE_W] -> paths[c]."""
+        from . import logs
+        rows = np.asarray(rows, dtype=float)
+        if rows.shape[0] == 0:
             return
-        with open(path, "a") as f:
-            w = csv.writer(f, delimiter='\t')
-            # (one tolist() per window: Python floats, which csv writes in their shortest round-trip form - per-element
-            # numpy scalars cost several times the formatting itself)
-            w.writerows([[int(r[0])] + r[1:] for r in np.asarray(rows, dtype=np.float64).tolist()])
-            f.flush()
-            os.fsync(f.fileno())
+        logs.append_table_logs(paths, self.log_table_from(rows.transpose(1, 0, 2), emp))

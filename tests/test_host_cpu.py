@@ -155,6 +155,31 @@ def test_native_number_format_is_python_str_of_float():
     assert logs._native_format([], [0]) == b"" and logs._native_format([], [0, 0]) == b"\n"
 
 
+def test_table_logs_native_and_csv_writer_write_the_same_bytes(tmp_path, monkeypatch):
+    """logs.append_table_logs (the DDRate.py / trend_rate.py logs: fixed-width rows, column 0 an integer) through
+    lr_format_rows and through csv.writer(delimiter='\\t') as the reference uses it (DD:236-238): the same bytes,
+    '\\r\\n' line ends included; several chains, an empty window."""
+    import csv
+    from literate_amd import logs
+    rng = np.random.default_rng(11)
+    tables = rng.normal(0, 1, (6, 37, 23)) * 10.0 ** rng.integers(-7, 17, (6, 37, 23))
+    tables[..., 0] = np.arange(37) * 1000
+    tables[2, 5, 7], tables[3, 1, 2], tables[0, 0, 3] = np.nan, np.inf, -0.0
+    out = {}
+    for fmt in ("native", "python"):
+        monkeypatch.setenv("LR_LOG_FORMAT", fmt)
+        monkeypatch.setattr(logs, "_NATIVE", [])
+        paths = [str(tmp_path / ("%s_%d.log" % (fmt, c))) for c in range(6)]
+        logs.append_table_logs(paths, tables[:, :20]), logs.append_table_logs(paths, tables[:, 20:]), logs.append_table_logs(paths, tables[:, :0])
+        out[fmt] = [open(p, "rb").read() for p in paths]
+    assert out["native"] == out["python"]
+    with open(tmp_path / "ref.log", "w", newline="") as f:
+        w = csv.writer(f, delimiter="\t")
+        for row in tables[4]:
+            w.writerow([int(row[0])] + [float(v) for v in row[1:]])
+    assert open(tmp_path / "ref.log", "rb").read() == out["native"][4] and out["native"][4].count(b"\r\n") == 37
+
+
 @pytest.mark.parametrize("fmt", ["native", "python"])
 def test_window_log_writer_is_byte_identical_to_a_row_by_row_formatter(tmp_path, monkeypatch, fmt):
     """ChainLogWriter.append formats a whole window at once (the adequacy columns of all rows in one set of array operations;

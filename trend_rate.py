@@ -79,8 +79,7 @@ def main(argv=None):
     def flush_window():
         rows, snap, (s0, s1, its) = streamer.collect()
         with torch.cuda.stream(streamer.side):          # the per-bin log columns are recomputed on the side stream
-            for c, path in enumerate(paths):
-                eng.append_log(path, rows[:, c], emp)
+            eng.append_logs(paths, rows, emp)
         if rank == 0:
             print(its, snap["likA"][0], snap["L"][0][:6])
             sys.stdout.flush()

@@ -152,17 +152,24 @@ def main(argv=None):
             print("resumed from %s at iteration %d" % (ckpt, done))
     # The logs are written as the run goes (the reference flushes every sample, LRF:334-359): a window's rows leave the
     # device on a side stream - gathered over RCCL when the chains are sharded - while the next window runs.  A resumed
-    # run rewrites the rows the checkpoint holds first (they are all in the workspace), then appends.
+    # run rewrites the rows the checkpoint holds first (they are all in the workspace), then appends.  A checkpoint per
+    # window: the state is copied on the device at the window's end (checkpoint_begin) and written - with the window's
+    # trace rows appended to <file>.trace - behind the next window, after collect() has shown that the run is not void.
     from literate_amd.engine import TraceStreamer
     streamer = TraceStreamer(eng, args.chains, n_local)
     writer = None
     if rank == 0 and n_samples:
         writer = logs.ChainLogWriter(args.d, model, args.out, args.chains, emp, eng.n_bins, args.pyrate_output, true_root_age)
+    tickets = []                     # one per marked window: its end as a checkpoint ticket (None: nothing to write)
     if done > 0:
         streamer.mark()
+        tickets.append(None)         # (the rows a resumed run re-reads are the checkpoint's own)
 
     def flush_window():
-        rows, snap, (s0, s1, its) = streamer.collect()
+        rows, snap, (s0, s1, its) = streamer.collect()      # (raises when the run is void: no checkpoint of it is written)
+        ticket = tickets.pop(0)
+        if ticket is not None:
+            eng.checkpoint_write(ticket, ckpt)              # the window's end, on disk while the next window runs
         if rank == 0:
             if writer is not None:
                 writer.append(rows)
@@ -178,8 +185,7 @@ def main(argv=None):
         eng.steps(n)
         streamer.mark()
         done += n
-        if ckpt:
-            eng.save(ckpt)          # (synchronises; refuses to replace the checkpoint with a void run)
+        tickets.append(eng.checkpoint_begin() if ckpt else None)    # a device-side copy of the state at the window's end
         if len(streamer.pending) > 1:
             flush_window()          # the window before this one, while this one runs
     while streamer.pending:

@@ -294,36 +294,97 @@ class ChainEngine:
         sig["data_sha1"] = self._data_hash
         return sig
 
-    def save(self, path):
-        """Write the run (all chain states, pending proposals, trace rows, iteration count) to `path` (.npz).
-        The workspace IS the run between two steps() calls; draws are addressed by (seed, chain, iteration), so a
-        run resumed with load() continues bit-identically."""
+    def _trace_span(self):
+        """(offset, end) of the trace region in the workspace (the status word follows it)."""
+        return int(self.layout.trace), int(self.layout.status)
+
+    def checkpoint_begin(self):
+        """First half of save(), asynchronous: a device-side copy of everything a checkpoint holds EXCEPT the trace rows
+        (chain states, pending proposals, tables, packed lineages, carried sums), taken on the current stream behind the
+        steps() calls so far.  The next window can be launched right away; checkpoint_write() puts the ticket on disk
+        later, from the side (the trace rows of a finished window never change again)."""
         import torch
-        self.check_status()          # (synchronises) a void run must not replace the last good checkpoint
-        sig = self._signature()
-        # written beside the target and renamed over it: a kill during save() leaves the previous checkpoint intact
+        t0, t1 = self._trace_span()
+        with torch.cuda.device(self.device):
+            head, tail = self.workspace[:t0].clone(), self.workspace[t1:].clone()
+            ev = torch.cuda.Event()
+            ev.record()
+        return dict(head=head, tail=tail, ev=ev, iterations=int(self.iterations), samples=int(self.samples_done()))
+
+    def checkpoint_write(self, ticket, path):
+        """Second half of save(): the ticket's state -> `path` (.npz, written beside the target and renamed over it: a
+        kill leaves the previous checkpoint intact), the trace rows sampled since the last write -> appended to
+        `path`.trace (raw float64 rows [chains, LR_TRACE_W] per sample: a checkpoint per window used to rewrite the whole
+        trace buffer every time - 1.2 GB per window at 1000 samples x 1024 chains).  The caller has made sure the run is
+        not void (check_status(), or TraceStreamer.collect() of the same window)."""
+        import torch
         path = str(path)
         if not path.endswith(".npz"):
             path += ".npz"
+        side = getattr(self, "_ckpt_stream", None)
+        if side is None:
+            side = self._ckpt_stream = torch.cuda.Stream(device=self.device)
+        row_bytes = self.n_chains * _hip.LR_TRACE_W * 8
+        s1 = ticket["samples"]
+        sidecar = path + ".trace"
+        saved = getattr(self, "_ckpt_saved", {}).get(path, 0)
+        if saved > s1 or not os.path.exists(sidecar) or os.path.getsize(sidecar) < saved * row_bytes:
+            saved = 0
+        with torch.cuda.device(self.device), torch.cuda.stream(side):
+            side.wait_event(ticket["ev"])
+            head, tail = ticket["head"].cpu().numpy(), ticket["tail"].cpu().numpy()
+            new_rows = self.trace[saved:s1].cpu().numpy() if s1 > saved else None
+        side.synchronize()
+        with open(sidecar, "r+b" if saved > 0 else "wb") as f:
+            f.seek(saved * row_bytes)
+            f.truncate()
+            if new_rows is not None:
+                f.write(new_rows.tobytes())
+            f.flush()
+            os.fsync(f.fileno())
+        sig = self._signature()
         tmp = path + ".tmp.npz"
-        np.savez(tmp, workspace=self.workspace.cpu().numpy(), iterations=np.int64(self.iterations),
+        np.savez(tmp, head=head, tail=tail, iterations=np.int64(ticket["iterations"]), n_trace_rows=np.int64(s1),
                  sig_keys=np.array(list(sig.keys())), sig_vals=np.array(list(sig.values())))
         os.replace(tmp, path)
+        if not hasattr(self, "_ckpt_saved"):
+            self._ckpt_saved = {}
+        self._ckpt_saved[path] = s1
+
+    def save(self, path):
+        """Write the run (all chain states, pending proposals, trace rows, iteration count) to `path` (.npz + .npz.trace).
+        The workspace IS the run between two steps() calls; draws are addressed by (seed, chain, iteration), so a
+        run resumed with load() continues bit-identically."""
+        ticket = self.checkpoint_begin()
+        self.check_status()          # (synchronises) a void run must not replace the last good checkpoint
+        self.checkpoint_write(ticket, path)
 
     def load(self, path):
         """Resume from save(): the engine must have been created on the same data with the same settings."""
         import torch
+        path = str(path)
         with np.load(path) as z:
             saved = dict(zip([str(k) for k in z["sig_keys"]], [str(v) for v in z["sig_vals"]]))
             mine = self._signature()
             bad = [k for k in mine if k not in saved or mine[k] != saved[k]]
             if bad or len(saved) != len(mine):
                 raise ValueError("checkpoint was written by a different configuration: " + ", ".join(bad))
-            ws = torch.from_numpy(z["workspace"])
-            if ws.numel() != self.workspace.numel():
+            t0, t1 = self._trace_span()
+            head, tail = torch.from_numpy(z["head"]), torch.from_numpy(z["tail"])
+            if head.numel() != t0 or tail.numel() != self.workspace.numel() - t1:
                 raise ValueError("checkpoint workspace size differs")
-            self.workspace.copy_(ws.to(self.device))
+            n_rows = int(z["n_trace_rows"])
+            row_bytes = self.n_chains * _hip.LR_TRACE_W * 8
+            if n_rows > 0:
+                sidecar = path + ".trace"
+                if not os.path.exists(sidecar) or os.path.getsize(sidecar) < n_rows * row_bytes:
+                    raise ValueError("checkpoint trace file %s is missing or shorter than the %d rows the checkpoint holds" % (sidecar, n_rows))
+                rows = np.fromfile(sidecar, dtype=np.uint8, count=n_rows * row_bytes)
+                self.workspace[t0:t0 + n_rows * row_bytes].copy_(torch.from_numpy(rows).to(self.device))
+            self.workspace[:t0].copy_(head.to(self.device))
+            self.workspace[t1:].copy_(tail.to(self.device))
             self.iterations = int(z["iterations"])
+        self._ckpt_saved = {path: n_rows}
         _hip.check(_hip.launch(self.lib.lr_mcmc_restore, self.device, self.handle), "lr_mcmc_restore")
 
     def close(self):

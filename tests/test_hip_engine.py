@@ -600,6 +600,55 @@ def test_checkpoint_resume_is_bit_identical(G, tmp_path, engine, C):
         e.close()
 
 
+def test_checkpoints_append_their_trace_rows_and_can_be_written_behind_the_next_window(G, tmp_path):
+    """A checkpoint per window: the state goes to <path>.npz (a few MB), the trace rows sampled since the last write are
+    APPENDED to <path>.npz.trace (no window rewrites the whole trace buffer); checkpoint_begin() takes the state on the
+    device and the write may follow while later windows run.  Resumed from the second of three checkpoints (with rows of a
+    later, unfinished write left in the trace file: a kill between the two halves of a write), the run ends bit-identical
+    to an uninterrupted one, and its next checkpoint truncates the stale rows."""
+    import torch
+    from literate_amd import _hip
+    from literate_amd.engine import ChainEngine
+    name, C = "metal_bands", 12
+    kw = dict(model=0, seed=5, s_freq=10, n_trace_slots=40)
+    full = ChainEngine(G[name + "/ts"], G[name + "/te"], C, **kw)
+    full.init(); full.steps(400)
+    a = ChainEngine(G[name + "/ts"], G[name + "/te"], C, **kw)
+    a.init()
+    path = str(tmp_path / "run.npz")
+    row_bytes = C * _hip.LR_TRACE_W * 8
+    a.steps(100); t1 = a.checkpoint_begin()
+    a.steps(100); t2 = a.checkpoint_begin()          # two windows launched before the first checkpoint is written
+    a.check_status()
+    a.checkpoint_write(t1, path)
+    assert os.path.getsize(path + ".trace") == 10 * row_bytes
+    a.checkpoint_write(t2, path)
+    assert os.path.getsize(path + ".trace") == 20 * row_bytes
+    assert os.path.getsize(path) < a.workspace.numel() - 40 * row_bytes + (1 << 16)         # the .npz holds no trace rows
+    keep = open(path, "rb").read()
+    a.steps(100); a.save(path)                        # a third checkpoint ...
+    assert os.path.getsize(path + ".trace") == 30 * row_bytes
+    open(path, "wb").write(keep)                      # ... whose .npz never replaced the second: its rows are stale
+    a.close()
+    b = ChainEngine(G[name + "/ts"], G[name + "/te"], C, **kw)
+    b.load(path)
+    assert b.iterations == 200
+    b.steps(100); b.save(path)
+    assert os.path.getsize(path + ".trace") == 30 * row_bytes
+    b.steps(100)
+    torch.cuda.synchronize()
+    bits = lambda t: t.contiguous().view(torch.int64)
+    assert torch.equal(bits(b.trace), bits(full.trace)) and torch.equal(bits(b.state_f64), bits(full.state_f64))
+    c = ChainEngine(G[name + "/ts"], G[name + "/te"], C, **kw)
+    c.load(path)
+    assert c.iterations == 300 and torch.equal(bits(c.trace[:30]), bits(full.trace[:30]))
+    os.truncate(path + ".trace", 29 * row_bytes)
+    with pytest.raises(ValueError):
+        c.load(path)
+    for e in (full, b, c):
+        e.close()
+
+
 @pytest.mark.parametrize("general", [False, True])
 def test_four_chain_kernel_does_not_depend_on_how_a_run_is_cut_into_launches(general):
     """The four-chain kernel leaves the scan sums of its last phase for the next launch instead of scoring pair 0 again: a

@@ -1062,13 +1062,15 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     if (env == 1 || cfg->engine_mode >= 2) return true;
     const double n = (double)cfg->n_lineages, c = (double)cfg->n_chains;
     // the best persistent kernel for the shape (microseconds) against the tiled launches (measured: 7e12 evals/s at unit
-    // resolution, 3e12 on general times, 14 us of launches per iteration)
+    // resolution, 3e12 on general times, 15.5 us of launches per iteration + 1 us per 1024 chains of the step blocks:
+    // scratch/exp_plan_small.py - with a flat 14 us, 4096 chains on short inputs went to the launches at 19.5 - 23 us
+    // where the two-chain kernel runs 15.7 - 19.1)
     double t_persist = lr_model_four_chain(cfg, general);
     if (!general) t_persist = fmin(t_persist, lr_model_two_chain(cfg));
     int k = 0;
     const double t_spec = (p.H > (general ? 136 : 264)) ? 1e30 : lr_spec_model(cfg, &k, general);   // few chains: a team of CUs per pair
     if (k > 0 && t_spec < t_persist) t_persist = t_spec;
-    const double t_launch = n * c / (general ? 3e12 : 7e12) * 1e6 + 14.0;
+    const double t_launch = n * c / (general ? 3e12 : 7e12) * 1e6 + 15.5 + c / 1024.0;
     return t_persist <= t_launch;
 }
 

@@ -87,6 +87,7 @@ inline char* lr_py_float(char* p, double v) {
 }
 
 inline char* lr_py_int(char* p, double v) {
+    if (!(std::fabs(v) < 9.2e18)) return lr_py_float(p, v);     // (nan, inf, beyond int64: no integer to write)
     const std::to_chars_result r = std::to_chars(p, p + 24, (long long)v);
     return r.ptr;
 }

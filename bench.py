@@ -663,6 +663,122 @@ def roofline_object(fig, kname, kernel_ms, n_ev, n_lin, chains, passes, cb_pass)
                             "the HBM peak; measured_GBs is what really reaches HBM"}}
 
 
+# ---- what is printed: ONE compact line (the driver parses the LAST stdout line) + the detail beside it -------------
+COMPACT_LIMIT = 4096          # target size of the final line; tests/test_bench_contract.py holds it under 8192
+
+
+def _sig(x, digits=5):
+    """floats to `digits` significant digits (the line is for reading and parsing, not for archiving)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    x = float(x)
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, x))
+
+
+def _pick(d, *keys):
+    """nested lookup that tolerates absent sections: _pick(d, 'roofline', 'issue', 'frac')"""
+    for k in keys:
+        if not isinstance(d, dict) or k not in d or d[k] is None:
+            return None
+        d = d[k]
+    return d
+
+
+def _abi_row(rows, n, **match):
+    """the abi row of `n` lineages whose fields equal `match` (None when the section was not run)"""
+    for r in rows or ():
+        if r.get("lineages") == n and all(r.get(k) == v for k, v in match.items()):
+            return r
+    return None
+
+
+def compact_line(d):
+    """The final stdout line: every field the driver's contract names + `roofline` + `cpu_baseline` + one-number
+    summaries of the side sections - scalars and short names only, no prose; everything else stays in the detail
+    (bench_detail.json, and `#detail` lines printed BEFORE this one).  Pure function of the detail dict."""
+    cfg, r, c = d["config"], d["roofline"], d.get("cpu_baseline")
+    out = {k: (_sig(d[k], 9) if isinstance(d[k], float) else d[k]) for k in (
+        "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data")}
+    out["config"] = {"workload": cfg["workload"][:110]}
+    for k in ("lineages", "chains_per_gpu", "chains_total", "n_bins", "sample_every", "trace_rows_gathered_in_region",
+              "process_group", "wall_over_device"):
+        out["config"][k] = _sig(cfg.get(k))
+    out["config"]["gathers_per_eval"] = _sig(r.get("gathers_per_eval"))
+    out["config"]["fp64_ops_per_eval"] = _sig(r.get("fp64_ops_per_eval"))
+    # the driver's parser keeps scalars of `roofline` / `cpu_baseline` only: nested figures are flattened (issue_frac, ...)
+    out["roofline"] = {k: _sig(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                                                   "iterations_per_launch", "lds_bytes_per_eval", "frac_engine")}
+    out["roofline"].update(issue_frac=_sig(_pick(r, "issue", "frac")), hbm_measured_GBs=_sig(_pick(r, "hbm", "measured_GBs")),
+                           hbm_peak_GBs=HBM_PEAK_GBS, hbm_frac_16B_convention=_sig(_pick(r, "hbm", "frac_of_peak_16B_convention")),
+                           us_per_iter_device=_sig(_pick(r, "engine", "us_per_iter_device")))
+    if c:
+        out["cpu_baseline"] = {k: _sig(c.get(k)) for k in ("value", "unit", "cores", "kind", "cpu_model")}
+        out["cpu_baseline"]["sample"] = (c.get("sample") or "")[:110]
+        out["cpu_baseline"].update(all_cores_value=_sig(_pick(c, "all_cores", "value")), all_cores=_pick(c, "all_cores", "cores"),
+                                   reference_loop_iters_per_s=_sig(_pick(c, "reference_loop", "iters_per_s") or c.get("iters_per_s")))
+    else:
+        out["cpu_baseline"] = None
+    co = d.get("co_headline")
+    if co:
+        out["co_headline"] = {"workload": "cfg4_general", "value": _sig(co["value"]), "us_per_iter": _sig(co["us_per_iter_device"]),
+                              "frac": _sig(_pick(co, "roofline", "frac"))}
+    if d.get("configs"):
+        out["configs"] = {n: {"us_per_iter": _sig(s["us_per_iter"]), "evals_per_s": _sig(s["evals_per_s"]), "frac": _sig(s["lds_frac"])}
+                          for n, s in d["configs"].items()}
+    s = d.get("strong_scaling")
+    if s:
+        out["strong_scaling"] = {k: _sig(s.get(k), 9) for k in ("chains_total", "chains_per_gpu", "value", "ms_per_step")}
+    a = d.get("abi")
+    if a:
+        rows = a.get("rows")
+        ab = {"peak_GBs": a.get("peak_GBs"), "stream2_GBs": {str(k): _sig(v) for k, v in (a.get("stream2_GBs") or {}).items()}}
+        for key, kern, ch in (("lr_bin_unit_events", "lr_bin_unit_events", 0), ("lr_bd_loglik_batch_c1", "lr_bd_loglik_batch", 1),
+                              ("lr_bd_loglik_batch_c8", "lr_bd_loglik_batch", 8), ("lr_bd_loglik_batch_c16", "lr_bd_loglik_batch", 16),
+                              ("lr_bd_loglik_batch_c256", "lr_bd_loglik_batch", 256)):
+            per_n = {}
+            for n in sorted({x["lineages"] for x in rows or ()}):
+                x = _abi_row(rows, n, kernel=kern, chains=ch, general_times=False, order="sorted")
+                if x:
+                    per_n["%.0e" % n] = _sig(x["hbm_frac"], 3)
+            if per_n:
+                ab[key] = {"hbm_frac": per_n}
+        for key in ("lr_bin_unit_events", "lr_bd_loglik_batch"):
+            if isinstance(a.get(key), dict) and key in ab:
+                ab[key]["traffic_over_algorithmic"] = _sig(a[key].get("traffic_over_algorithmic"), 4)
+        ab["engine_streaming"] = [{"lineages": x["lineages"], "chains": x["chains"], "us_per_iter": _sig(x["us_per_iter"], 4),
+                                   "hbm_frac": _sig(x.get("hbm_frac"), 3), "scan_hbm_frac": _sig(x.get("scan_hbm_frac"), 3)}
+                                  for x in a.get("engine_streaming") or ()]
+        ab["seam"] = {"us_per_call_1_state": _sig(_pick(a, "seam", "BDI_partial_lik", "us_per_call_1_state"), 3),
+                      "numpy_us_per_call": _sig(_pick(a, "seam", "BDI_partial_lik", "numpy_binned_us_per_call"), 3)}
+        out["abi"] = ab
+    out["detail"] = d.get("detail_file")
+    return out
+
+
+def emit(detail, stream=None):
+    """Write the detail (bench_detail.json; `#detail <section> <json>` lines on stdout) and print the compact line LAST."""
+    stream = stream or sys.stdout
+    path = os.environ.get("LR_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(detail, f)
+        detail["detail_file"] = os.path.relpath(path, ROOT)
+    except OSError:
+        detail["detail_file"] = None
+    for k in ("configs", "co_headline", "strong_scaling", "cpu_baseline", "abi", "config", "roofline"):
+        if detail.get(k) is not None:
+            stream.write("#detail %s %s\n" % (k, json.dumps(detail[k])))
+    line = json.dumps(compact_line(detail), separators=(",", ":"))
+    assert len(line) < 2 * COMPACT_LIMIT, len(line)
+    stream.write(line + "\n")
+    stream.flush()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -691,7 +807,15 @@ def main():
     if args.abi_child:
         return abi_child(args)
     if args.abi_only:
-        print(json.dumps({"abi": abi_section(pmc=not args.no_pmc)}))
+        a = abi_section(pmc=not args.no_pmc)
+        path = os.environ.get("LR_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "abi_detail.json")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump({"abi": a}, f)
+        print("#detail abi " + json.dumps(a))
+        print(json.dumps({"abi": compact_line({"config": {"workload": ""}, "roofline": {}, "abi": a, **{k: None for k in (
+            "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")}})["abi"]}, separators=(",", ":")))
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))           # nothing above has imported torch or touched the GPU
@@ -935,8 +1059,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out)
     if dist_on:
         dist.destroy_process_group()
 

@@ -63,6 +63,48 @@ def test_committed_bench_line_has_the_contract_fields():
     assert i["frac"] == pytest.approx(r["kernel_evals_per_s"] / i["peak_evals_per_s"]) and 0 < i["frac"] < 1
 
 
+@pytest.mark.parametrize("detail", ["r04_bench_cfg4_1gpu.json", "r04_bench_cfg4_1gpu_driver_args.json", "r03_bench_cfg4_1gpu.json"])
+def test_final_stdout_line_is_compact_and_survives_the_drivers_tail(detail, tmp_path, monkeypatch):
+    """Round 4's line had grown to 28 KB and the driver, which keeps the last 8 KB of stdout, could not parse it.  bench.py
+    now prints the detail as `#detail` lines (and writes bench_detail.json) and ends with ONE compact line built by
+    compact_line(): under 4 KB, scalars only inside `config` / `roofline` / `cpu_baseline` (the driver's parser drops nested
+    objects there), and recoverable from the last 8081 characters of stdout - the size of the driver's tail."""
+    import io
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    d = json.load(open(os.path.join(ROOT, "profiles", detail)))
+    monkeypatch.setenv("LR_BENCH_DETAIL", str(tmp_path / "bench_detail.json"))
+    buf = io.StringIO()
+    line = bench.emit(d, buf)
+    assert len(line) < bench.COMPACT_LIMIT < 8192
+    assert json.load(open(tmp_path / "bench_detail.json"))["value"] == d["value"]        # nothing is lost: the detail file
+    tail = buf.getvalue()[-8081:]
+    last = tail.rstrip("\n").splitlines()[-1]
+    assert last == line and sum(l.startswith("{") for l in buf.getvalue().splitlines()) == 1
+    b = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["value"] == pytest.approx(d["value"]) and b["ms_per_step"] == pytest.approx(d["ms_per_step"])
+    assert b["steps"] == d["steps"] and b["warmup"] == d["warmup"] and b["n_gpus"] == d["n_gpus"]
+    for sec in ("config", "roofline", "cpu_baseline"):
+        assert all(not isinstance(v, (dict, list)) for v in b[sec].values()), sec
+        assert all(len(v) <= 120 for v in b[sec].values() if isinstance(v, str)), sec     # the driver cuts strings at 120
+    r = b["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "iterations_per_launch"):
+        assert k in r, k
+    assert r["frac"] == pytest.approx(d["roofline"]["frac"], rel=1e-4) and r["kernel"] == d["roofline"]["kernel"]
+    assert r["traffic"] == pytest.approx(d["roofline"]["traffic"], rel=1e-4)
+    c = b["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] == pytest.approx(d["cpu_baseline"]["value"], rel=1e-4)
+    assert set(b["configs"]) >= {"cfg2", "cfg3", "cfg5", "cfg4_general"} and b["co_headline"]["value"] > 0
+    if "abi" in d:
+        a = b["abi"]
+        assert a["lr_bin_unit_events"]["hbm_frac"]["3e+07"] > 0.4 and a["lr_bd_loglik_batch_c1"]["hbm_frac"]["3e+07"] > 0.4
+        assert len(a["engine_streaming"]) == 2 and a["seam"]["us_per_call_1_state"] > a["seam"]["numpy_us_per_call"]
+
+
 def test_abi_section_prices_the_hbm_streaming_entry_points():
     """`abi`: lr_bin_unit_events and lr_bd_loglik_batch at 1e7 / 3e7 lineages against the 8 TB/s HBM peak - the kernels for
     which HBM IS the bound (16 B per lineage and pass) - with the FETCH_SIZE traffic of the same call, and the

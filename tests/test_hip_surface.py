@@ -331,6 +331,8 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=300, env=env).stdout
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                  # rank 0 only
+    # the line the driver parses is the LAST one and compact (the detail goes to `#detail` lines before it)
+    assert out.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 8192
     b = json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["config"]["chains_total"] == 128 and b["config"]["chains_per_gpu"] == 64
     assert b["scaling"] == "weak" and b["value"] > 0 and b["cpu_baseline"] is None
@@ -374,7 +376,7 @@ def test_rccl_on_the_one_gpu():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 8192
     b = json.loads(lines[0])
     assert b["n_gpus"] == 1 and b["config"]["process_group"] == "nccl" and b["config"]["trace_rows_gathered_in_region"] == 30
     assert b["value"] == pytest.approx(300 * b["config"]["lineages"] * 64 / (b["ms_per_step"] * 1e-3 * 300))

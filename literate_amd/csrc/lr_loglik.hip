@@ -155,7 +155,10 @@ __global__ __launch_bounds__(LR_SMALL_THREADS) void lr_loglik_small_kernel(
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < LR_SMALL_THREADS / LR_WAVE; ++k) t += red[k];
-        out[c] = t + cst;
+        // `out` may be pinned HOST memory the host polls (ops.LoglikSession): a system-scope release store, so the value
+        // leaves the device's caches whatever the coherence mode of the allocation
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + c), (unsigned long long)__double_as_longlong(t + cst),
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -292,6 +292,7 @@ class ChainEngine:
         sig = {k: repr(getattr(self.cfg, k)) for k in self._CFG_KEYS}
         sig.update({"layout_" + f: repr(getattr(self.layout, f)) for f, _ in self.layout._fields_})
         sig["data_sha1"] = self._data_hash
+        sig["format"] = "2: state in .npz (head, tail), trace rows in .npz.trace"
         return sig
 
     def _trace_span(self):
@@ -313,7 +314,8 @@ class ChainEngine:
 
     def checkpoint_write(self, ticket, path):
         """Second half of save(): the ticket's state -> `path` (.npz, written beside the target and renamed over it: a
-        kill leaves the previous checkpoint intact), the trace rows sampled since the last write -> appended to
+        kill leaves the previous checkpoint intact - also when a run starts over onto an existing checkpoint: its trace
+        file is then replaced by a rename next to the .npz's own, not truncated in place), the trace rows sampled since the last write -> appended to
         `path`.trace (raw float64 rows [chains, LR_TRACE_W] per sample: a checkpoint per window used to rewrite the whole
         trace buffer every time - 1.2 GB per window at 1000 samples x 1024 chains).  The caller has made sure the run is
         not void (check_status(), or TraceStreamer.collect() of the same window)."""
@@ -335,17 +337,29 @@ class ChainEngine:
             head, tail = ticket["head"].cpu().numpy(), ticket["tail"].cpu().numpy()
             new_rows = self.trace[saved:s1].cpu().numpy() if s1 > saved else None
         side.synchronize()
-        with open(sidecar, "r+b" if saved > 0 else "wb") as f:
-            f.seek(saved * row_bytes)
-            f.truncate()
-            if new_rows is not None:
-                f.write(new_rows.tobytes())
-            f.flush()
-            os.fsync(f.fileno())
         sig = self._signature()
         tmp = path + ".tmp.npz"
         np.savez(tmp, head=head, tail=tail, iterations=np.int64(ticket["iterations"]), n_trace_rows=np.int64(s1),
                  sig_keys=np.array(list(sig.keys())), sig_vals=np.array(list(sig.values())))
+        if saved > 0:
+            # the usual case: rows behind the ones the .npz on disk records are appended (a kill before the rename below
+            # leaves that checkpoint with surplus rows it never reads)
+            with open(sidecar, "r+b") as f:
+                f.seek(saved * row_bytes)
+                f.truncate()
+                if new_rows is not None:
+                    f.write(new_rows.tobytes())
+                f.flush()
+                os.fsync(f.fileno())
+        else:
+            # a run that starts over onto an existing checkpoint: the old trace file is never truncated in place - the
+            # new one is written beside it and renamed over it right before the .npz is
+            with open(sidecar + ".tmp", "wb") as f:
+                if new_rows is not None:
+                    f.write(new_rows.tobytes())
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(sidecar + ".tmp", sidecar)
         os.replace(tmp, path)
         if not hasattr(self, "_ckpt_saved"):
             self._ckpt_saved = {}

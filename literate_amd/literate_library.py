@@ -122,13 +122,14 @@ def _loglik(L_acc_vec, M_acc_vec, model):
     # one prepared session per (states per call, model): the per-iteration call of runMCMC (LRF:305-308) then costs one
     # upload of the rates, the launches, one read-back and one synchronisation - nothing is allocated or re-uploaded
     C = 1 if L.ndim == 1 else L.shape[0]
-    key = (C, model, id(br_length_bin), float(end_time))
+    # (br_length_bin is a module global a caller may edit or rebind, as in the reference: it goes up with every call)
+    key = (C, model, int(n_bins), float(end_time), br_length_bin is None)
     ses = _sessions.get(key)
     if ses is None:
         if len(_sessions) >= 8:
             _sessions.clear()
         ses = _sessions[key] = ops.LoglikSession(_ts_dev, _te_dev, _t0, n_bins, C, model, br_length_bin, end_time)
-    out = ses(L, M)
+    out = ses(L, M, br_length_bin)
     return np.float64(out[0]) if L.ndim == 1 else out.copy()
 
 
@@ -351,7 +352,9 @@ def parse_ts_te(input_file, TBP, first_year, last_year, death_jitter):
         else:
             born, died = born[inside], died[inside]
         died = np.array(died)
-        died[~not_later(died, last_year)] = last_year    # still alive at the end of the window
+        # still alive at the end of the window: a STRICT comparison, as the reference's (lib:212, 222) - a NaN death stays NaN
+        later = (died < last_year) if TBP else (died > last_year)
+        died[later] = last_year
     if TBP:
         oldest = max(born)
         ts_, te_ = oldest - born, oldest - died

@@ -26,6 +26,13 @@ def _dev(x, dtype, device=None):
     return t.contiguous()
 
 
+def _host_f64(x):
+    """host numpy float64 view / copy of a tensor or array-like"""
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x, dtype=np.float64)
+
+
 def _workspace(nbytes, device):
     """A reusable byte workspace per device (grown on demand)."""
     torch = _torch()
@@ -149,21 +156,29 @@ def bd_loglik_batch(ts, te, t0, lam_bins, mu_bins, model=2, br_length=None, end_
 
 class LoglikSession:
     """The calc_likelihood seam (LRF:305-308: one call per MCMC iteration) with everything that does not change
-    between calls prepared once: lineages, br_length and workspace resident in HBM, a pinned staging buffer for the
-    per-bin rates of `n_states` states and one for the result.  A call is then one host-to-device copy, the three
-    launches of lr_bd_loglik_batch, one device-to-host copy and one stream synchronisation."""
+    between calls prepared once: lineages and workspace resident in HBM, ONE pinned staging buffer for what a call may
+    change - the per-bin rates of `n_states` states and br_length (the reference's operator reads the module global
+    br_length_bin on every call, LRF:150-162, so the session takes it per call too) - and one for the result.
+    Few states on few lineages: one launch that reads the pinned buffer and writes its result into pinned host memory
+    the host polls (no copy, no stream synchronisation).  Otherwise: one host-to-device copy, the three launches of
+    lr_bd_loglik_batch, one device-to-host copy and one stream synchronisation."""
 
     def __init__(self, ts, te, t0, n_bins, n_states, model=2, br_length=None, end_time=0.0):
         torch = _torch()
         self.lib = _hip.load()
         self.ts = _dev(ts, torch.float64)
         self.te = _dev(te, torch.float64, self.ts.device)
-        dev = self.ts.device
+        dev = self.device = self.ts.device
         self.n, self.n_bins, self.C, self.model = self.ts.numel(), int(n_bins), int(n_states), int(model)
-        self.br = None if br_length is None else _dev(br_length, torch.float64, dev)
-        self.rates_host = torch.empty((2, self.C, self.n_bins), dtype=torch.float64).pin_memory()
-        self.rates_np = self.rates_host.numpy()
-        self.rates = torch.empty_like(self.rates_host, device=dev)
+        self.has_br = br_length is not None
+        # [lam: C x n_bins | mu: C x n_bins | br_length: n_bins], one pinned block and its device mirror
+        self.stage_host = torch.zeros((2 * self.C + 1) * self.n_bins, dtype=torch.float64).pin_memory()
+        self.stage_np = self.stage_host.numpy()
+        self.rates_np = self.stage_np[:2 * self.C * self.n_bins].reshape(2, self.C, self.n_bins)
+        self.br_np = self.stage_np[2 * self.C * self.n_bins:]
+        if self.has_br:
+            self.br_np[:] = _host_f64(br_length)
+        self.stage = torch.empty_like(self.stage_host, device=dev)
         self.out = torch.empty(self.C, dtype=torch.float64, device=dev)
         self.out_host = torch.empty(self.C, dtype=torch.float64).pin_memory()
         self.out_np = self.out_host.numpy()
@@ -172,48 +187,63 @@ class LoglikSession:
             _hip.check(int(nbytes), "lr_bd_loglik_workspace_bytes")
         self.ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)   # the session's own: nothing else scribbles on it
         self.stream = torch.cuda.current_stream(dev)
-        # Few states on few lineages (the reference's own use: one state per iteration): lr_bd_loglik_batch is then ONE
-        # launch (lr_loglik_small_kernel), and the call can do without copies and without a stream synchronisation - the
-        # kernel reads the rates from the pinned host buffer and writes its result into pinned host memory, which the host
-        # polls (pinned host memory is device-accessible under its own address).
         self.zero_copy = (self.C <= 16 and self.n <= (1 << 18) and self.n * self.C <= (1 << 21) and self.n_bins <= 900
                           and os.environ.get("LR_LOGLIK_SMALL", "1") != "0")
-        if self.zero_copy:
-            lam, mu, out = self.rates_host[0], self.rates_host[1], self.out_host
-            self.out_bits = self.out_np.view(np.uint64)
-        else:
-            lam, mu, out = self.rates[0], self.rates[1], self.out
-        self.args = (_hip.ptr(self.ts), _hip.ptr(self.te), self.n, float(t0), self.n_bins, _hip.ptr(lam), _hip.ptr(mu),
-                     self.C, self.model, _hip.ptr(self.br), float(end_time), _hip.ptr(out), _hip.ptr(self.ws),
-                     self.ws.numel(), _hip.c_vp(self.stream.cuda_stream))
+        self.out_bits = self.out_np.view(np.uint64)
+        self._t0, self._end_time = float(t0), float(end_time)
+        self.args_zero = self._args(self.stage_host, self.out_host)
+        self.args_copy = self._args(self.stage, self.out)
+
+    def _args(self, stage, out):
+        nb, C = self.n_bins, self.C
+        base = stage.data_ptr()
+        br = _hip.c_vp(base + 16 * C * nb) if self.has_br else None
+        return (_hip.ptr(self.ts), _hip.ptr(self.te), self.n, self._t0, nb, _hip.c_vp(base), _hip.c_vp(base + 8 * C * nb),
+                C, self.model, br, self._end_time, _hip.ptr(out), _hip.ptr(self.ws), self.ws.numel(),
+                _hip.c_vp(self.stream.cuda_stream))
 
     _SENTINEL = np.uint64(0x7FF8DEAD0000BEEF)      # a NaN payload no arithmetic produces: "not written yet"
 
-    def __call__(self, L, M):
-        """L, M: [n_states, n_bins] (or [n_bins] when n_states == 1) host arrays -> numpy [n_states] (a view of the
-        session's pinned result buffer: valid until the next call)."""
+    def __call__(self, L, M, br_length=None):
+        """L, M: [n_states, n_bins] (or [n_bins] when n_states == 1) host arrays, br_length: this call's [n_bins]
+        (None: the one given at construction) -> numpy [n_states] (a view of the session's pinned result buffer:
+        valid until the next call)."""
         torch = _torch()
         self.rates_np[0] = L
         self.rates_np[1] = M
-        if self.zero_copy:
-            self.out_bits[:] = self._SENTINEL
-            rc = self.lib.lr_bd_loglik_batch(*self.args)
-            _hip.check(rc, "lr_bd_loglik_batch")
-            bits, sent = self.out_bits, self._SENTINEL
-            for _ in range(200000):                       # ~0.2 s of polling at most, then the ordinary wait
-                if not (bits == sent).any():
-                    return self.out_np
+        if br_length is not None and self.has_br:
+            self.br_np[:] = br_length
+        # the launch goes to the stream captured at construction: that stream's device must be current for the call
+        switch = torch.cuda.current_device() != self.device.index
+        if switch:
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(self.device)
+        try:
+            if self.zero_copy:
+                self.out_bits[:] = self._SENTINEL
+                rc = self.lib.lr_bd_loglik_batch(*self.args_zero)
+                _hip.check(rc, "lr_bd_loglik_batch")
+                bits, sent = self.out_bits, self._SENTINEL
+                for _ in range(200000):                       # ~0.2 s of polling at most, then the ordinary wait
+                    if not (bits == sent).any():
+                        return self.out_np
+                # the result did not become visible to the polling host (non-coherent pinned memory, a stalled device):
+                # wait the ordinary way, and do not poll again in this session
+                self.zero_copy = False
+                self.stream.synchronize()
+                if (bits == sent).any():
+                    raise _hip.HipLibraryError("lr_bd_loglik_batch: the result never arrived in host memory")
+                return self.out_np
+            with torch.cuda.stream(self.stream):
+                self.stage.copy_(self.stage_host, non_blocking=True)
+                rc = self.lib.lr_bd_loglik_batch(*self.args_copy)
+                _hip.check(rc, "lr_bd_loglik_batch")
+                self.out_host.copy_(self.out, non_blocking=True)
             self.stream.synchronize()
-            if (bits == sent).any():
-                raise _hip.HipLibraryError("lr_bd_loglik_batch: the result never arrived in host memory")
             return self.out_np
-        with torch.cuda.stream(self.stream):
-            self.rates.copy_(self.rates_host, non_blocking=True)
-            rc = self.lib.lr_bd_loglik_batch(*self.args)
-            _hip.check(rc, "lr_bd_loglik_batch")
-            self.out_host.copy_(self.out, non_blocking=True)
-        self.stream.synchronize()
-        return self.out_np
+        finally:
+            if switch:
+                torch.cuda.set_device(prev)
 
 
 def rj_propose_score(rates, times, K, move, index, draws, mult_d=1.1):

@@ -685,14 +685,41 @@ def make_parse_paths(work):
                 out[tag + "/error"] = np.array(err)
                 cases.append([name, str(int(tbp)), str(fy), str(ly), repr(jitter), tag])
                 print(tag, err or "ok")
-    out["cases"] = np.array(cases)
     # the tables themselves (numeric columns of the shipped files), so that the test can write them back as TSV files
+    import pandas as pd
     for name in ("example_TBP", "example_TAD", "metal_bands"):
         rel = DATASETS[name][0]
-        import pandas as pd
         t = pd.read_csv(os.path.join(REF, rel), delimiter="\t")
         out[name + "/table"] = t.to_numpy().astype(float)            # (the TAD file carries two empty trailing columns: NaN)
         out[name + "/header"] = np.array([str(c) for c in t.columns])
+    # round 5: lineages with a MISSING death year (NaN): the reference's `te_years[te_years < last_year] = last_year` is a
+    # strict comparison and leaves them NaN.  Three-column tables made from the example files, every 7th death blanked
+    for name, base, tbp, filters in (("nan_TBP", "example_TBP", True, [(-1, -1), (-1, 0), (30, -1)]),
+                                     ("nan_TAD", "example_TAD", False, [(-1, -1), (-1, 2012), (1998, 2030)])):
+        tab = out[base + "/table"][:, :3].copy()
+        tab[::7, 2] = np.nan
+        out[name + "/table"], out[name + "/header"] = tab, out[base + "/header"][:3]
+        src = os.path.join(work, name + ".tsv")
+        t = pd.DataFrame(tab, columns=[str(c) for c in out[name + "/header"]])
+        for c in t.columns:
+            if not t[c].isna().any():
+                t[c] = t[c].astype(np.int64)
+        t.to_csv(src, sep="\t", index=False, na_rep="")
+        for fy, ly in filters:
+            tag = "%s/fy%d_ly%d_j0.5" % (name, fy, ly)
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    ts, te, present, origin = ref.parse_ts_te(src, tbp, fy, ly, 0.5)
+                out[tag + "/ts"], out[tag + "/te"] = np.asarray(ts, float), np.asarray(te, float)
+                out[tag + "/present_origin"] = np.array([present, origin], float)
+                err = ""
+            except Exception as ex:
+                err = type(ex).__name__
+            out[tag + "/error"] = np.array(err)
+            cases.append([name, str(int(tbp)), str(fy), str(ly), repr(0.5), tag])
+            print(tag, err or "ok")
+    out["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(HERE, "parse_paths.npz"), **out)
 
 

@@ -141,6 +141,28 @@ def test_bin_unit_events_against_oracle_and_general_kernel(ops):
         ops.bin_unit_events(np.array([1.0, 2.0]), np.array([2.5, 3.5]), 0.0, 5000)
 
 
+@pytest.mark.parametrize("blocks_per_cu", [1, 2, 4])
+def test_bin_unit_publication_under_out_of_step_blocks(blocks_per_cu):
+    """lr_bin_unit_kernel publishes its column sums without a release / acquire pair (csrc/lr_stats.hip: returning
+    agent-scope atomics, s_waitcnt vmcnt(0), barrier, ticket).  Stress of that hand-off: LR_UB_BLOCKS_PER_CU = 1 / 2 / 4
+    (256 / 512 / 1024 blocks on all eight XCDs, several per CU with 24 windows, four rounds of blocks with 128), the last
+    block 1/64 the size of the others so that tickets are taken far out of step, 200 launches per case - a lost or
+    late add shows as a run that differs from the first, which itself equals lr_bin_events and torch.bincount."""
+    import json
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "bin_unit_stress.py")
+    env = {k: v for k, v in os.environ.items() if k != "LR_UB_BLOCKS_PER_CU"}
+    r = subprocess.run([sys.executable, child, str(blocks_per_cu), "200"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("BIN_UNIT_STRESS ")]
+    assert len(line) == 1
+    out = json.loads(line[0][len("BIN_UNIT_STRESS "):])
+    assert out["blocks"] == min(1024, 256 * blocks_per_cu) and len(out["cases"]) == 2
+    for c in out["cases"]:
+        assert c["first_run_matches_lr_bin_events"] and c["reps"] == 200 and c["differing_runs"] == 0, c
+
+
 def _big_lineages(n, general, seed):
     """n synthetic lineages on the device: cfg4's generator tiled (bench.py's abi workload), unsorted"""
     import torch

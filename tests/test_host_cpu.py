@@ -420,7 +420,7 @@ def test_parse_ts_te_against_the_reference_outcomes(tmp_path, golden_dir):
     from literate_amd import literate_library as ll
     P = np.load(os.path.join(golden_dir, "parse_paths.npz"))
     files = {}
-    for name in ("example_TBP", "example_TAD", "metal_bands"):
+    for name in ("example_TBP", "example_TAD", "metal_bands", "nan_TBP", "nan_TAD"):     # nan_*: every 7th death missing
         t = pd.DataFrame(P[name + "/table"], columns=[str(c) for c in P[name + "/header"]])
         for c in t.columns:
             if not t[c].isna().any():
@@ -441,9 +441,11 @@ def test_parse_ts_te_against_the_reference_outcomes(tmp_path, golden_dir):
                 n_err += 1
                 continue
             ts, te, present, origin = ll.parse_ts_te(*args)
-        assert np.array_equal(np.asarray(ts, float), P[tag + "/ts"]), tag
-        assert np.array_equal(np.asarray(te, float), P[tag + "/te"]), tag
-        assert [float(present), float(origin)] == list(P[tag + "/present_origin"]), tag
+        assert np.array_equal(np.asarray(ts, float), P[tag + "/ts"], equal_nan=True), tag
+        assert np.array_equal(np.asarray(te, float), P[tag + "/te"], equal_nan=True), tag
+        assert np.array_equal([float(present), float(origin)], P[tag + "/present_origin"], equal_nan=True), tag
+        if name.startswith("nan_"):
+            assert np.isnan(np.asarray(te, float)).sum() >= 3, tag         # a missing death stays missing (strict comparison)
         n_ok += 1
     assert n_ok >= 16 and n_err >= 8
 

@@ -331,8 +331,10 @@ def measure_traffic(workload, chains, steps, kname, engine, sample_every):
 # (per-lineage get_BDlik, BDIx:124-146 = the calc_likelihood seam INTEGRATION.md binds) are the kernels that stream
 # ts / te from HBM: 16 B per lineage and pass.  The engines never re-read ts / te, so these two are where
 # the north star's HBM roofline is testable - at lineage counts where HBM matters (1e7, 3e7: 160 / 480 MB per pass).
-ABI_SIZES = (10_000_000, 30_000_000)
+ABI_SIZES = (10_000_000, 30_000_000, 100_000_000)      # 160 MB, 480 MB, 1.6 GB per pass: the last is 6 x the Infinity Cache
 ABI_BINS = 128
+ABI_ROTATE_BYTES = 1.2e9          # a timed call never finds its input in the 256 MiB Infinity Cache: >= this many bytes of
+                                  # OTHER lineage arrays are streamed between two uses of one (ts, te) pair
 
 
 def abi_lineages(n, general, order="sorted"):
@@ -414,37 +416,68 @@ def abi_calls(kernel, ts, te, n_chains, model=2):
     return call, (out, lam, mu), dict(passes=-(-n_chains // cb), Cb=cb, tiles=tiles, H=H), keep
 
 
-def abi_time(call, reps):
-    """average device time in ms of one ABI call: HIP events on the stream the call enqueues on, `reps` calls back to back"""
+def abi_time(calls, reps):
+    """average device time in ms of one ABI call: HIP events on the stream the calls enqueue on, `reps` calls back to
+    back.  `calls` = one closure, or a list of closures over DIFFERENT copies of the input that are used in turn (so that
+    no call re-reads what the one before it left in the Infinity Cache)."""
     import torch
-    call()
-    call()
+    if callable(calls):
+        calls = [calls]
+    for c in calls[:2] + calls[:1]:
+        c()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        call()
+    for i in range(reps):
+        calls[i % len(calls)]()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
 
+def abi_rotation(ts, te):
+    """copies of (ts, te) to rotate through: as many as it takes for ABI_ROTATE_BYTES to lie between two uses of one"""
+    k = max(1, int(-(-ABI_ROTATE_BYTES // (16.0 * ts.numel()))))
+    return [(ts, te)] + [(ts.clone(), te.clone()) for _ in range(k - 1)]
+
+
+def abi_stream2_call(ts, te):
+    """the yardstick: lr_debug_stream2 only READS the two arrays (csrc/lr_stats.hip)"""
+    import torch
+    from literate_amd import _hip
+    lib = _hip.load()
+    out = torch.zeros(1, dtype=torch.float64, device=ts.device)
+    args = (_hip.ptr(ts), _hip.ptr(te), ts.numel(), _hip.ptr(out), _hip.stream_ptr(ts.device))
+
+    def call():
+        rc = lib.lr_debug_stream2(*args)
+        assert rc == 0, rc
+    return call, out
+
+
 def abi_child(args):
-    """--abi-child: `kernel` on n lineages, three calls, nothing else (the rocprofv3 --pmc / --kernel-trace target)."""
+    """--abi-child: `kernel` on n lineages, three calls, then three calls of the read-only yardstick on the same arrays,
+    nothing else (the rocprofv3 --pmc / --kernel-trace target)."""
     import torch
     ts, te = abi_lineages(args.abi_n, args.abi_general, args.abi_order)
     call, _, _, keep = abi_calls(args.abi_kernel, ts, te, args.chains or 8)
     for _ in range(3):
         call()
     torch.cuda.synchronize()
+    y, keep2 = abi_stream2_call(ts, te)
+    for _ in range(3):
+        y()
+    torch.cuda.synchronize()
 
 
 def abi_fetch_bytes(kernel, n, chains, general, order):
-    """HBM bytes read by ONE call (all its kernels): rocprofv3 --pmc FETCH_SIZE child pass, doubled (gfx950 correction,
-    MI355X_MICROARCH.md HBM); the largest dispatch of three identical calls' kernels, summed per call."""
+    """HBM bytes read by ONE call (all its kernels): rocprofv3 --pmc FETCH_SIZE child pass.  Returns (bytes per call with
+    the guide's x 2 gfx950 correction, note, per-dispatch detail) - the detail lists every lr_* dispatch of the child with
+    its raw FETCH_SIZE, and the same counter for the read-only yardstick on the same arrays (lr_debug_stream2_kernel: 16 B
+    x n known bytes), which calibrates the counter for this access shape."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
     d = tempfile.mkdtemp(prefix="lr_abi_pmc_", dir="/tmp")
     cmd = [rocprof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--abi-child", "--abi-kernel", kernel, "--abi-n", str(n),
@@ -457,25 +490,51 @@ def abi_fetch_bytes(kernel, n, chains, general, order):
                            stderr=subprocess.STDOUT, timeout=240)
     except (subprocess.TimeoutExpired, OSError) as ex:
         shutil.rmtree(d, ignore_errors=True)
-        return None, "rocprofv3 --pmc FETCH_SIZE: %s" % type(ex).__name__
+        return None, "rocprofv3 --pmc FETCH_SIZE: %s" % type(ex).__name__, None
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             rows += [x for x in csv.DictReader(fh) if x.get("Counter_Name") == "FETCH_SIZE" and "lr_" in x.get("Kernel_Name", "")]
     shutil.rmtree(d, ignore_errors=True)
     if r.returncode != 0 or not rows:
-        return None, "rocprofv3 --pmc FETCH_SIZE: rc %d, %d rows" % (r.returncode, len(rows))
-    total_kib = sum(float(x["Counter_Value"]) for x in rows)
-    return 2.0 * total_kib * 1024.0 / 3.0, "FETCH_SIZE x 2 (gfx950), all lr_* kernels of three calls / 3"
+        return None, "rocprofv3 --pmc FETCH_SIZE: rc %d, %d rows" % (r.returncode, len(rows)), None
+    return abi_fetch_summary(rows, n)
+
+
+def abi_fetch_summary(rows, n):
+    """(bytes per call, note, detail) from the child's FETCH_SIZE rows (dicts with Kernel_Name, Counter_Value in KiB,
+    Dispatch_Id).  Pure: tests/test_bench_contract.py feeds it rows."""
+    per_kernel = {}
+    for x in sorted(rows, key=lambda x: int(x.get("Dispatch_Id") or 0)):
+        per_kernel.setdefault(x["Kernel_Name"].split("(")[0], []).append(float(x["Counter_Value"]))
+    yard = [v for k, v in per_kernel.items() if "lr_debug_stream2" in k]
+    call_kib = sum(sum(v) for k, v in per_kernel.items() if "lr_debug_stream2" not in k) / 3.0
+    alg = 16.0 * n
+    detail = {"algorithmic_bytes_per_pass": alg,
+              "dispatches": {k: {"count": len(v), "FETCH_SIZE_KiB": v} for k, v in per_kernel.items()},
+              "raw_bytes_per_call_over_algorithmic": call_kib * 1024.0 / alg}
+    if yard and yard[0]:
+        y = sum(yard[0]) / len(yard[0]) * 1024.0
+        # the yardstick reads exactly 16 n bytes: alg / y is what one counted byte stands for in this access shape
+        detail["yardstick_raw_bytes_over_algorithmic"] = y / alg
+        detail["counter_bytes_per_counted_byte"] = alg / y
+        detail["bytes_per_call_calibrated_on_yardstick"] = call_kib * 1024.0 * alg / y
+        detail["traffic_over_algorithmic_calibrated"] = call_kib * 1024.0 / y
+    return (2.0 * call_kib * 1024.0, "FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md HBM), all lr_* kernels of three calls / 3; "
+            "`fetch_detail` lists every dispatch and calibrates the counter on lr_debug_stream2_kernel", detail)
 
 
 def abi_section(pmc=True, sizes=ABI_SIZES):
-    """`abi`: the two HBM-streaming entry points at 1e7 / 3e7 lineages, and the cost of the calc_likelihood seam."""
+    """`abi`: the two HBM-streaming entry points at 1e7 / 3e7 / 1e8 lineages, and the cost of the calc_likelihood seam.
+    Timed calls rotate through copies of the input (abi_rotation), so `ms` / `hbm_frac` are figures no Infinity Cache hit
+    helps; `ms_same_buffer` is the back-to-back figure on ONE copy (what round 4 reported), and the read-only yardstick
+    lr_debug_stream2 is timed the same way at every size (`stream2_GBs`, `frac_of_stream2`)."""
     import torch
-    out = {"peak_GBs": HBM_PEAK_GBS, "bytes_per_lineage_pass": 16,
+    out = {"peak_GBs": HBM_PEAK_GBS, "bytes_per_lineage_pass": 16, "rotate_bytes": ABI_ROTATE_BYTES,
            "note": "achieved = 16 B x N x ceil(C / Cb) / device time of one ABI call (all its kernels; HIP events on the "
-                   "call's stream, back-to-back calls); lineages = cfg4's synthetic generator tiled to N, sorted by birth "
-                   "time as input files are (shuffled order beside it); general = continuous times"}
+                   "call's stream; calls in turn on copies of the input totalling >= rotate_bytes); lineages = cfg4's "
+                   "synthetic generator tiled to N, sorted by birth time as input files are (shuffled order beside it); "
+                   "general = continuous times"}
     src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
     dst = torch.empty_like(src)
     copy_ms = abi_time(lambda: dst.copy_(src), 10)
@@ -484,47 +543,63 @@ def abi_section(pmc=True, sizes=ABI_SIZES):
     out["read_GBs_measured_torch_sum"] = src.numel() / (read_ms * 1e-3) / 1e9
     del src, dst
     rows = []
+    out["stream2_GBs"], out["stream2_same_buffer_GBs"] = {}, {}
     for n in sizes:
         for general in (False, True):
             for order in ("sorted", "shuffled"):
                 if order == "shuffled" and (general or n != sizes[0]):
                     continue
                 ts, te = abi_lineages(n, general, order)
+                pairs = abi_rotation(ts, te)
+                if n not in out["stream2_GBs"]:
+                    ys = [abi_stream2_call(a, b) for a, b in pairs]
+                    ms = abi_time([y[0] for y in ys], max(20, 2 * len(pairs)))
+                    out["stream2_GBs"][n] = 16.0 * n / (ms * 1e-3) / 1e9
+                    out["stream2_same_buffer_GBs"][n] = 16.0 * n / (abi_time(ys[0][0], 20) * 1e-3) / 1e9
+                    del ys
                 cases = [("lr_bin_unit_events", 0), ("lr_bin_events", 0)] + [("lr_bd_loglik_batch", c) for c in (1, 8, 16, 256)]
                 for kernel, c in cases:
                     if kernel == "lr_bin_events" and (general or order != "sorted" or n != sizes[0]):
                         continue            # arbitrary windows, 8 per pass over the lineages: one row for comparison
-                    call, _, info, keep = abi_calls(kernel, ts, te, c)
-                    reps = 20 if c <= 16 else 3
-                    ms = abi_time(call, reps)
+                    made = [abi_calls(kernel, a, b, c) for a, b in pairs]
+                    info = made[0][2]
+                    reps = max(20, 2 * len(pairs)) if c <= 16 else max(3, len(pairs))
+                    ms = abi_time([m[0] for m in made], reps)
+                    ms_same = abi_time(made[0][0], min(reps, 20)) if len(pairs) > 1 else ms
                     if kernel == "lr_bin_events":
                         info["passes"] = -(-ABI_BINS // 8)      # LR_BW = 8 windows per block (csrc/lr_stats.hip)
                     gbs = 16.0 * n * info["passes"] / (ms * 1e-3) / 1e9
                     row = dict(kernel=kernel, lineages=n, general_times=general, order=order, chains=c, ms=ms,
+                               ms_same_buffer=ms_same, rotated_copies=len(pairs),
                                achieved_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS, frac_of_copy=gbs / out["copy_GBs_measured"],
+                               frac_of_stream2=gbs / out["stream2_GBs"][n],
+                               hbm_frac_same_buffer=16.0 * n * info["passes"] / (ms_same * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                lineages_per_s=n / (ms * 1e-3), **info)
                     if kernel == "lr_bd_loglik_batch":
                         row["evals_per_s"] = float(n) * c / (ms * 1e-3)
                     rows.append(row)
-                    del call, keep
-                del ts, te
+                    del made
+                del ts, te, pairs
                 torch.cuda.empty_cache()
     out["rows"] = rows
 
-    def best(kernel, pred):
-        r = [x for x in rows if x["kernel"] == kernel and pred(x)]
-        return max(r, key=lambda x: x["hbm_frac"]) if r else None
-    for kernel, key, pred in (("lr_bin_unit_events", "lr_bin_unit_events", lambda x: x["order"] == "sorted" and not x["general_times"]),
-                              ("lr_bd_loglik_batch", "lr_bd_loglik_batch", lambda x: x["order"] == "sorted" and x["chains"] <= x["Cb"])):
-        b = best(kernel, pred)
-        if b:
+    # the summary objects: the one-pass figures at the LARGEST size (past the Infinity Cache), sorted unit-resolution input
+    big = max(sizes)
+    for kernel, key, pred in (("lr_bin_unit_events", "lr_bin_unit_events", lambda x: True),
+                              ("lr_bd_loglik_batch", "lr_bd_loglik_batch", lambda x: x["chains"] == 1)):
+        r = [x for x in rows if x["kernel"] == kernel and x["lineages"] == big and x["order"] == "sorted"
+             and not x["general_times"] and pred(x)]
+        if r:
+            b = r[0]
             out[key] = dict(hbm_frac=b["hbm_frac"], achieved_GBs=b["achieved_GBs"], lineages=b["lineages"], chains=b["chains"],
-                            general_times=b["general_times"], ms=b["ms"], traffic=None)
+                            general_times=b["general_times"], ms=b["ms"], frac_of_stream2=b["frac_of_stream2"], traffic=None)
             if pmc:
-                traffic, note = abi_fetch_bytes(kernel, b["lineages"], b["chains"], b["general_times"], "sorted")
-                out[key]["traffic"], out[key]["traffic_note"] = traffic, note
+                traffic, note, detail = abi_fetch_bytes(kernel, b["lineages"], b["chains"], b["general_times"], "sorted")
+                out[key]["traffic"], out[key]["traffic_note"], out[key]["fetch_detail"] = traffic, note, detail
                 if traffic:
                     out[key]["traffic_over_algorithmic"] = traffic / (16.0 * b["lineages"])
+                if detail and detail.get("traffic_over_algorithmic_calibrated"):
+                    out[key]["traffic_over_algorithmic_calibrated"] = detail["traffic_over_algorithmic_calibrated"]
     out["engine_streaming"] = abi_engine_rows(sizes)
     out["seam"] = abi_seam()
     return out
@@ -745,9 +820,11 @@ def compact_line(d):
                     per_n["%.0e" % n] = _sig(x["hbm_frac"], 3)
             if per_n:
                 ab[key] = {"hbm_frac": per_n}
-        for key in ("lr_bin_unit_events", "lr_bd_loglik_batch"):
-            if isinstance(a.get(key), dict) and key in ab:
-                ab[key]["traffic_over_algorithmic"] = _sig(a[key].get("traffic_over_algorithmic"), 4)
+        for key, ckey in (("lr_bin_unit_events", "lr_bin_unit_events"), ("lr_bd_loglik_batch", "lr_bd_loglik_batch_c1")):
+            if isinstance(a.get(key), dict) and ckey in ab:
+                ab[ckey]["traffic_over_algorithmic"] = _sig(a[key].get("traffic_over_algorithmic"), 4)
+                ab[ckey]["traffic_over_algorithmic_calibrated"] = _sig(a[key].get("traffic_over_algorithmic_calibrated"), 4)
+                ab[ckey]["frac_of_stream2"] = _sig(a[key].get("frac_of_stream2"), 3)
         ab["engine_streaming"] = [{"lineages": x["lineages"], "chains": x["chains"], "us_per_iter": _sig(x["us_per_iter"], 4),
                                    "hbm_frac": _sig(x.get("hbm_frac"), 3), "scan_hbm_frac": _sig(x.get("scan_hbm_frac"), 3)}
                                   for x in a.get("engine_streaming") or ()]

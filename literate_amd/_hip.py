@@ -77,6 +77,7 @@ SIGNATURES = {
     "lr_mcmc_warnings": (c_i32, [c_vp, C.POINTER(c_i32), c_vp]),
     "lr_mcmc_destroy": (c_i32, [c_vp]),
     "lr_debug_draws": (c_i32, [C.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "lr_debug_stream2": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
 }
 
 _lib = None

@@ -10,6 +10,7 @@
 #endif
 #define LR_SCAN_LDS_BUDGET (48 * 1024) /* table bytes per block we aim for (3 blocks / CU) */
 #define LR_SCAN_LDS_MAX (150 * 1024)
+#define LR_SCAN_LDS_WIDE (72 * 1024)   /* tables of the 16-chain general scan (lr_scan_wide_kernel): two blocks per CU */
 
 struct lr_scan_plan {
     int cb;            // chains per block
@@ -21,11 +22,13 @@ struct lr_scan_plan {
     int fast;          // 1: templated immediate-offset kernel (n_cls == 1, H in {40,72,136,264})
     int unit;          // 1: unit-resolution tables (8-byte entries, fractions folded in); implies fast
     int n_cls;
+    int threads;       // threads per block: LR_SCAN_THREADS, or LR_SCAN_WIDE_THREADS for the 16-chain general scan
     size_t lds_bytes;
 };
 
 // choose the launch shape of the lineage scan for (n lineages, n_chains, n_bins, model)
-int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit, lr_scan_plan* plan);
+// `wide`: allow 16 chains of GENERAL tables per pass (lr_bd_loglik_batch; the engines keep their instantiated shapes)
+int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit, lr_scan_plan* plan, int wide = 0);
 
 // The tile partials are laid out CHAIN-major: partials[chain * lr_tile_stride(tiles) + tile] - whoever adds a chain's tiles
 // up reads one contiguous row (16 tiles to a 128-byte line), not one line per tile.  (Tile-major, a chain's ~2000 partials

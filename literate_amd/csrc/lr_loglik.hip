@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void lr_reduce_partials_kernel(const double* _
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res, lr_scan_plan* p) {
+int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res, lr_scan_plan* p, int wide) {
     if (n < 1 || n_chains < 1) return LR_ERR_SIZE;
     if (n_bins < 1 || n_bins > LR_MAX_BINS) return LR_ERR_SIZE;
     if (model < 0 || model > 3) return LR_ERR_MODEL;
@@ -232,6 +232,9 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res,
         const size_t per_chain_ = (size_t)p->tab_stride * sizeof(double2);
         cb = p->unit ? 16 : 8;
         while (cb > 1 && per_chain_ * cb > LR_SCAN_LDS_BUDGET) cb >>= 1;
+        // sixteen chains of general tables per pass when they fit half a CU's LDS (H <= 136) and there are chains for it
+        static const int wide_off = getenv("LR_SCAN_WIDE") ? atoi(getenv("LR_SCAN_WIDE")) == 0 : 0;
+        if (wide && !wide_off && !p->unit && p->fast && n_chains > 8 && per_chain_ * 16 <= LR_SCAN_LDS_WIDE) cb = 16;
         if (per_chain_ * cb > LR_SCAN_LDS_MAX) return LR_ERR_SIZE;
         while (cb > 1 && cb / 2 >= n_chains) cb >>= 1;  // do not carry empty chain slots
         if (p->unit && cb < 2) {
@@ -242,9 +245,10 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res,
     }
     const size_t per_chain = (size_t)p->tab_stride * sizeof(double2);
     p->cb = cb;
+    p->threads = (cb == 16 && !p->unit) ? LR_SCAN_WIDE_THREADS : LR_SCAN_THREADS;
     p->groups = (n_chains + cb - 1) / cb;
     if (p->groups > 65535) return LR_ERR_SIZE;
-    const long long unit = 2 * LR_SCAN_THREADS;
+    const long long unit = 2 * p->threads;
     static const long long target_blocks = getenv("LR_SCAN_BLOCKS") ? atoll(getenv("LR_SCAN_BLOCKS")) : 2048;
     long long tiles = (target_blocks + p->groups - 1) / p->groups;
     const long long max_tiles = (n + 4 * unit - 1) / (4 * unit);  // >= 8 lineages per thread
@@ -256,7 +260,7 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res,
     p->chunk = chunk;
     size_t lds = per_chain * cb;
     // block reduction scratch: generic kernel [waves][cb], fast/unit kernels [cb][threads] + [threads]
-    const size_t red = p->fast ? sizeof(double) * ((size_t)cb * LR_SCAN_THREADS + LR_SCAN_THREADS)
+    const size_t red = p->fast ? sizeof(double) * ((size_t)cb * p->threads + p->threads)
                                : sizeof(double) * (LR_SCAN_THREADS / LR_WAVE) * cb;
     if (lds < red) lds = red;
     p->lds_bytes = lds;
@@ -281,10 +285,27 @@ static int lr_launch_scan_fast(const lr_scan_plan& p, const double* ts, const do
 }
 
 template <int H>
+static int lr_launch_scan_wide(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0, int n_bins,
+                               const double2* tables, int n_chains, double* partials, int partial_stride,
+                               hipStream_t stream) {
+    if (p.lds_bytes > 64 * 1024) {
+        // (per call: the attribute belongs to the function on the CURRENT device, and a process may drive several)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_scan_wide_kernel<H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(p.tiles, (n_chains + 15) / 16);
+    hipLaunchKernelGGL((lr_scan_wide_kernel<H>), grid, dim3(LR_SCAN_WIDE_THREADS), p.lds_bytes, stream, ts, te, n, t0, n_bins,
+                       tables, n_chains, p.chunk, partials, partial_stride);
+    return (int)hipGetLastError();
+}
+
+template <int H>
 static int lr_launch_scan_fast_h(const lr_scan_plan& p, const double* ts, const double* te, long long n, double t0,
                                  int n_bins, const double2* tables, int n_chains, double* partials,
                                  int partial_stride, hipStream_t stream) {
     switch (p.cb) {
+        case 16: return lr_launch_scan_wide<H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
         case 8: return lr_launch_scan_fast<8, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
         case 4: return lr_launch_scan_fast<4, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
         case 2: return lr_launch_scan_fast<2, H>(p, ts, te, n, t0, n_bins, tables, n_chains, partials, partial_stride, stream);
@@ -373,7 +394,7 @@ static void lr_loglik_ws(const lr_scan_plan& p, int n_chains, size_t* off_tables
 
 extern "C" int64_t lr_bd_loglik_workspace_bytes(int64_t n, int32_t n_bins, int32_t n_chains, int32_t model) {
     lr_scan_plan p;
-    const int rc = lr_plan_scan(n, n_chains, n_bins, model, 0, &p);
+    const int rc = lr_plan_scan(n, n_chains, n_bins, model, 0, &p, 1);
     if (rc != LR_OK) return rc;
     size_t a, b, c, total;
     lr_loglik_ws(p, n_chains, &a, &b, &c, &total);
@@ -383,7 +404,7 @@ extern "C" int64_t lr_bd_loglik_workspace_bytes(int64_t n, int32_t n_bins, int32
 extern "C" int lr_bd_loglik_plan(int64_t n, int32_t n_bins, int32_t n_chains, int32_t model, int32_t* out) {
     if (!out) return LR_ERR_NULL;
     lr_scan_plan p;
-    const int rc = lr_plan_scan(n, n_chains, n_bins, model, 0, &p);
+    const int rc = lr_plan_scan(n, n_chains, n_bins, model, 0, &p, 1);
     if (rc != LR_OK) return rc;
     out[0] = p.cb, out[1] = p.tiles, out[2] = p.H, out[3] = p.groups;
     return LR_OK;
@@ -397,7 +418,7 @@ extern "C" int lr_bd_loglik_batch(const double* ts, const double* te, int64_t n,
     if ((model == LR_MODEL_BD || model == LR_MODEL_ID) && !br_length) return LR_ERR_MODEL;
     if (t0 != floor(t0)) return LR_ERR_T0;
     lr_scan_plan p;
-    int rc = lr_plan_scan(n, n_chains, n_bins, model, 0, &p);
+    int rc = lr_plan_scan(n, n_chains, n_bins, model, 0, &p, 1);
     if (rc != LR_OK) return rc;
     size_t o_tab, o_cst, o_par, total;
     lr_loglik_ws(p, n_chains, &o_tab, &o_cst, &o_par, &total);

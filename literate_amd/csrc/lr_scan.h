@@ -61,11 +61,10 @@ __device__ __forceinline__ void lr_xcd_remap(int sb, int tiles, int groups, int*
 // crossbar and cost ~3.5 us per block as 17 dependent steps): every thread stores its CB sums ([chain][thread],
 // conflict-free), THREADS/CB threads per chain each add CB of them in a fixed order, then one thread per chain
 // adds those.  Needs CB*THREADS + THREADS doubles of LDS (the staged tables are dead by then).
-template <int CB>
+template <int CB, int T = LR_SCAN_THREADS>
 __device__ __forceinline__ void lr_block_reduce_chains(const double (&acc)[CB], double* red, int tid, int nvalid,
                                                        double* __restrict__ out /* chain0's row of partials + tile */,
                                                        size_t chain_stride) {
-    constexpr int T = LR_SCAN_THREADS;
     constexpr int TPC = T / CB;            // threads per chain in stage 1
 #pragma unroll
     for (int c = 0; c < CB; ++c) red[c * T + tid] = acc[c];
@@ -84,12 +83,15 @@ __device__ __forceinline__ void lr_block_reduce_chains(const double (&acc)[CB], 
 }
 
 // One block: tile `tile` of the lineages x chains [chain0, chain0+CB) of the `n_chains` whose tables start at
-// `tables`; partial sums go to partials[chain * partial_stride + tile].
-template <int CB, int H>
+// `tables`; partial sums go to partials[chain * partial_stride + tile].  T threads; DEPTH pairs of lineages (32 B each) per
+// thread in flight: the wide form (CB = 16: 70 KB of tables at H = 136, two 512-thread blocks per CU) keeps two, so that a
+// CU has 64 KB on its way although only 16 waves fit.
+template <int CB, int H, int T = LR_SCAN_THREADS, int DEPTH = 1>
 __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int chain0, const double* __restrict__ ts,
                                                   const double* __restrict__ te, long long n, double t0, int n_bins,
                                                   const double2* __restrict__ tables, int n_chains, long long chunk,
                                                   double* __restrict__ partials, int partial_stride) {
+    static_assert(DEPTH == 1 || DEPTH == 2, "one or two pairs in flight");
     constexpr int STRIDE = 2 * H;
     const int tid = threadIdx.x;
     const int nvalid = min(CB, n_chains - chain0);
@@ -97,27 +99,31 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
     const long long end = min(start + chunk, n);
     const bool aligned = ((((uintptr_t)ts) | ((uintptr_t)te)) & 15) == 0;
     long long i = start + 2 * tid;
-    // first pair of lineages: in flight while the tables are staged.  (One pair - 32 B - per thread in flight is enough:
-    // with four to eight 256-thread blocks per CU a second pair measured the same at 1e7 - 3e7 lineages, round 4.)
-    double2 s2 = make_double2(0.0, 0.0), e2 = make_double2(0.0, 0.0);
+    // first pair(s) of lineages: in flight while the tables are staged.  (One pair - 32 B - per thread in flight is enough
+    // at T = 256: with four to eight blocks per CU a second pair measured the same at 1e7 - 3e7 lineages, round 4.)
+    double2 s2 = make_double2(0.0, 0.0), e2 = s2, s3 = s2, e3 = s2;
     if (aligned && i + 1 < end) {
         s2 = *reinterpret_cast<const double2*>(ts + i);
         e2 = *reinterpret_cast<const double2*>(te + i);
+        if (DEPTH == 2 && i + 2 * T + 1 < end) {
+            s3 = *reinterpret_cast<const double2*>(ts + i + 2 * T);
+            e3 = *reinterpret_cast<const double2*>(te + i + 2 * T);
+        }
     }
     {
         // stage the CB tables: all 16-byte global loads are issued back to back (one latency), then written
         const double2* src = tables + (size_t)chain0 * STRIDE;
         const int n_valid_entries = nvalid * STRIDE;
-        constexpr int NI = (CB * STRIDE + LR_SCAN_THREADS - 1) / LR_SCAN_THREADS;
+        constexpr int NI = (CB * STRIDE + T - 1) / T;
         double2 buf[NI];
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            const int i = tid + k * LR_SCAN_THREADS;
+            const int i = tid + k * T;
             buf[k] = src[min(i, n_valid_entries - 1)];
         }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            const int i = tid + k * LR_SCAN_THREADS;
+            const int i = tid + k * T;
             if (i < CB * STRIDE) lds[i] = (i < n_valid_entries) ? buf[k] : make_double2(0.0, 0.0);
         }
     }
@@ -130,26 +136,35 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
     if (aligned) {
         while (i + 1 < end) {
             const double2 sc = s2, ec = e2;
-            const long long nx = i + 2 * LR_SCAN_THREADS;
-            if (nx + 1 < end) {  // prefetch the next pair
-                s2 = *reinterpret_cast<const double2*>(ts + nx);
-                e2 = *reinterpret_cast<const double2*>(te + nx);
+            if (DEPTH == 2) {
+                s2 = s3, e2 = e3;
+                const long long nx2 = i + 4 * T;
+                if (nx2 + 1 < end) {  // prefetch the pair after the next
+                    s3 = *reinterpret_cast<const double2*>(ts + nx2);
+                    e3 = *reinterpret_cast<const double2*>(te + nx2);
+                }
+            } else {
+                const long long nx = i + 2 * T;
+                if (nx + 1 < end) {  // prefetch the next pair
+                    s2 = *reinterpret_cast<const double2*>(ts + nx);
+                    e2 = *reinterpret_cast<const double2*>(te + nx);
+                }
             }
             lr_score_lineage_fast<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
             lr_score_lineage_fast<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
-            i = nx;
+            i += 2 * T;
         }
         if (i < end) lr_score_lineage_fast<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
     } else {
-        for (; i < end; i += 2 * LR_SCAN_THREADS) {
+        for (; i < end; i += 2 * T) {
             lr_score_lineage_fast<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
             if (i + 1 < end) lr_score_lineage_fast<CB, H>(ts[i + 1], te[i + 1], t0, n_bins, lbase, acc);
         }
     }
 
     __syncthreads();
-    lr_block_reduce_chains<CB>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
-                               partials + (size_t)chain0 * partial_stride + tile, (size_t)partial_stride);
+    lr_block_reduce_chains<CB, T>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
+                                  partials + (size_t)chain0 * partial_stride + tile, (size_t)partial_stride);
 }
 
 
@@ -166,6 +181,26 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_fast_kernel(const dou
     lr_xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.y, &group, &tile);
     lr_scan_fast_body<CB, H>(lds, tile, group * CB, ts, te, n, t0, n_bins, tables, n_chains, chunk, partials,
                              partial_stride);
+}
+
+// The wide form of lr_bd_loglik_batch: SIXTEEN chains' general tables (4.3 KB each at H = 136) per pass over ts / te -
+// half the passes of the CB = 8 kernel for C > 8 chains.  Per lineage 32 ds_read_b128 = 2 cycles of the CU's LDS data
+// path: at 16 chains the LDS gathers (256 CUs x 2.4 GHz / 2 = 3.1e11 lineages/s = 4.9 TB/s of ts / te) and HBM are in
+// balance, so 32 chains per pass would take as long as two passes of 16.
+#define LR_SCAN_WIDE_THREADS 512
+template <int H>
+__global__ __launch_bounds__(LR_SCAN_WIDE_THREADS) void lr_scan_wide_kernel(const double* __restrict__ ts,
+                                                                            const double* __restrict__ te, long long n,
+                                                                            double t0, int n_bins,
+                                                                            const double2* __restrict__ tables,
+                                                                            int n_chains, long long chunk,
+                                                                            double* __restrict__ partials,
+                                                                            int partial_stride) {
+    extern __shared__ double2 lds[];
+    int group, tile;
+    lr_xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.y, &group, &tile);
+    lr_scan_fast_body<16, H, LR_SCAN_WIDE_THREADS, 2>(lds, tile, group * 16, ts, te, n, t0, n_bins, tables, n_chains, chunk,
+                                                      partials, partial_stride);
 }
 
 // ------------------------------------------------------------------------------------------

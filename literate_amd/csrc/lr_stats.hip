@@ -397,6 +397,33 @@ extern "C" int lr_bin_unit_events(const double* ts, const double* te, int64_t n,
 }
 
 // ------------------------------------------------------------------------------------------
+// bench / profile hook: the yardstick for the two kernels above and for lr_scan_*_kernel - a kernel that only READS two
+// n-double arrays (the access shape of a pass over ts / te: two 16-byte loads per array in flight per thread,
+// grid-stride over 2048 blocks of 256 threads) and computes nothing.  What it reaches on a box is what "the HBM
+// roofline" means for a pass on that box (bench.py abi.stream2_GBs; scratch/ubench/stream2.hip tried the other shapes).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lr_debug_stream2_kernel(const double2* __restrict__ a, const double2* __restrict__ b,
+                                                               long long n2, double* __restrict__ out) {
+    const long long step = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    for (; i + step < n2; i += 2 * step) {
+        const double2 x0 = a[i], y0 = b[i], x1 = a[i + step], y1 = b[i + step];
+        acc += (x0.x + x0.y) + (y0.x + y0.y) + (x1.x + x1.y) + (y1.x + y1.y);
+    }
+    if (i < n2) acc += (a[i].x + a[i].y) + (b[i].x + b[i].y);
+    if (acc == 123.456) out[0] = acc;       // (never true for the bench's inputs: the loads stay, nothing is written)
+}
+
+extern "C" int lr_debug_stream2(const double* a, const double* b, int64_t n, double* out, void* stream_) {
+    if (!a || !b || !out) return LR_ERR_NULL;
+    if (n < 2 || ((((uintptr_t)a) | ((uintptr_t)b)) & 15)) return LR_ERR_SIZE;
+    hipLaunchKernelGGL(lr_debug_stream2_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream_, (const double2*)a,
+                       (const double2*)b, (long long)(n / 2), out);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // A3: rate index expansion
 // ------------------------------------------------------------------------------------------
 __global__ void lr_expand_rates_kernel(const double* __restrict__ rates, const double* __restrict__ times,

@@ -312,12 +312,18 @@ def test_loglik_random_float_data_vs_oracle(ops):
 
 def test_loglik_tiled_path_ragged_sizes_vs_oracle(ops):
     """Beyond the one-launch kernel's window (more than 2^18 lineages) lr_bd_loglik_batch runs tiled: table kernel +
-    lr_scan_fast_kernel<1 / 2 / 4 / 8, H> + reduction of the tile partials.  Ragged sizes, ragged chain groups, non-integer
-    times, models 0 - 2, against the oracle's per-lineage evaluation; unaligned pointers give identical bits; a chain scores
-    the same alone, in a group of two or four and in a group of eight."""
+    lr_scan_fast_kernel<1 / 2 / 4 / 8, H> - or, for more than 8 chains whose 16 tables fit half a CU's LDS (H <= 136),
+    lr_scan_wide_kernel<H>: 16 chains per pass, 512 threads, two pairs of lineages in flight - + reduction of the tile
+    partials.  Ragged sizes, ragged chain groups (9, 17, 33 chains: one, two and three groups of sixteen with 7, 15 and 15
+    empty slots), non-integer times, models 0 - 2, against the oracle's per-lineage evaluation; unaligned pointers give
+    identical bits; a chain scores the same alone, in a group of two, four, eight or sixteen; LR_SCAN_WIDE=0 (the
+    eight-chain kernel in a process of its own) gives the same values."""
     import torch
+    from literate_amd import _hip
     from oracle import literate_oracle as lo
+    lib = _hip.load()
     rng = np.random.default_rng(7)
+    NC = 33
     for n, n_bins in ((262_145, 24), (300_001, 130), (270_003, 257)):
         t0 = 3.0
         ts = rng.uniform(t0 - 2, t0 + n_bins + 1, n)
@@ -326,19 +332,25 @@ def test_loglik_tiled_path_ragged_sizes_vs_oracle(ops):
         k = rng.integers(0, n, n // 20)
         ts[k] = np.floor(ts[k])
         te[k] = np.ceil(te[k])
-        lam = np.exp(rng.uniform(np.log(.02), np.log(1.5), (9, n_bins)))
-        mu = np.exp(rng.uniform(np.log(.02), np.log(1.5), (9, n_bins)))
+        lam = np.exp(rng.uniform(np.log(.02), np.log(1.5), (NC, n_bins)))
+        mu = np.exp(rng.uniform(np.log(.02), np.log(1.5), (NC, n_bins)))
         br = _np(ops.bin_events(ts, te, t0 + np.arange(n_bins), t0 + np.arange(n_bins) + 1.0)[2])
         tsd, ted = torch.as_tensor(ts).cuda(), torch.as_tensor(te).cuda()
+        plan = (_hip.c_i32 * 4)()
+        for C, want in ((8, 8 if n_bins < 257 else 4), (9, 16 if n_bins < 257 else 4), (NC, 16 if n_bins < 257 else 4)):
+            assert lib.lr_bd_loglik_plan(n, n_bins, C, 2, plan) == 0 and plan[0] == want, (n_bins, C, plan[0])
         for model in (0, 1, 2):
-            ref = np.array([lo.per_lineage_loglik(ts, te, t0, lam[c], mu[c], model, br) for c in range(9)])
-            got = {C: _np(ops.bd_loglik_batch(tsd, ted, t0, lam[:C], mu[:C], model, br)) for C in (1, 2, 3, 4, 9)}
+            ref = np.array([lo.per_lineage_loglik(ts, te, t0, lam[c], mu[c], model, br) for c in range(NC)])
+            got = {C: _np(ops.bd_loglik_batch(tsd, ted, t0, lam[:C], mu[:C], model, br)) for C in (1, 2, 3, 4, 8, 9, 16, 17, NC)}
             for C, g in got.items():
                 assert np.allclose(g, ref[:C], rtol=REL, atol=1e-9), (n, n_bins, model, C)
-                assert np.allclose(g, got[9][:C], rtol=1e-11, atol=0)
+                assert np.allclose(g, got[NC][:C], rtol=1e-11, atol=0)
+            # chains 16.. of the 33 are scored by the second and third group of sixteen: the same values as on their own
+            tail = _np(ops.bd_loglik_batch(tsd, ted, t0, lam[16:], mu[16:], model, br))
+            assert np.array_equal(tail[:16], got[NC][16:32]) and np.allclose(tail[16], got[NC][32], rtol=1e-11)
         tsu = torch.as_tensor(np.concatenate([[0.0], ts])).cuda()[1:]
         teu = torch.as_tensor(np.concatenate([[0.0], te])).cuda()[1:]
-        for C in (1, 3, 9):
+        for C in (1, 3, 9, 17):
             assert np.array_equal(_np(ops.bd_loglik_batch(tsu, teu, t0, lam[:C], mu[:C], 2)),
                                   _np(ops.bd_loglik_batch(tsd, ted, t0, lam[:C], mu[:C], 2)))
 

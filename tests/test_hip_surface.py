@@ -80,10 +80,10 @@ def test_likelihood_operator_reads_br_length_bin_on_every_call(G):
             return np.array([lo.calc_likelihood(0, L[i], M[i], st) for i in range(32)])
     r0 = ref()
     assert ll.BDI_partial_lik(L[0], M[0]) == pytest.approx(r0[0], rel=1e-9) and np.allclose(ll.BDI_partial_lik(L, M), r0, rtol=1e-9)
-    ll.br_length_bin[3] *= 1.5                                   # edited in place
+    ll.br_length_bin[3:9] *= 3.0                                 # edited in place
     ll.br_length_bin[nb - 2] += 11.0
     r1 = ref()
-    assert abs(r1[0] - r0[0]) > 1e-3 * abs(r0[0])
+    assert abs(r1[0] - r0[0]) > 1e-6 * abs(r0[0])                # (a stale br_length would miss the 1e-9 below by far)
     assert ll.BDI_partial_lik(L[0], M[0]) == pytest.approx(r1[0], rel=1e-9) and np.allclose(ll.BDI_partial_lik(L, M), r1, rtol=1e-9)
     for k in range(6):                                           # rebound (fresh arrays: ids get recycled)
         ll.br_length_bin = ll.br_length_bin * (1.0 + 0.1 * k)

@@ -324,7 +324,7 @@ def test_loglik_tiled_path_ragged_sizes_vs_oracle(ops):
     lib = _hip.load()
     rng = np.random.default_rng(7)
     NC = 33
-    for n, n_bins in ((262_145, 24), (300_001, 130), (270_003, 257)):
+    for n, n_bins in ((262_145, 24), (300_001, 120), (280_001, 130), (270_003, 257)):   # H = 40, 136, 264, generic
         t0 = 3.0
         ts = rng.uniform(t0 - 2, t0 + n_bins + 1, n)
         te = ts + rng.exponential(n_bins / 6.0, n)
@@ -337,8 +337,10 @@ def test_loglik_tiled_path_ragged_sizes_vs_oracle(ops):
         br = _np(ops.bin_events(ts, te, t0 + np.arange(n_bins), t0 + np.arange(n_bins) + 1.0)[2])
         tsd, ted = torch.as_tensor(ts).cuda(), torch.as_tensor(te).cuda()
         plan = (_hip.c_i32 * 4)()
-        for C, want in ((8, 8 if n_bins < 257 else 4), (9, 16 if n_bins < 257 else 4), (NC, 16 if n_bins < 257 else 4)):
-            assert lib.lr_bd_loglik_plan(n, n_bins, C, 2, plan) == 0 and plan[0] == want, (n_bins, C, plan[0])
+        for C, want in ((8, 8), (9, 16), (NC, 16)):          # sixteen per pass where their tables fit half a CU's LDS (H <= 136)
+            assert lib.lr_bd_loglik_plan(n, n_bins, C, 2, plan) == 0
+            assert plan[0] == (want if n_bins <= 120 else 4), (n_bins, C, plan[0])
+            assert plan[2] == {24: 40, 120: 136, 130: 264}.get(n_bins, n_bins + 2)
         for model in (0, 1, 2):
             ref = np.array([lo.per_lineage_loglik(ts, te, t0, lam[c], mu[c], model, br) for c in range(NC)])
             got = {C: _np(ops.bd_loglik_batch(tsd, ted, t0, lam[:C], mu[:C], model, br)) for C in (1, 2, 3, 4, 8, 9, 16, 17, NC)}

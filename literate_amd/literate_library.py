@@ -122,7 +122,10 @@ def _loglik(L_acc_vec, M_acc_vec, model):
     # one prepared session per (states per call, model): the per-iteration call of runMCMC (LRF:305-308) then costs one
     # upload of the rates, the launches, one read-back and one synchronisation - nothing is allocated or re-uploaded
     C = 1 if L.ndim == 1 else L.shape[0]
-    # (br_length_bin is a module global a caller may edit or rebind, as in the reference: it goes up with every call)
+    # (br_length_bin is a module global a caller may edit or rebind, as in the reference: it goes up with every call.  The
+    # device evaluates the per-lineage form: br_length_bin gives the constants log k_b and the k_b > 0 mask of LRF:150-162,
+    # the exposure itself comes from the bound lineages - identical to the reference whenever the global is what
+    # precompute_events returned for them)
     key = (C, model, int(n_bins), float(end_time), br_length_bin is None)
     ses = _sessions.get(key)
     if ses is None:

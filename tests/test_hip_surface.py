@@ -65,20 +65,25 @@ def test_likelihood_operator_reads_br_length_bin_on_every_call(G):
     """The reference's BDI_partial_lik reads the module global br_length_bin when it is CALLED (LRF:150-162): an in-place
     edit and a rebind of literate_library.br_length_bin must both show in the next value (the prepared session used to
     upload it once and was keyed by id() - a stale session, or a recycled id, gave a wrong likelihood without an error).
-    One state per call (the zero-copy one-launch path) and 32 states per call (the copy path)."""
+    The device evaluates the per-lineage form (BDIx:124-146): br_length_bin enters through the constants log k_b and the
+    k_b > 0 mask, the exposure comes from the bound lineages themselves - the expected values are the oracle's
+    per-lineage evaluator given the same array.  One state per call (the zero-copy one-launch path) and 32 states per
+    call (the copy path)."""
     import literate_library as ll
     from oracle import literate_oracle as lo
     name = "metal_bands"
-    ll.bind_lineages(G[name + "/ts"], G[name + "/te"], 0)
+    ts, te = G[name + "/ts"], G[name + "/te"]
+    ll.bind_lineages(ts, te, 0)
     nb = ll.n_bins
     rng = np.random.default_rng(8)
     L, M = np.exp(rng.uniform(-3, -1, (32, nb))), np.exp(rng.uniform(-3, -1, (32, nb)))
 
     def ref():
-        st = dict(sp=ll.sp_events_bin, ex=ll.ex_events_bin, br=np.array(ll.br_length_bin))
-        with np.errstate(all="ignore"):
-            return np.array([lo.calc_likelihood(0, L[i], M[i], st) for i in range(32)])
+        br = np.array(ll.br_length_bin)
+        return np.array([lo.per_lineage_loglik(ts, te, float(int(ts.min())), L[i], M[i], 0, br) for i in range(32)])
     r0 = ref()
+    st = dict(sp=ll.sp_events_bin, ex=ll.ex_events_bin, br=np.array(ll.br_length_bin))
+    assert lo.calc_likelihood(0, L[0], M[0], st) == pytest.approx(r0[0], rel=1e-9)      # consistent statistics: the binned form
     assert ll.BDI_partial_lik(L[0], M[0]) == pytest.approx(r0[0], rel=1e-9) and np.allclose(ll.BDI_partial_lik(L, M), r0, rtol=1e-9)
     ll.br_length_bin[3:9] *= 3.0                                 # edited in place
     ll.br_length_bin[nb - 2] += 11.0
@@ -90,7 +95,7 @@ def test_likelihood_operator_reads_br_length_bin_on_every_call(G):
         r2 = ref()
         assert ll.BDI_partial_lik(L[1], M[1]) == pytest.approx(r2[1], rel=1e-9)
     assert np.allclose(ll.BDI_partial_lik(L, M), r2, rtol=1e-9)
-    ll.bind_lineages(G[name + "/ts"], G[name + "/te"], 0)
+    ll.bind_lineages(ts, te, 0)
     assert ll.BDI_partial_lik(L[0], M[0]) == pytest.approx(r0[0], rel=1e-9)
 
 

@@ -43,6 +43,7 @@ struct lr_engine {
     lr_p4_shares p4;          // per scanner wave: trips more (+) or fewer (-) than the equal share (four-chain kernel)
     bool p4_help;             // four-chain kernel: the form with helper waves - latched by lr_set_shares (init / restore), so
                               // that the form, its shares and the sums carried between launches belong together for a whole run
+    bool p4_spec;             // ... whose steppers speculate on rejection (lr_chain_step_respec); latched with p4_help
     hipEvent_t fork;
     hipEvent_t ev0, ev1;      // timing events of lr_mcmc_time_steps / lr_mcmc_time_scan, created once
 };
@@ -96,6 +97,15 @@ static inline bool lr_p4_help_choice(const lr_engine* e) {
     const char* env = getenv("LR_P4_HELP");
     if (e->lay.persistent != 2 || e->plan.unit == LR_TAB_PAIRGEN || e->cfg.sampler != 0 || e->plan.H > 264) return false;
     return env ? atoi(env) != 0 : true;
+}
+
+// ... and whether its steppers speculate on rejection (lr_persist4_kernel's SPEC): LR_P4_SPEC = 1.  OFF by default: the
+// trajectories are bit-identical, but cfg4 runs 7.3 us per iteration against 6.3 - a phase of the four-chain kernel is
+// bound by what SIMDs 0, 1 issue (a stepper + three scanners each) and by the helper's build behind the scanners' LDS
+// gathers, not by the wait for the hand-over that the speculation removes (in-kernel stamps: profiles/EXPERIMENTS.md)
+static inline bool lr_p4_spec_choice(const lr_engine* e) {
+    const char* env = getenv("LR_P4_SPEC");
+    return lr_p4_help_choice(e) && (env ? atoi(env) != 0 : false);
 }
 
 // Which instantiation of the speculative kernel an engine runs (lr_spec.h): 0 = a team per pair; a team per chain: 1 = in

@@ -260,6 +260,21 @@ __device__ __forceinline__ void lr_persist_step_body(const __attribute__((addres
     LR_SSTAMP(8);
 }
 
+// The four-chain kernel's chain step that speculates on rejection (lr_chain_step_respec): the chain's two scratch / hand-over /
+// draw slots (parity of the iteration a proposal is for) and its staged candidate Q live in LDS beside the state rows.
+template <int PB>
+__device__ __forceinline__ void lr_persist_step_respec(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
+                                                       __attribute__((address_space(3))) lr_seg_scratch* scratch2,
+                                                       lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* br3,
+                                                       const lr_draw_slot* draws2, lr_table_hand* hands2, lr_respec_q* Q, int epoch) {
+    const lr_step_args& a = *(const lr_step_args*)a3;
+    const double* br_lds = (const double*)br3;
+    LR_SSTAMP(0);
+    lr_chain_step_respec<PB>(a, c, lane, lik, (double*)st_f64, (int*)st_i32, (lr_seg_scratch*)scratch2, hands2, draws2, Q, epoch, br_lds,
+                             br_lds + LR_H_WIDE);
+    LR_SSTAMP(8);
+}
+
 // End of a wave's share of scan number `scans_done` in the four-chain kernel: the lanes' sums into slot `slot` of
 // `part`, count in, and - the wave that arrives LAST of the NA scanning waves - add the block's sums up, per lane over the
 // slots in slot order, then across the lanes (the same order whoever is last), into out[0..1].
@@ -300,15 +315,18 @@ __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((a
 //   st_f64 / st_i32: the four chains' state rows; red: [pair][wave][chain of the pair] scan sums; tab: the two pair
 //   tables, tab_doubles apart
 //   HELP: waves 2, 3 are helper waves - hands[wave] is this stepper's hand-over to wave 2 + wave (lr_persist4_kernel)
-template <int PB, int ES, int NW, int SAMPLER, bool HELP>
+//   SPEC: the step speculates on rejection (lr_chain_step_respec) - scratch3 / draws / hands are then [chain of the block][parity]
+//   and specq [chain of the block]
+template <int PB, int ES, int NW, int SAMPLER, bool HELP, bool SPEC = false>
 __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute__((address_space(3))) lr_step_args* a3, int c0,
                                                                int n_chains, int wave, int lane,
                                                                __attribute__((address_space(3))) lr_seg_scratch* scratch3,
                                                                lr_lds_f64* st_f64, lr_lds_i32* st_i32, lr_lds_f64* red,
                                                                lr_lds_f64* tab, int tab_doubles, lr_lds_f64* br3, long long n_iters,
                                                                const lr_draw_slot* draws /* [4]: made ahead (RJ sampler) */,
-                                                               lr_table_hand* hands /* [2] */) {
+                                                               lr_table_hand* hands /* [2] */, lr_respec_q* specq = nullptr) {
     static_assert(!HELP || (LR_P4_DRAW_AHEAD != 0 && ES == 2 && SAMPLER == 0 && LR_P4_LAST_SUMS != 0), "helper waves: RJ sampler at unit resolution");
+    static_assert(!SPEC || HELP, "speculation on rejection: the form with helper waves");
     for (long long iter = 0; iter < n_iters; ++iter) {
 #pragma unroll 1
         for (int ph = 0; ph < 2; ++ph) {
@@ -320,6 +338,12 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
                 double lik = 0.0;
 #pragma unroll
                 for (int w2 = 2; w2 < (LR_P4_LAST_SUMS != 0 && ES == 2 /* unit resolution: the block's sums in slot 2 */ ? 3 : NW); ++w2) lik += red[(ph * NW + w2) * 2 + wave];
+                if (SPEC) {
+                    const int ch = 2 * ph + wave;
+                    lr_persist_step_respec<(PB > 0 ? PB : 1)>(a3, c, lane, scratch3 + 2 * ch, st_f64 + ch * (LR_STATE_ROWS * LR_ROW),
+                                                st_i32 + ch * (LR_ISTATE_ROWS * LR_ROW), lik, br3, draws + 2 * ch, hands + 2 * ch,
+                                                specq + ch, (int)((2 * iter + ph + 1) & 0x3fffffff));
+                } else
                 lr_persist_step_body<PB, ES, LR_P4_DRAW_AHEAD != 0 && ES == 2 /* unit resolution */ && SAMPLER == 0, SAMPLER, HELP>(
                     a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
                     st_i32 + (2 * ph + wave) * (LR_ISTATE_ROWS * LR_ROW), lik, tab + ph * tab_doubles + wave, br3,
@@ -501,12 +525,25 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 // and every SIMD carries one wave of the step and three scanners.  Before the hand-over arrives a helper scores the first
 // groups of the scan (sh.help_trips trips of the 128 helper lanes; the scanners stride over the rest), and the draws of the
 // OTHER pair's next step are one Philox call on each of the two oldest scanner waves (four waves, a call each, otherwise).
+// dynamic LDS of the SPEC form
+struct lr_p4_spec_lds {
+    lr_seg_scratch scratch[8];
+    lr_draw_slot draws[8];
+    lr_respec_q specq[4];
+    lr_table_hand hands[8];
+};
+
+// SPEC (with HELP): the steppers speculate on REJECTION (lr_chain_step_respec, lr_step.h): the proposal a chain makes next
+// if its pending one is rejected is staged one iteration early, so that a helper starts the table build at the DECISION
+// (~0.4 us into a phase) instead of after move + staging (~1.2 us); scratch, hand-over and draw slots are then per chain
+// and parity of the iteration, the draws are made two iterations ahead.
 template <int H, bool GENERAL, bool PARAM /* a parametric sampler's chain step (DDRate, trend_rate) instead of the RJ sampler's */,
-          bool HELP = false>
+          bool HELP = false, bool SPEC = false>
 __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
                                                                        lr_packed_lineages pk, long long n8,
                                                                        lr_p4_shares sh, long long n_iters, char* carry_all) {
     static_assert(!HELP || (!GENERAL && !PARAM), "helper waves: RJ sampler at unit resolution");
+    static_assert(!SPEC || HELP, "speculation on rejection: the form with helper waves");
     const lr_step_args& a = *ap;
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners (HELP: 2 + 2 helpers + 12)
     constexpr int W0 = HELP ? 4 : 2;                      // first scanner wave
@@ -523,8 +560,17 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     constexpr bool LAST_SUMS = LR_P4_LAST_SUMS != 0 && !GENERAL;
     __shared__ double2 part[LAST_SUMS ? NW - 2 : 1][LR_WAVE];
     __shared__ int arrived;
-    __shared__ lr_table_hand hands[2];
-    __shared__ lr_seg_scratch scratch[2];
+    // SPEC: hand-over, scratch, draw slots [chain][parity of the iteration the proposal is for] and the staged candidates live in
+    // DYNAMIC LDS (lr_p4_spec_lds, behind everything static): the pair tables must stay where a ds_read's 16-bit offset
+    // field reaches them - placed behind 45 KB more of static arrays their base no longer folded into the gathers, and the
+    // scan loop grew eight address adds per trip
+    __shared__ lr_table_hand hands_s[SPEC ? 1 : 2];
+    __shared__ lr_seg_scratch scratch_s[SPEC ? 1 : 2];
+    extern __shared__ double2 p4_dyn[];
+    lr_p4_spec_lds* const xs = reinterpret_cast<lr_p4_spec_lds*>(p4_dyn);
+    lr_table_hand* const hands = SPEC ? xs->hands : hands_s;
+    lr_seg_scratch* const scratch = SPEC ? xs->scratch : scratch_s;
+    lr_respec_q* const specq = xs->specq;
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
     __shared__ int st_i32[4][LR_ISTATE_ROWS * LR_ROW];
     __shared__ lr_step_args a_lds;
@@ -534,7 +580,8 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // finish first: the steppers are the kernel's critical path (one wave's instruction stream per chain step), the
     // scanners of a phase wait 1-2 us at its barrier.  Same (iteration, purpose, index) Philox addresses as the draws
     // made inside the step: the stream does not change.  RJ sampler only; the parametric samplers draw in the step.
-    __shared__ lr_draw_slot draws[4];
+    __shared__ lr_draw_slot draws_s[SPEC ? 1 : 4];
+    lr_draw_slot* const draws = SPEC ? xs->draws : draws_s;
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     if (tid < (int)(sizeof(lr_step_args) / 4)) reinterpret_cast<int*>(&a_lds)[tid] = reinterpret_cast<const int*>(ap)[tid];
     for (int b = tid; b < LR_H_WIDE; b += blockDim.x) {
@@ -545,22 +592,26 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // (unit resolution only: on general times the scan loops are the longer side of a phase and have nothing to spare)
     constexpr bool draw_ahead = LR_P4_DRAW_AHEAD && !GENERAL && !PARAM;
     // draw duty of scanner wave 2 + q, q < 4, for the pair `pr` that has just been scanned: part q >> 1 of chain q & 1
-    auto draw_duty = [&](int pr) {
-        const int q = wave - W0, k = q & 1, ch = 2 * pr + k;      // (the oldest scanner waves: the first to finish)
+    // (SPEC: `ahead` iterations beyond the pending one - 2 in the loop, 1 and 2 in the prologue -, by scanner waves
+    // qoff, qoff + 1, into the slot of that iteration's parity)
+    auto draw_duty = [&](int pr, int ahead = SPEC ? 2 : 1, int qoff = 0) {
+        const int q = wave - W0 - qoff, k = q & 1, ch = 2 * pr + k;      // (the oldest scanner waves: the first to finish)
         if (!draw_ahead || q < 0 || q >= (HELP ? 2 : 4) || (int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
         const int* I = st_i32[ch] + LR_IROW_SCALARS * LR_ROW;
-        const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + 1ull;
+        const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + (unsigned long long)ahead;
+        lr_draw_slot* slot = SPEC ? &draws[2 * ch + (int)(it & 1ull)] : &draws[ch];
         // (HELP: one wave per chain, one Philox call for both parts)
-        if (HELP) lr_spec_draw_both(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, &draws[ch]);
-        else lr_spec_draw_part(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, &draws[ch], q >> 1);
+        if (HELP) lr_spec_draw_both(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, slot);
+        else lr_spec_draw_part(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, slot, q >> 1);
     };
     // a helper wave's table duty of a phase whose steppers advance pair `ph`: once the stepper has handed them over, the
     // tables of its chain of pair ph
-    auto help_duty = [&](int ph, int epoch) {
+    // (SPEC: the slots of the chain's NEW pending iteration, it0 + iter + 1 - `par`)
+    auto help_duty = [&](int ph, int epoch, int par = 0) {
         const int k = wave - 2;
         const int ch = 2 * ph + k;
         if ((int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
-        lr_table_hand* hand = &hands[k];
+        lr_table_hand* hand = SPEC ? &hands[2 * ch + par] : &hands[k];
 #ifdef LR_DIAG
         const unsigned long long dh0 = wall_clock64();
 #endif
@@ -569,7 +620,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
 #ifdef LR_DIAG
         if (lane == 0 && blockIdx.x < 64) atomicAdd(&lr_diag_step[16384 + (blockIdx.x * 16 + wave) * 4 + 2], wall_clock64() - dh0);
 #endif
-        const lr_seg_scratch* sc = &scratch[k];
+        const lr_seg_scratch* sc = SPEC ? &scratch[2 * ch + par] : &scratch[k];
         const int eL = lane <= LR_KMAX ? sc->edge[0][lane] : 0, eM = lane <= LR_KMAX ? sc->edge[1][lane] : 0;
         double* tabd = reinterpret_cast<double*>(tab[ph]) + k;
         const double constP = lr_build_tables_segments<(H <= 264 ? lr_bins_per_lane(H) : 1), 2>(
@@ -579,7 +630,9 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         lr_pair_planes_wave(tabd, H, a_lds.cfg.n_bins, lane, 0);
         if (lane == 0) st_f64[ch][LR_ROW_SCALARS * LR_ROW + LR_S_CONST_P] = constP;
     };
-    if (tid == 0) arrived = 0, hands[0].epoch = 0, hands[1].epoch = 0;
+    if (tid == 0) arrived = 0;
+    if (tid < (SPEC ? 8 : 2)) hands[tid].epoch = 0;
+    if (SPEC && tid < 4) specq[tid].valid = 0;
     for (int i = tid; i < 2 * NW * 2; i += LR_P4_THREADS) (&red[0][0][0])[i] = 0.0;
     int scans_done = 0;
     // a scanning wave's end of scan number `scans_done` for pair `pr` (HELP: the helper waves score a share too - slots NS,
@@ -642,9 +695,15 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     static_assert(2 * NW * 8 + 4 <= LR_P4_CARRY_BYTES, "");
     char* carry = carry_all ? carry_all + (size_t)blockIdx.x * LR_P4_CARRY_BYTES : nullptr;
     const bool carried = carry && *reinterpret_cast<const int*>(carry + 2 * NW * 8) == 1;
+    // (SPEC: the first stepper phases need the draws of the iterations 1 and 2 beyond the pending one for pair 0, and of
+    // iteration 1 for pair 1 (phase A's scan of pair 1 adds its iteration 2): three pairs of scanner waves, a call each)
+    auto prologue_draws = [&]() {
+        if (SPEC) draw_duty(0, 1, 0), draw_duty(0, 2, 2), draw_duty(1, 1, 4);
+        else draw_duty(0);
+    };
     if (carried) {
         if (tid < 2 * NW) (&red[0][0][0])[tid] = reinterpret_cast<const double*>(carry)[tid];
-        if (scanner) draw_duty(0);
+        if (scanner) prologue_draws();
     } else if (scanner) {
         double s0 = 0.0, s1 = 0.0;
         lr_scan_tail tail;
@@ -656,9 +715,15 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
             if (lane == 0) red[0][wave][0] = s0, red[0][wave][1] = s1;
         }
         lr_scan_drain(tail);
-        draw_duty(0);
+        prologue_draws();
     }
     if (helper && !carried) help_scan(0);
+    // (SPEC: parity of the pending iteration of this helper's two chains at the start of the launch)
+    int it0_par[2] = {0, 0};
+    if (SPEC && helper) {
+        it0_par[0] = st_i32[wave - 2][LR_IROW_SCALARS * LR_ROW + LR_I_IT_LO] & 1;
+        it0_par[1] = st_i32[2 + wave - 2][LR_IROW_SCALARS * LR_ROW + LR_I_IT_LO] & 1;
+    }
     __syncthreads();
     // phase ph of an iteration: the steppers advance pair `ph`, the scanners score pair `1 - ph`
     if (helper) {
@@ -669,7 +734,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
                 const unsigned long long dq0 = wall_clock64();
 #endif
                 help_scan(1 - ph);
-                help_duty(ph, (int)((2 * iter + ph + 1) & 0x3fffffff));
+                help_duty(ph, (int)((2 * iter + ph + 1) & 0x3fffffff), SPEC ? (it0_par[ph] + (int)(iter & 1) + 1) & 1 : 0);
 #ifdef LR_DIAG
                 const unsigned long long dq1 = wall_clock64();
 #endif
@@ -683,11 +748,11 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
             }
         }
     } else if (!scanner)
-        lr_persist4_steppers<(H <= 264 ? lr_bins_per_lane(H) : 0), ES, NW, PARAM ? 1 : 0, HELP>(
+        lr_persist4_steppers<(H <= 264 ? lr_bins_per_lane(H) : 0), ES, NW, PARAM ? 1 : 0, HELP, SPEC>(
             (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c0, C, wave, lane,
-            (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[wave], (lr_lds_f64*)&st_f64[0][0], (lr_lds_i32*)&st_i32[0][0],
+            (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[SPEC ? 0 : wave], (lr_lds_f64*)&st_f64[0][0], (lr_lds_i32*)&st_i32[0][0],
             (lr_lds_f64*)&red[0][0][0], (lr_lds_f64*)reinterpret_cast<double*>(tab[0]), 2 * LR_UNIT_PLANES * H,
-            (lr_lds_f64*)&br_lds[0][0], n_iters, &draws[0], &hands[0]);
+            (lr_lds_f64*)&br_lds[0][0], n_iters, &draws[0], &hands[0], &specq[0]);
     else
     for (long long iter = 0; iter < n_iters; ++iter) {
 #pragma unroll
@@ -1211,6 +1276,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
     e->p4.n_slots = 8;
     e->p4_help = lr_p4_help_choice(e);                  // (lr_mcmc_describe before init; latched again by lr_set_shares)
+    e->p4_spec = lr_p4_spec_choice(e);
     e->fork = nullptr;
     e->ev0 = e->ev1 = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
@@ -1534,7 +1600,14 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);   \
         else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);      \
         else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);        \
-        else if (e->p4_help) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
+        else if (e->p4_help && e->p4_spec) {                                                                                   \
+            /* (helper waves: H <= 264, lr_p4_help_choice; the attribute belongs to the function on the CURRENT device) */     \
+            hipError_t he_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lr_p4_spec_lds));     \
+            if (he_ != hipSuccess) return (int)he_;                                                                            \
+            hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), g4, b4, sizeof(lr_p4_spec_lds), stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
+        }                                                                                                                      \
+        else if (e->p4_help) hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
         else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);                  \
     } else if (wide) {                                                                                                        \
         hipLaunchKernelGGL((lr_persist_kernel<HH, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); \
@@ -1630,8 +1703,8 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
             snprintf(buf, (size_t)n, "lr_spec_kernel<%d, %d, %s, %s, %d>", e->plan.H, e->lay.reserved1, e->cfg.sampler == 0 ? "true" : "false", gen,
                      lr_spec_mode(e));
         else if (e->lay.persistent == 2)
-            snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s, %s, %s>", e->plan.H, gen, e->cfg.sampler != 0 ? "true" : "false",
-                     e->p4_help ? "true" : "false");
+            snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s, %s, %s, %s>", e->plan.H, gen, e->cfg.sampler != 0 ? "true" : "false",
+                     e->p4_help ? "true" : "false", (e->p4_help && e->p4_spec) ? "true" : "false");
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
     } else if (e->part[0].pipelined) {
         snprintf(buf, (size_t)n, "lr_fused_iter_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");

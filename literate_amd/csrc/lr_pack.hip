@@ -213,6 +213,7 @@ static void lr_set_shares(lr_engine* e) {
     for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
     e->p4.help_trips = 0;
     e->p4_help = lr_p4_help_choice(e);
+    e->p4_spec = lr_p4_spec_choice(e);
     if (e->lay.persistent == 2 && e->p4_help) {
         // a helper wave is idle until its stepper's hand-over arrives (~1.2 us into a phase, a scan trip takes ~0.3 us):
         // it scores the first groups meanwhile (the 128 helper lanes stride over [0, 128 trips), the scanners over the rest).

@@ -41,6 +41,48 @@ __device__ __forceinline__ void lr_score_lineage_fast(double s, double e, double
     }
 }
 
+// The same for a PAIR of lineages with the LDS gathers issued in batches: the entries of B chains x 2 lineages x {S, E}
+// (4 B ds_read_b128) are requested back to back and consumed behind ONE wait, instead of two gathers - wait - four fp64
+// instructions per (lineage, chain) as the compiler schedules the plain loop (a wave then spends an LDS round trip per
+// chain: 16 chains x 2 lineages x ~100 cycles, which four waves per SIMD do not hide - the wide kernel ran at 0.39 of the
+// HBM peak, 64 % of what its LDS traffic allows).  Same operations in the same order per chain: the sums are unchanged.
+template <int CB, int H, int B>
+__device__ __forceinline__ void lr_score_pair_batched(double2 s2, double2 e2, double t0, int n_bins, const char* __restrict__ lds,
+                                                      double (&acc)[CB]) {
+    static_assert(CB % B == 0, "whole batches");
+    const double fl0 = floor(s2.x), fl1 = floor(s2.y), ce0 = ceil(e2.x), ce1 = ceil(e2.y);
+    const int a0 = min(max(__double2int_rz(fl0 - t0), -1), n_bins), a1 = min(max(__double2int_rz(fl1 - t0), -1), n_bins);
+    const int b0 = min(max(__double2int_rz(ce0 - t0), 0), n_bins + 1), b1 = min(max(__double2int_rz(ce1 - t0), 0), n_bins + 1);
+    const double fs0 = s2.x - fl0, fs1 = s2.y - fl1;
+    const double fe0 = (e2.x - ce0) + 1.0, fe1 = (e2.y - ce1) + 1.0;
+    const char* pS0 = lds + ((a0 + 1) << 4);
+    const char* pS1 = lds + ((a1 + 1) << 4);
+    const char* pE0 = lds + (b0 << 4) + H * 16;
+    const char* pE1 = lds + (b1 << 4) + H * 16;
+#pragma unroll
+    for (int c0 = 0; c0 < CB; c0 += B) {
+        double2 S0[B], E0[B], S1[B], E1[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            S0[j] = *reinterpret_cast<const double2*>(pS0 + (c0 + j) * (2 * H * 16));
+            E0[j] = *reinterpret_cast<const double2*>(pE0 + (c0 + j) * (2 * H * 16));
+            S1[j] = *reinterpret_cast<const double2*>(pS1 + (c0 + j) * (2 * H * 16));
+            E1[j] = *reinterpret_cast<const double2*>(pE1 + (c0 + j) * (2 * H * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            double t = S0[j].x + E0[j].x;
+            t = fma(fs0, S0[j].y, t);
+            t = fma(fe0, E0[j].y, t);
+            acc[c0 + j] += t;
+            double u = S1[j].x + E1[j].x;
+            u = fma(fs1, S1[j].y, u);
+            u = fma(fe1, E1[j].y, u);
+            acc[c0 + j] += u;
+        }
+    }
+}
+
 // XCD-aware block -> (chain group, tile) map.  Blocks are dealt round-robin over the 8 XCDs (block b and
 // b + 8 share an XCD and its L2, MI355X_MICROARCH.md "Workgroup dispatch"), and L2 does not survive a kernel
 // boundary, so every XCD re-fetches what its blocks stage.  Keeping ALL tiles of a chain group on ONE XCD
@@ -86,7 +128,7 @@ __device__ __forceinline__ void lr_block_reduce_chains(const double (&acc)[CB], 
 // `tables`; partial sums go to partials[chain * partial_stride + tile].  T threads; DEPTH pairs of lineages (32 B each) per
 // thread in flight: the wide form (CB = 16: 70 KB of tables at H = 136, two 512-thread blocks per CU) keeps two, so that a
 // CU has 64 KB on its way although only 16 waves fit.
-template <int CB, int H, int T = LR_SCAN_THREADS, int DEPTH = 1>
+template <int CB, int H, int T = LR_SCAN_THREADS, int DEPTH = 1, int BATCH = 0>
 __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int chain0, const double* __restrict__ ts,
                                                   const double* __restrict__ te, long long n, double t0, int n_bins,
                                                   const double2* __restrict__ tables, int n_chains, long long chunk,
@@ -150,8 +192,12 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
                     e2 = *reinterpret_cast<const double2*>(te + nx);
                 }
             }
-            lr_score_lineage_fast<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
-            lr_score_lineage_fast<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
+            if (BATCH > 0) {
+                lr_score_pair_batched<CB, H, (BATCH > 0 ? BATCH : 1)>(sc, ec, t0, n_bins, lbase, acc);
+            } else {
+                lr_score_lineage_fast<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
+                lr_score_lineage_fast<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
+            }
             i += 2 * T;
         }
         if (i < end) lr_score_lineage_fast<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
@@ -189,7 +235,10 @@ __global__ __launch_bounds__(LR_SCAN_THREADS) void lr_scan_fast_kernel(const dou
 // balance, so 32 chains per pass would take as long as two passes of 16.
 #define LR_SCAN_WIDE_THREADS 512
 template <int H>
-__global__ __launch_bounds__(LR_SCAN_WIDE_THREADS) void lr_scan_wide_kernel(const double* __restrict__ ts,
+#ifndef LR_SCAN_WIDE_BATCH
+#define LR_SCAN_WIDE_BATCH 4
+#endif
+__global__ __launch_bounds__(LR_SCAN_WIDE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void lr_scan_wide_kernel(const double* __restrict__ ts,
                                                                             const double* __restrict__ te, long long n,
                                                                             double t0, int n_bins,
                                                                             const double2* __restrict__ tables,
@@ -199,8 +248,8 @@ __global__ __launch_bounds__(LR_SCAN_WIDE_THREADS) void lr_scan_wide_kernel(cons
     extern __shared__ double2 lds[];
     int group, tile;
     lr_xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.y, &group, &tile);
-    lr_scan_fast_body<16, H, LR_SCAN_WIDE_THREADS, 2>(lds, tile, group * 16, ts, te, n, t0, n_bins, tables, n_chains, chunk,
-                                                      partials, partial_stride);
+    lr_scan_fast_body<16, H, LR_SCAN_WIDE_THREADS, 2, LR_SCAN_WIDE_BATCH>(lds, tile, group * 16, ts, te, n, t0, n_bins, tables, n_chains,
+                                                                          chunk, partials, partial_stride);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -105,6 +105,33 @@ def test_final_stdout_line_is_compact_and_survives_the_drivers_tail(detail, tmp_
         assert len(a["engine_streaming"]) == 2 and a["seam"]["us_per_call_1_state"] > a["seam"]["numpy_us_per_call"]
 
 
+def test_fetch_summary_counts_the_librarys_own_kernels_only():
+    """Round 4 reported traffic = 7/6 of the algorithmic bytes for BOTH streaming kernels: the child's FETCH_SIZE rows were
+    summed over every kernel whose name CONTAINED "lr_" - and __amd_rocclr_copyBuffer (torch's copy while the input is
+    made, half a pass at FETCH_SIZE's gfx950 scale) does.  abi_fetch_summary takes names that START with lr_, lists every
+    dispatch, and calibrates the counter on the read-only yardstick (16 n known bytes).  Rows as the 1e8-lineage child of
+    round 5 printed them."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    n = 100_000_000
+    rows = [{"Kernel_Name": "__amd_rocclr_copyBuffer", "Counter_Value": "390660.5", "Dispatch_Id": "3"},
+            {"Kernel_Name": "__amd_rocclr_fillBufferAligned", "Counter_Value": "14.5", "Dispatch_Id": "4"}]
+    rows += [{"Kernel_Name": "lr_build_tables_kernel(double const*)", "Counter_Value": "5.3", "Dispatch_Id": str(10 + 3 * i)} for i in range(3)]
+    rows += [{"Kernel_Name": "void lr_scan_fast_kernel<1, 136>(double const*, double const*)", "Counter_Value": v, "Dispatch_Id": str(11 + 3 * i)}
+             for i, v in enumerate(("781328.0", "781295.7", "781295.25"))]
+    rows += [{"Kernel_Name": "lr_debug_stream2_kernel(HIP_vector_type<double, 2u> const*)", "Counter_Value": v, "Dispatch_Id": str(30 + i)}
+             for i, v in enumerate(("781265.2", "781263.1", "781262.75"))]
+    traffic, note, d = bench.abi_fetch_summary(rows, n)
+    assert traffic / (16.0 * n) == pytest.approx(1.0, abs=2e-3)                 # x 2 (gfx950): one pass, no over-fetch
+    assert d["yardstick_raw_bytes_over_algorithmic"] == pytest.approx(0.5, abs=1e-4)      # the guide's factor, measured
+    assert d["traffic_over_algorithmic_calibrated"] == pytest.approx(1.0, abs=2e-3)
+    assert d["dispatches"]["void lr_scan_fast_kernel<1, 136>"]["count"] == 3 and "__amd_rocclr_copyBuffer" in d["dispatches"]
+    # what round 4's filter would have said
+    old = sum(float(x["Counter_Value"]) for x in rows if "lr_" in x["Kernel_Name"] and "stream2" not in x["Kernel_Name"]) * 2 * 1024 / 3
+    assert old / (16.0 * n) == pytest.approx(7 / 6, abs=2e-3)
+
+
 def test_abi_section_prices_the_hbm_streaming_entry_points():
     """`abi`: lr_bin_unit_events and lr_bd_loglik_batch at 1e7 / 3e7 lineages against the 8 TB/s HBM peak - the kernels for
     which HBM IS the bound (16 B per lineage and pass) - with the FETCH_SIZE traffic of the same call, and the

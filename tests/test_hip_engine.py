@@ -47,6 +47,9 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        (0, dict(engine="spec", team=1, cpt=1, planes_by_scanners=0)),
                                        # (the four-chain kernel's form without helper waves: fourteen scanner waves)
                                        (0, dict(engine="persistent4", p4_help=0)), (3, dict(engine="persistent4", p4_help=0)),
+                                       # (... and its form whose steppers speculate on rejection, LR_P4_SPEC=1: lr_chain_step_respec)
+                                       (0, dict(engine="persistent4", p4_spec=1)), (3, dict(engine="persistent4", p4_spec=1)),
+                                       (2, dict(engine="persistent4", p4_spec=1, const_death_rate=1)),
                                        (1, dict(engine="spec", team=1, cpt=1, planes_by_scanners=0, unit_resolution=False))])
 def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
     from literate_amd.engine import ChainEngine, split_trace_row
@@ -56,6 +59,8 @@ def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
         monkeypatch.setenv("LR_SPEC_PLANES_BY_SCANNERS", str(kw.pop("planes_by_scanners")))
     if "p4_help" in kw:
         monkeypatch.setenv("LR_P4_HELP", str(kw.pop("p4_help")))
+    p4_spec = kw.pop("p4_spec", 0)
+    monkeypatch.setenv("LR_P4_SPEC", str(p4_spec))
     ekw = dict(const_rates=kw.get("const_rates", 0), const_death_rate=kw.get("const_death_rate", 0),
                use_rate_HP=kw.get("use_rate_HP", 1), poisson_HP=kw.get("Poisson_HP", 0.0),
                unit_resolution=kw.pop("unit_resolution", None), engine=kw.pop("engine", "auto"), team=kw.pop("team", 0),
@@ -70,7 +75,7 @@ def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
     if ekw["engine"] == "persistent2":
         assert eng.layout.persistent == 1
     if ekw["engine"] == "persistent4" and ekw["unit_resolution"] is not False:
-        assert eng.kernel_name().endswith("false>" if "LR_P4_HELP" in os.environ else "true>")
+        assert eng.kernel_name().endswith("false, false>" if "LR_P4_HELP" in os.environ else ("true, true>" if p4_spec else "true, false>"))
     # binning done by the engine's own kernel must equal the reference's
     assert np.array_equal(eng.sp_events.cpu().numpy(), G[name + "/sp"])
     assert np.array_equal(eng.br_length.cpu().numpy(), G[name + "/br"])
@@ -649,8 +654,8 @@ def test_checkpoints_append_their_trace_rows_and_can_be_written_behind_the_next_
         e.close()
 
 
-@pytest.mark.parametrize("general", [False, True])
-def test_four_chain_kernel_does_not_depend_on_how_a_run_is_cut_into_launches(general):
+@pytest.mark.parametrize("general", [False, True, "respec"])
+def test_four_chain_kernel_does_not_depend_on_how_a_run_is_cut_into_launches(general, monkeypatch):
     """The four-chain kernel leaves the scan sums of its last phase for the next launch instead of scoring pair 0 again: a
     run cut into launches of 7 + 1 + 32 iterations equals one launch of 40 bit for bit (60k lineages: several trips per
     scanner lane, the helper waves' share included), and a second init() of the same engine - which sets the state
@@ -659,6 +664,10 @@ def test_four_chain_kernel_does_not_depend_on_how_a_run_is_cut_into_launches(gen
     from literate_amd import synth
     from literate_amd.engine import ChainEngine
     ts, te, _ = synth.make_lineages(60_000, n_bins=128, n_shifts=20, seed=11)
+    # "respec": the form whose steppers speculate on rejection drops its staged candidates at every launch boundary and
+    # re-proposes - the same doubles (LR_P4_SPEC is read at init)
+    monkeypatch.setenv("LR_P4_SPEC", "1" if general == "respec" else "0")
+    respec, general = general == "respec", general is True
     if general:
         rng = np.random.default_rng(3)
         ts = ts + rng.uniform(0, 0.999, len(ts))
@@ -670,7 +679,7 @@ def test_four_chain_kernel_does_not_depend_on_how_a_run_is_cut_into_launches(gen
     cut.init(); cut.steps(13)                 # a run whose sums must not leak into the next one
     cut.init(); cut.steps(7); cut.steps(1); cut.steps(32)
     torch.cuda.synchronize()
-    assert one.layout.persistent == 2 and one.kernel_name().endswith("false>" if general else "true>")
+    assert one.layout.persistent == 2 and one.kernel_name().endswith("false, false>" if general else ("true, true>" if respec else "true, false>"))
     bits = lambda t: t.contiguous().view(torch.int64)
     assert torch.equal(bits(cut.trace), bits(one.trace))
     assert torch.equal(bits(cut.state_f64), bits(one.state_f64)) and torch.equal(cut.state_i32, one.state_i32)

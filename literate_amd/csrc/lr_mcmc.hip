@@ -517,6 +517,11 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 #ifndef LR_P4_UNROLL
 #define LR_P4_UNROLL 1
 #endif
+#ifdef LR_DIAG
+#define LR_PSTAMP(k) if (threadIdx.x == 0 && blockIdx.x < 64) lr_diag_step[28672 + blockIdx.x * 8 + (k)] = wall_clock64()
+#else
+#define LR_PSTAMP(k)
+#endif
 
 // HELP (RJ sampler at unit resolution): waves 2, 3 - the oldest waves of the two SIMDs that carry no stepper - are HELPER
 // waves and twelve waves scan.  A stepper hands the segments of its proposal over through LDS as soon as they stand
@@ -539,12 +544,15 @@ struct lr_p4_spec_lds {
 // and parity of the iteration, the draws are made two iterations ahead.
 template <int H, bool GENERAL, bool PARAM /* a parametric sampler's chain step (DDRate, trend_rate) instead of the RJ sampler's */,
           bool HELP = false, bool SPEC = false>
-__global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args* __restrict__ ap,
+__global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args ak /* by value: kernel arguments come
+                                                                       with the dispatch - read through a pointer they cost every block a round trip to
+                                                                       memory before it can fetch its chains' state */,
                                                                        lr_packed_lineages pk, long long n8,
                                                                        lr_p4_shares sh, long long n_iters, char* carry_all) {
     static_assert(!HELP || (!GENERAL && !PARAM), "helper waves: RJ sampler at unit resolution");
     static_assert(!SPEC || HELP, "speculation on rejection: the form with helper waves");
-    const lr_step_args& a = *ap;
+    const lr_step_args& a = ak;
+    LR_PSTAMP(0);      // entry (LR_DIAG: wall-clock stamps of a launch's stages, blocks < 64; scratch/diag_p4_launch.py)
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners (HELP: 2 + 2 helpers + 12)
     constexpr int W0 = HELP ? 4 : 2;                      // first scanner wave
     constexpr int NS = NW - W0;                           // scanner waves
@@ -583,11 +591,11 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     __shared__ lr_draw_slot draws_s[SPEC ? 1 : 4];
     lr_draw_slot* const draws = SPEC ? xs->draws : draws_s;
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
-    if (tid < (int)(sizeof(lr_step_args) / 4)) reinterpret_cast<int*>(&a_lds)[tid] = reinterpret_cast<const int*>(ap)[tid];
+    if (tid == 0) a_lds = ak;      // (field by field from the kernel-argument segment: indexing &ak would copy it to scratch)
     for (int b = tid; b < LR_H_WIDE; b += blockDim.x) {
-        const bool in = b < ap->cfg.n_bins;
-        br_lds[0][b] = (in && ap->br_length) ? ap->br_length[b] : 0.0;
-        br_lds[1][b] = in ? ap->log_br[b] : 0.0;
+        const bool in = b < ak.cfg.n_bins;
+        br_lds[0][b] = (in && ak.br_length) ? ak.br_length[b] : 0.0;
+        br_lds[1][b] = in ? ak.log_br[b] : 0.0;
     }
     // (unit resolution only: on general times the scan loops are the longer side of a phase and have nothing to spare)
     constexpr bool draw_ahead = LR_P4_DRAW_AHEAD && !GENERAL && !PARAM;
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // qoff, qoff + 1, into the slot of that iteration's parity)
     auto draw_duty = [&](int pr, int ahead = SPEC ? 2 : 1, int qoff = 0) {
         const int q = wave - W0 - qoff, k = q & 1, ch = 2 * pr + k;      // (the oldest scanner waves: the first to finish)
-        if (!draw_ahead || q < 0 || q >= (HELP ? 2 : 4) || (int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
+        if (!draw_ahead || q < 0 || q >= (HELP ? 2 : 4) || (int)(blockIdx.x * 4) + ch >= ak.cfg.n_chains) return;
         const int* I = st_i32[ch] + LR_IROW_SCALARS * LR_ROW;
         const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + (unsigned long long)ahead;
         lr_draw_slot* slot = SPEC ? &draws[2 * ch + (int)(it & 1ull)] : &draws[ch];
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     auto help_duty = [&](int ph, int epoch, int par = 0) {
         const int k = wave - 2;
         const int ch = 2 * ph + k;
-        if ((int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
+        if ((int)(blockIdx.x * 4) + ch >= ak.cfg.n_chains) return;
         lr_table_hand* hand = SPEC ? &hands[2 * ch + par] : &hands[k];
 #ifdef LR_DIAG
         const unsigned long long dh0 = wall_clock64();
@@ -657,6 +665,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         tab[0][e] = g0[i], tab[1][e] = g1[i];
     }
     __syncthreads();
+    LR_PSTAMP(1);      // arguments, data constants, the four chains' state rows and the two pair tables are in LDS
     if (GENERAL) {
         lr_pair_planes_block_general(tab[0], H, a.cfg.n_bins, tid, LR_P4_THREADS);
         lr_pair_planes_block_general(tab[1], H, a.cfg.n_bins, tid, LR_P4_THREADS);
@@ -665,6 +674,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         lr_pair_planes_block(tab[1], H, a.cfg.n_bins, tid, LR_P4_THREADS);
     }
     __syncthreads();
+    LR_PSTAMP(2);      // pair planes derived
     const bool scanner = wave >= W0;
     const bool helper = HELP && (wave == 2 || wave == 3);
     const int sid = tid - W0 * LR_WAVE;
@@ -725,6 +735,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         it0_par[1] = st_i32[2 + wave - 2][LR_IROW_SCALARS * LR_ROW + LR_I_IT_LO] & 1;
     }
     __syncthreads();
+    LR_PSTAMP(3);      // prologue done: pair 0's sums (scanned or carried), the first draws
     // phase ph of an iteration: the steppers advance pair `ph`, the scanners score pair `1 - ph`
     if (helper) {
         for (long long iter = 0; iter < n_iters; ++iter) {
@@ -785,6 +796,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
 #endif
         }
     }
+    LR_PSTAMP(4);      // the launch's iterations done
     if (wave < 4 && c0 + wave < C) {
         const int c = c0 + wave;
         double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
@@ -801,6 +813,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         if (tid < 2 * NW) reinterpret_cast<double*>(carry)[tid] = (&red[0][0][0])[tid];
         if (tid == 0) *reinterpret_cast<int*>(carry + 2 * NW * 8) = 1;
     }
+    LR_PSTAMP(5);      // state, tables and carried sums stored (issued: the stores drain behind the last instruction)
 }
 
 __global__ void lr_store_args_kernel(lr_step_args a, lr_step_args* dst) {
@@ -1597,18 +1610,18 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
 #define LR_P_LAUNCH(HH)                                                                                                       \
     if (p4) {                                                                                                                 \
         const dim3 g4((e->cfg.n_chains + 3) / 4), b4(LR_P4_THREADS);                                                          \
-        if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);   \
-        else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);      \
-        else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);        \
+        if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry);   \
+        else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry);      \
+        else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry);        \
         else if (e->p4_help && e->p4_spec) {                                                                                   \
             /* (helper waves: H <= 264, lr_p4_help_choice; the attribute belongs to the function on the CURRENT device) */     \
             hipError_t he_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), \
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lr_p4_spec_lds));     \
             if (he_ != hipSuccess) return (int)he_;                                                                            \
-            hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), g4, b4, sizeof(lr_p4_spec_lds), stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
+            hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), g4, b4, sizeof(lr_p4_spec_lds), stream, a, pk, e->n8, e->p4, (long long)n, p4_carry); \
         }                                                                                                                      \
-        else if (e->p4_help) hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
-        else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);                  \
+        else if (e->p4_help) hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry); \
+        else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry);                  \
     } else if (wide) {                                                                                                        \
         hipLaunchKernelGGL((lr_persist_kernel<HH, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); \
     } else {                                                                                                                  \

@@ -398,28 +398,44 @@ extern "C" int lr_bin_unit_events(const double* ts, const double* te, int64_t n,
 
 // ------------------------------------------------------------------------------------------
 // bench / profile hook: the yardstick for the two kernels above and for lr_scan_*_kernel - a kernel that only READS two
-// n-double arrays (the access shape of a pass over ts / te: two 16-byte loads per array in flight per thread,
-// grid-stride over 2048 blocks of 256 threads) and computes nothing.  What it reaches on a box is what "the HBM
-// roofline" means for a pass on that box (bench.py abi.stream2_GBs; scratch/ubench/stream2.hip tried the other shapes).
+// n-double arrays and computes nothing, in the access shape of lr_bin_unit_kernel (the fastest of the streaming kernels: one
+// 1024-thread block per CU over a contiguous chunk, two 16-byte loads per array and thread in flight).  What it reaches on
+// a box is what "the HBM roofline" means for a pass over ts / te on that box (bench.py abi.stream2_GBs;
+// scratch/ubench/stream2.hip tried the other shapes: 2048 blocks of 256 threads in grid stride read 5-10 % slower at 1e8).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lr_debug_stream2_kernel(const double2* __restrict__ a, const double2* __restrict__ b,
-                                                               long long n2, double* __restrict__ out) {
-    const long long step = (long long)gridDim.x * 256;
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(1024) void lr_debug_stream2_kernel(const double2* __restrict__ a, const double2* __restrict__ b,
+                                                                long long n2, long long chunk2, double* __restrict__ out) {
+    const long long start = (long long)blockIdx.x * chunk2, end = min(start + chunk2, n2);
+    long long i = start + threadIdx.x;
     double acc = 0.0;
-    for (; i + step < n2; i += 2 * step) {
-        const double2 x0 = a[i], y0 = b[i], x1 = a[i + step], y1 = b[i + step];
-        acc += (x0.x + x0.y) + (y0.x + y0.y) + (x1.x + x1.y) + (y1.x + y1.y);
+    double2 x0 = make_double2(0.0, 0.0), y0 = x0, x1 = x0, y1 = x0;
+    if (i < end) x0 = a[i], y0 = b[i];
+    if (i + 1024 < end) x1 = a[i + 1024], y1 = b[i + 1024];
+    while (i < end) {
+        const double2 xc = x0, yc = y0;
+        x0 = x1, y0 = y1;
+        if (i + 2048 < end) x1 = a[i + 2048], y1 = b[i + 2048];
+        acc += (xc.x + xc.y) + (yc.x + yc.y);
+        i += 1024;
     }
-    if (i < n2) acc += (a[i].x + a[i].y) + (b[i].x + b[i].y);
     if (acc == 123.456) out[0] = acc;       // (never true for the bench's inputs: the loads stay, nothing is written)
 }
 
 extern "C" int lr_debug_stream2(const double* a, const double* b, int64_t n, double* out, void* stream_) {
     if (!a || !b || !out) return LR_ERR_NULL;
     if (n < 2 || ((((uintptr_t)a) | ((uintptr_t)b)) & 15)) return LR_ERR_SIZE;
-    hipLaunchKernelGGL(lr_debug_stream2_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream_, (const double2*)a,
-                       (const double2*)b, (long long)(n / 2), out);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long n2 = n / 2;
+    const long long chunk2 = lr_align_up64((n2 + n_cu - 1) / n_cu, 1024);
+    const long long blocks = (n2 + chunk2 - 1) / chunk2;
+    hipLaunchKernelGGL(lr_debug_stream2_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream_, (const double2*)a,
+                       (const double2*)b, n2, chunk2, out);
     return (int)hipGetLastError();
 }
 

@@ -6,9 +6,21 @@ profiles/<tag>_bench_cfg4_1gpu_driver_args.json (the two bench lines)."""
 import csv, glob, json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1], sys.argv[2]
-line = lambda p: json.loads(open(p).read().strip().splitlines()[-1])
-b = line(os.path.join(src, "bench_default.json"))
-d = line(os.path.join(src, "bench_driver_args.json"))
+def line(p):
+    """bench_detail.json of a run (one document), or a captured stdout whose last line is the (compact) bench line"""
+    txt = open(p).read().strip()
+    try:
+        return json.loads(txt)
+    except ValueError:
+        return json.loads(txt.splitlines()[-1])
+
+
+b = line(os.path.join(src, "bench_default_detail.json"))
+d = line(os.path.join(src, "bench_driver_args_detail.json"))
+# the compact lines as the driver sees them (the last stdout line of each run)
+json.dump({"default": json.loads(open(os.path.join(src, "bench_default.out")).read().strip().splitlines()[-1]),
+           "driver_args": json.loads(open(os.path.join(src, "bench_driver_args.out")).read().strip().splitlines()[-1])},
+          open(os.path.join(root, "profiles/%s_bench_compact_lines.json" % tag), "w"), indent=1)
 json.dump(b, open(os.path.join(root, "profiles/%s_bench_cfg4_1gpu.json" % tag), "w"), indent=1)
 json.dump(d, open(os.path.join(root, "profiles/%s_bench_cfg4_1gpu_driver_args.json" % tag), "w"), indent=1)
 json.dump(b["abi"], open(os.path.join(root, "profiles/%s_abi.json" % tag), "w"), indent=1)

@@ -4,11 +4,23 @@ files under profiles/ (run in the build container after the gpurun call):
 import csv, glob, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, bench_json, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def load(path):
+    """a bench DETAIL file (bench_detail.json: one JSON document) or a captured stdout (the compact line is its last line)"""
+    txt = open(path).read().strip()
+    try:
+        return json.loads(txt)
+    except ValueError:
+        return json.loads(txt.splitlines()[-1])
+
+
+
 ks = sorted(glob.glob(os.path.join(src, "stats/*/*_kernel_stats.csv")), key=os.path.getmtime)[-1]
 kt = ks.replace("_kernel_stats", "_kernel_trace")
 shutil.copy(ks, os.path.join(root, "profiles/%s_bench_cfg4_kernel_stats.csv" % tag))
 rows = list(csv.DictReader(open(kt)))
-prof_bench = json.loads(open(os.path.join(src, "stats_bench.json")).read().strip().splitlines()[-1])
+prof_bench = load(os.path.join(src, "stats_bench_detail.json") if os.path.exists(os.path.join(src, "stats_bench_detail.json")) else os.path.join(src, "stats_bench.json"))
 kname = prof_bench["roofline"]["kernel"]
 d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if kname.split("<")[0] in r["Kernel_Name"])
 json.dump(prof_bench, open(os.path.join(root, "profiles/%s_bench_cfg4_1gpu_profiled.json" % tag), "w"), indent=1)
@@ -48,7 +60,7 @@ summary = {"kernel": kname, "workload": "cfg4: 1024 chains x 100k lineages", "it
            "source": "rocprofv3 --pmc <counter group> --kernel-trace (separate passes) -- python3 scratch/prof_persist.py (one launch of "
                      "1000 iterations)"}
 json.dump(summary, open(os.path.join(root, "profiles/%s_pmc_1000it.json" % tag), "w"), indent=1)
-b = json.loads(open(bench_json).read().strip().splitlines()[-1])
+b = load(bench_json)
 json.dump(b, open(os.path.join(root, "profiles/%s_bench_cfg4_1gpu.json" % tag), "w"), indent=1)
 print(json.dumps(launch, indent=1)); print(json.dumps(summary, indent=1))
 print("value %.4e  kernel_ms %.3f  cpu %s" % (b["value"], b["roofline"]["kernel_ms"], b.get("cpu_baseline") and b["cpu_baseline"]["value"]))
@@ -79,7 +91,7 @@ if len(sys.argv) > 4:
     print(json.dumps({k: v for k, v in spec.items() if k != "counters_mean_per_launch"}, indent=1))
 # optional: the bench line at the driver's arguments
 if len(sys.argv) > 5:
-    b20 = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])
+    b20 = load(sys.argv[5])
     json.dump(b20, open(os.path.join(root, "profiles/%s_bench_cfg4_1gpu_driver_args.json" % tag), "w"), indent=1)
     print("driver args: value %.4e  wall/device %.3f" % (b20["value"], b20["ms_per_step"] * b20["steps"] / b20["roofline"]["kernel_ms"]))
 # optional: the SQ counters over one 4000-iteration launch (bash scratch/pmc_persist_long.sh <dir>)
@@ -103,13 +115,13 @@ if len(sys.argv) > 6:
              "valu_busy_fraction_profiled": vl["SQ_ACTIVE_INST_VALU"] / cyc / 256, "lds_busy_fraction_profiled": vl["SQ_LDS_IDX_ACTIVE"] / cyc / 256,
              "lds_bank_conflict_fraction": vl["SQ_LDS_BANK_CONFLICT"] / vl["SQ_LDS_IDX_ACTIVE"],
              "valu_issue_fraction_at_bench_speed_bounds": [valu * 2.35 / 4 / (us_bench * 2400), valu * 4.2 / 4 / (us_bench * 2400)],
-             "scan_loop_valu_issue_fraction_at_bench_speed": 4 * 7143 / 64.0 * 92.55 / 4 / (us_bench * 2400),
+             "scan_loop_valu_issue_fraction_at_bench_speed": 2 * 7143 / 64.0 * 92.55 / 4 / (us_bench * 2400),
              "lds_data_cycles_fraction_at_bench_speed": vl["SQ_LDS_IDX_ACTIVE"] / 256 / n_it / (us_bench * 2400),
              "note": "the counter passes slow the launch (us_per_iteration_profiled against the unprofiled bench line); the *_at_bench_speed "
                      "fractions put the counts of this launch over the unprofiled iteration time.  VALU issue: a wave64 instruction costs "
                      "2.35 (plain 32-bit) or 4.2 cycles (fp64, SDWA / DPP, three-operand integer, compares) of its SIMD (profiles/r04_ubench.txt) - "
-                     "the bounds take all instructions as one class; the scan loop's own share is exact (4 chains = 2 pairs x 7143 groups / 64 lanes "
-                     "x 92.55 cycles per trip over 4 SIMDs).  SQ_LDS_IDX_ACTIVE = cycles the LDS data path is busy, per CU",
+                     "the bounds take all instructions as one class; the scan loop's own share is exact (2 pairs x 7143 groups / 64 lanes x 92.55 cycles per trip "
+                     "over 4 SIMDs; rounds 3 and 4 filed twice that - the pairs counted as four chains).  SQ_LDS_IDX_ACTIVE = cycles the LDS data path is busy, per CU",
              "source": "bash scratch/pmc_persist_long.sh <dir>: rocprofv3 --pmc <group> --kernel-trace (separate passes) -- python3 "
                        "scratch/prof_persist.py with LR_PROF_ITERS=4000"}
     json.dump(long_, open(os.path.join(root, "profiles/%s_pmc_4000it.json" % tag), "w"), indent=1)

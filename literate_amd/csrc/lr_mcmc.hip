@@ -266,12 +266,13 @@ template <int PB>
 __device__ __forceinline__ void lr_persist_step_respec(const __attribute__((address_space(3))) lr_step_args* a3, int c, int lane,
                                                        __attribute__((address_space(3))) lr_seg_scratch* scratch2,
                                                        lr_lds_f64* st_f64, lr_lds_i32* st_i32, double lik, lr_lds_f64* br3,
-                                                       const lr_draw_slot* draws2, lr_table_hand* hands2, lr_respec_q* Q, int epoch) {
+                                                       const lr_draw_slot* draws2, lr_table_hand* hands2, lr_pend* pend2, bool first,
+                                                       int epoch) {
     const lr_step_args& a = *(const lr_step_args*)a3;
     const double* br_lds = (const double*)br3;
     LR_SSTAMP(0);
-    lr_chain_step_respec<PB>(a, c, lane, lik, (double*)st_f64, (int*)st_i32, (lr_seg_scratch*)scratch2, hands2, draws2, Q, epoch, br_lds,
-                             br_lds + LR_H_WIDE);
+    lr_chain_step_respec<PB>(a, c, lane, lik, (double*)st_f64, (int*)st_i32, pend2, (lr_seg_scratch*)scratch2, hands2, draws2, first,
+                             epoch, br_lds, br_lds + LR_H_WIDE);
     LR_SSTAMP(8);
 }
 
@@ -316,7 +317,7 @@ __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((a
 //   tables, tab_doubles apart
 //   HELP: waves 2, 3 are helper waves - hands[wave] is this stepper's hand-over to wave 2 + wave (lr_persist4_kernel)
 //   SPEC: the step speculates on rejection (lr_chain_step_respec) - scratch3 / draws / hands are then [chain of the block][parity]
-//   and specq [chain of the block]
+//   and pend [chain of the block][parity]
 template <int PB, int ES, int NW, int SAMPLER, bool HELP, bool SPEC = false>
 __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute__((address_space(3))) lr_step_args* a3, int c0,
                                                                int n_chains, int wave, int lane,
@@ -324,7 +325,7 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
                                                                lr_lds_f64* st_f64, lr_lds_i32* st_i32, lr_lds_f64* red,
                                                                lr_lds_f64* tab, int tab_doubles, lr_lds_f64* br3, long long n_iters,
                                                                const lr_draw_slot* draws /* [4]: made ahead (RJ sampler) */,
-                                                               lr_table_hand* hands /* [2] */, lr_respec_q* specq = nullptr) {
+                                                               lr_table_hand* hands /* [2] */, lr_pend* pend = nullptr) {
     static_assert(!HELP || (LR_P4_DRAW_AHEAD != 0 && ES == 2 && SAMPLER == 0 && LR_P4_LAST_SUMS != 0), "helper waves: RJ sampler at unit resolution");
     static_assert(!SPEC || HELP, "speculation on rejection: the form with helper waves");
     for (long long iter = 0; iter < n_iters; ++iter) {
@@ -342,7 +343,7 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
                     const int ch = 2 * ph + wave;
                     lr_persist_step_respec<(PB > 0 ? PB : 1)>(a3, c, lane, scratch3 + 2 * ch, st_f64 + ch * (LR_STATE_ROWS * LR_ROW),
                                                 st_i32 + ch * (LR_ISTATE_ROWS * LR_ROW), lik, br3, draws + 2 * ch, hands + 2 * ch,
-                                                specq + ch, (int)((2 * iter + ph + 1) & 0x3fffffff));
+                                                pend + 2 * ch, iter == 0, (int)((2 * iter + ph + 1) & 0x3fffffff));
                 } else
                 lr_persist_step_body<PB, ES, LR_P4_DRAW_AHEAD != 0 && ES == 2 /* unit resolution */ && SAMPLER == 0, SAMPLER, HELP>(
                     a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
@@ -517,6 +518,9 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 #ifndef LR_P4_UNROLL
 #define LR_P4_UNROLL 1
 #endif
+#ifndef LR_P4_DRAW_WAVE
+#define LR_P4_DRAW_WAVE 2    /* SPEC form: first of the two scanner slots (wave 4 + slot) that make the draws ahead */
+#endif
 #ifdef LR_DIAG
 #define LR_PSTAMP(k) if (threadIdx.x == 0 && blockIdx.x < 64) lr_diag_step[28672 + blockIdx.x * 8 + (k)] = wall_clock64()
 #else
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 struct lr_p4_spec_lds {
     lr_seg_scratch scratch[8];
     lr_draw_slot draws[8];
-    lr_respec_q specq[4];
+    lr_pend pend[8];
     lr_table_hand hands[8];
 };
 
@@ -544,14 +548,14 @@ struct lr_p4_spec_lds {
 // and parity of the iteration, the draws are made two iterations ahead.
 template <int H, bool GENERAL, bool PARAM /* a parametric sampler's chain step (DDRate, trend_rate) instead of the RJ sampler's */,
           bool HELP = false, bool SPEC = false>
-__global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args ak /* by value: kernel arguments come
-                                                                       with the dispatch - read through a pointer they cost every block a round trip to
-                                                                       memory before it can fetch its chains' state */,
+__global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist4_kernel(const lr_step_args* __restrict__ ap /* in global memory: a by-value argument struct measured
+                                                                       0.2 us per launch faster, but one instantiation then kept a copy of it in scratch
+                                                                       memory and read its fields from there in every phase */,
                                                                        lr_packed_lineages pk, long long n8,
                                                                        lr_p4_shares sh, long long n_iters, char* carry_all) {
     static_assert(!HELP || (!GENERAL && !PARAM), "helper waves: RJ sampler at unit resolution");
     static_assert(!SPEC || HELP, "speculation on rejection: the form with helper waves");
-    const lr_step_args& a = ak;
+    const lr_step_args& a = *ap;
     LR_PSTAMP(0);      // entry (LR_DIAG: wall-clock stamps of a launch's stages, blocks < 64; scratch/diag_p4_launch.py)
     constexpr int NW = LR_P4_THREADS / LR_WAVE;          // 16 waves: 2 steppers + 14 scanners (HELP: 2 + 2 helpers + 12)
     constexpr int W0 = HELP ? 4 : 2;                      // first scanner wave
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     lr_p4_spec_lds* const xs = reinterpret_cast<lr_p4_spec_lds*>(p4_dyn);
     lr_table_hand* const hands = SPEC ? xs->hands : hands_s;
     lr_seg_scratch* const scratch = SPEC ? xs->scratch : scratch_s;
-    lr_respec_q* const specq = xs->specq;
+    lr_pend* const pend = xs->pend;
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
     __shared__ int st_i32[4][LR_ISTATE_ROWS * LR_ROW];
     __shared__ lr_step_args a_lds;
@@ -591,20 +595,24 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     __shared__ lr_draw_slot draws_s[SPEC ? 1 : 4];
     lr_draw_slot* const draws = SPEC ? xs->draws : draws_s;
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
-    if (tid == 0) a_lds = ak;      // (field by field from the kernel-argument segment: indexing &ak would copy it to scratch)
+    if (tid < (int)(sizeof(lr_step_args) / 4)) reinterpret_cast<int*>(&a_lds)[tid] = reinterpret_cast<const int*>(ap)[tid];
     for (int b = tid; b < LR_H_WIDE; b += blockDim.x) {
-        const bool in = b < ak.cfg.n_bins;
-        br_lds[0][b] = (in && ak.br_length) ? ak.br_length[b] : 0.0;
-        br_lds[1][b] = in ? ak.log_br[b] : 0.0;
+        const bool in = b < ap->cfg.n_bins;
+        br_lds[0][b] = (in && ap->br_length) ? ap->br_length[b] : 0.0;
+        br_lds[1][b] = in ? ap->log_br[b] : 0.0;
     }
     // (unit resolution only: on general times the scan loops are the longer side of a phase and have nothing to spare)
     constexpr bool draw_ahead = LR_P4_DRAW_AHEAD && !GENERAL && !PARAM;
     // draw duty of scanner wave 2 + q, q < 4, for the pair `pr` that has just been scanned: part q >> 1 of chain q & 1
     // (SPEC: `ahead` iterations beyond the pending one - 2 in the loop, 1 and 2 in the prologue -, by scanner waves
     // qoff, qoff + 1, into the slot of that iteration's parity)
-    auto draw_duty = [&](int pr, int ahead = SPEC ? 2 : 1, int qoff = 0) {
+    // (HELP: waves 4, 5 - the oldest scanners - sit on the steppers' SIMDs and end their scans last of all scanners (in-kernel
+    // stamps: 3.1 us of a 3.15 us phase against 2.2-2.9 for the others) - and still the draws cost least there: by waves 6, 7
+    // (SIMDs 2, 3, beside the helpers) cfg4 ran 6.37-6.40 us per iteration against 6.25, A/B twice on one box; under SPEC, whose
+    // helpers build early, the other way round: 7.05 against 6.87)
+    auto draw_duty = [&](int pr, int ahead = SPEC ? 2 : 1, int qoff = SPEC ? LR_P4_DRAW_WAVE : 0) {
         const int q = wave - W0 - qoff, k = q & 1, ch = 2 * pr + k;      // (the oldest scanner waves: the first to finish)
-        if (!draw_ahead || q < 0 || q >= (HELP ? 2 : 4) || (int)(blockIdx.x * 4) + ch >= ak.cfg.n_chains) return;
+        if (!draw_ahead || q < 0 || q >= (HELP ? 2 : 4) || (int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
         const int* I = st_i32[ch] + LR_IROW_SCALARS * LR_ROW;
         const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + (unsigned long long)ahead;
         lr_draw_slot* slot = SPEC ? &draws[2 * ch + (int)(it & 1ull)] : &draws[ch];
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     auto help_duty = [&](int ph, int epoch, int par = 0) {
         const int k = wave - 2;
         const int ch = 2 * ph + k;
-        if ((int)(blockIdx.x * 4) + ch >= ak.cfg.n_chains) return;
+        if ((int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
         lr_table_hand* hand = SPEC ? &hands[2 * ch + par] : &hands[k];
 #ifdef LR_DIAG
         const unsigned long long dh0 = wall_clock64();
@@ -636,11 +644,13 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
             reinterpret_cast<double2*>(tabd), lane, LR_TAB_UNIT, a_lds.cfg.frac_birth, a_lds.cfg.frac_death, ES, nullptr);
         LR_WAVE_LDS_ORDER();
         lr_pair_planes_wave(tabd, H, a_lds.cfg.n_bins, lane, 0);
-        if (lane == 0) st_f64[ch][LR_ROW_SCALARS * LR_ROW + LR_S_CONST_P] = constP;
+        if (lane == 0) {
+            if (SPEC) pend[2 * ch + par].sc[LR_S_CONST_P] = constP;
+            else st_f64[ch][LR_ROW_SCALARS * LR_ROW + LR_S_CONST_P] = constP;
+        }
     };
     if (tid == 0) arrived = 0;
     if (tid < (SPEC ? 8 : 2)) hands[tid].epoch = 0;
-    if (SPEC && tid < 4) specq[tid].valid = 0;
     for (int i = tid; i < 2 * NW * 2; i += LR_P4_THREADS) (&red[0][0][0])[i] = 0.0;
     int scans_done = 0;
     // a scanning wave's end of scan number `scans_done` for pair `pr` (HELP: the helper waves score a share too - slots NS,
@@ -657,6 +667,8 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         const int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
         for (int r = 0; r < LR_STATE_ROWS; ++r) st_f64[wave][r * LR_ROW + lane] = S[r * LR_ROW + lane];
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) st_i32[wave][r * LR_ROW + lane] = I[r * LR_ROW + lane];
+        // SPEC: the pending proposal into the slot of its iteration's parity (the rows keep the accepted side)
+        if (SPEC) lr_pend_from_rows(S, I, &pend[2 * wave + (I[LR_IROW_SCALARS * LR_ROW + LR_I_IT_LO] & 1)], lane);
     }
     double2* g0 = lr_chain_table(a, c0);
     double2* g1 = lr_chain_table(a, c0 + 2);             // tables are allocated for whole groups of cb >= 4 chains
@@ -708,7 +720,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // (SPEC: the first stepper phases need the draws of the iterations 1 and 2 beyond the pending one for pair 0, and of
     // iteration 1 for pair 1 (phase A's scan of pair 1 adds its iteration 2): three pairs of scanner waves, a call each)
     auto prologue_draws = [&]() {
-        if (SPEC) draw_duty(0, 1, 0), draw_duty(0, 2, 2), draw_duty(1, 1, 4);
+        if (SPEC) draw_duty(0, 1, 2), draw_duty(0, 2, 6), draw_duty(1, 1, 10);     // (waves 6, 7; 10, 11; 14, 15: SIMDs 2, 3)
         else draw_duty(0);
     };
     if (carried) {
@@ -729,10 +741,10 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     }
     if (helper && !carried) help_scan(0);
     // (SPEC: parity of the pending iteration of this helper's two chains at the start of the launch)
-    int it0_par[2] = {0, 0};
+    int it0_par0 = 0, it0_par1 = 0;
     if (SPEC && helper) {
-        it0_par[0] = st_i32[wave - 2][LR_IROW_SCALARS * LR_ROW + LR_I_IT_LO] & 1;
-        it0_par[1] = st_i32[2 + wave - 2][LR_IROW_SCALARS * LR_ROW + LR_I_IT_LO] & 1;
+        it0_par0 = st_i32[wave - 2][LR_IROW_SCALARS * LR_ROW + LR_I_IT_LO] & 1;
+        it0_par1 = st_i32[2 + wave - 2][LR_IROW_SCALARS * LR_ROW + LR_I_IT_LO] & 1;
     }
     __syncthreads();
     LR_PSTAMP(3);      // prologue done: pair 0's sums (scanned or carried), the first draws
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
                 const unsigned long long dq0 = wall_clock64();
 #endif
                 help_scan(1 - ph);
-                help_duty(ph, (int)((2 * iter + ph + 1) & 0x3fffffff), SPEC ? (it0_par[ph] + (int)(iter & 1) + 1) & 1 : 0);
+                help_duty(ph, (int)((2 * iter + ph + 1) & 0x3fffffff), SPEC ? ((ph ? it0_par1 : it0_par0) + (int)(iter & 1) + 1) & 1 : 0);
 #ifdef LR_DIAG
                 const unsigned long long dq1 = wall_clock64();
 #endif
@@ -763,7 +775,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
             (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c0, C, wave, lane,
             (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[SPEC ? 0 : wave], (lr_lds_f64*)&st_f64[0][0], (lr_lds_i32*)&st_i32[0][0],
             (lr_lds_f64*)&red[0][0][0], (lr_lds_f64*)reinterpret_cast<double*>(tab[0]), 2 * LR_UNIT_PLANES * H,
-            (lr_lds_f64*)&br_lds[0][0], n_iters, &draws[0], &hands[0], &specq[0]);
+            (lr_lds_f64*)&br_lds[0][0], n_iters, &draws[0], &hands[0], &pend[0]);
     else
     for (long long iter = 0; iter < n_iters; ++iter) {
 #pragma unroll
@@ -801,6 +813,10 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         const int c = c0 + wave;
         double* S = a.state_f64 + (size_t)c * LR_STATE_ROWS * LR_ROW;
         int* I = a.state_i32 + (size_t)c * LR_ISTATE_ROWS * LR_ROW;
+        if (SPEC) {      // the pending proposal back into the rows (the staged candidate is dropped: the next launch re-proposes)
+            lr_pend_to_rows(st_f64[wave], st_i32[wave], &pend[2 * wave + (st_i32[wave][LR_IROW_SCALARS * LR_ROW + LR_I_IT_LO] & 1)], lane);
+            LR_WAVE_LDS_ORDER();
+        }
         for (int r = 0; r < LR_STATE_ROWS; ++r) S[r * LR_ROW + lane] = st_f64[wave][r * LR_ROW + lane];
         for (int r = 0; r < LR_ISTATE_ROWS; ++r) I[r * LR_ROW + lane] = st_i32[wave][r * LR_ROW + lane];
     }
@@ -1610,18 +1626,18 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
 #define LR_P_LAUNCH(HH)                                                                                                       \
     if (p4) {                                                                                                                 \
         const dim3 g4((e->cfg.n_chains + 3) / 4), b4(LR_P4_THREADS);                                                          \
-        if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry);   \
-        else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry);      \
-        else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry);        \
+        if (general && param) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);   \
+        else if (general) hipLaunchKernelGGL((lr_persist4_kernel<HH, true, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);      \
+        else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);        \
         else if (e->p4_help && e->p4_spec) {                                                                                   \
             /* (helper waves: H <= 264, lr_p4_help_choice; the attribute belongs to the function on the CURRENT device) */     \
             hipError_t he_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), \
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lr_p4_spec_lds));     \
             if (he_ != hipSuccess) return (int)he_;                                                                            \
-            hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), g4, b4, sizeof(lr_p4_spec_lds), stream, a, pk, e->n8, e->p4, (long long)n, p4_carry); \
+            hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), g4, b4, sizeof(lr_p4_spec_lds), stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
         }                                                                                                                      \
-        else if (e->p4_help) hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry); \
-        else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, a, pk, e->n8, e->p4, (long long)n, p4_carry);                  \
+        else if (e->p4_help) hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
+        else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);                  \
     } else if (wide) {                                                                                                        \
         hipLaunchKernelGGL((lr_persist_kernel<HH, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); \
     } else {                                                                                                                  \

@@ -945,88 +945,107 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
 // On cfg4-sized data a chain's accepted state changes in 11-13 % of its first 3000 iterations and in < 1 % of the later
 // ones (scratch/exp_accept_mix.py: multiplier moves of +-10 % against a posterior ~1 % wide are rejected, the no-op
 // "times" moves are accepted but change nothing).  So while the pending proposal P of iteration `it` is being scanned the
-// stepper wave already stages Q = propose(A, it + 1) - the proposal the chain makes next IF P is rejected - in LDS.  At the
-// decision, one phase later:
-//   * state unchanged (the usual case): Q becomes the pending proposal, its segments already stand in the scratch, and the
+// stepper wave already stages Q = propose(A, it + 1) - the proposal the chain makes next IF P is rejected.  At the decision,
+// one phase later:
+//   * state unchanged (the usual case): Q IS the pending proposal, its segments already stand in the scratch, and the
 //     helper wave starts the table build right at the decision instead of waiting ~1.2 us for move + staging;
 //   * state changed: Q is dropped, propose(A', it + 1) runs as before (staging, hand-over, helper's build).
-// Either way the wave then stages the next Q = propose(A', it + 2).  lr_propose_rj is a pure function of (state, iteration,
-// draws): the trajectories are those of lr_chain_step_core bit for bit, whatever is dropped at a launch boundary.
-struct lr_respec_q {
+// Either way the wave then stages propose(A', it + 2).  A proposal lives in the slot of its iteration's PARITY (rows,
+// bookkeeping scalars, scratch, hand-over word, draws): the slot of `it` is dead at the decision and takes the proposal of
+// it + 2, the slot of it + 1 holds Q - nothing is copied when Q is adopted.  lr_propose_rj is a pure function of (state,
+// iteration, draws): the trajectories are those of lr_chain_step_core bit for bit, whatever is dropped at a launch boundary.
+struct lr_pend {
     double L[LR_ROW], M[LR_ROW], tL[LR_ROW], tM[LR_ROW];
-    double sc[LR_ROW];      // LR_S_* layout, the slots of the PENDING side (lr_sc_pending_side)
+    double sc[LR_ROW];      // LR_S_* layout: the slots of the PENDING side (lr_sc_pending_side) and LR_S_CONST_P (the helper's)
     int eL[LR_ROW], eM[LR_ROW];
-    int isc[LR_ROW];        // LR_I_* layout, the slots of the pending side (lr_isc_pending_side)
-    int valid, pad_[3];     // 0 at the start of a launch: the first decision of a chain takes the non-speculative path
+    int isc[LR_ROW];        // LR_I_* layout: PKL, PKM, GIBBS, INVALID, MOVE
 };
-// scalar slots that describe the pending proposal (LR_S_CONST_P is the helper wave's to write): hyper-parameters and their
-// logs ride with the pending proposal (a Gibbs step's draws; it is always accepted)
+// scalar slots that describe a pending proposal: hyper-parameters and their logs ride with it (a Gibbs step's draws)
 __device__ __forceinline__ bool lr_sc_pending_side(int lane) {
     constexpr unsigned m = (1u << LR_S_GRATE_L) | (1u << LR_S_GRATE_M) | (1u << LR_S_POI) | (1u << LR_S_HASTING) | (1u << LR_S_PRIOR_P) |
-                           (1u << LR_S_PRIORPOI_P) | (1u << LR_S_LOG_G0) | (1u << LR_S_LOG_G1) | (1u << LR_S_LOG_POI) | (1u << LR_S_LOG_U);
+                           (1u << LR_S_PRIORPOI_P) | (1u << LR_S_CONST_P) | (1u << LR_S_LOG_G0) | (1u << LR_S_LOG_G1) |
+                           (1u << LR_S_LOG_POI) | (1u << LR_S_LOG_U);
     return lane < 32 && ((m >> lane) & 1u);
 }
 __device__ __forceinline__ bool lr_isc_pending_side(int lane) {
     constexpr unsigned m = (1u << LR_I_PKL) | (1u << LR_I_PKM) | (1u << LR_I_GIBBS) | (1u << LR_I_INVALID) | (1u << LR_I_MOVE);
     return lane < 32 && ((m >> lane) & 1u);
 }
+// the chain's state rows (include/literate_hip.h layout) <-> the accepted side in the rows + the pending proposal in a slot.
+// In the rows' scalar row the hyper-parameter slots then mean the ACCEPTED state's.
+__device__ __forceinline__ void lr_pend_from_rows(const double* S, const int* I, lr_pend* P, int lane) {
+    P->L[lane] = S[LR_ROW_PL * LR_ROW + lane], P->M[lane] = S[LR_ROW_PM * LR_ROW + lane];
+    P->tL[lane] = S[LR_ROW_PTL * LR_ROW + lane], P->tM[lane] = S[LR_ROW_PTM * LR_ROW + lane];
+    P->eL[lane] = I[LR_IROW_PEL * LR_ROW + lane], P->eM[lane] = I[LR_IROW_PEM * LR_ROW + lane];
+    P->sc[lane] = S[LR_ROW_SCALARS * LR_ROW + lane], P->isc[lane] = I[LR_IROW_SCALARS * LR_ROW + lane];
+}
+__device__ __forceinline__ void lr_pend_to_rows(double* S, int* I, const lr_pend* P, int lane) {
+    S[LR_ROW_PL * LR_ROW + lane] = P->L[lane], S[LR_ROW_PM * LR_ROW + lane] = P->M[lane];
+    S[LR_ROW_PTL * LR_ROW + lane] = P->tL[lane], S[LR_ROW_PTM * LR_ROW + lane] = P->tM[lane];
+    I[LR_IROW_PEL * LR_ROW + lane] = P->eL[lane], I[LR_IROW_PEM * LR_ROW + lane] = P->eM[lane];
+    if (lr_sc_pending_side(lane)) S[LR_ROW_SCALARS * LR_ROW + lane] = P->sc[lane];
+    if (lr_isc_pending_side(lane)) I[LR_IROW_SCALARS * LR_ROW + lane] = P->isc[lane];
+}
 
-// scratch2 / hands2 / draws2: the chain's two slots each, indexed by the parity of the iteration a proposal is FOR.
-// S / I: the chain's state rows (LDS).  The rows are read and written where they are needed instead of living in registers
-// for the whole step: a proposal is ~100 live registers by itself, and what is held across it spills to scratch memory
-// (a first form kept the accepted and the adopted rows in registers: five scratch reloads per step, +1 us per phase).
+// pend2 / scratch2 / hands2 / draws2: the chain's two slots each, indexed by the parity of the iteration a proposal is FOR.
+// S / I: the chain's state rows (LDS), accepted side.  `first`: the first decision of a launch (no staged candidate yet).
+// Rows are read and written where they are needed instead of living in registers for the whole step: a proposal is ~100
+// live registers by itself, and what is held across it spills to scratch memory.
 template <int PB>
 __device__ __forceinline__ void lr_chain_step_respec(const lr_step_args& a, int c, int lane, double lik_sum, double* S, int* I,
-                                                     lr_seg_scratch* scratch2, lr_table_hand* hands2, const lr_draw_slot* draws2,
-                                                     lr_respec_q* Q, int epoch, const double* br_lds, const double* logbr_lds) {
+                                                     lr_pend* pend2, lr_seg_scratch* scratch2, lr_table_hand* hands2,
+                                                     const lr_draw_slot* draws2, bool first, int epoch, const double* br_lds,
+                                                     const double* logbr_lds) {
     const lr_mcmc_config& cfg = a.cfg;
     const double sc = S[LR_ROW_SCALARS * LR_ROW + lane];
     const int isc = I[LR_IROW_SCALARS * LR_ROW + lane];
-    const int q_valid = Q->valid;
+    const uint64_t it = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_HI) << 32);
+    const int pp = (int)(it & 1);                      // slot of the pending proposal; 1 - pp: of the staged candidate
+    const double psc = pend2[pp].sc[lane];
+    const int pisc = pend2[pp].isc[lane];
     double likA = lr_bcast(sc, LR_S_LIKA), priorA = lr_bcast(sc, LR_S_PRIORA);
     double constA = lr_bcast(sc, LR_S_CONST_A), priorPoiA = lr_bcast(sc, LR_S_PRIORPOIA);
     int KL = lr_bcast_i(isc, LR_I_KL), KM = lr_bcast_i(isc, LR_I_KM);
-    // hyper-parameters of the accepted state: the row carries the pending proposal's, which are the accepted ones unless it
-    // is a Gibbs step - and that is always accepted
-    const double g0 = lr_bcast(sc, LR_S_GRATE_L), g1 = lr_bcast(sc, LR_S_GRATE_M), poi = lr_bcast(sc, LR_S_POI);
-    const double lg0 = lr_bcast(sc, LR_S_LOG_G0), lg1 = lr_bcast(sc, LR_S_LOG_G1), lpoi = lr_bcast(sc, LR_S_LOG_POI);
-    const uint64_t it = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_IT_HI) << 32);
+    double g0 = lr_bcast(sc, LR_S_GRATE_L), g1 = lr_bcast(sc, LR_S_GRATE_M), poi = lr_bcast(sc, LR_S_POI);
+    double lg0 = lr_bcast(sc, LR_S_LOG_G0), lg1 = lr_bcast(sc, LR_S_LOG_G1), lpoi = lr_bcast(sc, LR_S_LOG_POI);
     int n_acc = lr_bcast_i(isc, LR_I_ACCEPTED);
     uint64_t next_sample = (uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_LO) | ((uint64_t)(uint32_t)lr_bcast_i(isc, LR_I_NEXT_HI) << 32);
     int trace_slot = lr_bcast_i(isc, LR_I_SLOT);
     LR_SSTAMP(1);
 
     // ---- Metropolis-Hastings accept of iteration `it` (LRF:305-319) ----
-    const int gibbs = lr_bcast_i(isc, LR_I_GIBBS), invalid = lr_bcast_i(isc, LR_I_INVALID);
-    const double priorP = lr_bcast(sc, LR_S_PRIOR_P), constP = lr_bcast(sc, LR_S_CONST_P);
+    const int gibbs = lr_bcast_i(pisc, LR_I_GIBBS), invalid = lr_bcast_i(pisc, LR_I_INVALID);
+    const double priorP = lr_bcast(psc, LR_S_PRIOR_P), constP = lr_bcast(psc, LR_S_CONST_P);
     double lik;
-    const bool ok = lr_mh_accept(gibbs, invalid, lik_sum, constP, likA, priorP, priorA, lr_bcast(sc, LR_S_HASTING),
-                                 lr_bcast(sc, LR_S_LOG_U), &lik);
+    const bool ok = lr_mh_accept(gibbs, invalid, lik_sum, constP, likA, priorP, priorA, lr_bcast(psc, LR_S_HASTING),
+                                 lr_bcast(psc, LR_S_LOG_U), &lik);
     const double lik_p = invalid ? -INFINITY : lik;
     lr_warn_kcap(a.warn, invalid, lane);
     // Does the decision change what the next proposal is made FROM?  Not when P is rejected, and not when an accepted P is a
     // no-op "times" move whose re-floored edges are the accepted ones (LRF:178-195): rates, times, edges, hyper-parameters
     // and the cached Poisson prior are then what they were (likA / priorA / the counter are not read by a proposal).
-    bool changed = !q_valid;
+    bool changed = first;
     if (ok) {
-        const int mv = lr_bcast_i(isc, LR_I_MOVE);
-        const int peL = I[LR_IROW_PEL * LR_ROW + lane], peM = I[LR_IROW_PEM * LR_ROW + lane];
+        const int mv = lr_bcast_i(pisc, LR_I_MOVE);
+        const int peL = pend2[pp].eL[lane], peM = pend2[pp].eM[lane];
         const int eL = I[LR_IROW_EL * LR_ROW + lane], eM = I[LR_IROW_EM * LR_ROW + lane];
         const bool same = (mv == 1 || mv == 3) && __ballot(lane <= LR_KMAX && (peL != eL || peM != eM)) == 0ull;
         changed |= !same;
         if (!same) {
             // the pending rows become the accepted ones (a no-op move's are the very same values)
-            S[LR_ROW_L * LR_ROW + lane] = S[LR_ROW_PL * LR_ROW + lane], S[LR_ROW_M * LR_ROW + lane] = S[LR_ROW_PM * LR_ROW + lane];
-            S[LR_ROW_TL * LR_ROW + lane] = S[LR_ROW_PTL * LR_ROW + lane], S[LR_ROW_TM * LR_ROW + lane] = S[LR_ROW_PTM * LR_ROW + lane];
+            S[LR_ROW_L * LR_ROW + lane] = pend2[pp].L[lane], S[LR_ROW_M * LR_ROW + lane] = pend2[pp].M[lane];
+            S[LR_ROW_TL * LR_ROW + lane] = pend2[pp].tL[lane], S[LR_ROW_TM * LR_ROW + lane] = pend2[pp].tM[lane];
             I[LR_IROW_EL * LR_ROW + lane] = peL, I[LR_IROW_EM * LR_ROW + lane] = peM;
+            KL = lr_bcast_i(pisc, LR_I_PKL), KM = lr_bcast_i(pisc, LR_I_PKM);
+            g0 = lr_bcast(psc, LR_S_GRATE_L), g1 = lr_bcast(psc, LR_S_GRATE_M), poi = lr_bcast(psc, LR_S_POI);
+            lg0 = lr_bcast(psc, LR_S_LOG_G0), lg1 = lr_bcast(psc, LR_S_LOG_G1), lpoi = lr_bcast(psc, LR_S_LOG_POI);
         }
-        KL = lr_bcast_i(isc, LR_I_PKL), KM = lr_bcast_i(isc, LR_I_PKM);
-        likA = lik, priorA = priorP, priorPoiA = lr_bcast(sc, LR_S_PRIORPOI_P), constA = constP;
+        likA = lik, priorA = priorP, priorPoiA = lr_bcast(psc, LR_S_PRIORPOI_P), constA = constP;
         n_acc += 1;
     }
-    const uint64_t it1 = it + 1;                      // iteration of the new pending proposal
-    if (!changed && lane == 0)                        // Q (staged two phases ago) IS that proposal: the helper may build its table
-        __hip_atomic_store(&hands2[it1 & 1].epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint64_t it1 = it + 1;                      // iteration of the new pending proposal: slot 1 - pp
+    if (!changed && lane == 0)                        // the staged candidate IS that proposal: the helper may build its table
+        __hip_atomic_store(&hands2[1 - pp].epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     LR_WAVE_LDS_ORDER();
     // ---- trace row (LRF:321-359) ----
     if (it == next_sample) {
@@ -1041,22 +1060,39 @@ __device__ __forceinline__ void lr_chain_step_respec(const lr_step_args& a, int 
             lr_write_trace_row(a, c, lane, slot, it, likA, priorA, s);
         }
     }
+    // the accepted side of the scalar rows (nothing below changes it)
+    {
+        double so = 0.0;
+        so = (lane == LR_S_LIKA) ? likA : so;
+        so = (lane == LR_S_PRIORA) ? priorA : so;
+        so = (lane == LR_S_PRIORPOIA) ? priorPoiA : so;
+        so = (lane == LR_S_CONST_A) ? constA : so;
+        so = (lane == LR_S_LIK_P) ? lik_p : so;
+        so = (lane == LR_S_GRATE_L) ? g0 : so;
+        so = (lane == LR_S_GRATE_M) ? g1 : so;
+        so = (lane == LR_S_POI) ? poi : so;
+        so = (lane == LR_S_LOG_G0) ? lg0 : so;
+        so = (lane == LR_S_LOG_G1) ? lg1 : so;
+        so = (lane == LR_S_LOG_POI) ? lpoi : so;
+        S[LR_ROW_SCALARS * LR_ROW + lane] = so;
+        int io = 0;
+        io = (lane == LR_I_KL) ? KL : io;
+        io = (lane == LR_I_KM) ? KM : io;
+        io = (lane == LR_I_IT_LO) ? (int)(uint32_t)it1 : io;
+        io = (lane == LR_I_IT_HI) ? (int)(uint32_t)(it1 >> 32) : io;
+        io = (lane == LR_I_ACCEPTED) ? n_acc : io;
+        io = (lane == LR_I_NEXT_LO) ? (int)(uint32_t)next_sample : io;
+        io = (lane == LR_I_NEXT_HI) ? (int)(uint32_t)(next_sample >> 32) : io;
+        io = (lane == LR_I_SLOT) ? trace_slot : io;
+        I[LR_IROW_SCALARS * LR_ROW + lane] = io;
+    }
     LR_SSTAMP(2);
 
-    // ---- k = 0 (state changed only): Q = propose(A', it1), handed to the helper at once; k = 1: Q is adopted as the
-    // pending proposal, then Q = propose(A', it1 + 1) is staged for the next decision.  ONE instance of the proposal code.
-    double q_sc = 0.0;
-    int q_isc = 0;
+    // ---- k = 0 (state changed only): propose(A', it1) into slot 1 - pp, handed to the helper at once;
+    //      k = 1: propose(A', it1 + 1) into slot pp, staged for the next decision.  ONE instance of the proposal code.
     int k = changed ? 0 : 1;
 #pragma unroll 1
     while (true) {
-        if (k == 1) {
-            S[LR_ROW_PL * LR_ROW + lane] = Q->L[lane], S[LR_ROW_PM * LR_ROW + lane] = Q->M[lane];
-            S[LR_ROW_PTL * LR_ROW + lane] = Q->tL[lane], S[LR_ROW_PTM * LR_ROW + lane] = Q->tM[lane];
-            I[LR_IROW_PEL * LR_ROW + lane] = Q->eL[lane], I[LR_IROW_PEM * LR_ROW + lane] = Q->eM[lane];
-            q_sc = Q->sc[lane], q_isc = Q->isc[lane];
-            LR_WAVE_LDS_ORDER();                      // (read before the rows are written again below)
-        }
         const uint64_t itk = it1 + (uint64_t)k;
         const int par = (int)(itk & 1);
         lr_rj_state sk;
@@ -1071,6 +1107,7 @@ __device__ __forceinline__ void lr_chain_step_respec(const lr_step_args& a, int 
         lr_draws_load(&draws2[par], pre, lane);
         lr_propose_rj<true, PB, 2, true, true>(a, c, lane, &scratch2[par], itk, sk, p, nullptr, 2, &pre, br_lds, logbr_lds, nullptr, 0,
                                                0.0, &hands2[par], k == 0 ? epoch : 0);
+        lr_pend* Q = &pend2[par];
         Q->L[lane] = sk.L, Q->M[lane] = sk.M, Q->tL[lane] = sk.tL, Q->tM[lane] = sk.tM;
         Q->eL[lane] = sk.eL, Q->eM[lane] = sk.eM;
         double so = 0.0;
@@ -1084,7 +1121,7 @@ __device__ __forceinline__ void lr_chain_step_respec(const lr_step_args& a, int 
         so = (lane == LR_S_LOG_G1) ? sk.lg1 : so;
         so = (lane == LR_S_LOG_POI) ? sk.lpoi : so;
         so = (lane == LR_S_LOG_U) ? p.log_u : so;
-        Q->sc[lane] = so;
+        if (lane != LR_S_CONST_P) Q->sc[lane] = so;           // (LR_S_CONST_P of a slot: written by the helper that builds its table)
         int io = 0;
         io = (lane == LR_I_PKL) ? sk.KL : io;
         io = (lane == LR_I_PKM) ? sk.KM : io;
@@ -1095,30 +1132,6 @@ __device__ __forceinline__ void lr_chain_step_respec(const lr_step_args& a, int 
         LR_WAVE_LDS_ORDER();
         if (k == 1) break;
         k = 1;
-    }
-    if (lane == 0) Q->valid = 1;
-
-    // ---- the scalar rows: accepted side from the decision, pending side from the adopted Q ----
-    {
-        double so = 0.0;
-        so = (lane == LR_S_LIKA) ? likA : so;
-        so = (lane == LR_S_PRIORA) ? priorA : so;
-        so = (lane == LR_S_PRIORPOIA) ? priorPoiA : so;
-        so = (lane == LR_S_CONST_A) ? constA : so;
-        so = (lane == LR_S_LIK_P) ? lik_p : so;
-        so = lr_sc_pending_side(lane) ? q_sc : so;
-        if (lane != LR_S_CONST_P) S[LR_ROW_SCALARS * LR_ROW + lane] = so;      // (LR_S_CONST_P: the helper wave's to write)
-        int io = 0;
-        io = (lane == LR_I_KL) ? KL : io;
-        io = (lane == LR_I_KM) ? KM : io;
-        io = (lane == LR_I_IT_LO) ? (int)(uint32_t)it1 : io;
-        io = (lane == LR_I_IT_HI) ? (int)(uint32_t)(it1 >> 32) : io;
-        io = (lane == LR_I_ACCEPTED) ? n_acc : io;
-        io = (lane == LR_I_NEXT_LO) ? (int)(uint32_t)next_sample : io;
-        io = (lane == LR_I_NEXT_HI) ? (int)(uint32_t)(next_sample >> 32) : io;
-        io = (lane == LR_I_SLOT) ? trace_slot : io;
-        io = lr_isc_pending_side(lane) ? q_isc : io;
-        I[LR_IROW_SCALARS * LR_ROW + lane] = io;
     }
     LR_SSTAMP(7);
 }

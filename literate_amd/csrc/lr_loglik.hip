@@ -249,7 +249,10 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res,
     p->groups = (n_chains + cb - 1) / cb;
     if (p->groups > 65535) return LR_ERR_SIZE;
     const long long unit = 2 * p->threads;
-    static const long long target_blocks = getenv("LR_SCAN_BLOCKS") ? atoll(getenv("LR_SCAN_BLOCKS")) : 2048;
+    // (lineage tiles aimed at: 1024 = four 256-thread blocks per CU, one round of blocks.  16 chains x 1e7 / 3e7 / 1e8 lineages
+    // in the launch-based engine, per iteration: 2048 tiles 43.1 / 103.5 / 297.6 us, 1024: 42.0 / 102.2 / 290.7, 512: 42.4 / 104.7 /
+    // 299.9, 4096: 48.6 / 106.1 / 293.5 - every block stages its chains' tables, and the step sums a chain's tile partials)
+    static const long long target_blocks = getenv("LR_SCAN_BLOCKS") ? atoll(getenv("LR_SCAN_BLOCKS")) : 1024;
     long long tiles = (target_blocks + p->groups - 1) / p->groups;
     const long long max_tiles = (n + 4 * unit - 1) / (4 * unit);  // >= 8 lineages per thread
     if (tiles > max_tiles) tiles = max_tiles;

@@ -696,7 +696,9 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // make them finish together.  lr_pack_lineages_kernel stores the moved groups where the takers keep striding, so
     // this is only a per-wave end of the loop: a fixed partition, the summation order - and with it bitwise
     // reproducibility - stays.
-    const int k_tot = (int)((n8 + LR_P4_SCANNERS - 1) / LR_P4_SCANNERS);
+    // (HELP: the first sh.help_trips * 128 groups are the helper waves'; the shares apply to the scanners' region behind them)
+    const long long nh_ = HELP ? (long long)sh.help_trips * (2 * LR_WAVE) : 0;
+    const int k_tot = (int)((n8 - nh_ + LR_P4_SCANNERS - 1) / LR_P4_SCANNERS);
     const int k_mine = k_tot + (scanner ? sh.delta[wave - W0] : 0);
     // equal shares (short scans): the true end, so that the ragged last trip costs only the lanes that have a group
     bool any_shift = false;
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // HELP: the first `nh` groups are the helper waves' (equal shares behind them)
     // ([0, nh): helper waves, the rest: the scanner waves)
     const long long nh = HELP ? (long long)sh.help_trips * (2 * LR_WAVE) : 0;
-    const long long n8w = HELP ? n8 - nh : (any_shift ? (long long)k_mine * LR_P4_SCANNERS : n8);
+    const long long n8w = any_shift ? (long long)k_mine * LR_P4_SCANNERS : n8 - nh;
     auto help_scan = [&](int pr) {
         double s0 = 0.0, s1 = 0.0;
         if (nh > 0) lr_persist_scan<H, GENERAL, 1, false, false>(reinterpret_cast<const char*>(tab[pr]), pk, 0, nh, tid - 2 * LR_WAVE, 2 * LR_WAVE, &s0, &s1);

@@ -124,7 +124,7 @@ __global__ void lr_pack_slot_flags_kernel(const int* __restrict__ run_start, con
 __global__ void lr_pack_slots_kernel(const double* __restrict__ ts, const double* __restrict__ te, long long n, double t0,
                                      int n_bins, int H, const int* __restrict__ run_start, const int* __restrict__ stretch_start,
                                      const int* __restrict__ head_incl, const int* __restrict__ group_incl, int permute,
-                                     int k_tot, lr_p4_shares sh, unsigned short* __restrict__ out, int extant_block,
+                                     int k_tot, long long share_base, lr_p4_shares sh, unsigned short* __restrict__ out, int extant_block,
                                      double end_time, unsigned int* __restrict__ frac, long long fstride) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -133,7 +133,8 @@ __global__ void lr_pack_slots_kernel(const double* __restrict__ ts, const double
     const int slot_in_run = head_incl[i] - head_incl[rs];
     const int slot = slot_in_run % LR_SLOTS;
     long long g = group_incl[i] - 1;
-    if (permute) g = lr_share_permute(g, k_tot, sh);
+    // (the shares apply behind the helper waves' groups [0, share_base) of the four-chain kernel's helper form)
+    if (permute && g >= share_base) g = share_base + lr_share_permute(g - share_base, k_tot, sh);
     unsigned short* grp = out + g * 8;
     bool x0;
     const int d0 = lr_pack_death_entry(ts, te, i, t0, n_bins, extant_block, end_time, &x0);
@@ -236,10 +237,16 @@ static void lr_set_shares(lr_engine* e) {
         // equal; the knob stays for experiments)
         int base[7] = {0, 0, 0, 0, 0, 0, 0};
         if (env && e->p4.n_slots == 14) sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5], &base[6]);
-        const int k_tot = (int)((e->n8 + 895) / 896);
+        // helper form: "d4,d6,d8,d10,d12,d14" per wave pair (4,5) ... (14,15), trips per 9 trips of a scanner lane
+        // (SIMDs 0, 1 - pairs (4,5), (8,9), (12,13) - also carry the steppers, SIMDs 2, 3 the helpers)
+        static const char* env12 = getenv("LR_P4_SHARES12");
+        if (env12 && e->p4.n_slots == 12) sscanf(env12, "%d,%d,%d,%d,%d,%d", &base[0], &base[1], &base[2], &base[3], &base[4], &base[5]);
+        const long long behind = e->p4_help ? (long long)e->p4.help_trips * 128 : 0;
+        const int per = e->p4.n_slots * 64;
+        const int k_tot = (int)((e->n8 - behind + per - 1) / per);
         int sum = 0;
         for (int j = 0; j < 7; ++j) {
-            int d = (k_tot >= 6) ? (int)lrint((double)base[j] * k_tot / 14.0) : 0;
+            int d = (k_tot >= 6) ? (int)lrint((double)base[j] * k_tot / (e->p4.n_slots == 12 ? 9.0 : 14.0)) : 0;
             if (d < -(k_tot - 1)) d = -(k_tot - 1);
             if (d > LR_P4_MAX_GIVE) d = LR_P4_MAX_GIVE;
             e->p4.delta[2 * j] = e->p4.delta[2 * j + 1] = d;
@@ -279,10 +286,10 @@ static void lr_set_shares(lr_engine* e) {
     }
     // the takers' extra trips must stay inside the zero-filled spare behind the packed groups
     const long long stride = (long long)e->p4.n_slots * 64;
-    const long long k_tot = (e->n8 + stride - 1) / stride;
+    const long long k_tot = (e->n8 + stride - 1) / stride;        // (an upper bound in the helper form, whose region is shorter)
     int dmax = 0;
     for (int j = 0; j < 16; ++j) dmax = e->p4.delta[j] > dmax ? e->p4.delta[j] : dmax;
-    if ((k_tot + dmax + 1) * stride > e->n8_alloc)
+    if ((k_tot + dmax + 1) * stride + (e->p4_help ? (long long)e->p4.help_trips * 128 : 0) > e->n8_alloc)
         for (int j = 0; j < 16; ++j) e->p4.delta[j] = 0;
 }
 
@@ -336,11 +343,12 @@ int lr_pack_lineages(lr_engine* e, hipStream_t stream) {
     if (he != hipSuccess) return (int)he;
     bool any = false;
     for (int j = 0; j < 16; ++j) any |= e->p4.delta[j] != 0;
-    const int k_tot = (int)((e->n8 + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64));
+    const long long share_base = (e->lay.persistent == 2 && e->p4_help) ? (long long)e->p4.help_trips * 128 : 0;
+    const int k_tot = (int)((e->n8 - share_base + e->p4.n_slots * 64 - 1) / (e->p4.n_slots * 64));
     // (an all-zero group of the spare: birth entry 0 x count 0 and seven gathers of S[0] = 0 - contribution 0)
     hipLaunchKernelGGL(lr_pack_slots_kernel, grid, blk, 0, stream, e->ts, e->te, n, e->cfg.t0, e->cfg.n_bins, e->plan.H,
                        (const int*)run_start, (const int*)stretch_start, (const int*)head_incl, (const int*)group_incl,
-                       any ? 1 : 0, k_tot, e->p4, (unsigned short*)(e->ws + e->lay.lineage_idx), extant_block, e->cfg.end_time,
+                       any ? 1 : 0, k_tot, share_base, e->p4, (unsigned short*)(e->ws + e->lay.lineage_idx), extant_block, e->cfg.end_time,
                        general ? (unsigned int*)(e->ws + e->lay.lineage_frac) : nullptr, (long long)e->n8_alloc);
     return (int)hipGetLastError();
 }

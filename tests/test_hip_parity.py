@@ -403,6 +403,40 @@ def test_loglik_bad_arguments(ops):
         ops.bd_loglik_batch(ts, te, 0.0, np.full((1, 5000), .1), np.full((1, 5000), .1), 2)
 
 
+def test_streaming_kernels_at_1e8_lineages(ops):
+    """The size bench.py's `abi` rows now reach - 1e8 lineages, 1.6 GB per pass, six times the Infinity Cache - through the
+    same size-independent properties: lr_bin_unit_events against torch.bincount and conservation of lineage-time, additive
+    over a split bit for bit; lr_bd_loglik_batch with 17 chains (lr_scan_wide_kernel: sixteen per pass, and a second pass of
+    one) == binned Keiding on those statistics, additive over the split, bitwise reproducible, a chain the same alone."""
+    import torch
+    n, W, t0 = 100_000_000, 128, 0.0
+    ts, te = _big_lineages(n, True, 5)
+    sp, ex, br = ops.bin_unit_events(ts, te, t0, W)
+    assert torch.equal(sp, torch.bincount(torch.floor(ts).long(), minlength=W)[:W])
+    be = (torch.ceil(te) - 1).long()
+    assert torch.equal(ex, torch.bincount(be[be < W], minlength=W)[:W])
+    del be
+    total = (torch.clamp(te, max=float(W)) - torch.clamp(ts, min=0.0)).clamp(min=0.0).sum()
+    assert float(br.sum()) == pytest.approx(float(total), rel=1e-11)
+    cut = 41_234_567                                        # (odd: the second part starts on an unaligned pointer)
+    a = ops.bin_unit_events(ts[:cut], te[:cut], t0, W)
+    b = ops.bin_unit_events(ts[cut:], te[cut:], t0, W)
+    assert torch.equal(a[0] + b[0], sp) and torch.equal(a[1] + b[1], ex) and torch.allclose(a[2] + b[2], br, rtol=1e-15, atol=0)
+    rng = np.random.default_rng(12)
+    C = 17
+    lam = np.exp(rng.uniform(np.log(.05), np.log(.6), (C, W)))
+    mu = np.exp(rng.uniform(np.log(.02), np.log(.3), (C, W)))
+    full = _np(ops.bd_loglik_batch(ts, te, t0, lam, mu, 2))
+    sp_, ex_, br_ = _np(sp), _np(ex), _np(br)
+    keiding = (np.log(lam) * sp_ - lam * br_).sum(1) + (np.log(mu) * ex_ - mu * br_).sum(1)
+    assert np.allclose(full, keiding, rtol=REL)
+    pa = _np(ops.bd_loglik_batch(ts[:cut], te[:cut], t0, lam, mu, 2))
+    pb = _np(ops.bd_loglik_batch(ts[cut:], te[cut:], t0, lam, mu, 2))
+    assert np.allclose(pa + pb, full, rtol=1e-11)
+    assert np.array_equal(_np(ops.bd_loglik_batch(ts, te, t0, lam, mu, 2)), full)
+    assert _np(ops.bd_loglik_batch(ts, te, t0, lam[3:4], mu[3:4], 2))[0] == pytest.approx(full[3], rel=1e-11)
+
+
 def test_loglik_properties_full_size(ops):
     """cfg4-sized input (1e5 lineages): size-independent properties instead of an O(N*bins) oracle."""
     import torch

@@ -348,8 +348,9 @@ def test_loglik_tiled_path_ragged_sizes_vs_oracle(ops):
                 assert np.allclose(g, ref[:C], rtol=REL, atol=1e-9), (n, n_bins, model, C)
                 assert np.allclose(g, got[NC][:C], rtol=1e-11, atol=0)
             # chains 16.. of the 33 are scored by the second and third group of sixteen: the same values as on their own
+            # (to rounding: the number of lineage tiles - the summation order - depends on the number of chain groups)
             tail = _np(ops.bd_loglik_batch(tsd, ted, t0, lam[16:], mu[16:], model, br))
-            assert np.array_equal(tail[:16], got[NC][16:32]) and np.allclose(tail[16], got[NC][32], rtol=1e-11)
+            assert np.allclose(tail, got[NC][16:], rtol=1e-11, atol=0)
         tsu = torch.as_tensor(np.concatenate([[0.0], ts])).cuda()[1:]
         teu = torch.as_tensor(np.concatenate([[0.0], te])).cuda()[1:]
         for C in (1, 3, 9, 17):

@@ -3,7 +3,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + '/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        agg[r['Kernel_Name'].split('(')[0][-48:]][r['Counter_Name']].append(float(r['Counter_Value']))
+        agg[r['Kernel_Name'].split('(')[0][-72:]][r['Counter_Name']].append(float(r['Counter_Value']))
 res = {}
 for k, d in agg.items():
     if 'lr_' not in k:

@@ -28,9 +28,11 @@ rows = []
 for run in sorted(glob.glob(os.path.join(src, "abi_*"))):
     for f in glob.glob(os.path.join(run, "*", "*kernel_stats.csv")) + glob.glob(os.path.join(run, "*kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
+            if not r["Name"].startswith(("lr_", "void lr_")):          # the library's kernels (torch's while the input is made: not filed)
+                continue
             rows.append({"run": os.path.basename(run), "kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]),
                          "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])})
 json.dump({"source": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --abi-child --abi-kernel <k> "
-                     "--abi-n <n> --chains <c> (three calls each; scratch/collect_r04.sh)", "rows": rows},
+                     "--abi-n <n> --chains <c> (three calls each, then three of the read-only yardstick on the same arrays; scratch/collect_r05.sh)", "rows": rows},
           open(os.path.join(root, "profiles/%s_abi_kernel_stats.json" % tag), "w"), indent=1)
 print(len(rows), "kernel-stat rows;", "value %.3e" % b["value"], "driver args %.3e" % d["value"])

@@ -218,6 +218,10 @@ __global__ __launch_bounds__(256) void lr_pairscan_kernel(lr_packed_lineages pk,
 // not add to the scan loop's, and both fit the 128-VGPR budget of 4 waves per SIMD.
 // Every pointer is LDS-typed: the argument block (copied to LDS once per launch; reading it through the generic pointer
 // to global memory costs an L2 round trip per field), the per-wave scratch, the state rows and the pair table.
+#ifndef LR_P4_STEPPER_DRAWS
+#define LR_P4_STEPPER_DRAWS 0   /* helper form, 1: a stepper makes the draws of its chain's NEXT step itself, behind its step
+                                   (measured: cfg4 6.66 us per iteration against 6.36 - EXPERIMENTS.md, round 5) */
+#endif
 #ifndef LR_P4_LAST_SUMS
 #define LR_P4_LAST_SUMS 1    /* four-chain kernel: the last scanner wave to finish reduces the block's scan sums */
 #endif
@@ -335,7 +339,11 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
             const unsigned long long dq0 = wall_clock64();
 #endif
             const int c = c0 + 2 * ph + wave;
+#ifdef LR_P4_NOSTEP
+            if (false) {        // (timing experiment: the phases without their chain steps - the scan alone; results are void)
+#else
             if (c < n_chains) {
+#endif
                 double lik = 0.0;
 #pragma unroll
                 for (int w2 = 2; w2 < (LR_P4_LAST_SUMS != 0 && ES == 2 /* unit resolution: the block's sums in slot 2 */ ? 3 : NW); ++w2) lik += red[(ph * NW + w2) * 2 + wave];
@@ -349,6 +357,17 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
                     a3, c, lane, scratch3, st_f64 + (2 * ph + wave) * (LR_STATE_ROWS * LR_ROW),
                     st_i32 + (2 * ph + wave) * (LR_ISTATE_ROWS * LR_ROW), lik, tab + ph * tab_doubles + wave, br3,
                     draws + (2 * ph + wave), HELP ? hands + wave : nullptr, (int)((2 * iter + ph + 1) & 0x3fffffff));
+                if (HELP && !SPEC && LR_P4_STEPPER_DRAWS) {
+                    // (experiment, off) The state-independent draws of this chain's NEXT step (iteration IT + 1, used two
+                    // phases on) by the stepper itself, which is done 1.7 us into a 3.15 us phase: on the scanner waves 4, 5
+                    // the Philox call sits BEHIND their scans (the four-chain kernel with its steps compiled out: 3.53 us per
+                    // phase with the draws, 2.97 without).  Same (iteration, purpose, index) addresses: the stream does not
+                    // change - and cfg4 runs 5 % SLOWER: more work on the steppers' SIMDs, once more.
+                    const int* Ic = (const int*)(st_i32 + (2 * ph + wave) * (LR_ISTATE_ROWS * LR_ROW)) + LR_IROW_SCALARS * LR_ROW;
+                    LR_WAVE_LDS_ORDER();
+                    const unsigned long long itn = ((unsigned long long)(unsigned int)Ic[LR_I_IT_HI] << 32 | (unsigned int)Ic[LR_I_IT_LO]) + 1ull;
+                    lr_spec_draw_both(*(const lr_step_args*)a3, c, lane, itn, const_cast<lr_draw_slot*>(draws) + (2 * ph + wave));
+                }
             }
 #ifdef LR_DIAG
             const unsigned long long dq1 = wall_clock64();
@@ -613,6 +632,9 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     auto draw_duty = [&](int pr, int ahead = SPEC ? 2 : 1, int qoff = SPEC ? LR_P4_DRAW_WAVE : 0) {
         const int q = wave - W0 - qoff, k = q & 1, ch = 2 * pr + k;      // (the oldest scanner waves: the first to finish)
         if (!draw_ahead || q < 0 || q >= (HELP ? 2 : 4) || (int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
+#if defined(LR_P4_NOSTEP) && LR_P4_NOSTEP >= 2
+        return;                    // (timing experiment: not even the draws)
+#endif
         const int* I = st_i32[ch] + LR_IROW_SCALARS * LR_ROW;
         const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + (unsigned long long)ahead;
         lr_draw_slot* slot = SPEC ? &draws[2 * ch + (int)(it & 1ull)] : &draws[ch];
@@ -627,6 +649,9 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
         const int k = wave - 2;
         const int ch = 2 * ph + k;
         if ((int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
+#ifdef LR_P4_NOSTEP
+        return;
+#endif
         lr_table_hand* hand = SPEC ? &hands[2 * ch + par] : &hands[k];
 #ifdef LR_DIAG
         const unsigned long long dh0 = wall_clock64();
@@ -723,6 +748,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // iteration 1 for pair 1 (phase A's scan of pair 1 adds its iteration 2): three pairs of scanner waves, a call each)
     auto prologue_draws = [&]() {
         if (SPEC) draw_duty(0, 1, 2), draw_duty(0, 2, 6), draw_duty(1, 1, 10);     // (waves 6, 7; 10, 11; 14, 15: SIMDs 2, 3)
+        else if (HELP && LR_P4_STEPPER_DRAWS) draw_duty(0, 1, 0), draw_duty(1, 1, 2);    // both pairs' first steps; later ones: the steppers
         else draw_duty(0);
     };
     if (carried) {
@@ -796,7 +822,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
                     if (lane == 0) red[1 - ph][wave][0] = s0, red[1 - ph][wave][1] = s1;
                 }
                 lr_scan_drain(tail);      // the idle prefetch of the scan's last trip (lr_scan.h)
-                draw_duty(1 - ph);
+                if (!(HELP && !SPEC && LR_P4_STEPPER_DRAWS)) draw_duty(1 - ph);
             }
 #ifdef LR_DIAG
             const unsigned long long dq1 = wall_clock64();

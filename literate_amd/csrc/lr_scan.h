@@ -453,9 +453,17 @@ __device__ __forceinline__ void lr_gload_wait(lr_u32x4& a, lr_u32x4& b, lr_u32x4
 struct lr_scan_tail {
     lr_u32x4 w, f0, f1, f2;
 };
+#ifndef LR_SCAN_DEPTH2
+#define LR_SCAN_DEPTH2 0     /* unit-resolution ZERO_TAIL scans (lr_persist_scan_pair), experiments of round 5: 1 = two groups per
+                                lane in flight (cfg4 6.28-6.30 us per iteration against 6.27-6.33: the scan does not wait for its
+                                group loads), 2 = two groups per TRIP (6.70: a wasted half trip at 8.5 trips, more registers) */
+#endif
 __device__ __forceinline__ void lr_scan_drain(lr_scan_tail& t, bool with_fractions = false) {
     lr_gload_wait<0>(t.w);
     if (with_fractions) lr_gload_wait<0>(t.f0, t.f1, t.f2);
+#if LR_SCAN_DEPTH2
+    else lr_gload_wait<0>(t.f0);       // (unit resolution: the second idle load of a two-deep scan; a no-op wait otherwise)
+#endif
 }
 
 // Scan of `n8` groups against ONE pair table (unit resolution, six planes of 16-byte entries = the two chains' values)
@@ -553,10 +561,105 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
     static_assert(!(ONE && ASYNC), "the one-chain form exists for the plain-load slices only");
     if (!ASYNC) {
         lr_persist_scan_pair_slice<H, UNROLL, ONE>(lbase, idx8, n8, sid, n_scan, acc0_, acc1_, first);
-        if (tail) tail->w = lr_u32x4{0u, 0u, 0u, 0u};
+        if (tail) tail->w = lr_u32x4{0u, 0u, 0u, 0u}, tail->f0 = lr_u32x4{0u, 0u, 0u, 0u};
         return;
     }
     double acc0 = *acc0_, acc1 = *acc1_;
+#if LR_SCAN_DEPTH2
+    if (ZERO_TAIL && !first && tail) {
+        // (experiment, off by default) TWO groups in flight per lane: registers A and B take the groups of alternate trips, a
+        // wait leaves the younger load in flight (vmcnt(1): vector-memory loads return in order).  The four-chain kernel with
+        // its chain steps compiled out (-DLR_P4_NOSTEP=2) takes 2.97 us per phase for 9 trips = 0.33 us a trip, twice what the
+        // trip's LDS gathers (35 cycles of the CU's LDS path x 12 waves) and vector instructions need - but not because the scan
+        // waited for its group loads: with two in flight nothing changes.
+        const int n = __builtin_amdgcn_readfirstlane((int)n8);
+        const char* gnext = lr_uniform_ptr(idx8);
+        const unsigned int stride_b = (unsigned int)n_scan * 16u;
+        const unsigned int off = (unsigned int)sid * 16u;
+        int i0 = __builtin_amdgcn_readfirstlane((int)sid);
+        bool has = i0 < n;
+        lr_u32x4 wA = {0u, 0u, 0u, 0u}, wB = {0u, 0u, 0u, 0u};
+        lr_gload16_async(wA, gnext, off);
+        gnext += (i0 + n_scan < n) ? stride_b : 0u;       // (past the end: the same group again - a line the wave has just had)
+        lr_gload16_async(wB, gnext, off);
+#define LR_SCAN_TRIP(W)                                                                                                        \
+        {                                                                                                                      \
+            lr_gload_wait<1>(W);                                                                                               \
+            const unsigned int oS = W.x & 0xfff0u;                                                                             \
+            const double cnt = (double)(W.x & 0xfu);                                                                           \
+            const unsigned int o0 = lr_word_off16(W.x, 1), o1 = lr_word_off16(W.y, 0), o2 = lr_word_off16(W.y, 1),             \
+                               o3 = lr_word_off16(W.z, 0), o4 = lr_word_off16(W.z, 1), o5 = lr_word_off16(W.w, 0),             \
+                               o6 = lr_word_off16(W.w, 1);                                                                     \
+            i0 += n_scan, has = i0 < n;                                                                                        \
+            gnext += (i0 + n_scan < n) ? stride_b : 0u;                                                                        \
+            lr_gload16_async(W, gnext, off);               /* the group two trips on, into the registers just decoded */      \
+            const double2 S = *reinterpret_cast<const double2*>(lbase + oS);                                                   \
+            const double2 E0 = *reinterpret_cast<const double2*>(lbase + o0), E1 = *reinterpret_cast<const double2*>(lbase + o1); \
+            const double2 E2 = *reinterpret_cast<const double2*>(lbase + o2), E3 = *reinterpret_cast<const double2*>(lbase + o3); \
+            const double2 E4 = *reinterpret_cast<const double2*>(lbase + o4), E5 = *reinterpret_cast<const double2*>(lbase + o5); \
+            const double2 E6 = *reinterpret_cast<const double2*>(lbase + o6);                                                  \
+            const double u0 = ((E0.x + E1.x) + (E2.x + E3.x)) + ((E4.x + E5.x) + E6.x);                                        \
+            const double u1 = ((E0.y + E1.y) + (E2.y + E3.y)) + ((E4.y + E5.y) + E6.y);                                        \
+            acc0 += fma(cnt, S.x, u0);                                                                                         \
+            acc1 += fma(cnt, S.y, u1);                                                                                         \
+        }
+#if LR_SCAN_DEPTH2 == 2
+        // TWO groups per trip: both decoded, both next loads issued, sixteen gathers in flight, then the arithmetic of both -
+        // half as many waits for the LDS per group
+        while (has) {
+            lr_gload_wait<0>(wA);
+            lr_gload_wait<0>(wB);
+            const unsigned int aS = wA.x & 0xfff0u, bS = wB.x & 0xfff0u;
+            const double acnt = (double)(wA.x & 0xfu);
+            const unsigned int a0 = lr_word_off16(wA.x, 1), a1 = lr_word_off16(wA.y, 0), a2 = lr_word_off16(wA.y, 1),
+                               a3 = lr_word_off16(wA.z, 0), a4 = lr_word_off16(wA.z, 1), a5 = lr_word_off16(wA.w, 0),
+                               a6 = lr_word_off16(wA.w, 1);
+            i0 += n_scan;
+            const bool hasB = i0 < n;                      // the second group of this trip exists
+            // (a B past the end: the re-read of A's line - its count and offsets are masked to entry 0 = 0.0 below)
+            const unsigned int mB = hasB ? 0xffffffffu : 0u;
+            const double bcnt = (double)(wB.x & 0xfu & mB);
+            const unsigned int bSo = bS & mB;
+            const unsigned int b0 = lr_word_off16(wB.x, 1) & mB, b1 = lr_word_off16(wB.y, 0) & mB, b2 = lr_word_off16(wB.y, 1) & mB,
+                               b3 = lr_word_off16(wB.z, 0) & mB, b4 = lr_word_off16(wB.z, 1) & mB, b5 = lr_word_off16(wB.w, 0) & mB,
+                               b6 = lr_word_off16(wB.w, 1) & mB;
+            i0 += n_scan, has = i0 < n;
+            gnext += (i0 < n) ? stride_b : 0u;
+            lr_gload16_async(wA, gnext, off);
+            gnext += (i0 + n_scan < n) ? stride_b : 0u;
+            lr_gload16_async(wB, gnext, off);
+            const double2 S = *reinterpret_cast<const double2*>(lbase + aS), T = *reinterpret_cast<const double2*>(lbase + bSo);
+            const double2 E0 = *reinterpret_cast<const double2*>(lbase + a0), E1 = *reinterpret_cast<const double2*>(lbase + a1);
+            const double2 E2 = *reinterpret_cast<const double2*>(lbase + a2), E3 = *reinterpret_cast<const double2*>(lbase + a3);
+            const double2 E4 = *reinterpret_cast<const double2*>(lbase + a4), E5 = *reinterpret_cast<const double2*>(lbase + a5);
+            const double2 E6 = *reinterpret_cast<const double2*>(lbase + a6);
+            const double2 F0 = *reinterpret_cast<const double2*>(lbase + b0), F1 = *reinterpret_cast<const double2*>(lbase + b1);
+            const double2 F2 = *reinterpret_cast<const double2*>(lbase + b2), F3 = *reinterpret_cast<const double2*>(lbase + b3);
+            const double2 F4 = *reinterpret_cast<const double2*>(lbase + b4), F5 = *reinterpret_cast<const double2*>(lbase + b5);
+            const double2 F6 = *reinterpret_cast<const double2*>(lbase + b6);
+            const double u0 = ((E0.x + E1.x) + (E2.x + E3.x)) + ((E4.x + E5.x) + E6.x);
+            const double u1 = ((E0.y + E1.y) + (E2.y + E3.y)) + ((E4.y + E5.y) + E6.y);
+            acc0 += fma(acnt, S.x, u0);
+            acc1 += fma(acnt, S.y, u1);
+            const double v0 = ((F0.x + F1.x) + (F2.x + F3.x)) + ((F4.x + F5.x) + F6.x);
+            const double v1 = ((F0.y + F1.y) + (F2.y + F3.y)) + ((F4.y + F5.y) + F6.y);
+            acc0 += fma(bcnt, T.x, v0);
+            acc1 += fma(bcnt, T.y, v1);
+        }
+#else
+        while (has) {
+            LR_SCAN_TRIP(wA)
+            if (!has) break;
+            LR_SCAN_TRIP(wB)
+        }
+#endif
+#undef LR_SCAN_TRIP
+        // both idle loads are still in flight: the caller drains them (lr_scan_drain)
+        tail->w = wA, tail->f0 = wB;
+        *acc0_ = acc0, *acc1_ = acc1;
+        return;
+    }
+#endif
     // 32-bit loop arithmetic (fewer than 2^27 groups)
     const int n = ZERO_TAIL ? __builtin_amdgcn_readfirstlane((int)n8) : (int)n8;
     // The group address of a trip = a wave-uniform base (scalar registers, advanced by scalar instructions) + the lane's
@@ -600,7 +703,7 @@ __device__ __forceinline__ void lr_persist_scan_pair(const char* __restrict__ lb
     }
     // the idle load of the last trip is still in flight: the caller drains it (lr_scan_drain) once it has done what does
     // not need the registers - or it is waited for here
-    if (tail) tail->w = w;
+    if (tail) tail->w = w, tail->f0 = lr_u32x4{0u, 0u, 0u, 0u};
     else lr_gload_wait<0>(w);
     *acc0_ = acc0, *acc1_ = acc1;
 }

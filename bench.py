@@ -777,7 +777,7 @@ def _abi_row(rows, n, **match):
 def compact_line(d):
     """The final stdout line: every field the driver's contract names + `roofline` + `cpu_baseline` + one-number
     summaries of the side sections - scalars and short names only, no prose; everything else stays in the detail
-    (bench_detail.json, and `#detail` lines printed BEFORE this one).  Pure function of the detail dict."""
+    (bench_detail.json, and `#detail` lines on stderr).  Pure function of the detail dict."""
     cfg, r, c = d["config"], d["roofline"], d.get("cpu_baseline")
     out = {k: (_sig(d[k], 9) if isinstance(d[k], float) else d[k]) for k in (
         "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -840,9 +840,11 @@ def compact_line(d):
     return out
 
 
-def emit(detail, stream=None):
-    """Write the detail (bench_detail.json; `#detail <section> <json>` lines on stdout) and print the compact line LAST."""
+def emit(detail, stream=None, detail_stream=None):
+    """Write the detail (bench_detail.json; `#detail <section> <json>` lines on STDERR) and print the compact line - the ONLY
+    stdout line of the run, so that it is what the driver parses whichever end of stdout it keeps."""
     stream = stream or sys.stdout
+    detail_stream = detail_stream or (sys.stderr if stream is sys.stdout else stream)
     path = os.environ.get("LR_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -853,7 +855,8 @@ def emit(detail, stream=None):
         detail["detail_file"] = None
     for k in ("configs", "co_headline", "strong_scaling", "cpu_baseline", "abi", "config", "roofline"):
         if detail.get(k) is not None:
-            stream.write("#detail %s %s\n" % (k, json.dumps(detail[k])))
+            detail_stream.write("#detail %s %s\n" % (k, json.dumps(detail[k])))
+    detail_stream.flush()
     line = json.dumps(compact_line(detail), separators=(",", ":"))
     assert len(line) < 2 * COMPACT_LIMIT, len(line)
     stream.write(line + "\n")
@@ -894,7 +897,7 @@ def main():
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "w") as f:
             json.dump({"abi": a}, f)
-        print("#detail abi " + json.dumps(a))
+        print("#detail abi " + json.dumps(a), file=sys.stderr)
         print(json.dumps({"abi": compact_line({"config": {"workload": ""}, "roofline": {}, "abi": a, **{k: None for k in (
             "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data")}})["abi"]}, separators=(",", ":")))

@@ -68,15 +68,19 @@ def test_committed_bench_line_has_the_contract_fields():
                                     "r04_bench_cfg4_1gpu_driver_args.json", "r03_bench_cfg4_1gpu.json"])
 def test_final_stdout_line_is_compact_and_survives_the_drivers_tail(detail, tmp_path, monkeypatch):
     """Round 4's line had grown to 28 KB and the driver, which keeps the last 8 KB of stdout, could not parse it.  bench.py
-    now prints the detail as `#detail` lines (and writes bench_detail.json) and ends with ONE compact line built by
-    compact_line(): under 4 KB, scalars only inside `config` / `roofline` / `cpu_baseline` (the driver's parser drops nested
-    objects there), and recoverable from the last 8081 characters of stdout - the size of the driver's tail."""
+    now writes the detail to bench_detail.json (and as `#detail` lines to STDERR) and prints ONE compact line built by
+    compact_line() - the only stdout line: under 4 KB, scalars only inside `config` / `roofline` / `cpu_baseline` (the
+    driver's parser drops nested objects there).  Even with the detail lines on the same stream (as here) it is recoverable
+    from the last 8081 characters - the size of the driver's tail."""
     import io
     import sys
     sys.path.insert(0, ROOT)
     import bench
     d = json.load(open(os.path.join(ROOT, "profiles", detail)))
     monkeypatch.setenv("LR_BENCH_DETAIL", str(tmp_path / "bench_detail.json"))
+    out, err = io.StringIO(), io.StringIO()
+    assert bench.emit(dict(d), out, err) == out.getvalue().rstrip("\n") and out.getvalue().count("\n") == 1       # stdout: the line alone
+    assert err.getvalue().startswith("#detail ") and all(l.startswith("#detail ") for l in err.getvalue().splitlines())
     buf = io.StringIO()
     line = bench.emit(d, buf)
     assert len(line) < bench.COMPACT_LIMIT < 8192

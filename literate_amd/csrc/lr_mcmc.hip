@@ -537,6 +537,9 @@ __global__ __launch_bounds__(T, LR_PERSIST_MINWAVES) void lr_persist_kernel(
 #ifndef LR_P4_UNROLL
 #define LR_P4_UNROLL 1
 #endif
+#ifndef LR_P4_AGE_PRIO
+#define LR_P4_AGE_PRIO 0
+#endif
 #ifndef LR_P4_DRAW_WAVE
 #define LR_P4_DRAW_WAVE 2    /* SPEC form: first of the two scanner slots (wave 4 + slot) that make the draws ahead */
 #endif
@@ -715,6 +718,15 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     const bool scanner = wave >= W0;
     const bool helper = HELP && (wave == 2 || wave == 3);
     const int sid = tid - W0 * LR_WAVE;
+#if LR_P4_AGE_PRIO
+    // (experiment) issue priorities that offset the arbiter's oldest-first rule among the scanners of a SIMD: waves 4..7
+    // priority 0, 8..11 1, 12..15 2, steppers and helpers 3 - in the step-less kernel the youngest scanners end their scans
+    // 0.6 us after the oldest, and a phase waits for them
+    if (!scanner) __builtin_amdgcn_s_setprio(3);
+    else if (wave >= 12) __builtin_amdgcn_s_setprio(LR_P4_AGE_PRIO == 2 ? 1 : 2);
+    else if (wave >= 8) __builtin_amdgcn_s_setprio(LR_P4_AGE_PRIO == 2 ? 0 : 1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     // The SIMD issue arbiter serves its oldest wave first: with equal shares the scanner waves of a SIMD finish one
     // after the other (5.0 / 6.4 / 7.9 / 9.5 us per phase, measured with in-kernel stamps), the youngest runs the tail
     // alone, and SIMDs 0, 1 carry the stepper waves on top.  So the waves get unequal shares (lr_p4_shares) chosen to

@@ -330,7 +330,7 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
                                                                lr_lds_f64* tab, int tab_doubles, lr_lds_f64* br3, long long n_iters,
                                                                const lr_draw_slot* draws /* [4]: made ahead (RJ sampler) */,
                                                                lr_table_hand* hands /* [2] */, lr_pend* pend = nullptr) {
-    static_assert(!HELP || (LR_P4_DRAW_AHEAD != 0 && ES == 2 && SAMPLER == 0 && LR_P4_LAST_SUMS != 0), "helper waves: RJ sampler at unit resolution");
+    static_assert(!HELP || (LR_P4_DRAW_AHEAD != 0 && ES == 2 && SAMPLER == 0), "helper waves: RJ sampler at unit resolution");
     static_assert(!SPEC || HELP, "speculation on rejection: the form with helper waves");
     for (long long iter = 0; iter < n_iters; ++iter) {
 #pragma unroll 1
@@ -685,7 +685,13 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // NS + 1)
     constexpr int NA = NS + (HELP ? 2 : 0);
     auto leave_sums = [&](int pr, double s0, double s1) {
-        lr_p4_leave_sums<NA>(part, &arrived, &red[pr][2][0], wave >= W0 ? wave - W0 : NS + wave - 2, lane, scans_done, s0, s1);
+        if (LAST_SUMS) {
+            lr_p4_leave_sums<NA>(part, &arrived, &red[pr][2][0], wave >= W0 ? wave - W0 : NS + wave - 2, lane, scans_done, s0, s1);
+        } else {
+            // (-DLR_P4_LAST_SUMS=0: every scanning wave adds its own lanes up; the stepper adds the waves' sums in wave order)
+            s0 = lr_wave_sum(s0), s1 = lr_wave_sum(s1);
+            if (lane == 0) red[pr][wave][0] = s0, red[pr][wave][1] = s1;
+        }
     };
     const int c0 = blockIdx.x * 4;
     const int C = a.cfg.n_chains;

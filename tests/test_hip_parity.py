@@ -201,6 +201,16 @@ def test_streaming_kernels_at_1e7_lineages(ops, general):
     # lineage-time is conserved: sum over the windows = sum of the clipped durations
     total = (torch.clamp(te, max=float(W)) - torch.clamp(ts, min=0.0)).clamp(min=0.0).sum()
     assert float(br.sum()) == pytest.approx(float(total), rel=1e-12)
+    # ... and window by window against torch's own arithmetic (no kernel of this library: get_br's definition, lib:74-85,
+    # overlap of [ts, te] with [w, w + 1] summed over the lineages, in chunks of windows)
+    br_torch = torch.empty(W, dtype=torch.float64, device="cuda")
+    for w0 in range(0, W, 8):
+        lo_w = torch.arange(w0, min(w0 + 8, W), dtype=torch.float64, device="cuda")[:, None]
+        ov = (torch.minimum(te[None, :], lo_w + 1.0) - torch.maximum(ts[None, :], lo_w)).clamp_(min=0.0)
+        ov[:, te <= ts] = 0.0                                # (a lineage with te <= ts carries no time: lib:74-79)
+        br_torch[w0:w0 + ov.shape[0]] = ov.sum(1)
+        del ov
+    assert torch.allclose(br, br_torch, rtol=1e-11, atol=0)
     # a split, and a permutation: bit-identical (the accumulation is integer)
     cut = 3_333_333
     a = ops.bin_unit_events(ts[:cut], te[:cut], t0, W)
@@ -217,7 +227,8 @@ def test_streaming_kernels_at_1e7_lineages(ops, general):
     lam = np.exp(rng.uniform(np.log(.05), np.log(.6), (C, W)))
     mu = np.exp(rng.uniform(np.log(.02), np.log(.3), (C, W)))
     full = _np(ops.bd_loglik_batch(ts, te, t0, lam, mu, 2))
-    sp_, ex_, br_ = _np(sp), _np(ex), _np(br)
+    # (the statistics of the binned form from torch - bincount and the overlap sums above -, not from this library's binning)
+    sp_, ex_, br_ = _np(torch.bincount(torch.floor(ts).long(), minlength=W)[:W]), _np(torch.bincount(be[be < W], minlength=W)[:W]), _np(br_torch)
     keiding = (np.log(lam) * sp_ - lam * br_).sum(1) + (np.log(mu) * ex_ - mu * br_).sum(1)
     assert np.allclose(full, keiding, rtol=REL)
     a = _np(ops.bd_loglik_batch(ts[:cut], te[:cut], t0, lam, mu, 2))

@@ -312,6 +312,39 @@ __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((a
     lr_persist_step_body<PB, ES>(a3, c, lane, scratch3, st_f64, st_i32, lik, table3, br3);
 }
 
+// ---- FLOW (-DLR_P4_FLOW=1; helper form): the phases of the four-chain kernel without their block-wide barrier -------------
+// In-kernel stamps of the step-less kernel (profiles/r05_p4_wave_stamps.txt): the twelve scanner waves of a phase start
+// together behind the barrier, the oldest are done after 1.9-2.2 us, the youngest after 2.5-2.65, the wave that arrives last
+// adds the block's sums (~0.3 us), then 0.3-0.5 us of barrier - about 1 us of a 3.15 us phase is waiting for one another.
+// Here every role runs on what it really needs:
+//   a scanning wave starts the scan of pair p's proposal q when both columns of its table stand (tab_epoch[p] >= 2 (q + 1));
+//   the wave that arrives LAST at the end of that scan (arrived[p] == NA (q + 1)) adds the sums and publishes sums_epoch[p] = q + 1;
+//   a stepper decides proposal q of its chain when sums_epoch[p] >= q + 1; its helper builds proposal q + 1's column behind
+//   the hand-over and bumps tab_epoch[p].
+// No wait can cycle: a wave finishes scan (p, q) before it waits for (p, q + 1), whose table needs the step that needs the
+// sums of (p, q).  The sums are added in slot order by whoever is last: the same doubles as with barriers.  A wait that
+// does not end within ~0.25 s raises the engine's status word and ends the launch (every other wait then ends too).
+#ifndef LR_P4_FLOW
+#define LR_P4_FLOW 0
+#endif
+struct lr_p4_flow_lds {
+    double2 part[2][14][LR_WAVE];                                // [pair][scanning wave][lane]: the lanes' sums of the pair's current scan
+    int arrived[2], sums_epoch[2], tab_epoch[2];
+    int abort, pad_;
+};
+__device__ __forceinline__ bool lr_flow_wait(const int* flag, int target, int* abort) {
+    for (unsigned int spins = 0;; ++spins) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) break;
+        if (spins > (1u << 21) || __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+            __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
 // The stepper waves' whole launch in the four-chain kernel as ONE call: a call per step costs the callee-saved
 // registers' round trip through scratch memory every time (24 dwords x 64 lanes out and back: 0.5 + 0.2 us of a 3.6 us
 // step, measured with in-kernel stamps), a call per launch costs it once.  The function keeps the step's own register
@@ -322,14 +355,15 @@ __device__ __attribute__((noinline)) void lr_persist_step(const __attribute__((a
 //   HELP: waves 2, 3 are helper waves - hands[wave] is this stepper's hand-over to wave 2 + wave (lr_persist4_kernel)
 //   SPEC: the step speculates on rejection (lr_chain_step_respec) - scratch3 / draws / hands are then [chain of the block][parity]
 //   and pend [chain of the block][parity]
-template <int PB, int ES, int NW, int SAMPLER, bool HELP, bool SPEC = false>
+template <int PB, int ES, int NW, int SAMPLER, bool HELP, bool SPEC = false, bool FLOW = false>
 __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute__((address_space(3))) lr_step_args* a3, int c0,
                                                                int n_chains, int wave, int lane,
                                                                __attribute__((address_space(3))) lr_seg_scratch* scratch3,
                                                                lr_lds_f64* st_f64, lr_lds_i32* st_i32, lr_lds_f64* red,
                                                                lr_lds_f64* tab, int tab_doubles, lr_lds_f64* br3, long long n_iters,
                                                                const lr_draw_slot* draws /* [4]: made ahead (RJ sampler) */,
-                                                               lr_table_hand* hands /* [2] */, lr_pend* pend = nullptr) {
+                                                               lr_table_hand* hands /* [2] */, lr_pend* pend = nullptr,
+                                                               lr_p4_flow_lds* fl = nullptr) {
     static_assert(!HELP || (LR_P4_DRAW_AHEAD != 0 && ES == 2 && SAMPLER == 0), "helper waves: RJ sampler at unit resolution");
     static_assert(!SPEC || HELP, "speculation on rejection: the form with helper waves");
     for (long long iter = 0; iter < n_iters; ++iter) {
@@ -339,6 +373,8 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
             const unsigned long long dq0 = wall_clock64();
 #endif
             const int c = c0 + 2 * ph + wave;
+            // FLOW: the sums of this pair's scan number `iter` instead of a barrier
+            if (FLOW && !lr_flow_wait(&fl->sums_epoch[ph], (int)iter + 1, &fl->abort)) return;
 #ifdef LR_P4_NOSTEP
             if (false) {        // (timing experiment: the phases without their chain steps - the scan alone; results are void)
 #else
@@ -372,7 +408,7 @@ __device__ __attribute__((noinline)) void lr_persist4_steppers(const __attribute
 #ifdef LR_DIAG
             const unsigned long long dq1 = wall_clock64();
 #endif
-            __syncthreads();
+            if (!FLOW) __syncthreads();
 #ifdef LR_DIAG
             if (lane == 0 && blockIdx.x < 64) {
                 atomicAdd(&lr_diag_step[16384 + (blockIdx.x * 16 + wave) * 4 + 0], dq1 - dq0);
@@ -564,6 +600,8 @@ struct lr_p4_spec_lds {
     lr_table_hand hands[8];
 };
 
+#define LR_P4_SPEC_LDS_BYTES ((sizeof(lr_p4_spec_lds) + 255) / 256 * 256)      /* the FLOW arrays follow the SPEC ones in dynamic LDS */
+
 // SPEC (with HELP): the steppers speculate on REJECTION (lr_chain_step_respec, lr_step.h): the proposal a chain makes next
 // if its pending one is rejected is staged one iteration early, so that a helper starts the table build at the DECISION
 // (~0.4 us into a phase) instead of after move + staging (~1.2 us); scratch, hand-over and draw slots are then per chain
@@ -605,6 +643,8 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     lr_table_hand* const hands = SPEC ? xs->hands : hands_s;
     lr_seg_scratch* const scratch = SPEC ? xs->scratch : scratch_s;
     lr_pend* const pend = xs->pend;
+    constexpr bool FLOW = LR_P4_FLOW != 0 && HELP;                   // (the phases without their barrier: lr_p4_flow_lds)
+    lr_p4_flow_lds* const fl = reinterpret_cast<lr_p4_flow_lds*>(reinterpret_cast<char*>(p4_dyn) + (SPEC ? LR_P4_SPEC_LDS_BYTES : 0));
     __shared__ double st_f64[4][LR_STATE_ROWS * LR_ROW];
     __shared__ int st_i32[4][LR_ISTATE_ROWS * LR_ROW];
     __shared__ lr_step_args a_lds;
@@ -632,14 +672,16 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     // stamps: 3.1 us of a 3.15 us phase against 2.2-2.9 for the others) - and still the draws cost least there: by waves 6, 7
     // (SIMDs 2, 3, beside the helpers) cfg4 ran 6.37-6.40 us per iteration against 6.25, A/B twice on one box; under SPEC, whose
     // helpers build early, the other way round: 7.05 against 6.87)
-    auto draw_duty = [&](int pr, int ahead = SPEC ? 2 : 1, int qoff = SPEC ? LR_P4_DRAW_WAVE : 0) {
+    auto draw_duty = [&](int pr, int ahead = SPEC ? 2 : 1, int qoff = SPEC ? LR_P4_DRAW_WAVE : 0, unsigned long long it_given = 0ull) {
         const int q = wave - W0 - qoff, k = q & 1, ch = 2 * pr + k;      // (the oldest scanner waves: the first to finish)
         if (!draw_ahead || q < 0 || q >= (HELP ? 2 : 4) || (int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
 #if defined(LR_P4_NOSTEP) && LR_P4_NOSTEP >= 2
         return;                    // (timing experiment: not even the draws)
 #endif
         const int* I = st_i32[ch] + LR_IROW_SCALARS * LR_ROW;
-        const unsigned long long it = ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + (unsigned long long)ahead;
+        // (FLOW: the iteration is given - the state row of a chain may still be in its stepper's hands)
+        const unsigned long long it = it_given ? it_given
+                                               : ((unsigned long long)(unsigned int)I[LR_I_IT_HI] << 32 | (unsigned int)I[LR_I_IT_LO]) + (unsigned long long)ahead;
         lr_draw_slot* slot = SPEC ? &draws[2 * ch + (int)(it & 1ull)] : &draws[ch];
         // (HELP: one wave per chain, one Philox call for both parts)
         if (HELP) lr_spec_draw_both(a_lds, (int)(blockIdx.x * 4) + ch, lane, it, slot);
@@ -651,14 +693,32 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     auto help_duty = [&](int ph, int epoch, int par = 0) {
         const int k = wave - 2;
         const int ch = 2 * ph + k;
-        if ((int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) return;
+        // (FLOW: a column that is not built - no such chain - still counts as standing)
+        auto column_stands = [&]() {
+            if (FLOW) {
+                LR_WAVE_LDS_ORDER();
+                if (lane == 0) __hip_atomic_fetch_add(&fl->tab_epoch[ph], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        if ((int)(blockIdx.x * 4) + ch >= ap->cfg.n_chains) { column_stands(); return; }
 #ifdef LR_P4_NOSTEP
+        column_stands();
         return;
 #endif
         lr_table_hand* hand = SPEC ? &hands[2 * ch + par] : &hands[k];
 #ifdef LR_DIAG
         const unsigned long long dh0 = wall_clock64();
 #endif
+        if (FLOW) {
+            // (bounded, and ended by any other wait's time-out: a stepper that gave up hands nothing over)
+            for (unsigned int spins = 0; __hip_atomic_load(&hand->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch; ++spins) {
+                if (spins > (1u << 21) || __hip_atomic_load(&fl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                    __hip_atomic_store(&fl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } else
         while (__hip_atomic_load(&hand->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
 #ifdef LR_DIAG
@@ -676,6 +736,7 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
             if (SPEC) pend[2 * ch + par].sc[LR_S_CONST_P] = constP;
             else st_f64[ch][LR_ROW_SCALARS * LR_ROW + LR_S_CONST_P] = constP;
         }
+        column_stands();
     };
     if (tid == 0) arrived = 0;
     if (tid < (SPEC ? 8 : 2)) hands[tid].epoch = 0;
@@ -794,6 +855,87 @@ __global__ __launch_bounds__(LR_P4_THREADS, LR_P4_THREADS / 256) void lr_persist
     }
     __syncthreads();
     LR_PSTAMP(3);      // prologue done: pair 0's sums (scanned or carried), the first draws
+    if (FLOW) {
+        // ---- the phases without their barrier (see lr_p4_flow_lds) ----
+        // pair 0's proposal 0 is scored (prologue / carried), both pairs' tables of proposal 0 stand
+        static_assert(!FLOW || NA == 14, "lr_p4_flow_lds holds fourteen scanning waves' sums per pair");
+        if (tid == 0) {
+            fl->arrived[0] = NA, fl->arrived[1] = 0, fl->sums_epoch[0] = 1, fl->sums_epoch[1] = 0;
+            fl->tab_epoch[0] = 2, fl->tab_epoch[1] = 2, fl->abort = 0;
+        }
+        // the pending iterations of the two chains a drawing wave serves (scanner slots 0, 1: chain k of either pair)
+        unsigned long long itd0 = 0, itd1 = 0;
+        constexpr int DQ = SPEC ? LR_P4_DRAW_WAVE : 0;          // first of the two scanner slots that draw
+        const bool drawer = scanner && wave - W0 >= DQ && wave - W0 < DQ + 2;
+        if (drawer) {
+            const int* I0 = st_i32[wave - W0 - DQ] + LR_IROW_SCALARS * LR_ROW;
+            const int* I1 = st_i32[2 + wave - W0 - DQ] + LR_IROW_SCALARS * LR_ROW;
+            itd0 = (unsigned long long)(unsigned int)I0[LR_I_IT_HI] << 32 | (unsigned int)I0[LR_I_IT_LO];
+            itd1 = (unsigned long long)(unsigned int)I1[LR_I_IT_HI] << 32 | (unsigned int)I1[LR_I_IT_LO];
+        }
+        __syncthreads();
+        // end of a wave's share of scan `q` of pair `pr`: its lanes' sums, its count - and the sums of the block by the wave
+        // that arrives last (per lane over the slots in slot order, then across the lanes: the same order whoever it is)
+        auto leave_flow = [&](int pr, int q, double s0, double s1) {
+            const int slot = wave >= W0 ? wave - W0 : NS + wave - 2;
+            fl->part[pr][slot][lane] = make_double2(s0, s1);
+            int prev = 0;
+            if (lane == 0) prev = __hip_atomic_fetch_add(&fl->arrived[pr], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            if (prev == NA * (q + 1) - 1) {
+                asm volatile("" ::: "memory");
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int w = 0; w < NA; ++w) {
+                    const double2 v = fl->part[pr][w][lane];
+                    a0 += v.x, a1 += v.y;
+                }
+                a0 = lr_wave_sum(a0), a1 = lr_wave_sum(a1);
+                if (lane == 0) red[pr][2][0] = a0, red[pr][2][1] = a1;
+                LR_WAVE_LDS_ORDER();
+                if (lane == 0) __hip_atomic_store(&fl->sums_epoch[pr], q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        if (helper) {
+            for (long long iter = 0; iter < n_iters; ++iter) {
+#pragma unroll 1
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int pr = 1 - ph, q = (int)iter + ph;          // pair 1's scan `iter`, then pair 0's scan `iter + 1`
+                    if (!lr_flow_wait(&fl->tab_epoch[pr], 2 * (q + 1), &fl->abort)) goto flow_done;
+                    double s0 = 0.0, s1 = 0.0;
+                    if (nh > 0) lr_persist_scan<H, GENERAL, 1, false, false>(reinterpret_cast<const char*>(tab[pr]), pk, 0, nh, tid - 2 * LR_WAVE, 2 * LR_WAVE, &s0, &s1);
+                    leave_flow(pr, q, s0, s1);
+                    help_duty(ph, (int)((2 * iter + ph + 1) & 0x3fffffff), SPEC ? ((ph ? it0_par1 : it0_par0) + (int)(iter & 1) + 1) & 1 : 0);
+                    if (__hip_atomic_load(&fl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) goto flow_done;
+                }
+            }
+        } else if (!scanner) {
+            lr_persist4_steppers<(H <= 264 ? lr_bins_per_lane(H) : 0), ES, NW, PARAM ? 1 : 0, HELP, SPEC, true>(
+                (const __attribute__((address_space(3))) lr_step_args*)&a_lds, c0, C, wave, lane,
+                (__attribute__((address_space(3))) lr_seg_scratch*)&scratch[SPEC ? 0 : wave], (lr_lds_f64*)&st_f64[0][0], (lr_lds_i32*)&st_i32[0][0],
+                (lr_lds_f64*)&red[0][0][0], (lr_lds_f64*)reinterpret_cast<double*>(tab[0]), 2 * LR_UNIT_PLANES * H,
+                (lr_lds_f64*)&br_lds[0][0], n_iters, &draws[0], &hands[0], &pend[0], fl);
+        } else {
+            for (long long iter = 0; iter < n_iters; ++iter) {
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int pr = 1 - ph, q = (int)iter + ph;
+                    if (!lr_flow_wait(&fl->tab_epoch[pr], 2 * (q + 1), &fl->abort)) goto flow_done;
+                    double s0 = 0.0, s1 = 0.0;
+                    lr_scan_tail tail;
+                    lr_persist_scan<H, GENERAL, LR_P4_UNROLL, false, true>(reinterpret_cast<const char*>(tab[pr]), pk, nh, n8w, sid, LR_P4_SCANNERS, &s0, &s1, nullptr, &tail);
+                    // the draws of the step that follows this scan BEFORE this wave counts as arrived (the stepper starts on the count)
+                    // (SPEC: two iterations beyond the proposal just scored - what the stepper stages at this decision)
+                    if (drawer) draw_duty(pr, SPEC ? 2 : 1, DQ, (pr ? itd1 : itd0) + (unsigned long long)q + (SPEC ? 2ull : 1ull));
+                    leave_flow(pr, q, s0, s1);
+                    lr_scan_drain(tail);
+                }
+            }
+        }
+    flow_done:
+        __syncthreads();
+        if (tid == 0 && fl->abort) __hip_atomic_store(ap->warn - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // status: a wait timed out
+    } else
     // phase ph of an iteration: the steppers advance pair `ph`, the scanners score pair `1 - ph`
     if (helper) {
         for (long long iter = 0; iter < n_iters; ++iter) {
@@ -1677,12 +1819,20 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         else if (param) hipLaunchKernelGGL((lr_persist4_kernel<HH, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);        \
         else if (e->p4_help && e->p4_spec) {                                                                                   \
             /* (helper waves: H <= 264, lr_p4_help_choice; the attribute belongs to the function on the CURRENT device) */     \
+            const size_t dyn_ = LR_P4_FLOW ? LR_P4_SPEC_LDS_BYTES + sizeof(lr_p4_flow_lds) : sizeof(lr_p4_spec_lds);            \
             hipError_t he_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lr_p4_spec_lds));     \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_);                       \
             if (he_ != hipSuccess) return (int)he_;                                                                            \
-            hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), g4, b4, sizeof(lr_p4_spec_lds), stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
+            hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true, true>), g4, b4, dyn_, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
         }                                                                                                                      \
-        else if (e->p4_help) hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
+        else if (e->p4_help) {                                                                                                 \
+            if (LR_P4_FLOW) {                                                                                                  \
+                hipError_t he_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true>), \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lr_p4_flow_lds)); \
+                if (he_ != hipSuccess) return (int)he_;                                                                        \
+            }                                                                                                                  \
+            hipLaunchKernelGGL((lr_persist4_kernel<(HH <= 264 ? HH : 264), false, false, true>), g4, b4, LR_P4_FLOW ? sizeof(lr_p4_flow_lds) : 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry); \
+        }                                                                                                                      \
         else hipLaunchKernelGGL((lr_persist4_kernel<HH, false, false>), g4, b4, 0, stream, ap, pk, e->n8, e->p4, (long long)n, p4_carry);                  \
     } else if (wide) {                                                                                                        \
         hipLaunchKernelGGL((lr_persist_kernel<HH, 1024>), dim3(blocks), dim3(1024), 0, stream, ap, idx8, e->n8, e->p4, (long long)n, 0); \

@@ -207,7 +207,9 @@ typedef struct lr_mcmc_config {
     int32_t unit_resolution;
     int32_t engine_mode;      /* 0 = auto, 1 = launch-per-iteration engine (fused, pipelined), 2 = a persistent kernel
                                * (the library picks which), 3 = four chains per block, 4 = two chains per block,
-                               * 5 = speculative team kernel (lr_mcmc_layout.persistent tells what runs)               */
+                               * 5 = speculative team kernel, 6 = the launch-based plan with its iterations inside the
+                               * resident streaming kernel where it applies (lr_mcmc_layout.persistent / .streaming tell
+                               * what runs)                                                                             */
     double frac_birth;
     double frac_death;
     /* ---- sampler 1: the DDRate.py Metropolis-Hastings loop (DD:124-241) on the same engine -------------
@@ -259,7 +261,10 @@ typedef struct lr_mcmc_layout {
     int64_t lineage_frac; /* [3][groups] uint4: fe' of the 7 slots + sum of fs (table_mode 2)                               */
     int64_t pack_tmp;     /* scratch of the lineage packing (two int32 per lineage + the scans' temporary storage)       */
     int32_t spec_chains_per_team; /* speculative kernel: chains a team of blocks owns - 2 (a pair) or 1; 0 for the other engines */
-    int32_t reserved2;
+    int32_t streaming;    /* 1 (persistent == 0 only): too few chains for the pipelined schedule - the iterations run inside one
+                           * RESIDENT kernel (csrc/lr_stream.hip: scanner blocks + a stepper wave per chain, the step taken
+                           * ahead on the assumption that the pending proposal is rejected) wherever its grid fits the device
+                           * at once; xchg then holds the launch's counters and the second table buffer                      */
 } lr_mcmc_layout;
 
 /* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */

@@ -44,6 +44,8 @@ struct lr_engine {
     bool p4_help;             // four-chain kernel: the form with helper waves - latched by lr_set_shares (init / restore), so
                               // that the form, its shares and the sums carried between launches belong together for a whole run
     bool p4_spec;             // ... whose steppers speculate on rejection (lr_chain_step_respec); latched with p4_help
+    bool streaming;           // launch-based plan, but the iterations run inside ONE resident kernel (lr_stream.hip): latched by
+                              // lr_mcmc_create, which asks the device in use whether the whole grid fits it at once
     hipEvent_t fork;
     hipEvent_t ev0, ev1;      // timing events of lr_mcmc_time_steps / lr_mcmc_time_scan, created once
 };
@@ -121,6 +123,31 @@ static inline int lr_spec_mode(const lr_engine* e) {
     const bool by_scanners = env ? atoi(env) != 0 : trips <= 3.0;
     return by_scanners ? 2 : 3;
 }
+
+// ---- resident streaming engine (lr_stream.hip) ----
+#define LR_STEP_WAVES_PER_BLOCK (LR_SCAN_THREADS / LR_WAVE)
+// counters of one launch, in the workspace at lr_mcmc_layout.xchg, each on a cache line of its own; the second table buffer
+// follows LR_STREAM_SYNC_BYTES behind
+#define LR_STREAM_COPIES 64
+#define LR_STREAM_MAX_CHAINS 16
+struct lr_stream_sync {
+    unsigned long long arrived;      // scanner blocks that have stored their tile's partial sums, over the launch's iterations
+    unsigned long long pad0[15];
+    // what the stepper wave of chain c has published, LR_STREAM_COPIES times - one 128-byte line per copy holds all chains'
+    // words, and scanner block b polls copy b % LR_STREAM_COPIES (a thousand blocks polling ONE line kept the memory channel
+    // that holds it so busy that the blocks still streaming took twice as long):
+    //   bits 40-63  early: iterations whose early table stands (the step taken ahead)
+    //   bits 16-39  ready: iterations decided - the next iteration's table is final
+    //   bits  0-15  changed: +1 before and +1 behind every table written AGAIN (an accepted proposal); a scanner block
+    //               that staged the early tables stages again if this moved since
+    unsigned long long word[LR_STREAM_COPIES][LR_STREAM_MAX_CHAINS];
+};
+#define LR_STREAM_SYNC_BYTES (128 + LR_STREAM_COPIES * 128 + 128)
+static_assert(sizeof(lr_stream_sync) + 128 == LR_STREAM_SYNC_BYTES && LR_STREAM_SYNC_BYTES % 256 == 0, "counter line + a line per copy");
+bool lr_stream_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p);
+void lr_stream_plan(const lr_mcmc_config* cfg, lr_scan_plan* p, int cus);
+// n_iters iterations in launches of at most 4096; query = true only asks whether the grid fits the current device at once
+int lr_launch_stream(lr_engine* e, const lr_step_args& a, int64_t n_iters, bool query, hipStream_t stream);
 
 // lr_mcmc.hip
 lr_step_args lr_make_args(const lr_engine* e);

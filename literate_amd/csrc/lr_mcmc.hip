@@ -1153,6 +1153,7 @@ static int lr_partition(int n_chains, int cb, bool fused_ok, int base[LR_MAX_PAR
 // sized so that the fused launches that run concurrently (one per partition: step blocks of one half + scan
 // blocks of the other) fill the resident block slots of the chip (256 CUs x 4 blocks) exactly once.
 static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k, int* team_cpb);
+static int lr_device_cus();
 static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, cfg->unit_resolution, p);
     if (rc) return rc;
@@ -1208,7 +1209,11 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
     const int parts = lr_partition(cfg->n_chains, p->cb, lr_fused_supported(*p), base, hA, pipelined);
-    if (!pipelined[0]) return LR_OK;
+    if (!pipelined[0]) {
+        // too few chains for two halves: the resident streaming kernel, its tiles sized to the device's block slots
+        if (parts == 1 && lr_stream_eligible(cfg, *p)) lr_stream_plan(cfg, p, lr_device_cus());
+        return LR_OK;
+    }
     const int count = base[1] - base[0];
     const int half = hA[0] > count - hA[0] ? hA[0] : count - hA[0];
     const int groups_half = (half + p->cb - 1) / p->cb;
@@ -1335,7 +1340,7 @@ static double lr_model_four_chain(const lr_mcmc_config* cfg, bool general) {
 
 static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
     static const int env = lr_env_int("LR_PERSIST", -1);   // debugging override: 0 off, 1 on
-    if (env == 0 || cfg->engine_mode == 1) return false;
+    if (env == 0 || cfg->engine_mode == 1 || cfg->engine_mode == 6) return false;
     if (!p.unit || cfg->n_bins + 2 > LR_H_WIDE || p.cb < 2) return false;
     const bool general = p.unit == LR_TAB_PAIRGEN;
     // the packing holds lineage indices as int32 and the scan loops address the groups by 32-bit byte offsets
@@ -1440,15 +1445,23 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     out->trace = o, o += lr_align_up64((long long)cfg->n_trace_slots * C * LR_TRACE_W * 8, 256);
     int team_k = 0, team_cpb = 0;
     out->persistent = lr_persist_variant(cfg, p, &team_k, &team_cpb);
-    out->spec_chains_per_team = team_cpb, out->reserved2 = 0;
+    out->spec_chains_per_team = team_cpb;
+    {
+        int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
+        bool pipelined[LR_MAX_PARTS];
+        const int parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined);
+        out->streaming = (out->persistent == 0 && parts == 1 && !pipelined[0] && lr_stream_eligible(cfg, p)) ? 1 : 0;
+    }
     if (p.unit == LR_TAB_PAIRGEN && out->persistent == 0) return LR_ERR_STATE;   // (planned only when a kernel takes it)
     out->team_blocks = team_k;
     out->table_mode = p.unit;
     out->status = o, o += 256;   // engine status word
     // team exchange granules of the speculative kernel: [2 parities][pairs][LR_TEAM_MAX][LR_SPEC_GRANULES] x 8 bytes
     // (four-chain kernel: the scan sums a launch leaves for the next one, LR_P4_CARRY_BYTES per block - lr_persist4_kernel)
+    // (streaming engine: the counters of a launch and the second table buffer)
     out->xchg = o, o += (team_k > 1) ? lr_align_up64(2ll * C * LR_TEAM_MAX * LR_SPEC_GRANULES * 8, 256)   // (room for a team per chain)
-                                     : (out->persistent == 2 ? lr_align_up64((C + 3) / 4 * LR_P4_CARRY_BYTES, 256) : 0);
+                                     : (out->persistent == 2 ? lr_align_up64((C + 3) / 4 * LR_P4_CARRY_BYTES, 256)
+                                        : (out->streaming ? LR_STREAM_SYNC_BYTES + lr_align_up64((long long)lr_align_up64(C, p.cb < 2 ? 2 : p.cb) * p.tab_stride * 16, 256) : 0));
     out->total_bytes = o;
     out->table_stride = p.tab_stride;
     out->tiles = p.tiles;
@@ -1494,6 +1507,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->p4.n_slots = 8;
     e->p4_help = lr_p4_help_choice(e);                  // (lr_mcmc_describe before init; latched again by lr_set_shares)
     e->p4_spec = lr_p4_spec_choice(e);
+    e->streaming = false;
     e->fork = nullptr;
     e->ev0 = e->ev1 = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
@@ -1521,6 +1535,16 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
             lr_mcmc_destroy(e);
             return (int)he;
         }
+    }
+    if (lay.streaming) {
+        // the resident kernel's blocks wait for each other: it runs only where the whole grid fits at once (LR_ERR_STATE =
+        // it does not: the launches take over, same plan, same results)
+        const int rcq = lr_launch_stream(e, lr_make_args(e), 0, true, nullptr);
+        if (rcq != LR_OK && rcq != LR_ERR_STATE) {
+            lr_mcmc_destroy(e);
+            return rcq;
+        }
+        e->streaming = rcq == LR_OK;
     }
     *out = e;
     return LR_OK;
@@ -1853,6 +1877,7 @@ extern "C" int lr_mcmc_steps(lr_engine* e, int64_t n_iters, void* stream_) {
         }
         return LR_OK;
     }
+    if (e->streaming) return lr_launch_stream(e, a, n_iters, false, stream);
     if (e->n_parts == 1) return lr_run_part(e, a, e->part[0], n_iters, stream);
     // fork: every partition's stream waits for the caller's stream, runs its own sequence, and is joined back
     hipError_t he = hipEventRecord(e->fork, stream);
@@ -1931,6 +1956,8 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
             snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s, %s, %s, %s>", e->plan.H, gen, e->cfg.sampler != 0 ? "true" : "false",
                      e->p4_help ? "true" : "false", (e->p4_help && e->p4_spec) ? "true" : "false");
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
+    } else if (e->streaming) {
+        snprintf(buf, (size_t)n, "lr_stream_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");
     } else if (e->part[0].pipelined) {
         snprintf(buf, (size_t)n, "lr_fused_iter_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");
     } else if (e->plan.fast) {

@@ -99,11 +99,21 @@ __device__ __forceinline__ void lr_xcd_remap(int sb, int tiles, int groups, int*
     }
 }
 
+// what a scan body does between issuing its first loads of ts / te and staging the tables: nothing in the launch-based
+// kernels; the resident streaming kernel (lr_stream_kernel) waits there for the tables of its iteration to be published
+// ... and how it reads a table entry and stores a partial sum (plain accesses; that kernel's go to the agent's point of
+// coherence, see lr_stream.hip)
+struct lr_no_wait {
+    __device__ __forceinline__ bool operator()() const { return false; }   // true: the tables already stand in LDS
+    static __device__ __forceinline__ double2 load16(const double2* p) { return *p; }
+    static __device__ __forceinline__ void store_partial(double* p, double v) { *p = v; }
+};
+
 // Block reduction of the per-thread accumulators through LDS (no cross-lane shuffles, which run on the LDS
 // crossbar and cost ~3.5 us per block as 17 dependent steps): every thread stores its CB sums ([chain][thread],
 // conflict-free), THREADS/CB threads per chain each add CB of them in a fixed order, then one thread per chain
 // adds those.  Needs CB*THREADS + THREADS doubles of LDS (the staged tables are dead by then).
-template <int CB, int T = LR_SCAN_THREADS>
+template <int CB, int T = LR_SCAN_THREADS, class IO = lr_no_wait>
 __device__ __forceinline__ void lr_block_reduce_chains(const double (&acc)[CB], double* red, int tid, int nvalid,
                                                        double* __restrict__ out /* chain0's row of partials + tile */,
                                                        size_t chain_stride) {
@@ -120,7 +130,7 @@ __device__ __forceinline__ void lr_block_reduce_chains(const double (&acc)[CB], 
     if (tid < nvalid) {
         double t = 0.0;
         for (int k = 0; k < TPC; ++k) t += red[CB * T + tid * TPC + k];
-        out[(size_t)tid * chain_stride] = t;
+        IO::store_partial(out + (size_t)tid * chain_stride, t);
     }
 }
 
@@ -128,11 +138,32 @@ __device__ __forceinline__ void lr_block_reduce_chains(const double (&acc)[CB], 
 // `tables`; partial sums go to partials[chain * partial_stride + tile].  T threads; DEPTH pairs of lineages (32 B each) per
 // thread in flight: the wide form (CB = 16: 70 KB of tables at H = 136, two 512-thread blocks per CU) keeps two, so that a
 // CU has 64 KB on its way although only 16 waves fit.
-template <int CB, int H, int T = LR_SCAN_THREADS, int DEPTH = 1, int BATCH = 0>
+// stage the CB general tables of chains [chain0, chain0 + nvalid): all 16-byte global loads are issued back to back (one
+// latency), then written; chain slots past nvalid are zeroed
+template <int CB, int H, int T, class IO>
+__device__ __forceinline__ void lr_stage_fast_tables(double2* lds, const double2* __restrict__ tables, int chain0, int nvalid, int tid) {
+    constexpr int STRIDE = 2 * H;
+    const double2* src = tables + (size_t)chain0 * STRIDE;
+    const int n_valid_entries = nvalid * STRIDE;
+    constexpr int NI = (CB * STRIDE + T - 1) / T;
+    double2 buf[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = tid + k * T;
+        buf[k] = IO::load16(src + min(i, n_valid_entries - 1));
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = tid + k * T;
+        if (i < CB * STRIDE) lds[i] = (i < n_valid_entries) ? buf[k] : make_double2(0.0, 0.0);
+    }
+}
+
+template <int CB, int H, int T = LR_SCAN_THREADS, int DEPTH = 1, int BATCH = 0, class WAIT = lr_no_wait>
 __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int chain0, const double* __restrict__ ts,
                                                   const double* __restrict__ te, long long n, double t0, int n_bins,
                                                   const double2* __restrict__ tables, int n_chains, long long chunk,
-                                                  double* __restrict__ partials, int partial_stride) {
+                                                  double* __restrict__ partials, int partial_stride, WAIT wait_tables = WAIT()) {
     static_assert(DEPTH == 1 || DEPTH == 2, "one or two pairs in flight");
     constexpr int STRIDE = 2 * H;
     const int tid = threadIdx.x;
@@ -152,23 +183,7 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
             e3 = *reinterpret_cast<const double2*>(te + i + 2 * T);
         }
     }
-    {
-        // stage the CB tables: all 16-byte global loads are issued back to back (one latency), then written
-        const double2* src = tables + (size_t)chain0 * STRIDE;
-        const int n_valid_entries = nvalid * STRIDE;
-        constexpr int NI = (CB * STRIDE + T - 1) / T;
-        double2 buf[NI];
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            const int i = tid + k * T;
-            buf[k] = src[min(i, n_valid_entries - 1)];
-        }
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            const int i = tid + k * T;
-            if (i < CB * STRIDE) lds[i] = (i < n_valid_entries) ? buf[k] : make_double2(0.0, 0.0);
-        }
-    }
+    if (!wait_tables()) lr_stage_fast_tables<CB, H, T, WAIT>(lds, tables, chain0, nvalid, tid);
     __syncthreads();
 
     double acc[CB];
@@ -209,7 +224,7 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
     }
 
     __syncthreads();
-    lr_block_reduce_chains<CB, T>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
+    lr_block_reduce_chains<CB, T, WAIT>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
                                   partials + (size_t)chain0 * partial_stride + tile, (size_t)partial_stride);
 }
 
@@ -279,11 +294,36 @@ __device__ __forceinline__ void lr_score_lineage_unit(double s, double e, double
     }
 }
 
-template <int CB, int H>
+#ifndef LR_UNIT_DEPTH
+#define LR_UNIT_DEPTH 1   /* 32-byte (ts, te) pairs a thread of the unit-resolution scan keeps in flight (2: measured, no gain - the kernel
+                             runs at 0.97 of the read-only yardstick at 1e8 lineages with one) */
+#endif
+
+// stage the pair tables of the group of CB chains from chain0 on: the whole group region - pair tables of chains past
+// n_chains hold zeros (the workspace is zeroed)
+template <int CB, int H, class IO>
+__device__ __forceinline__ void lr_stage_unit_tables(double2* lds, const double2* __restrict__ tables, int chain0, int tid) {
+    constexpr int GROUP_ENTRIES = (CB < 2 ? 2 : CB) * H;
+    const double2* src = tables + (size_t)chain0 * H;
+    constexpr int NI = (GROUP_ENTRIES + LR_SCAN_THREADS - 1) / LR_SCAN_THREADS;
+    double2 buf[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int j = tid + k * LR_SCAN_THREADS;
+        buf[k] = IO::load16(src + min(j, GROUP_ENTRIES - 1));
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int j = tid + k * LR_SCAN_THREADS;
+        if (j < GROUP_ENTRIES) lds[j] = buf[k];
+    }
+}
+
+template <int CB, int H, int DEPTH = LR_UNIT_DEPTH, class WAIT = lr_no_wait>
 __device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int chain0, const double* __restrict__ ts,
                                                   const double* __restrict__ te, long long n, double t0, int n_bins,
                                                   const double2* __restrict__ tables, int n_chains, long long chunk,
-                                                  double* __restrict__ partials, int partial_stride) {
+                                                  double* __restrict__ partials, int partial_stride, WAIT wait_tables = WAIT()) {
     constexpr int STRIDE = H;  // double2 entries per chain; a group of CB chains owns max(CB,2)*H entries
     constexpr int GROUP_ENTRIES = (CB < 2 ? 2 : CB) * STRIDE;
     const int tid = threadIdx.x;
@@ -295,27 +335,17 @@ __device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int ch
     const long long end = min(start + chunk, n);
     const bool aligned = ((((uintptr_t)ts) | ((uintptr_t)te)) & 15) == 0;
     long long i = start + 2 * tid;
-    double2 s2 = make_double2(0.0, 0.0), e2 = make_double2(0.0, 0.0);
-    if (aligned && i + 1 < end) {
-        s2 = *reinterpret_cast<const double2*>(ts + i);
-        e2 = *reinterpret_cast<const double2*>(te + i);
-    }
-    {
-        // the whole group region is staged: pair tables of chains past n_chains hold zeros (workspace is zeroed)
-        const double2* src = tables + (size_t)chain0 * STRIDE;
-        constexpr int NI = (GROUP_ENTRIES + LR_SCAN_THREADS - 1) / LR_SCAN_THREADS;
-        double2 buf[NI];
+    double2 s2[DEPTH], e2[DEPTH];
 #pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            const int j = tid + k * LR_SCAN_THREADS;
-            buf[k] = src[min(j, GROUP_ENTRIES - 1)];
-        }
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            const int j = tid + k * LR_SCAN_THREADS;
-            if (j < GROUP_ENTRIES) lds[j] = buf[k];
+    for (int d = 0; d < DEPTH; ++d) {
+        s2[d] = make_double2(0.0, 0.0), e2[d] = make_double2(0.0, 0.0);
+        const long long j = i + (long long)d * 2 * LR_SCAN_THREADS;
+        if (aligned && j + 1 < end) {
+            s2[d] = *reinterpret_cast<const double2*>(ts + j);
+            e2[d] = *reinterpret_cast<const double2*>(te + j);
         }
     }
+    if (!wait_tables()) lr_stage_unit_tables<CB, H, WAIT>(lds, tables, chain0, tid);
     __syncthreads();
     LR_STAMP(diag_blk, 1);
 
@@ -324,16 +354,24 @@ __device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int ch
     for (int c = 0; c < CB; ++c) acc[c] = 0.0;
     const char* lbase = reinterpret_cast<const char*>(lds);
     if (aligned) {
-        while (i + 1 < end) {
-            const double2 sc = s2, ec = e2;
-            const long long nx = i + 2 * LR_SCAN_THREADS;
-            if (nx + 1 < end) {
-                s2 = *reinterpret_cast<const double2*>(ts + nx);
-                e2 = *reinterpret_cast<const double2*>(te + nx);
+        // DEPTH pairs in flight per thread, in a ring of registers: slot d holds the pair of trip (DEPTH m + d)
+        bool more = i + 1 < end;
+        while (more) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (more) {
+                    const double2 sc = s2[d], ec = e2[d];
+                    const long long nx = i + (long long)DEPTH * 2 * LR_SCAN_THREADS;
+                    if (nx + 1 < end) {
+                        s2[d] = *reinterpret_cast<const double2*>(ts + nx);
+                        e2[d] = *reinterpret_cast<const double2*>(te + nx);
+                    }
+                    lr_score_lineage_unit<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
+                    lr_score_lineage_unit<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
+                    i += 2 * LR_SCAN_THREADS;
+                    more = i + 1 < end;
+                }
             }
-            lr_score_lineage_unit<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
-            lr_score_lineage_unit<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
-            i = nx;
         }
         if (i < end) lr_score_lineage_unit<CB, H>(ts[i], te[i], t0, n_bins, lbase, acc);
     } else {
@@ -346,7 +384,7 @@ __device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int ch
     LR_STAMP(diag_blk, 2);
     __syncthreads();
     LR_STAMP(diag_blk, 3);
-    lr_block_reduce_chains<CB>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
+    lr_block_reduce_chains<CB, LR_SCAN_THREADS, WAIT>(acc, reinterpret_cast<double*>(lds), tid, nvalid,
                                partials + (size_t)chain0 * partial_stride + tile, (size_t)partial_stride);
     LR_STAMP(diag_blk, 4);
 #ifdef LR_DIAG

@@ -829,7 +829,9 @@ __device__ __forceinline__ void lr_propose_rj(const lr_step_args& a, int c, int 
 // One chain step on register-resident state: accept the pending proposal given its log-likelihood sum
 // (lik_sum, without the model constant), write the trace row, draw the next proposal and build its lookup
 // tables at `table` (global memory or LDS; see lr_chain_table for the addressing).
-// mode: 0 = regular step, 1 = finish init (adopt the evaluated initial state, then propose iteration 0)
+// mode: 0 = regular step, 1 = finish init (adopt the evaluated initial state, then propose iteration 0), 2 = regular step
+// with the pending proposal taken as REJECTED whatever lik_sum is (the streaming kernel's speculation, lr_stream.hip: its
+// caller knows the proposal to be neither a Gibbs step nor invalid, and sets LR_S_LIK_P once the scan's sums are in)
 // HAND (four-chain kernel with helper waves): the proposal's lookup tables, pair planes and model constant are another
 // wave's (lr_propose_rj's HAND) - the scalar LR_S_CONST_P of the state then belongs to that wave, see lr_chain_store_handed
 template <bool LDS_CONSTS = false, int PB = 0, bool HAND = false>
@@ -871,7 +873,7 @@ __device__ __forceinline__ void lr_chain_step_core(lr_chain_regs& st, const lr_s
         const double priorP = lr_bcast(sc, LR_S_PRIOR_P), constP = lr_bcast(sc, LR_S_CONST_P);
         double lik;
         const bool ok = lr_mh_accept(gibbs, invalid, lik_sum, constP, likA, priorP, priorA, lr_bcast(sc, LR_S_HASTING),
-                                     lr_bcast(sc, LR_S_LOG_U), &lik);
+                                     lr_bcast(sc, LR_S_LOG_U), &lik) && mode != 2;
         lik_p = invalid ? -INFINITY : lik;
         lr_warn_kcap(a.warn, invalid, lane);
         if (ok) {
@@ -1370,13 +1372,26 @@ __device__ __forceinline__ void lr_dd_step_core(lr_chain_regs& st, const lr_step
     }
 }
 
-template <int Q>
+// COHERENT: the partials were stored by blocks of the SAME launch (lr_stream.hip) - read at the agent's point of coherence
+template <int Q, bool COHERENT = false>
 __device__ __forceinline__ double lr_partials_round(const double* row, int tiles, int t0, double part) {
     double v[Q];
+    if (COHERENT) {
+        // unconditional loads from clamped addresses, all issued before the first is looked at (behind a branch, or with
+        // the selects between them, every one of these atomic loads waits for the one before)
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        unsigned long long raw[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int t = t0 + q * LR_WAVE;
-        v[q] = t < tiles ? row[t] : 0.0;
+        for (int q = 0; q < Q; ++q) raw[q] = __hip_atomic_load((gu64*)(row + min(t0 + q * LR_WAVE, tiles - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < Q; ++q) v[q] = (t0 + q * LR_WAVE < tiles) ? __longlong_as_double((long long)raw[q]) : 0.0;
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int t = t0 + q * LR_WAVE;
+            v[q] = t < tiles ? row[t] : 0.0;
+        }
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) part += v[q];
@@ -1384,12 +1399,12 @@ __device__ __forceinline__ double lr_partials_round(const double* row, int tiles
 }
 
 // sum over the tiles lane, lane + 64, ... of one chain's row of partials, in ascending order
-template <int Q>
+template <int Q, bool COHERENT = false>
 __device__ __forceinline__ double lr_sum_tile_partials(const double* row, int tiles, int lane) {
     double part = 0.0;
     int t = lane;
-    for (; t - lane + 8 * LR_WAVE < tiles; t += Q * LR_WAVE) part = lr_partials_round<Q>(row, tiles, t, part);
-    if (t - lane < tiles) part = lr_partials_round<8>(row, tiles, t, part);
+    for (; t - lane + 8 * LR_WAVE < tiles; t += Q * LR_WAVE) part = lr_partials_round<Q, COHERENT>(row, tiles, t, part);
+    if (t - lane < tiles) part = lr_partials_round<8, COHERENT>(row, tiles, t, part);
     return part;
 }
 

@@ -69,7 +69,7 @@ class ChainEngine:
             s_freq=int(s_freq), n_trace_slots=int(n_trace_slots), poisson_HP=float(poisson_HP),
             update_fraction=float(update_fraction), t0=self.t0, start_time=self.start_time, end_time=self.end_time,
             seed=int(seed), chain_offset=int(chain_offset), unit_resolution=int(self.unit_resolution),
-            engine_mode={"auto": 0, "launch": 1, "persistent": 2, "persistent4": 3, "persistent2": 4, "spec": 5}[engine],
+            engine_mode={"auto": 0, "launch": 1, "persistent": 2, "persistent4": 3, "persistent2": 4, "spec": 5, "stream": 6}[engine],
             frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0,
             sampler=0 if dd is None else (2 if dd.get("kind") == "trend" else 1),
             m_birth=0 if dd is None else int(dd["m_birth"]), m_death=0 if dd is None else int(dd["m_death"]),
@@ -225,14 +225,15 @@ class ChainEngine:
         return float(ms.value)
 
     def check_status(self):
-        """Synchronise and raise if the engine flagged an error on the device (a team exchange of the speculative kernel
-        that timed out: its blocks were not all resident)."""
+        """Synchronise and raise if the engine flagged an error on the device (a bounded wait between blocks ran out - a
+        team exchange of the speculative kernel, a counter of the resident streaming kernel: the blocks were not all
+        resident)."""
         st = C.c_int32(0)
         _hip.check(_hip.launch(self.lib.lr_mcmc_status, self.device, self.handle, C.byref(st)), "lr_mcmc_status")
         if st.value != 0:
-            raise _hip.HipLibraryError("engine status %d: a team exchange timed out (the team's blocks were not all "
-                                       "resident: is the GPU shared? LR_SHARED_DEVICE=1 runs without teams), the run "
-                                       "is void" % st.value)
+            raise _hip.HipLibraryError("engine status %d: a wait between blocks timed out (the kernel's blocks were not all "
+                                       "resident: is the GPU shared? LR_SHARED_DEVICE=1 runs without teams, LR_STREAM=0 "
+                                       "without the resident streaming kernel), the run is void" % st.value)
 
     def warnings(self):
         """Synchronise and return the engine's warning bits (include/literate_hip.h: LR_WARN_*)."""

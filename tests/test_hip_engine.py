@@ -50,6 +50,10 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        # (... and its form whose steppers speculate on rejection, LR_P4_SPEC=1: lr_chain_step_respec)
                                        (0, dict(engine="persistent4", p4_spec=1)), (3, dict(engine="persistent4", p4_spec=1)),
                                        (2, dict(engine="persistent4", p4_spec=1, const_death_rate=1)),
+                                       # (the resident streaming kernel - the planner's choice for few chains x very many
+                                       # lineages - forced on this short input: lr_stream.hip)
+                                       (0, dict(engine="stream")), (2, dict(engine="stream", const_rates=1)),
+                                       (1, dict(engine="stream", unit_resolution=False)), (2, dict(engine="stream", use_rate_HP=0, Poisson_HP=2.5)),
                                        (1, dict(engine="spec", team=1, cpt=1, planes_by_scanners=0, unit_resolution=False))])
 def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
     from literate_amd.engine import ChainEngine, split_trace_row
@@ -74,6 +78,8 @@ def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
             assert eng.kernel_name().endswith(", 3>")
     if ekw["engine"] == "persistent2":
         assert eng.layout.persistent == 1
+    if ekw["engine"] == "stream":
+        assert eng.layout.persistent == 0 and eng.layout.streaming == 1 and eng.kernel_name().startswith("lr_stream_kernel<")
     if ekw["engine"] == "persistent4" and ekw["unit_resolution"] is not False:
         assert eng.kernel_name().endswith("false, false>" if "LR_P4_HELP" in os.environ else ("true, true>" if p4_spec else "true, false>"))
     # binning done by the engine's own kernel must equal the reference's
@@ -1182,9 +1188,45 @@ def test_planner_self_check_against_a_measurement(monkeypatch, n_lin, C):
     assert r["ok"] == (not any("LR_PLAN_CHECK" in str(w.message) for w in caught))
 
 
-def test_launch_engine_streams_1e7_lineages_from_hbm():
+_STREAM_RUN = {}
+
+
+@pytest.mark.parametrize("cuts", [(1, 1, 1, 37), (40,), (7, 2, 31)])
+@pytest.mark.parametrize("general", [False, True])
+def test_streaming_kernel_equals_the_launches_however_a_run_is_cut(general, cuts):
+    """The resident streaming kernel against the launch-based engine on the same plan (300k lineages x 8 chains, unit
+    resolution and general times): trace rows, state rows and the pending proposal's lookup tables are identical bit for
+    bit, whatever the calls' lengths - an odd one leaves the pending tables in the kernel's second buffer, from which
+    they are copied back."""
+    from literate_amd import synth
+    from literate_amd.engine import ChainEngine
+    ts, te, _ = synth.make_lineages(300_000, n_bins=100, n_shifts=12, seed=5)
+    if general:
+        ts, te = _off_year_grid(ts, te, np.random.default_rng(3))
+    runs = {}
+    for engine in ("stream", "launch"):
+        eng = ChainEngine(ts, te, 8, model=0, seed=77, s_freq=1, n_trace_slots=sum(cuts), engine=engine)
+        assert eng.layout.persistent == 0 and eng.layout.streaming == (1 if engine == "stream" else 0)
+        assert eng.kernel_name().startswith("lr_stream_kernel<8," if engine == "stream" else ("lr_scan_fast_kernel<8," if general else "lr_scan_unit_kernel<8,"))
+        eng.init()
+        for n in cuts:
+            eng.steps(n)
+        off, stride = int(eng.layout.tables), int(eng.layout.table_stride) * 16 * 8
+        runs[engine] = (eng.trace_rows().copy(), eng.state_f64.cpu().numpy().copy(), eng.state_i32.cpu().numpy().copy(),
+                        eng.workspace[off:off + stride].cpu().numpy().copy())
+        eng.check_status()
+        eng.close()
+    for a, b in zip(runs["stream"], runs["launch"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert len(set(np.round(runs["stream"][0][:, 0, 2], 6))) > 5      # the chain moved
+
+
+@pytest.mark.parametrize("engine", ["stream", "auto"])
+def test_launch_engine_streams_1e7_lineages_from_hbm(engine):
     """Few chains x very many lineages - 16 chains x 1e7 lineages, the regime where the ENGINE is HBM-bound: the planner
-    picks the launch-based engine, whose scan kernel reads ts / te (160 MB) in every iteration.  Two chains row by row
+    picks the launch-based engine - tiles of the lineages, 16 chains per pass, ts / te (160 MB) read in every iteration, a
+    scan and a step kernel per iteration; engine="stream" runs the same plan's iterations inside the resident streaming
+    kernel (lr_stream.hip: opt-in, measured no faster), and both must give the same run bit for bit.  Two chains row by row
     against the oracle loop on statistics binned from the same lineages, and every chain's accepted state re-evaluated by
     lr_bd_loglik_batch and by the oracle's binned calc_likelihood."""
     import torch
@@ -1195,10 +1237,16 @@ def test_launch_engine_streams_1e7_lineages_from_hbm():
     ts0, te0, _ = synth.make_lineages(100_000, n_bins=128, n_shifts=20, seed=0)
     reps, C, n_it, seed = 100, 16, 60, 2026
     ts, te = np.tile(ts0, reps), np.tile(te0, reps)
-    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it)
-    assert eng.layout.persistent == 0 and eng.unit_resolution and eng.kernel_name().startswith("lr_scan_unit_kernel<16,")
-    eng.init(); eng.steps(25); eng.steps(n_it - 25)
+    eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine)
+    assert eng.layout.persistent == 0 and eng.unit_resolution
+    assert eng.kernel_name().startswith("lr_stream_kernel<16," if engine == "stream" else "lr_scan_unit_kernel<16,")
+    assert eng.layout.streaming == (1 if engine == "stream" else 0)
+    eng.init(); eng.steps(25); eng.steps(n_it - 25)      # (an odd cut: the pending tables change buffers in the streaming kernel)
     tr = eng.trace_rows()
+    if engine == "stream":
+        _STREAM_RUN["trace"], _STREAM_RUN["state"] = tr.copy(), eng.state_f64.cpu().numpy().copy()
+    elif "trace" in _STREAM_RUN:
+        assert np.array_equal(tr, _STREAM_RUN["trace"], equal_nan=True) and np.array_equal(eng.state_f64.cpu().numpy(), _STREAM_RUN["state"], equal_nan=True)
     snap = eng.snapshot()
     assert np.all(snap["it"] == n_it) and np.all(np.isfinite(snap["likA"]))
     # the statistics of the tiled data are `reps` times those of one copy (exact: integer counts, half-integer lineage-time)

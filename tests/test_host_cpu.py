@@ -54,7 +54,16 @@ def test_library_exports_every_declared_symbol():
     cfg.engine_mode = 1
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0
     cfg.engine_mode, cfg.n_chains, cfg.n_lineages = 0, 16, 10_000_000   # few chains, huge input: tiled launches
-    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0 and lay.streaming == 0
+    tiles_launch, xchg_launch = lay.tiles, lay.total_bytes - lay.xchg
+    # ... or, asked for (engine="stream"), the same plan's iterations inside the resident streaming kernel: tiles sized to
+    # the device's block slots less the stepper blocks, a second table buffer + the launch's counters in xchg
+    cfg.engine_mode = 6
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0 and lay.streaming == 1 and lay.n_parts == 1 and lay.pipelined == 0
+    assert lay.tiles <= 1024 - 4 and lay.tiles <= tiles_launch and lay.total_bytes - lay.xchg > xchg_launch + 16 * 136 * 16
+    cfg.n_chains = 64                                                 # (chains for two halves: the pipelined launches stay)
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.streaming == 0 and lay.pipelined == 1
+    cfg.engine_mode = 0
     cfg.n_chains, cfg.n_lineages = 1024, 100000
     cfg.t0 = 0.5
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == -5        # LR_ERR_T0

@@ -253,7 +253,11 @@ int lr_plan_scan(long long n, int n_chains, int n_bins, int model, int unit_res,
     // in the launch-based engine, per iteration: 2048 tiles 43.1 / 103.5 / 297.6 us, 1024: 42.0 / 102.2 / 290.7, 512: 42.4 / 104.7 /
     // 299.9, 4096: 48.6 / 106.1 / 293.5 - every block stages its chains' tables, and the step sums a chain's tile partials)
     static const long long target_blocks = getenv("LR_SCAN_BLOCKS") ? atoll(getenv("LR_SCAN_BLOCKS")) : 1024;
+    // (the sixteen-chain general scan runs two 512-thread blocks per CU - 512 blocks, one round of them: measured 4-6 % slower)
     long long tiles = (target_blocks + p->groups - 1) / p->groups;
+    // ... but with many groups of sixteen, at least 256 tiles per group (C = 256 at 1e8 lineages: 64 tiles per group 0.54 of the
+    // HBM peak, 128: 0.61, 256: 0.63 - a group's tiles share an XCD, and its 64 block slots want several rounds to even out)
+    if (p->threads == LR_SCAN_WIDE_THREADS && tiles < 256 && !getenv("LR_SCAN_BLOCKS")) tiles = 256;
     const long long max_tiles = (n + 4 * unit - 1) / (4 * unit);  // >= 8 lineages per thread
     if (tiles > max_tiles) tiles = max_tiles;
     if (tiles < 1) tiles = 1;

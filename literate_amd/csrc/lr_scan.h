@@ -1,6 +1,7 @@
 // lr_scan.h - the fast lineage-scan block body, shared by the stand-alone scan kernel
 // (lr_loglik.hip) and the fused scan+chain-step kernel of the engine (lr_mcmc.hip).
 #pragma once
+#include <climits>
 #include "lr_device.h"
 #include "lr_internal.h"
 
@@ -81,6 +82,81 @@ __device__ __forceinline__ void lr_score_pair_batched(double2 s2, double2 e2, do
             acc[c0 + j] += u;
         }
     }
+}
+
+// Lineages sorted by birth time (how the reference's input files are written): the 128 lineages a wave scores per trip
+// nearly always share their birth bin, so their birth-side entries (S, slope) of the CB chains are the same 16 bytes for
+// every lane.  The wave then keeps them in SCALAR registers (read once per bin through lane 0) and gathers only the
+// death-side entries: half the ds_read_b128 per lineage - the wide kernel, bound by exactly those gathers (32 per lineage
+// at 16 chains = 2 cycles of the CU's LDS path against 1.2 for the HBM stream), ran at 0.40 of the HBM peak.  The same
+// values enter the same operations in the same order: the sums are bit for bit those of the gather path, which every
+// trip whose lanes disagree takes as before (the test is wave-uniform: no divergence).
+#ifndef LR_SCAN_BIRTH_CACHE
+#define LR_SCAN_BIRTH_CACHE 1
+#endif
+#ifndef LR_SCAN_CACHED_BATCH
+#define LR_SCAN_CACHED_BATCH 4   /* chains whose death-side entries (of two lineages) are gathered behind one wait */
+#endif
+template <int CB>
+struct lr_birth_cache {
+    int bin;            // birth bin the entries below belong to; INT_MIN: none yet
+    double2 S[CB];      // wave-uniform (the compiler keeps them in SGPRs: they come out of v_readfirstlane)
+};
+
+__device__ __forceinline__ double lr_uniform_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+template <int CB, int H>
+__device__ __forceinline__ void lr_birth_cache_fill(lr_birth_cache<CB>& bc, int bin, const char* __restrict__ lds) {
+    bc.bin = bin;
+    const char* pS = lds + ((bin + 1) << 4);
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(pS + c * (2 * H * 16));
+        bc.S[c].x = lr_uniform_f64(v.x), bc.S[c].y = lr_uniform_f64(v.y);
+    }
+}
+
+// a pair of lineages whose birth bin is the cached one in every lane of the wave: death-side gathers only, B chains per batch
+template <int CB, int H, int B>
+__device__ __forceinline__ void lr_score_pair_cached(double2 s2, double2 e2, double t0, int n_bins, const char* __restrict__ lds,
+                                                     const lr_birth_cache<CB>& bc, double (&acc)[CB]) {
+    static_assert(CB % B == 0, "whole batches");
+    const double fl0 = floor(s2.x), fl1 = floor(s2.y), ce0 = ceil(e2.x), ce1 = ceil(e2.y);
+    const int b0 = min(max(__double2int_rz(ce0 - t0), 0), n_bins + 1), b1 = min(max(__double2int_rz(ce1 - t0), 0), n_bins + 1);
+    const double fs0 = s2.x - fl0, fs1 = s2.y - fl1;
+    const double fe0 = (e2.x - ce0) + 1.0, fe1 = (e2.y - ce1) + 1.0;
+    const char* pE0 = lds + (b0 << 4) + H * 16;
+    const char* pE1 = lds + (b1 << 4) + H * 16;
+#pragma unroll
+    for (int c0 = 0; c0 < CB; c0 += B) {
+        double2 E0[B], E1[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            E0[j] = *reinterpret_cast<const double2*>(pE0 + (c0 + j) * (2 * H * 16));
+            E1[j] = *reinterpret_cast<const double2*>(pE1 + (c0 + j) * (2 * H * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            double t = bc.S[c0 + j].x + E0[j].x;
+            t = fma(fs0, bc.S[c0 + j].y, t);
+            t = fma(fe0, E0[j].y, t);
+            acc[c0 + j] += t;
+            double u = bc.S[c0 + j].x + E1[j].x;
+            u = fma(fs1, bc.S[c0 + j].y, u);
+            u = fma(fe1, E1[j].y, u);
+            acc[c0 + j] += u;
+        }
+    }
+}
+
+// -> true if both lineages of every lane of the wave are born in one and the same bin (then *bin is it)
+__device__ __forceinline__ bool lr_pair_birth_uniform(double2 s2, double t0, int n_bins, int* bin) {
+    const int a0 = min(max(__double2int_rz(floor(s2.x) - t0), -1), n_bins), a1 = min(max(__double2int_rz(floor(s2.y) - t0), -1), n_bins);
+    const int ua = __builtin_amdgcn_readfirstlane(a0);
+    *bin = ua;
+    return __all(a0 == ua && a1 == ua) != 0;
 }
 
 // XCD-aware block -> (chain group, tile) map.  Blocks are dealt round-robin over the 8 XCDs (block b and
@@ -190,6 +266,10 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
 #pragma unroll
     for (int c = 0; c < CB; ++c) acc[c] = 0.0;
     const char* lbase = reinterpret_cast<const char*>(lds);
+    lr_birth_cache<CB> bc;
+    bc.bin = INT_MIN;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) bc.S[c] = make_double2(0.0, 0.0);
     if (aligned) {
         while (i + 1 < end) {
             const double2 sc = s2, ec = e2;
@@ -207,7 +287,11 @@ __device__ __forceinline__ void lr_scan_fast_body(double2* lds, int tile, int ch
                     e2 = *reinterpret_cast<const double2*>(te + nx);
                 }
             }
-            if (BATCH > 0) {
+            int ubin = 0;
+            if (LR_SCAN_BIRTH_CACHE && CB >= 4 && lr_pair_birth_uniform(sc, t0, n_bins, &ubin)) {
+                if (ubin != bc.bin) lr_birth_cache_fill<CB, H>(bc, ubin, lbase);
+                lr_score_pair_cached<CB, H, (CB >= LR_SCAN_CACHED_BATCH ? LR_SCAN_CACHED_BATCH : CB)>(sc, ec, t0, n_bins, lbase, bc, acc);
+            } else if (BATCH > 0) {
                 lr_score_pair_batched<CB, H, (BATCH > 0 ? BATCH : 1)>(sc, ec, t0, n_bins, lbase, acc);
             } else {
                 lr_score_lineage_fast<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, torch
 for n in (30_000_000, 100_000_000):
     ts, te = bench.abi_lineages(n, False, "sorted")
-    for c in (1, 8, 16, 32, 256):
+    for c in [int(x) for x in os.environ.get('LR_EXP_C', '1,8,16,32,256').split(',')]:
         call, outs, info, keep = bench.abi_calls("lr_bd_loglik_batch", ts, te, c)
         ms = bench.abi_time(call, 10 if c <= 32 else 3)
         gbs = 16.0 * n * info["passes"] / (ms * 1e-3) / 1e9

@@ -362,6 +362,14 @@ def test_loglik_tiled_path_ragged_sizes_vs_oracle(ops):
             # (to rounding: the number of lineage tiles - the summation order - depends on the number of chain groups)
             tail = _np(ops.bd_loglik_batch(tsd, ted, t0, lam[16:], mu[16:], model, br))
             assert np.allclose(tail, got[NC][16:], rtol=1e-11, atol=0)
+            # the same lineages SORTED BY BIRTH (how the reference's input files come): a wave's 128 lineages then share their
+            # birth bin, and the kernels keep that bin's entries in scalar registers instead of gathering them per lane
+            # (lr_scan.h: lr_birth_cache) - same operations on the same values
+            order = np.argsort(ts, kind="stable")
+            tss, tes = torch.as_tensor(ts[order]).cuda(), torch.as_tensor(te[order]).cuda()
+            for C in (4, 8, 16, NC):
+                g = _np(ops.bd_loglik_batch(tss, tes, t0, lam[:C], mu[:C], model, br))
+                assert np.allclose(g, ref[:C], rtol=REL, atol=1e-9), (n, n_bins, model, C, "sorted")
         tsu = torch.as_tensor(np.concatenate([[0.0], ts])).cuda()[1:]
         teu = torch.as_tensor(np.concatenate([[0.0], te])).cuda()[1:]
         for C in (1, 3, 9, 17):

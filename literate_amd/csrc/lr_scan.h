@@ -94,6 +94,9 @@ __device__ __forceinline__ void lr_score_pair_batched(double2 s2, double2 e2, do
 #ifndef LR_SCAN_BIRTH_CACHE
 #define LR_SCAN_BIRTH_CACHE 1
 #endif
+#ifndef LR_UNIT_BIRTH_CACHE
+#define LR_UNIT_BIRTH_CACHE 1    /* the same in the unit-resolution scan */
+#endif
 #ifndef LR_SCAN_CACHED_BATCH
 #define LR_SCAN_CACHED_BATCH 4   /* chains whose death-side entries (of two lineages) are gathered behind one wait */
 #endif
@@ -358,6 +361,30 @@ __global__ __launch_bounds__(LR_SCAN_WIDE_THREADS) __attribute__((amdgpu_waves_p
 // two ds_read_b128 gathers + 4 fp64 adds (b128 reads reach the LDS rate with few waves per SIMD, b64 do not).
 // Layout per group of CB chains: [CB/2 pairs][2 (S', E')][H] double2 = (chain 2p, chain 2p+1).
 // ------------------------------------------------------------------------------------------
+// ... and with the wave's shared birth-bin entries in scalar registers (lr_birth_cache above; CB / 2 pair entries)
+template <int CB, int H>
+__device__ __forceinline__ void lr_unit_cache_fill(lr_birth_cache<(CB + 1) / 2>& bc, int bin, const char* __restrict__ lds) {
+    bc.bin = bin;
+    const char* pS = lds + ((bin + 1) << 4);
+#pragma unroll
+    for (int p = 0; p < CB / 2; ++p) {
+        const double2 v = *reinterpret_cast<const double2*>(pS + p * (2 * H * 16));
+        bc.S[p].x = lr_uniform_f64(v.x), bc.S[p].y = lr_uniform_f64(v.y);
+    }
+}
+template <int CB, int H>
+__device__ __forceinline__ void lr_score_lineage_unit_cached(double e, double t0, int n_bins, const char* __restrict__ lds,
+                                                             const lr_birth_cache<(CB + 1) / 2>& bc, double (&acc)[CB]) {
+    const int b = min(max(__double2int_rz(ceil(e) - t0), 0), n_bins + 1);
+    const char* pE = lds + (b << 4) + H * 16;
+#pragma unroll
+    for (int p = 0; p < CB / 2; ++p) {
+        const double2 E = *reinterpret_cast<const double2*>(pE + p * (2 * H * 16));
+        acc[2 * p] += bc.S[p].x + E.x;
+        acc[2 * p + 1] += bc.S[p].y + E.y;
+    }
+}
+
 template <int CB, int H>
 __device__ __forceinline__ void lr_score_lineage_unit(double s, double e, double t0, int n_bins,
                                                       const char* __restrict__ lds, double (&acc)[CB]) {
@@ -437,6 +464,10 @@ __device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int ch
 #pragma unroll
     for (int c = 0; c < CB; ++c) acc[c] = 0.0;
     const char* lbase = reinterpret_cast<const char*>(lds);
+    lr_birth_cache<(CB + 1) / 2> bc;
+    bc.bin = INT_MIN;
+#pragma unroll
+    for (int p = 0; p < (CB + 1) / 2; ++p) bc.S[p] = make_double2(0.0, 0.0);
     if (aligned) {
         // DEPTH pairs in flight per thread, in a ring of registers: slot d holds the pair of trip (DEPTH m + d)
         bool more = i + 1 < end;
@@ -450,8 +481,15 @@ __device__ __forceinline__ void lr_scan_unit_body(double2* lds, int tile, int ch
                         s2[d] = *reinterpret_cast<const double2*>(ts + nx);
                         e2[d] = *reinterpret_cast<const double2*>(te + nx);
                     }
-                    lr_score_lineage_unit<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
-                    lr_score_lineage_unit<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
+                    int ubin = 0;
+                    if (LR_UNIT_BIRTH_CACHE && CB >= 4 && lr_pair_birth_uniform(sc, t0, n_bins, &ubin)) {
+                        if (ubin != bc.bin) lr_unit_cache_fill<CB, H>(bc, ubin, lbase);
+                        lr_score_lineage_unit_cached<CB, H>(ec.x, t0, n_bins, lbase, bc, acc);
+                        lr_score_lineage_unit_cached<CB, H>(ec.y, t0, n_bins, lbase, bc, acc);
+                    } else {
+                        lr_score_lineage_unit<CB, H>(sc.x, ec.x, t0, n_bins, lbase, acc);
+                        lr_score_lineage_unit<CB, H>(sc.y, ec.y, t0, n_bins, lbase, acc);
+                    }
                     i += 2 * LR_SCAN_THREADS;
                     more = i + 1 < end;
                 }

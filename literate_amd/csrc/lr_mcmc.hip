@@ -1155,7 +1155,9 @@ static int lr_partition(int n_chains, int cb, bool fused_ok, int base[LR_MAX_PAR
 static int lr_persist_variant(const lr_mcmc_config* cfg, const lr_scan_plan& p, int* team_k, int* team_cpb);
 static int lr_device_cus();
 static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
-    int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, cfg->unit_resolution, p);
+    // (general times, 9 to 16 chains: ONE pass of the sixteen-chain scan - lr_scan_wide_kernel - instead of two halves of eight)
+    int rc = lr_plan_scan(cfg->n_lineages, cfg->n_chains, cfg->n_bins, cfg->model, cfg->unit_resolution, p,
+                          (!cfg->unit_resolution && cfg->n_chains > 8 && cfg->n_chains <= 16 && lr_env_int("LR_ENGINE_WIDE", 1)) ? 1 : 0);
     if (rc) return rc;
     if (cfg->model == LR_MODEL_KEIDING_DEAD && cfg->n_bins <= 258) {
         // model 3 on a persistent engine: one table class with an extant block behind the death-side entries (lr_step.h),
@@ -1960,6 +1962,8 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
         snprintf(buf, (size_t)n, "lr_stream_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");
     } else if (e->part[0].pipelined) {
         snprintf(buf, (size_t)n, "lr_fused_iter_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");
+    } else if (e->plan.fast && !e->plan.unit && e->plan.cb == 16) {
+        snprintf(buf, (size_t)n, "lr_scan_wide_kernel<%d>", e->plan.H);
     } else if (e->plan.fast) {
         snprintf(buf, (size_t)n, "%s<%d, %d>", e->plan.unit ? "lr_scan_unit_kernel" : "lr_scan_fast_kernel", e->plan.cb, e->plan.H);
     } else {

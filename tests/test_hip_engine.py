@@ -141,7 +141,7 @@ def _pipelined_case(G, unit, engine):
     eng.close()
 
 
-@pytest.mark.parametrize("engine,kw", [("launch", {}), ("auto", {}), ("spec", dict(team=1)), ("spec", dict(team=4)),
+@pytest.mark.parametrize("engine,kw", [("launch", {}), ("launch", dict(C=12)), ("auto", {}), ("spec", dict(team=1)), ("spec", dict(team=4)),
                                        ("persistent4", {})])
 def test_engine_continuous_times_general_path(G, engine, kw):
     """Lineage times that are NOT unit-resolution (uniform jitter added): the engine must pick the general-times
@@ -157,10 +157,15 @@ def test_engine_continuous_times_general_path(G, engine, kw):
     ts = G["metal_bands/ts"][:6000] + grid(rng.uniform(0, 0.999, 6000))
     te = np.maximum(G["metal_bands/te"][:6000] + grid(rng.uniform(0, 0.4, 6000)), ts + 0.0078125)
     te[G["metal_bands/te"][:6000] >= 2000.5] = 2000.5
-    n_it, seed, C = 300, 21, 40
+    kw = dict(kw)
+    n_it, seed, C = 300, 21, kw.pop("C", 40)
     eng = ChainEngine(ts, te, C, model=2, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine, **kw)
     assert not eng.unit_resolution
-    if engine == "launch":
+    if engine == "launch" and C == 12:
+        # 9 to 16 chains: one pass of the sixteen-chain scan per iteration instead of two pipelined halves of eight
+        assert eng.layout.persistent == 0 and eng.layout.chains_per_block == 16 and eng.layout.pipelined == 0
+        assert eng.layout.table_mode == 0 and eng.kernel_name().startswith("lr_scan_wide_kernel<")
+    elif engine == "launch":
         assert eng.layout.persistent == 0 and eng.layout.chains_per_block == 8 and eng.layout.pipelined == 1
         assert eng.layout.table_mode == 0
     else:
@@ -173,7 +178,7 @@ def test_engine_continuous_times_general_path(G, engine, kw):
     tr = eng.trace_rows()
     t0, sp, ex, br = lo.bin_events_cli(ts, te)
     assert np.array_equal(eng.sp_events.cpu().numpy(), sp) and np.allclose(eng.br_length.cpu().numpy(), br, rtol=1e-12)
-    for c in (0, 19, 20, 39):
+    for c in sorted({0, C // 2 - 1, C // 2, C - 1}):
         with np.errstate(all="ignore"):
             ref = mo.run_mcmc(dict(sp=sp, ex=ex, br=br), ts.min(), te.max(), mo.Settings(model_BDI=2),
                               mo.PhiloxDraws(seed, c), n_it, 1, k_max=32)

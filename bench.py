@@ -43,6 +43,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+_POLLING_SET_HERE = False   # main() switched the runtime to polling for completion signals (children get the default back)
 
 WORKLOADS = {
     # name: (lineages, n_bins, true shifts, chains per GPU, model, general times)
@@ -304,7 +305,7 @@ def measure_traffic(workload, chains, steps, kname, engine, sample_every):
                sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload, "--chains", str(chains),
                "--steps", str(steps), "--engine", engine, "--sample-every", str(sample_every)]
         env = dict(os.environ, TMPDIR="/tmp")
-        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") + (("HSA_ENABLE_INTERRUPT",) if _POLLING_SET_HERE else ()):
             env.pop(k, None)
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
@@ -484,7 +485,7 @@ def abi_fetch_bytes(kernel, n, chains, general, order):
            sys.executable, os.path.join(ROOT, "bench.py"), "--abi-child", "--abi-kernel", kernel, "--abi-n", str(n),
            "--chains", str(chains), "--abi-order", order] + (["--abi-general"] if general else [])
     env = dict(os.environ, TMPDIR="/tmp")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") + (("HSA_ENABLE_INTERRUPT",) if _POLLING_SET_HERE else ()):
         env.pop(k, None)
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
@@ -784,7 +785,7 @@ def compact_line(d):
         "dtype", "data")}
     out["config"] = {"workload": cfg["workload"][:110]}
     for k in ("lineages", "chains_per_gpu", "chains_total", "n_bins", "sample_every", "trace_rows_gathered_in_region",
-              "process_group", "wall_over_device"):
+              "process_group", "wall_over_device", "host_wait"):
         out["config"][k] = _sig(cfg.get(k))
     out["config"]["gathers_per_eval"] = _sig(r.get("gathers_per_eval"))
     out["config"]["fp64_ops_per_eval"] = _sig(r.get("fp64_ops_per_eval"))
@@ -904,6 +905,15 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))           # nothing above has imported torch or touched the GPU
+
+    # The host waits for completion signals by POLLING (the ROCm runtime's HSA_ENABLE_INTERRUPT=0; set before anything
+    # initialises the GPU, and only if the caller has not chosen): woken by an interrupt, torch.cuda.synchronize() returned
+    # 20 - 100 us after the kernel had ended - a 140-us region at --steps 20 read wall / device 1.22 - 1.79 from run to run,
+    # polling 1.18 - 1.23 (scratch/exp_sync_latency.sh).  The profiler children keep the runtime's default.
+    global _POLLING_SET_HERE
+    if "HSA_ENABLE_INTERRUPT" not in os.environ:
+        os.environ["HSA_ENABLE_INTERRUPT"] = "0"
+        _POLLING_SET_HERE = True
 
     import torch
     import torch.distributed as dist
@@ -1068,6 +1078,7 @@ def main():
                        "process_group": (dist.get_backend() if dist_on else None),
                        "iters_per_s_per_chain": args.steps / elapsed,
                        "wall_over_device": elapsed * 1e3 / region_kernel_ms,
+                       "host_wait": "polling" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupt",
                        "eval_note": "one eval = one lineage scored under one chain's rates in one iteration.  The scan does NOT "
                                     "spend two gathers per eval: lineages are sorted, a run of up to 14 lineages of one birth "
                                     "bin shares ONE gather of the birth entry (multiplied by the run count - a per-birth-bin "

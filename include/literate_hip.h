@@ -208,8 +208,8 @@ typedef struct lr_mcmc_config {
     int32_t engine_mode;      /* 0 = auto, 1 = launch-per-iteration engine (fused, pipelined), 2 = a persistent kernel
                                * (the library picks which), 3 = four chains per block, 4 = two chains per block,
                                * 5 = speculative team kernel, 6 = the launch-based plan with its iterations inside the
-                               * resident streaming kernel where it applies (lr_mcmc_layout.persistent / .streaming tell
-                               * what runs)                                                                             */
+                               * resident streaming kernel where it applies, 7 = the launch-based engine scanning the
+                               * PACKED lineages (lr_mcmc_layout.persistent / .streaming / .packed_scan tell what runs) */
     double frac_birth;
     double frac_death;
     /* ---- sampler 1: the DDRate.py Metropolis-Hastings loop (DD:124-241) on the same engine -------------
@@ -265,6 +265,11 @@ typedef struct lr_mcmc_layout {
                            * RESIDENT kernel (csrc/lr_stream.hip: scanner blocks + a stepper wave per chain, the step taken
                            * ahead on the assumption that the pending proposal is rejected) wherever its grid fits the device
                            * at once; xchg then holds the launch's counters and the second table buffer                      */
+    int32_t packed_scan;  /* 1 (persistent == 0 only): the launch-based engine scans the PACKED lineages (lineage_idx: 1.14 bytes
+                           * per lineage at unit resolution) once per iteration for all its chains (csrc/lr_packscan.hip)
+                           * instead of ts / te (16 bytes per lineage); unit-resolution data, too few chains for the
+                           * pipelined schedule.  engine_mode 1 keeps the scan of ts / te                               */
+    int32_t reserved3;
 } lr_mcmc_layout;
 
 /* rows of the fp64 state block (element j of a row lives in lane j of the chain's wave) */

@@ -40,7 +40,7 @@ class McmcLayout(C.Structure):
                 ("tiles", c_i32), ("chains_per_block", c_i32), ("trace_width", c_i32), ("n_parts", c_i32),
                 ("pipelined", c_i32), ("persistent", c_i32), ("reserved1", c_i32), ("status", c_i64), ("xchg", c_i64),
                 ("team_blocks", c_i32), ("table_mode", c_i32), ("lineage_frac", c_i64), ("pack_tmp", c_i64),
-                ("spec_chains_per_team", c_i32), ("streaming", c_i32)]
+                ("spec_chains_per_team", c_i32), ("streaming", c_i32), ("packed_scan", c_i32), ("reserved3", c_i32)]
 
 
 # name -> (restype, argtypes); exactly the symbols include/literate_hip.h declares (+ the RNG debug hook)

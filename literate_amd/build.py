@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libliterate_hip.so")
 BUILD_INFO = os.path.join(CSRC, "libliterate_hip.build.json")
 OBJ_DIR = os.path.join(CSRC, "_build")
-SOURCES = ["lr_stats.hip", "lr_loglik.hip", "lr_mcmc.hip", "lr_spec.hip", "lr_stream.hip", "lr_pack.hip", "lr_sim.hip", "lr_format.hip"]
+SOURCES = ["lr_stats.hip", "lr_loglik.hip", "lr_mcmc.hip", "lr_spec.hip", "lr_stream.hip", "lr_packscan.hip", "lr_pack.hip", "lr_sim.hip", "lr_format.hip"]
 HEADERS = ["lr_device.h", "lr_math.h", "lr_chain.h", "lr_dd.h", "lr_scan.h", "lr_step.h", "lr_spec.h", "lr_engine.h", "lr_internal.h",
            os.path.join("..", "..", "include", "literate_hip.h")]
 # Per translation unit.  The speculative kernel's loop body is ~8000 instructions at a 168-VGPR budget: machine LICM
@@ -34,7 +34,7 @@ TU_FLAGS = {"lr_spec.hip": os.environ.get("LR_SPEC_FLAGS", "-mllvm -disable-mach
 # translation units whose device assembly is checked, and the least number of saddr-form 16-byte loads the checker must
 # find there (lr_mcmc.hip holds the hand-placed ones; lr_spec.hip includes the same scan header but its slices use plain
 # loads - it is checked all the same)
-ASYNC_UNITS = {"lr_mcmc.hip": 60, "lr_spec.hip": 0}
+ASYNC_UNITS = {"lr_mcmc.hip": 60, "lr_spec.hip": 0, "lr_packscan.hip": 16}
 
 
 def _stale():

@@ -44,6 +44,9 @@ struct lr_engine {
     bool p4_help;             // four-chain kernel: the form with helper waves - latched by lr_set_shares (init / restore), so
                               // that the form, its shares and the sums carried between launches belong together for a whole run
     bool p4_spec;             // ... whose steppers speculate on rejection (lr_chain_step_respec); latched with p4_help
+    bool packed_scan;         // launch-based engine whose scan kernel reads the PACKED lineages (lr_packscan.hip) instead of ts / te:
+                              // planned by lr_mcmc_query_layout (lay.packed_scan), dropped by init / restore if the packing
+                              // refuses the input (unsorted beyond LR_MAX_RUNS runs)
     bool streaming;           // launch-based plan, but the iterations run inside ONE resident kernel (lr_stream.hip): latched by
                               // lr_mcmc_create, which asks the device in use whether the whole grid fits it at once
     hipEvent_t fork;
@@ -148,6 +151,12 @@ bool lr_stream_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p);
 void lr_stream_plan(const lr_mcmc_config* cfg, lr_scan_plan* p, int cus);
 // n_iters iterations in launches of at most 4096; query = true only asks whether the grid fits the current device at once
 int lr_launch_stream(lr_engine* e, const lr_step_args& a, int64_t n_iters, bool query, hipStream_t stream);
+
+// ---- packed scan of the launch-based engine (lr_packscan.hip) ----
+bool lr_packscan_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p);
+void lr_packscan_plan(const lr_mcmc_config* cfg, lr_scan_plan* p, int cus);
+int lr_packscan_pairs(const lr_scan_plan& p, int n_chains);
+int lr_launch_packscan(const lr_engine* e, hipStream_t stream);
 
 // lr_mcmc.hip
 lr_step_args lr_make_args(const lr_engine* e);

@@ -1125,13 +1125,26 @@ static int lr_pipeline_env() {
     return env;
 }
 
+// The launch-based engine scans the PACKED lineages (lr_packscan.hip) where that applies and pays: always with too few chains
+// for the pipelined schedule; with more, once a pass is long against the chain step it no longer hides (the packed scan runs
+// at ~3e13 evals/s - the pipelined launches on ts / te at 7e12 - but serially before the step kernel)
+static bool lr_packscan_planned(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
+    if (!lr_packscan_eligible(cfg, p)) return false;
+    return cfg->engine_mode == 7 || cfg->n_chains < 2 * p.cb || (double)cfg->n_lineages * (double)cfg->n_chains >= 3.0e8;
+}
+
 // Partition layout of the engine.  LR_PARTS (default 2) independent partitions run on their own streams so
 // that the ramp-up / drain of one partition's launches overlaps the other's; each partition with at least
 // 2*cb chains is software-pipelined in two halves.  All boundaries are multiples of cb.
+// single: one partition, not pipelined (the packed scan: one launch scores a group against ALL chains)
 static int lr_partition(int n_chains, int cb, bool fused_ok, int base[LR_MAX_PARTS + 1], int hA[LR_MAX_PARTS],
-                        bool pipelined[LR_MAX_PARTS]) {
+                        bool pipelined[LR_MAX_PARTS], bool single = false) {
     static const int want_parts = lr_env_int("LR_PARTS", 2);
     int parts = want_parts < 1 ? 1 : (want_parts > LR_MAX_PARTS ? LR_MAX_PARTS : want_parts);
+    if (single) {
+        base[0] = 0, base[1] = n_chains, hA[0] = n_chains, pipelined[0] = false;
+        return 1;
+    }
     const int groups = (n_chains + cb - 1) / cb;
     const bool pipe = lr_pipeline_env() && fused_ok;
     while (parts > 1 && groups < parts * (pipe ? 2 : 1)) --parts;
@@ -1210,10 +1223,13 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     }
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
-    const int parts = lr_partition(cfg->n_chains, p->cb, lr_fused_supported(*p), base, hA, pipelined);
+    const bool packed = lr_packscan_planned(cfg, *p);
+    const int parts = lr_partition(cfg->n_chains, p->cb, lr_fused_supported(*p), base, hA, pipelined, packed);
     if (!pipelined[0]) {
-        // too few chains for two halves: the resident streaming kernel, its tiles sized to the device's block slots
-        if (parts == 1 && lr_stream_eligible(cfg, *p)) lr_stream_plan(cfg, p, lr_device_cus());
+        // the scan over the packed lineages (unit resolution), or - too few chains for two halves, opt-in - the resident
+        // streaming kernel, its tiles sized to the device's block slots
+        if (packed) lr_packscan_plan(cfg, p, lr_device_cus());
+        else if (parts == 1 && lr_stream_eligible(cfg, *p)) lr_stream_plan(cfg, p, lr_device_cus());
         return LR_OK;
     }
     const int count = base[1] - base[0];
@@ -1342,7 +1358,7 @@ static double lr_model_four_chain(const lr_mcmc_config* cfg, bool general) {
 
 static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
     static const int env = lr_env_int("LR_PERSIST", -1);   // debugging override: 0 off, 1 on
-    if (env == 0 || cfg->engine_mode == 1 || cfg->engine_mode == 6) return false;
+    if (env == 0 || cfg->engine_mode == 1 || cfg->engine_mode == 6 || cfg->engine_mode == 7) return false;
     if (!p.unit || cfg->n_bins + 2 > LR_H_WIDE || p.cb < 2) return false;
     const bool general = p.unit == LR_TAB_PAIRGEN;
     // the packing holds lineage indices as int32 and the scan loops address the groups by 32-bit byte offsets
@@ -1359,7 +1375,10 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     int k = 0;
     const double t_spec = (p.H > (general ? 136 : 264)) ? 1e30 : lr_spec_model(cfg, &k, general);   // few chains: a team of CUs per pair
     if (k > 0 && t_spec < t_persist) t_persist = t_spec;
-    const double t_launch = n * c / (general ? 3e12 : 7e12) * 1e6 + 15.5 + c / 1024.0;
+    double t_launch = n * c / (general ? 3e12 : 7e12) * 1e6 + 15.5 + c / 1024.0;
+    // ... or, at unit resolution, one launch over the packed lineages for all chains + the step kernel (16 chains x 1e7 / 3e7 /
+    // 1e8 lineages: 16.3 / 27.0 / 63.9 us per iteration, scan alone 9.6 / 19.7 / 55.8: round 5)
+    if (!general && lr_packscan_eligible(cfg, p)) t_launch = fmin(t_launch, 11.5 + 5.0 * c / 1024.0 + n * c / 3.1e13 * 1e6);
     return t_persist <= t_launch;
 }
 
@@ -1451,8 +1470,11 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     {
         int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
         bool pipelined[LR_MAX_PARTS];
-        const int parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined);
-        out->streaming = (out->persistent == 0 && parts == 1 && !pipelined[0] && lr_stream_eligible(cfg, p)) ? 1 : 0;
+        const bool packed = lr_packscan_planned(cfg, p);
+        const int parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined, packed);
+        out->packed_scan = (out->persistent == 0 && packed) ? 1 : 0;
+        out->streaming = (out->persistent == 0 && !out->packed_scan && parts == 1 && !pipelined[0] && lr_stream_eligible(cfg, p)) ? 1 : 0;
+        out->reserved3 = 0;
     }
     if (p.unit == LR_TAB_PAIRGEN && out->persistent == 0) return LR_ERR_STATE;   // (planned only when a kernel takes it)
     out->team_blocks = team_k;
@@ -1472,7 +1494,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     {
         int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
         bool pipelined[LR_MAX_PARTS];
-        out->n_parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined);
+        out->n_parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined, lr_packscan_planned(cfg, p));
         out->pipelined = pipelined[0] ? 1 : 0;
     }
     {
@@ -1501,7 +1523,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->initialised = false;
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
-    e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, lr_fused_supported(e->plan), base, hA, pipelined);
+    e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, lr_fused_supported(e->plan), base, hA, pipelined, lay.packed_scan != 0);
     e->persistent = lay.persistent != 0;
     e->n8 = 0;                                          // groups of packed lineages: known once lr_pack_lineages has run
     e->n8_alloc = lr_groups_alloc(cfg->n_lineages);
@@ -1510,6 +1532,7 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->p4_help = lr_p4_help_choice(e);                  // (lr_mcmc_describe before init; latched again by lr_set_shares)
     e->p4_spec = lr_p4_spec_choice(e);
     e->streaming = false;
+    e->packed_scan = lay.packed_scan != 0;
     e->fork = nullptr;
     e->ev0 = e->ev1 = nullptr;
     for (int p = 0; p < e->n_parts; ++p) {
@@ -1591,6 +1614,10 @@ static int lr_launch_pairscan(const lr_engine* e, hipStream_t stream) {
 }
 
 static int lr_enqueue_scan_range(const lr_engine* e, int base, int count, hipStream_t stream) {
+    if (e->packed_scan) {
+        if (base != 0 || count != e->cfg.n_chains) return LR_ERR_STATE;      // (never pipelined: all chains in one launch)
+        return lr_launch_packscan(e, stream);
+    }
     if (e->plan.unit == LR_TAB_PAIRGEN || (e->persistent && (e->cfg.model == LR_MODEL_KEIDING_DEAD || e->plan.H == LR_H_WIDE))) {
         // pair-general tables / the extant block of model 3: the launch-based twin of the persistent scan, all chains at once
         if (base != 0 || count != e->cfg.n_chains) return LR_ERR_STATE;
@@ -1643,6 +1670,13 @@ static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipS
     }
 }
 
+// the launch-based engine's packed scan: (re)pack; an input the packing refuses (unsorted beyond LR_MAX_RUNS runs of one
+// birth bin) falls back to the scan of ts / te - same plan, same partials, same results to rounding
+static void lr_pack_for_scan(lr_engine* e, hipStream_t stream) {
+    if (!e->lay.packed_scan) return;
+    e->packed_scan = lr_pack_lineages(e, stream) == LR_OK;
+}
+
 extern "C" int lr_mcmc_restore(lr_engine* e, void* stream_) {
     if (!e) return LR_ERR_NULL;
     hipStream_t stream = (hipStream_t)stream_;
@@ -1652,6 +1686,7 @@ extern "C" int lr_mcmc_restore(lr_engine* e, void* stream_) {
     if (rc) return rc;
     if (e->persistent) rc = lr_pack_lineages(e, stream);
     if (rc) return rc;
+    lr_pack_for_scan(e, stream);
     e->initialised = true;
     return LR_OK;
 }
@@ -1669,6 +1704,7 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
         const int rcp = lr_pack_lineages(e, stream);
         if (rcp) return rcp;
     }
+    lr_pack_for_scan(e, stream);
     hipLaunchKernelGGL(lr_chain_init_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, L, M, tL, tM, KL, KM,
                        kmax);
     int rc = (int)hipGetLastError();
@@ -1958,6 +1994,8 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
             snprintf(buf, (size_t)n, "lr_persist4_kernel<%d, %s, %s, %s, %s>", e->plan.H, gen, e->cfg.sampler != 0 ? "true" : "false",
                      e->p4_help ? "true" : "false", (e->p4_help && e->p4_spec) ? "true" : "false");
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
+    } else if (e->packed_scan) {
+        snprintf(buf, (size_t)n, "lr_packscan_kernel<%d, %d>", lr_packscan_pairs(e->plan, e->cfg.n_chains), e->plan.H);
     } else if (e->streaming) {
         snprintf(buf, (size_t)n, "lr_stream_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");
     } else if (e->part[0].pipelined) {

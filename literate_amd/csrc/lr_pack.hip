@@ -229,8 +229,8 @@ static void lr_set_shares(lr_engine* e) {
         if (e->p4.help_trips < 0) e->p4.help_trips = 0;
         if ((long long)e->p4.help_trips * 128 > e->n8) e->p4.help_trips = 0;
     }
-    if (e->lay.persistent == 3) {
-        e->p4.n_slots = 8;       // speculative kernel: plain layout, every scanner wave strides over its block's slice
+    if (e->lay.persistent == 0 || e->lay.persistent == 3) {
+        e->p4.n_slots = 8;       // speculative kernel / the launch-based engine's packed scan: plain layout, the groups in order
     } else if (e->lay.persistent == 2) {
         e->p4.n_slots = e->p4_help ? 12 : 14;      // (with helper waves: twelve scanners, equal shares)
         // (with 14-lineage groups a scan is ~8 trips of cfg4 and equal shares measure as fast as any: the default is

@@ -69,7 +69,7 @@ class ChainEngine:
             s_freq=int(s_freq), n_trace_slots=int(n_trace_slots), poisson_HP=float(poisson_HP),
             update_fraction=float(update_fraction), t0=self.t0, start_time=self.start_time, end_time=self.end_time,
             seed=int(seed), chain_offset=int(chain_offset), unit_resolution=int(self.unit_resolution),
-            engine_mode={"auto": 0, "launch": 1, "persistent": 2, "persistent4": 3, "persistent2": 4, "spec": 5, "stream": 6}[engine],
+            engine_mode={"auto": 0, "launch": 1, "persistent": 2, "persistent4": 3, "persistent2": 4, "spec": 5, "stream": 6, "packed": 7}[engine],
             frac_birth=fs0 if self.unit_resolution else 0.0, frac_death=fe0 if self.unit_resolution else 0.0,
             sampler=0 if dd is None else (2 if dd.get("kind") == "trend" else 1),
             m_birth=0 if dd is None else int(dd["m_birth"]), m_death=0 if dd is None else int(dd["m_death"]),
@@ -111,7 +111,7 @@ class ChainEngine:
         ChainEngine._in_plan_check = True
         times = {}
         try:
-            for name in ("auto", "persistent4", "persistent2", "spec", "launch"):
+            for name in ("auto", "persistent4", "persistent2", "spec", "packed", "launch"):
                 try:
                     e = ChainEngine(self.ts, self.te, self.n_chains, seed=int(self.cfg.seed), s_freq=1 << 30, n_trace_slots=2,
                                     chain_offset=int(self.cfg.chain_offset), device=self.device, sort_lineages=False,

@@ -10,7 +10,7 @@ sizes = [int(float(x)) for x in os.environ.get("LR_EXP_SIZES", "1e7,3e7,1e8").sp
 for n in sizes:
     ts, te = bench.abi_lineages(n, False, "sorted")
     for engine in os.environ.get("LR_EXP_ENGINES", "auto,stream").split(","):
-        eng = ChainEngine(ts, te, 16, model=0, seed=2026, s_freq=100, n_trace_slots=8, sort_lineages=False, engine=engine)
+        eng = ChainEngine(ts, te, 16, model=0, seed=2026, s_freq=100, n_trace_slots=8, sort_lineages=os.environ.get('LR_EXP_SORT', '1') == '1', engine=engine)
         eng.init(); eng.steps(40); torch.cuda.synchronize()
         it = 200 if n <= 30_000_000 else 60
         us = min(eng.timed_steps(it) for _ in range(3)) / it * 1e3

@@ -52,6 +52,9 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        (2, dict(engine="persistent4", p4_spec=1, const_death_rate=1)),
                                        # (the resident streaming kernel - the planner's choice for few chains x very many
                                        # lineages - forced on this short input: lr_stream.hip)
+                                       # (the launch-based engine scanning the PACKED lineages - the planner's choice for very
+                                       # many lineages at unit resolution - forced on this short input: lr_packscan.hip)
+                                       (0, dict(engine="packed")), (2, dict(engine="packed", const_rates=1)), (1, dict(engine="packed")),
                                        (0, dict(engine="stream")), (2, dict(engine="stream", const_rates=1)),
                                        (1, dict(engine="stream", unit_resolution=False)), (2, dict(engine="stream", use_rate_HP=0, Poisson_HP=2.5)),
                                        (1, dict(engine="spec", team=1, cpt=1, planes_by_scanners=0, unit_resolution=False))])
@@ -80,6 +83,8 @@ def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
         assert eng.layout.persistent == 1
     if ekw["engine"] == "stream":
         assert eng.layout.persistent == 0 and eng.layout.streaming == 1 and eng.kernel_name().startswith("lr_stream_kernel<")
+    if ekw["engine"] == "packed":
+        assert eng.layout.persistent == 0 and eng.layout.packed_scan == 1 and eng.kernel_name().startswith("lr_packscan_kernel<4,")
     if ekw["engine"] == "persistent4" and ekw["unit_resolution"] is not False:
         assert eng.kernel_name().endswith("false, false>" if "LR_P4_HELP" in os.environ else ("true, true>" if p4_spec else "true, false>"))
     # binning done by the engine's own kernel must equal the reference's
@@ -578,7 +583,7 @@ def test_engine_chain_count_shapes(G, engine):
         eng.close(); last.close()
 
 
-@pytest.mark.parametrize("engine,C", [("launch", 24), ("persistent", 24), ("persistent", 10), ("persistent4", 10), ("spec", 9),
+@pytest.mark.parametrize("engine,C", [("launch", 24), ("packed", 24), ("persistent", 24), ("persistent", 10), ("persistent4", 10), ("spec", 9),
                                       ("spec2", 10), ("spec1x2", 7), ("spec2x1", 9)])
 def test_checkpoint_resume_is_bit_identical(G, tmp_path, engine, C):
     """save() after 130 iterations, load() into a fresh engine, 170 more: state, pending proposals and all 300
@@ -1181,7 +1186,7 @@ def test_planner_self_check_against_a_measurement(monkeypatch, n_lin, C):
         eng = ChainEngine(ts, te, C, model=0, seed=3, s_freq=100, n_trace_slots=4)
     r = eng.plan_report
     eng.close()
-    assert r is not None and r["auto"].startswith("lr_") and set(r["us_per_iter"]) == {"auto", "persistent4", "persistent2", "spec", "launch"}
+    assert r is not None and r["auto"].startswith("lr_") and set(r["us_per_iter"]) == {"auto", "persistent4", "persistent2", "spec", "packed", "launch"}
     t = r["us_per_iter"]
     assert t["auto"] is not None and t["launch"] is not None and t[r["best"]] == min(v for k, v in t.items() if v is not None and k != "auto")
     # structure is asserted; the timing bound is a WARNING (a shared pool box can be slow for one of the two
@@ -1194,6 +1199,33 @@ def test_planner_self_check_against_a_measurement(monkeypatch, n_lin, C):
 
 
 _STREAM_RUN = {}
+
+
+@pytest.mark.parametrize("C,model", [(2, 0), (5, 2), (24, 0), (70, 1)])
+def test_packed_scan_engine_against_the_scan_of_ts_te(C, model):
+    """The launch-based engine scanning the packed lineages (lr_packscan.hip: one launch scores every group against all
+    chains, four chain pairs per block - here 1, 3, 12 and 35 pairs: one to nine pair groups, the last one ragged) against
+    the same engine scanning ts / te: same proposals, same decisions, likelihoods to rounding (the packed form adds a
+    group's lineages in another order), however the run is cut (resume: test_checkpoint_resume_is_bit_identical)."""
+    from literate_amd import synth
+    from literate_amd.engine import ChainEngine
+    ts, te, _ = synth.make_lineages(200_000, n_bins=100, n_shifts=12, seed=9)
+    runs = {}
+    for engine in ("packed", "launch"):
+        eng = ChainEngine(ts, te, C, model=model, seed=31, s_freq=1, n_trace_slots=120, engine=engine)
+        assert eng.layout.persistent == 0 and eng.layout.packed_scan == (1 if engine == "packed" else 0)
+        if engine == "packed":
+            assert eng.layout.n_parts == 1 and eng.layout.pipelined == 0 and eng.kernel_name().startswith("lr_packscan_kernel<")
+        eng.init()
+        for n in (1, 50, 69):
+            eng.steps(n)
+        runs[engine] = (eng.trace_rows().copy(), eng.snapshot())
+        eng.close()
+    a, b = runs["packed"][0], runs["launch"][0]
+    assert np.array_equal(a[:, :, 6:8], b[:, :, 6:8]) and np.array_equal(a[:, :, 0], b[:, :, 0])          # K_l, K_m: the same decisions
+    assert np.allclose(a[:, :, 1:4], b[:, :, 1:4], rtol=1e-10, atol=1e-9)
+    assert np.allclose(np.nan_to_num(a[:, :, 13:]), np.nan_to_num(b[:, :, 13:]), rtol=1e-12)
+    assert np.array_equal(runs["packed"][1]["accepted"], runs["launch"][1]["accepted"]) and runs["packed"][1]["accepted"].sum() > 10 * C
 
 
 @pytest.mark.parametrize("cuts", [(1, 1, 1, 37), (40,), (7, 2, 31)])
@@ -1226,12 +1258,13 @@ def test_streaming_kernel_equals_the_launches_however_a_run_is_cut(general, cuts
     assert len(set(np.round(runs["stream"][0][:, 0, 2], 6))) > 5      # the chain moved
 
 
-@pytest.mark.parametrize("engine", ["stream", "auto"])
+@pytest.mark.parametrize("engine", ["stream", "launch", "auto"])
 def test_launch_engine_streams_1e7_lineages_from_hbm(engine):
-    """Few chains x very many lineages - 16 chains x 1e7 lineages, the regime where the ENGINE is HBM-bound: the planner
-    picks the launch-based engine - tiles of the lineages, 16 chains per pass, ts / te (160 MB) read in every iteration, a
-    scan and a step kernel per iteration; engine="stream" runs the same plan's iterations inside the resident streaming
-    kernel (lr_stream.hip: opt-in, measured no faster), and both must give the same run bit for bit.  Two chains row by row
+    """Few chains x very many lineages - 16 chains x 1e7 lineages: the planner picks the launch-based engine (a scan and a
+    step kernel per iteration) and has its scan read the PACKED lineages (lr_packscan.hip: 11 MB per pass, all sixteen
+    chains per group decode); engine="launch" keeps the scan of ts / te (160 MB in every iteration: the HBM-bound form),
+    engine="stream" runs that plan's iterations inside the resident streaming kernel (lr_stream.hip: opt-in, measured no
+    faster) - those two must give the same run bit for bit, the packed scan the same run to rounding.  Two chains row by row
     against the oracle loop on statistics binned from the same lineages, and every chain's accepted state re-evaluated by
     lr_bd_loglik_batch and by the oracle's binned calc_likelihood."""
     import torch
@@ -1244,13 +1277,13 @@ def test_launch_engine_streams_1e7_lineages_from_hbm(engine):
     ts, te = np.tile(ts0, reps), np.tile(te0, reps)
     eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine)
     assert eng.layout.persistent == 0 and eng.unit_resolution
-    assert eng.kernel_name().startswith("lr_stream_kernel<16," if engine == "stream" else "lr_scan_unit_kernel<16,")
-    assert eng.layout.streaming == (1 if engine == "stream" else 0)
+    assert eng.kernel_name().startswith({"stream": "lr_stream_kernel<16,", "launch": "lr_scan_unit_kernel<16,", "auto": "lr_packscan_kernel<4, 136>"}[engine])
+    assert eng.layout.streaming == (1 if engine == "stream" else 0) and eng.layout.packed_scan == (1 if engine == "auto" else 0)
     eng.init(); eng.steps(25); eng.steps(n_it - 25)      # (an odd cut: the pending tables change buffers in the streaming kernel)
     tr = eng.trace_rows()
     if engine == "stream":
         _STREAM_RUN["trace"], _STREAM_RUN["state"] = tr.copy(), eng.state_f64.cpu().numpy().copy()
-    elif "trace" in _STREAM_RUN:
+    elif engine == "launch" and "trace" in _STREAM_RUN:
         assert np.array_equal(tr, _STREAM_RUN["trace"], equal_nan=True) and np.array_equal(eng.state_f64.cpu().numpy(), _STREAM_RUN["state"], equal_nan=True)
     snap = eng.snapshot()
     assert np.all(snap["it"] == n_it) and np.all(np.isfinite(snap["likA"]))

@@ -53,16 +53,23 @@ def test_library_exports_every_declared_symbol():
     cfg.n_chains = 1024
     cfg.engine_mode = 1
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0
-    cfg.engine_mode, cfg.n_chains, cfg.n_lineages = 0, 16, 10_000_000   # few chains, huge input: tiled launches
-    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0 and lay.streaming == 0
+    # few chains, huge input at unit resolution: tiled launches whose scan reads the PACKED lineages once for all chains
+    # (two rounds of one 1024-thread block per CU) ...
+    cfg.engine_mode, cfg.n_chains, cfg.n_lineages = 0, 16, 10_000_000
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0 and lay.streaming == 0 and lay.packed_scan == 1
+    assert lay.tiles <= 512 and lay.n_parts == 1 and lay.pipelined == 0 and lay.chains_per_block == 16 and lay.lineage_idx > 0
+    # ... engine_mode 1: the scan of ts / te (one round of four 256-thread blocks per CU)
+    cfg.engine_mode = 1
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0 and lay.streaming == 0 and lay.packed_scan == 0
     tiles_launch, xchg_launch = lay.tiles, lay.total_bytes - lay.xchg
+    assert 900 <= tiles_launch <= 1024
     # ... or, asked for (engine="stream"), the same plan's iterations inside the resident streaming kernel: tiles sized to
     # the device's block slots less the stepper blocks, a second table buffer + the launch's counters in xchg
     cfg.engine_mode = 6
-    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0 and lay.streaming == 1 and lay.n_parts == 1 and lay.pipelined == 0
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0 and lay.streaming == 1 and lay.packed_scan == 0 and lay.n_parts == 1 and lay.pipelined == 0
     assert lay.tiles <= 1024 - 4 and lay.tiles <= tiles_launch and lay.total_bytes - lay.xchg > xchg_launch + 16 * 136 * 16
     cfg.n_chains = 64                                                 # (chains for two halves: the pipelined launches stay)
-    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.streaming == 0 and lay.pipelined == 1
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.streaming == 0 and lay.packed_scan == 0 and lay.pipelined == 1
     cfg.engine_mode = 0
     cfg.n_chains, cfg.n_lineages = 1024, 100000
     cfg.t0 = 0.5

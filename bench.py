@@ -612,35 +612,52 @@ def abi_section(pmc=True, sizes=ABI_SIZES):
 
 
 def abi_engine_rows(sizes=ABI_SIZES, chains=16):
-    """The RJMCMC loop itself where HBM bounds it: few chains x very many lineages.  The planner then runs the
-    launch-based engine, whose scan kernel streams ts / te from HBM in EVERY iteration (16 B per lineage and pass of Cb
-    chains), followed by the chain-step kernel: us per iteration of the whole loop, evals/s, and 16 B x N x ceil(C / Cb) /
-    t against the 8 TB/s peak - for the whole iteration and for the scan kernel alone (lr_mcmc_time_scan)."""
+    """The RJMCMC loop itself on few chains x very many lineages (unit resolution), the engine sorting the lineages by
+    (birth bin, death) as it does by default.  Two forms of the launch-based engine per size:
+      * what the planner runs: the scan reads the PACKED lineages (lr_packscan.hip: 16 bytes per group of 14 lineages)
+        once per iteration and scores every group against all chains - bound by the LDS gathers, not by HBM: us per
+        iteration, evals/s, and the LDS fraction as in the headline's roofline (lds_bytes_per_eval x evals / t / LDS peak),
+        for the whole iteration and for the scan kernel alone;
+      * `ts_te` (engine="launch"): the scan re-reads ts / te, 16 bytes per lineage and pass of Cb chains, in every
+        iteration - the HBM-bound form: 16 B x N x ceil(C / Cb) / t against the 8 TB/s peak, whole iteration and scan alone."""
     import torch
     from literate_amd.engine import ChainEngine
     rows = []
     for n in sizes:
         ts, te = abi_lineages(n, False, "sorted")
-        eng = ChainEngine(ts, te, chains, model=0, seed=2026, s_freq=100, n_trace_slots=8, sort_lineages=False)
-        eng.init()
-        eng.steps(40)
-        torch.cuda.synchronize()
-        n_it = 100
-        ms = eng.timed_steps(n_it)
-        us = ms / n_it * 1e3
-        row = dict(lineages=n, chains=chains, kernel=eng.kernel_name(), persistent=int(eng.layout.persistent), us_per_iter=us,
-                   evals_per_s=float(n) * chains / (us * 1e-6))
-        if not eng.layout.persistent:
-            cb = int(eng.layout.chains_per_block)
-            passes = -(-chains // cb)
-            scan_us = eng.time_scan(20) * 1e3
-            row.update(Cb=cb, passes=passes, hbm_GBs=16.0 * n * passes / (us * 1e-6) / 1e9, scan_kernel_us=scan_us,
-                       scan_hbm_GBs=16.0 * n * passes / (scan_us * 1e-6) / 1e9)
-            row["hbm_frac"] = row["hbm_GBs"] / HBM_PEAK_GBS
-            row["scan_hbm_frac"] = row["scan_hbm_GBs"] / HBM_PEAK_GBS
+        row = dict(lineages=n, chains=chains)
+        for form in ("auto", "launch"):
+            eng = ChainEngine(ts, te, chains, model=0, seed=2026, s_freq=100, n_trace_slots=8, engine=form)
+            eng.init()
+            eng.steps(40)
+            torch.cuda.synchronize()
+            n_it = 100
+            us = min(eng.timed_steps(n_it) for _ in range(2)) / n_it * 1e3
+            r = dict(kernel=eng.kernel_name(), persistent=int(eng.layout.persistent), packed_scan=int(eng.layout.packed_scan),
+                     us_per_iter=us, evals_per_s=float(n) * chains / (us * 1e-6))
+            if not eng.layout.persistent:
+                cb = int(eng.layout.chains_per_block)
+                passes = 1 if eng.layout.packed_scan else -(-chains // cb)
+                scan_us = eng.time_scan(20) * 1e3
+                r.update(Cb=cb, passes=passes, scan_kernel_us=scan_us)
+                if eng.layout.packed_scan:
+                    # one birth + seven slot gathers of 16 bytes score 14 lineages x 2 chains (as the headline's kernel)
+                    lds_b = 8 * 16 / 28.0
+                    r.update(lds_bytes_per_eval=lds_b, lds_frac=r["evals_per_s"] * lds_b / 1e9 / LDS_PEAK_GBS,
+                             scan_lds_frac=float(n) * chains / (scan_us * 1e-6) * lds_b / 1e9 / LDS_PEAK_GBS,
+                             packed_bytes_per_lineage=16.0 / 14.0)
+                else:
+                    r.update(hbm_GBs=16.0 * n * passes / (us * 1e-6) / 1e9, scan_hbm_GBs=16.0 * n * passes / (scan_us * 1e-6) / 1e9)
+                    r["hbm_frac"] = r["hbm_GBs"] / HBM_PEAK_GBS
+                    r["scan_hbm_frac"] = r["scan_hbm_GBs"] / HBM_PEAK_GBS
+            if form == "auto":
+                row.update(r)
+            else:
+                row["ts_te"] = r
+            eng.close()
+            del eng
         rows.append(row)
-        eng.close()
-        del eng, ts, te
+        del ts, te
         torch.cuda.empty_cache()
     return rows
 
@@ -831,8 +848,12 @@ def compact_line(d):
                 ab[ckey]["traffic_over_algorithmic"] = _sig(a[key].get("traffic_over_algorithmic"), 4)
                 ab[ckey]["traffic_over_algorithmic_calibrated"] = _sig(a[key].get("traffic_over_algorithmic_calibrated"), 4)
                 ab[ckey]["frac_of_stream2"] = _sig(a[key].get("frac_of_stream2"), 3)
+        # (`ts_te`: the same loop with the scan re-reading ts / te - the HBM-bound form; rounds before 5 have only that one)
         ab["engine_streaming"] = [{"lineages": x["lineages"], "chains": x["chains"], "us_per_iter": _sig(x["us_per_iter"], 4),
-                                   "hbm_frac": _sig(x.get("hbm_frac"), 3), "scan_hbm_frac": _sig(x.get("scan_hbm_frac"), 3)}
+                                   "evals_per_s": _sig(x.get("evals_per_s"), 4), "lds_frac": _sig(x.get("lds_frac"), 3),
+                                   "us_per_iter_ts_te": _sig(_pick(x, "ts_te", "us_per_iter") if "ts_te" in x else x["us_per_iter"], 4),
+                                   "hbm_frac_ts_te": _sig(_pick(x, "ts_te", "hbm_frac") if "ts_te" in x else x.get("hbm_frac"), 3),
+                                   "scan_hbm_frac_ts_te": _sig(_pick(x, "ts_te", "scan_hbm_frac") if "ts_te" in x else x.get("scan_hbm_frac"), 3)}
                                   for x in a.get("engine_streaming") or ()]
         ab["seam"] = {"us_per_call_1_state": _sig(_pick(a, "seam", "BDI_partial_lik", "us_per_call_1_state"), 3),
                       "numpy_us_per_call": _sig(_pick(a, "seam", "BDI_partial_lik", "numpy_binned_us_per_call"), 3)}

@@ -195,15 +195,22 @@ def test_abi_section_prices_the_hbm_streaming_entry_points():
         assert k_ns * 1e-6 == pytest.approx(call_ms, rel=0.15)
         y_ns = [x["avg_ns"] for x in st if x["run"] == run and "lr_debug_stream2_kernel" in x["kernel"]][0]
         assert y_ns <= k_ns                                        # the yardstick of the same child: never slower than the kernel
-    # the RJMCMC loop itself where HBM bounds it (few chains x 1e7 / 3e7 / 1e8 lineages: the launch-based engine streams
-    # ts / te in every iteration): the WHOLE iteration against the HBM peak, and its scan kernel alone
+    # the RJMCMC loop itself on few chains x 1e7 / 3e7 / 1e8 lineages: what the planner runs (the launch-based engine scanning
+    # the PACKED lineages: LDS-bound) and, beside it, the form that re-reads ts / te in every iteration (HBM-bound): the WHOLE
+    # iteration against the LDS / HBM peak, and the scan kernel alone
     es = a["engine_streaming"]
     assert [r["lineages"] for r in es] == [10_000_000, 30_000_000, 100_000_000] and all(r["persistent"] == 0 and r["passes"] == 1 for r in es)
     for r in es:
-        assert r["hbm_GBs"] == pytest.approx(16.0 * r["lineages"] * r["passes"] / (r["us_per_iter"] * 1e-6) / 1e9)
-        assert r["evals_per_s"] == pytest.approx(r["lineages"] * r["chains"] / (r["us_per_iter"] * 1e-6)) and r["evals_per_s"] > 1e12
-        assert r["hbm_frac"] >= 0.40 and r["scan_hbm_frac"] >= 0.55 and "lr_scan_unit_kernel" in r["kernel"]
-    assert es[1]["hbm_frac"] >= 0.50 and es[2]["hbm_frac"] >= 0.62
+        assert r["packed_scan"] == 1 and "lr_packscan_kernel" in r["kernel"] and r["packed_bytes_per_lineage"] == pytest.approx(16 / 14)
+        assert r["evals_per_s"] == pytest.approx(r["lineages"] * r["chains"] / (r["us_per_iter"] * 1e-6)) and r["evals_per_s"] > 5e12
+        assert r["lds_frac"] == pytest.approx(r["evals_per_s"] * r["lds_bytes_per_eval"] / 1e9 / (256 * 256 * 2.4), rel=1e-6)
+        assert 0.2 <= r["lds_frac"] <= r["scan_lds_frac"] <= 1.0
+        t = r["ts_te"]
+        assert t["packed_scan"] == 0 and "lr_scan_unit_kernel" in t["kernel"] and t["passes"] == 1
+        assert t["hbm_GBs"] == pytest.approx(16.0 * r["lineages"] * t["passes"] / (t["us_per_iter"] * 1e-6) / 1e9)
+        assert t["hbm_frac"] >= 0.45 and t["scan_hbm_frac"] >= 0.60
+        assert r["us_per_iter"] < 0.75 * t["us_per_iter"]                       # the packed scan is what makes the difference
+    assert es[1]["ts_te"]["hbm_frac"] >= 0.55 and es[2]["ts_te"]["hbm_frac"] >= 0.65 and es[2]["lds_frac"] >= 0.55
     seam = a["seam"]["BDI_partial_lik"]
     assert seam["us_per_call_1_state"] > seam["numpy_binned_us_per_call"] and seam["states_per_call_to_break_even"] < 64
 

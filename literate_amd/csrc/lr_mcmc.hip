@@ -1128,9 +1128,13 @@ static int lr_pipeline_env() {
 // The launch-based engine scans the PACKED lineages (lr_packscan.hip) where that applies and pays: always with too few chains
 // for the pipelined schedule; with more, once a pass is long against the chain step it no longer hides (the packed scan runs
 // at ~3e13 evals/s - the pipelined launches on ts / te at 7e12 - but serially before the step kernel)
+// (p: the plan with the PAIR tables the packed scan reads - unit resolution: the launches' own; general times: the
+// pair-general layout of the persistent engines, 32-bit fixed-point fractions)
 static bool lr_packscan_planned(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
     if (!lr_packscan_eligible(cfg, p)) return false;
-    return cfg->engine_mode == 7 || cfg->n_chains < 2 * p.cb || (double)cfg->n_lineages * (double)cfg->n_chains >= 3.0e8;
+    const bool general = p.unit == LR_TAB_PAIRGEN;
+    const double evals = (double)cfg->n_lineages * (double)cfg->n_chains;
+    return cfg->engine_mode == 7 || cfg->n_chains < (general ? 16 : 32) || evals >= (general ? 1.5e8 : 3.0e8);
 }
 
 // Partition layout of the engine.  LR_PARTS (default 2) independent partitions run on their own streams so
@@ -1200,8 +1204,15 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
         // in-bin fractions packed as 32-bit fixed point; if none applies the plan stays the launch-based engine's
         lr_scan_plan q = *p;
         q.unit = LR_TAB_PAIRGEN, q.cb = 4;
+        q.groups = (cfg->n_chains + q.cb - 1) / q.cb;
         if (lr_persist_variant(cfg, q, nullptr, nullptr) != 0) {
             *p = q;
+            return LR_OK;
+        }
+        // ... or the launch-based engine scanning the packed lineages, on the same pair-general tables
+        if (lr_packscan_planned(cfg, q)) {
+            *p = q;
+            lr_packscan_plan(cfg, p, lr_device_cus());
             return LR_OK;
         }
     }
@@ -1378,7 +1389,8 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     double t_launch = n * c / (general ? 3e12 : 7e12) * 1e6 + 15.5 + c / 1024.0;
     // ... or, at unit resolution, one launch over the packed lineages for all chains + the step kernel (16 chains x 1e7 / 3e7 /
     // 1e8 lineages: 16.3 / 27.0 / 63.9 us per iteration, scan alone 9.6 / 19.7 / 55.8: round 5)
-    if (!general && lr_packscan_eligible(cfg, p)) t_launch = fmin(t_launch, 11.5 + 5.0 * c / 1024.0 + n * c / 3.1e13 * 1e6);
+    // (general times: sixteen gathers per group and pair instead of eight)
+    if (lr_packscan_eligible(cfg, p)) t_launch = fmin(t_launch, 11.5 + 5.0 * c / 1024.0 + n * c / (general ? 1.5e13 : 3.1e13) * 1e6);
     return t_persist <= t_launch;
 }
 
@@ -1476,7 +1488,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
         out->streaming = (out->persistent == 0 && !out->packed_scan && parts == 1 && !pipelined[0] && lr_stream_eligible(cfg, p)) ? 1 : 0;
         out->reserved3 = 0;
     }
-    if (p.unit == LR_TAB_PAIRGEN && out->persistent == 0) return LR_ERR_STATE;   // (planned only when a kernel takes it)
+    if (p.unit == LR_TAB_PAIRGEN && out->persistent == 0 && !lr_packscan_planned(cfg, p)) return LR_ERR_STATE;   // (planned only when a kernel takes it)
     out->team_blocks = team_k;
     out->table_mode = p.unit;
     out->status = o, o += 256;   // engine status word
@@ -1672,9 +1684,12 @@ static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipS
 
 // the launch-based engine's packed scan: (re)pack; an input the packing refuses (unsorted beyond LR_MAX_RUNS runs of one
 // birth bin) falls back to the scan of ts / te - same plan, same partials, same results to rounding
-static void lr_pack_for_scan(lr_engine* e, hipStream_t stream) {
-    if (!e->lay.packed_scan) return;
-    e->packed_scan = lr_pack_lineages(e, stream) == LR_OK;
+// (general times have no such twin: their tables are the pair-general ones - the error is the caller's)
+static int lr_pack_for_scan(lr_engine* e, hipStream_t stream) {
+    if (!e->lay.packed_scan) return LR_OK;
+    const int rc = lr_pack_lineages(e, stream);
+    e->packed_scan = rc == LR_OK;
+    return (rc != LR_OK && e->plan.unit == LR_TAB_PAIRGEN) ? rc : LR_OK;
 }
 
 extern "C" int lr_mcmc_restore(lr_engine* e, void* stream_) {
@@ -1686,7 +1701,8 @@ extern "C" int lr_mcmc_restore(lr_engine* e, void* stream_) {
     if (rc) return rc;
     if (e->persistent) rc = lr_pack_lineages(e, stream);
     if (rc) return rc;
-    lr_pack_for_scan(e, stream);
+    rc = lr_pack_for_scan(e, stream);
+    if (rc) return rc;
     e->initialised = true;
     return LR_OK;
 }
@@ -1704,7 +1720,10 @@ extern "C" int lr_mcmc_init(lr_engine* e, const double* L, const double* M, cons
         const int rcp = lr_pack_lineages(e, stream);
         if (rcp) return rcp;
     }
-    lr_pack_for_scan(e, stream);
+    {
+        const int rcp = lr_pack_for_scan(e, stream);
+        if (rcp) return rcp;
+    }
     hipLaunchKernelGGL(lr_chain_init_kernel, dim3(e->cfg.n_chains), dim3(LR_WAVE), 0, stream, a, L, M, tL, tM, KL, KM,
                        kmax);
     int rc = (int)hipGetLastError();
@@ -1995,7 +2014,8 @@ extern "C" int lr_mcmc_describe(const lr_engine* e, char* buf, int32_t n) {
                      e->p4_help ? "true" : "false", (e->p4_help && e->p4_spec) ? "true" : "false");
         else snprintf(buf, (size_t)n, "lr_persist_kernel<%d, %d>", e->plan.H, e->lay.reserved1);
     } else if (e->packed_scan) {
-        snprintf(buf, (size_t)n, "lr_packscan_kernel<%d, %d>", lr_packscan_pairs(e->plan, e->cfg.n_chains), e->plan.H);
+        snprintf(buf, (size_t)n, "lr_packscan_kernel<%d, %d, %s>", lr_packscan_pairs(e->plan, e->cfg.n_chains), e->plan.H,
+                 e->plan.unit == LR_TAB_PAIRGEN ? "true" : "false");
     } else if (e->streaming) {
         snprintf(buf, (size_t)n, "lr_stream_kernel<%d, %d, %s>", e->plan.cb, e->plan.H, e->plan.unit ? "true" : "false");
     } else if (e->part[0].pipelined) {

@@ -19,29 +19,37 @@
 
 #define LR_PACKSCAN_THREADS 1024
 
-template <int PAIRS, int H>
-__global__ __launch_bounds__(LR_PACKSCAN_THREADS) void lr_packscan_kernel(const uint4* __restrict__ idx8, long long n8,
+// GENERAL lineage times: the pair-general form of the tables and groups (csrc/lr_scan.h, lr_persist_scan_pair_general): six
+// planes S | E | 2 E | their slopes scaled by 2^-32, a slot = one lineage or two of the run that die in the same bin, beside
+// the groups three arrays of 16 bytes per group - the slots' in-bin fractions as 32-bit fixed point and the sum of the
+// group's birth fractions as one double: 64 bytes per group of 14 lineages instead of 224 bytes of ts / te.  Per group and
+// pair 16 ds_read_b128 and the persistent scan's operations.
+template <int PAIRS, int H, bool GENERAL>
+__global__ __launch_bounds__(LR_PACKSCAN_THREADS) void lr_packscan_kernel(const uint4* __restrict__ idx8, const uint4* __restrict__ frac,
+                                                                          long long fstride, long long n8,
                                                                           const double2* __restrict__ tables, int n_chains, int n_bins,
                                                                           int tiles, double* __restrict__ partials) {
     extern __shared__ double2 tab[];                       // [PAIRS][LR_UNIT_PLANES * H]
     __shared__ double red[LR_PACKSCAN_THREADS / LR_WAVE][2 * PAIRS];
     constexpr int PLANES = LR_UNIT_PLANES * H;             // entries of one pair's table in LDS
+    constexpr int ENTS = (GENERAL ? 4 : 2) * H;            // ... and in global memory: S | E (| slopes of S | slopes of E)
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
     const int tile = blockIdx.x, pair0 = blockIdx.y * PAIRS;
     const int n_pairs = (n_chains + 1) / 2;
     const int np = min(PAIRS, n_pairs - pair0);
-    // S and E planes of the block's pairs (global memory: [pair][2 H] double2 = (chain 2 p, chain 2 p + 1)); pair slots
+    // the planes global memory holds, of the block's pairs ([pair][ENTS] double2 = (chain 2 p, chain 2 p + 1)); pair slots
     // beyond the last pair read as zeros
-    for (int i = tid; i < PAIRS * 2 * H; i += LR_PACKSCAN_THREADS) {
-        const int p = i / (2 * H), j = i - p * (2 * H);
-        tab[p * PLANES + j] = p < np ? tables[(size_t)(pair0 + p) * (2 * H) + j] : make_double2(0.0, 0.0);
+    for (int i = tid; i < PAIRS * ENTS; i += LR_PACKSCAN_THREADS) {
+        const int p = i / ENTS, j = i - p * ENTS;
+        tab[p * PLANES + (GENERAL ? lr_pairgen_lds_entry(j, H) : j)] = p < np ? tables[(size_t)(pair0 + p) * ENTS + j] : make_double2(0.0, 0.0);
     }
     __syncthreads();
     {
-        // the pair-sum planes of every pair, one pair per 128 threads at a time
-        constexpr int TPP = LR_PACKSCAN_THREADS / PAIRS;   // threads per pair
+        // the derived planes of every pair, one pair per LR_PACKSCAN_THREADS / PAIRS threads
+        constexpr int TPP = LR_PACKSCAN_THREADS / PAIRS;
         const int p = tid / TPP;
-        lr_pair_planes_block(tab + p * PLANES, H, n_bins, tid - p * TPP, TPP);
+        if (GENERAL) lr_pair_planes_block_general(tab + p * PLANES, H, n_bins, tid - p * TPP, TPP);
+        else lr_pair_planes_block(tab + p * PLANES, H, n_bins, tid - p * TPP, TPP);
     }
     __syncthreads();
 
@@ -57,14 +65,21 @@ __global__ __launch_bounds__(LR_PACKSCAN_THREADS) void lr_packscan_kernel(const 
     // it will not score (the next tile's, or the zeros behind the data: lr_groups_alloc keeps more spare groups than a
     // block's stride).  32-bit byte offsets from the tile's uniform base.
     const char* gbase = lr_uniform_ptr(idx8 + g0);
+    const char* fb0 = GENERAL ? lr_uniform_ptr(frac + g0) : gbase;
+    const char* fb1 = GENERAL ? lr_uniform_ptr(frac + fstride + g0) : gbase;
+    const char* fb2 = GENERAL ? lr_uniform_ptr(frac + 2 * fstride + g0) : gbase;
+    static_assert(LR_FRAC_ARRAYS == 3, "three fraction arrays");
     constexpr unsigned int stride_b = LR_PACKSCAN_THREADS * 16u;
+    constexpr int SLOPES = 3 * H * 16;                      // (general) bytes from a value entry to its slope entry
     const unsigned int end_b = (unsigned int)(g1 - g0) * 16u;
     unsigned int off = (unsigned int)tid * 16u;
     bool has = off < end_b;
-    lr_u32x4 w = {0u, 0u, 0u, 0u};
+    lr_u32x4 w = {0u, 0u, 0u, 0u}, f0 = {0u, 0u, 0u, 0u}, f1 = {0u, 0u, 0u, 0u}, f2 = {0u, 0u, 0u, 0u};
     lr_gload16_async(w, gbase, off);
+    if (GENERAL) lr_gload16_async(f0, fb0, off), lr_gload16_async(f1, fb1, off), lr_gload16_async(f2, fb2, off);
     while (has) {
-        lr_gload_wait<0>(w);
+        if (GENERAL) lr_gload_wait<0>(w), lr_gload_wait<0>(f0, f1, f2);
+        else lr_gload_wait<0>(w);
         unsigned int oS = w.x & 0xfff0u, c4 = w.x & 0xfu;
         unsigned int o0 = lr_word_off16(w.x, 1), o1 = lr_word_off16(w.y, 0), o2 = lr_word_off16(w.y, 1), o3 = lr_word_off16(w.z, 0),
                      o4 = lr_word_off16(w.z, 1), o5 = lr_word_off16(w.w, 0), o6 = lr_word_off16(w.w, 1);
@@ -72,25 +87,58 @@ __global__ __launch_bounds__(LR_PACKSCAN_THREADS) void lr_packscan_kernel(const 
         // word selects into the gathers' address arithmetic behind the load, keep the old registers alive and copy the new
         // ones while the load is in flight: literate_amd/check_async_loads.py)
         asm volatile("" : "+v"(oS), "+v"(c4), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), "+v"(o6));
+        double fe[LR_SLOTS], sfs = 0.0;
+        if (GENERAL) {
+            // the fractions came with the group: into doubles before their registers are refilled
+            fe[0] = (double)f0.x, fe[1] = (double)f0.y, fe[2] = (double)f0.z, fe[3] = (double)f0.w, fe[4] = (double)f1.x, fe[5] = (double)f1.y,
+            fe[6] = (double)f1.z;
+            asm volatile("" : "+v"(fe[0]), "+v"(fe[1]), "+v"(fe[2]), "+v"(fe[3]), "+v"(fe[4]), "+v"(fe[5]), "+v"(fe[6]));
+            // (the sum is used as it is: a move the compiler cannot postpone - read as plain registers it would be copied out
+            // of f2 whenever convenient, after the refill below has been issued for one; as lr_persist_scan_pair_general)
+            unsigned int s_lo, s_hi;
+            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(s_lo), "=&v"(s_hi) : "v"(f2.x), "v"(f2.y));
+            sfs = __hiloint2double((int)s_hi, (int)s_lo);
+        }
         const double cnt = (double)c4;
         off += stride_b, has = off < end_b;
         lr_gload16_async(w, gbase, off);
+        if (GENERAL) lr_gload16_async(f0, fb0, off), lr_gload16_async(f1, fb1, off), lr_gload16_async(f2, fb2, off);
 #pragma unroll
         for (int p = 0; p < PAIRS; ++p) {
             const char* b = lbase + (size_t)p * PLANES * sizeof(double2);
-            const double2 S = *reinterpret_cast<const double2*>(b + oS);
-            const double2 E0 = *reinterpret_cast<const double2*>(b + o0), E1 = *reinterpret_cast<const double2*>(b + o1);
-            const double2 E2 = *reinterpret_cast<const double2*>(b + o2), E3 = *reinterpret_cast<const double2*>(b + o3);
-            const double2 E4 = *reinterpret_cast<const double2*>(b + o4), E5 = *reinterpret_cast<const double2*>(b + o5);
-            const double2 E6 = *reinterpret_cast<const double2*>(b + o6);
-            // fixed pairwise tree over the slots, then the birth entry `count` times (as lr_persist_scan_pair_slice)
-            const double u0 = ((E0.x + E1.x) + (E2.x + E3.x)) + ((E4.x + E5.x) + E6.x);
-            const double u1 = ((E0.y + E1.y) + (E2.y + E3.y)) + ((E4.y + E5.y) + E6.y);
-            acc[2 * p] += fma(cnt, S.x, u0);
-            acc[2 * p + 1] += fma(cnt, S.y, u1);
+            if (GENERAL) {
+                const unsigned int o[LR_SLOTS] = {o0, o1, o2, o3, o4, o5, o6};
+                const double2 Sv = *reinterpret_cast<const double2*>(b + oS), Ss = *reinterpret_cast<const double2*>(b + oS + SLOPES);
+                double p0[LR_SLOTS], p1[LR_SLOTS];
+#pragma unroll
+                for (int k = 0; k < LR_SLOTS; ++k) {
+                    const double2 Ev = *reinterpret_cast<const double2*>(b + o[k]), Es = *reinterpret_cast<const double2*>(b + o[k] + SLOPES);
+                    p0[k] = fma(fe[k], Es.x, Ev.x);
+                    p1[k] = fma(fe[k], Es.y, Ev.y);
+                }
+                // the same fixed tree over the slots as at unit resolution, then the birth side of the whole group
+                // (as lr_persist_scan_pair_general)
+                const double u0 = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + p0[6]);
+                const double u1 = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + p1[6]);
+                acc[2 * p] += fma(sfs, Ss.x, fma(cnt, Sv.x, u0));
+                acc[2 * p + 1] += fma(sfs, Ss.y, fma(cnt, Sv.y, u1));
+            } else {
+                const double2 S = *reinterpret_cast<const double2*>(b + oS);
+                const double2 E0 = *reinterpret_cast<const double2*>(b + o0), E1 = *reinterpret_cast<const double2*>(b + o1);
+                const double2 E2 = *reinterpret_cast<const double2*>(b + o2), E3 = *reinterpret_cast<const double2*>(b + o3);
+                const double2 E4 = *reinterpret_cast<const double2*>(b + o4), E5 = *reinterpret_cast<const double2*>(b + o5);
+                const double2 E6 = *reinterpret_cast<const double2*>(b + o6);
+                // fixed pairwise tree over the slots, then the birth entry `count` times (as lr_persist_scan_pair_slice)
+                const double u0 = ((E0.x + E1.x) + (E2.x + E3.x)) + ((E4.x + E5.x) + E6.x);
+                const double u1 = ((E0.y + E1.y) + (E2.y + E3.y)) + ((E4.y + E5.y) + E6.y);
+                acc[2 * p] += fma(cnt, S.x, u0);
+                acc[2 * p + 1] += fma(cnt, S.y, u1);
+            }
         }
     }
-    lr_gload_wait<0>(w);      // the idle load of the last trip
+    // the idle loads of the last trip
+    lr_gload_wait<0>(w);
+    if (GENERAL) lr_gload_wait<0>(f0, f1, f2);
     // lanes -> wave (a fixed tree), waves in order
 #pragma unroll
     for (int k = 0; k < 2 * PAIRS; ++k) {
@@ -114,6 +162,7 @@ int lr_packscan_pairs(const lr_scan_plan& p, int n_chains) {
     // iteration against 24.2 / 33.1 / 69.5 with eight pairs and one block per CU; two pairs: 16.2 / 26.6 / 65.9)
     static const int cap = getenv("LR_PACKSCAN_PAIRS") ? atoi(getenv("LR_PACKSCAN_PAIRS")) : 4;      // (A/B runs)
     int pairs = (cap == 1 || cap == 2 || cap == 8) ? cap : 4;
+    if (p.unit == LR_TAB_PAIRGEN && pairs > 4) pairs = 4;      // (general times: sixteen gathers and seven fractions per group and pair)
     while (pairs > 1 && ((size_t)pairs * LR_UNIT_PLANES * p.H * sizeof(double2) > 120 * 1024 || pairs / 2 >= n_pairs)) pairs >>= 1;
     return pairs;
 }
@@ -122,7 +171,7 @@ int lr_packscan_pairs(const lr_scan_plan& p, int n_chains) {
 bool lr_packscan_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
     static const int env = getenv("LR_PACKED_SCAN") ? atoi(getenv("LR_PACKED_SCAN")) : 1;
     if (cfg->engine_mode != 7 && (!env || cfg->engine_mode != 0)) return false;     // (7 = asked for; auto unless switched off)
-    if (p.unit != LR_TAB_UNIT || !p.fast || p.cb < 2) return false;                      // pair tables of unit-resolution data
+    if ((p.unit != LR_TAB_UNIT && p.unit != LR_TAB_PAIRGEN) || !p.fast || p.cb < 2) return false;    // pair tables
     if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264) return false;
     // the packing holds lineage indices as int32 and the groups are addressed by 32-bit offsets (as lr_persist_eligible)
     if (cfg->n_lineages >= (1ll << 31) - 1 || lr_groups_alloc(cfg->n_lineages) * 16 >= (1ll << 32)) return false;
@@ -150,10 +199,10 @@ void lr_packscan_plan(const lr_mcmc_config* cfg, lr_scan_plan* p, int cus) {
     p->tiles = (int)((cfg->n_lineages + p->chunk - 1) / p->chunk);
 }
 
-template <int PAIRS, int H>
+template <int PAIRS, int H, bool GENERAL>
 static int lr_packscan_launch(const lr_engine* e, hipStream_t stream) {
     const size_t lds = (size_t)PAIRS * LR_UNIT_PLANES * H * sizeof(double2);
-    const void* fn = reinterpret_cast<const void*>(&lr_packscan_kernel<PAIRS, H>);
+    const void* fn = reinterpret_cast<const void*>(&lr_packscan_kernel<PAIRS, H, GENERAL>);
     if (lds > 64 * 1024) {
         // (per call: the attribute belongs to the function on the CURRENT device)
         const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -161,19 +210,27 @@ static int lr_packscan_launch(const lr_engine* e, hipStream_t stream) {
     }
     const int n_pairs = (e->cfg.n_chains + 1) / 2;
     const dim3 grid(e->plan.tiles, (n_pairs + PAIRS - 1) / PAIRS);
-    hipLaunchKernelGGL((lr_packscan_kernel<PAIRS, H>), grid, dim3(LR_PACKSCAN_THREADS), lds, stream,
-                       (const uint4*)(e->ws + e->lay.lineage_idx), e->n8, (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains,
-                       e->cfg.n_bins, e->plan.tiles, (double*)(e->ws + e->lay.partials));
+    hipLaunchKernelGGL((lr_packscan_kernel<PAIRS, H, GENERAL>), grid, dim3(LR_PACKSCAN_THREADS), lds, stream,
+                       (const uint4*)(e->ws + e->lay.lineage_idx), (const uint4*)(e->ws + e->lay.lineage_frac), (long long)e->n8_alloc, e->n8,
+                       (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->cfg.n_bins, e->plan.tiles,
+                       (double*)(e->ws + e->lay.partials));
     return (int)hipGetLastError();
 }
 
 template <int H>
 static int lr_packscan_launch_h(const lr_engine* e, hipStream_t stream) {
+    if (e->plan.unit == LR_TAB_PAIRGEN) {
+        switch (lr_packscan_pairs(e->plan, e->cfg.n_chains)) {
+            case 4: return lr_packscan_launch<4, H, true>(e, stream);
+            case 2: return lr_packscan_launch<2, H, true>(e, stream);
+            default: return lr_packscan_launch<1, H, true>(e, stream);
+        }
+    }
     switch (lr_packscan_pairs(e->plan, e->cfg.n_chains)) {
-        case 8: return lr_packscan_launch<8, H>(e, stream);
-        case 4: return lr_packscan_launch<4, H>(e, stream);
-        case 2: return lr_packscan_launch<2, H>(e, stream);
-        default: return lr_packscan_launch<1, H>(e, stream);
+        case 8: return lr_packscan_launch<8, H, false>(e, stream);
+        case 4: return lr_packscan_launch<4, H, false>(e, stream);
+        case 2: return lr_packscan_launch<2, H, false>(e, stream);
+        default: return lr_packscan_launch<1, H, false>(e, stream);
     }
 }
 

@@ -8,7 +8,7 @@ from literate_amd.engine import ChainEngine
 for n in [int(float(x)) for x in os.environ.get("LR_EXP_SIZES", "1e7,3e7").split(",")]:
     ts, te = bench.abi_lineages(n, True, "sorted")
     for C in (8, 12, 16):
-        eng = ChainEngine(ts, te, C, model=0, seed=2026, s_freq=100, n_trace_slots=8, sort_lineages=False, engine="launch")
+        eng = ChainEngine(ts, te, C, model=0, seed=2026, s_freq=100, n_trace_slots=8, engine=os.environ.get("LR_EXP_ENGINE", "launch"))
         eng.init(); eng.steps(40); torch.cuda.synchronize()
         us = min(eng.timed_steps(100) for _ in range(3)) / 100 * 1e3
         print("N=%.0e C=%2d %-30s Cb=%2d pipelined=%d: %8.2f us/iter  %.3e evals/s" % (n, C, eng.kernel_name()[:30], eng.layout.chains_per_block, eng.layout.pipelined, us, n * C / (us * 1e-6)), flush=True)

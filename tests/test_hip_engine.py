@@ -1201,8 +1201,9 @@ def test_planner_self_check_against_a_measurement(monkeypatch, n_lin, C):
 _STREAM_RUN = {}
 
 
-@pytest.mark.parametrize("C,model", [(2, 0), (5, 2), (24, 0), (70, 1)])
-def test_packed_scan_engine_against_the_scan_of_ts_te(C, model):
+@pytest.mark.parametrize("C,model,general", [(2, 0, False), (5, 2, False), (24, 0, False), (70, 1, False),
+                                             (3, 0, True), (12, 2, True), (38, 1, True)])
+def test_packed_scan_engine_against_the_scan_of_ts_te(C, model, general):
     """The launch-based engine scanning the packed lineages (lr_packscan.hip: one launch scores every group against all
     chains, four chain pairs per block - here 1, 3, 12 and 35 pairs: one to nine pair groups, the last one ragged) against
     the same engine scanning ts / te: same proposals, same decisions, likelihoods to rounding (the packed form adds a
@@ -1210,12 +1211,17 @@ def test_packed_scan_engine_against_the_scan_of_ts_te(C, model):
     from literate_amd import synth
     from literate_amd.engine import ChainEngine
     ts, te, _ = synth.make_lineages(200_000, n_bins=100, n_shifts=12, seed=9)
+    if general:
+        # continuous times on the 2^-32 grid: the packed form's fixed-point fractions are exact there (pair-general tables,
+        # three more 16-byte arrays per group: lr_packscan_kernel<.., true>)
+        ts, te = _off_year_grid(ts, te, np.random.default_rng(2))
     runs = {}
     for engine in ("packed", "launch"):
         eng = ChainEngine(ts, te, C, model=model, seed=31, s_freq=1, n_trace_slots=120, engine=engine)
-        assert eng.layout.persistent == 0 and eng.layout.packed_scan == (1 if engine == "packed" else 0)
+        assert eng.layout.persistent == 0 and eng.layout.packed_scan == (1 if engine == "packed" else 0) and eng.unit_resolution == (not general)
         if engine == "packed":
             assert eng.layout.n_parts == 1 and eng.layout.pipelined == 0 and eng.kernel_name().startswith("lr_packscan_kernel<")
+            assert eng.kernel_name().endswith("true>" if general else "false>") and eng.layout.table_mode == (2 if general else 1)
         eng.init()
         for n in (1, 50, 69):
             eng.steps(n)
@@ -1223,7 +1229,11 @@ def test_packed_scan_engine_against_the_scan_of_ts_te(C, model):
         eng.close()
     a, b = runs["packed"][0], runs["launch"][0]
     assert np.array_equal(a[:, :, 6:8], b[:, :, 6:8]) and np.array_equal(a[:, :, 0], b[:, :, 0])          # K_l, K_m: the same decisions
-    assert np.allclose(a[:, :, 1:4], b[:, :, 1:4], rtol=1e-10, atol=1e-9)
+    # (likelihoods of +-5e6 built from terms 100 x larger; general times: the north star's 1e-9; the posterior = likelihood +
+    # prior may cancel, so it is held to the likelihood's scale)
+    rtol = 1e-9 if general else 1e-10
+    assert np.allclose(a[:, :, 2:4], b[:, :, 2:4], rtol=rtol, atol=1e-9)
+    assert np.all(np.abs(a[:, :, 1] - b[:, :, 1]) <= 1e-9 + rtol * (np.abs(b[:, :, 2]) + np.abs(b[:, :, 3])))
     assert np.allclose(np.nan_to_num(a[:, :, 13:]), np.nan_to_num(b[:, :, 13:]), rtol=1e-12)
     assert np.array_equal(runs["packed"][1]["accepted"], runs["launch"][1]["accepted"]) and runs["packed"][1]["accepted"].sum() > 10 * C
 
@@ -1277,7 +1287,7 @@ def test_launch_engine_streams_1e7_lineages_from_hbm(engine):
     ts, te = np.tile(ts0, reps), np.tile(te0, reps)
     eng = ChainEngine(ts, te, C, model=0, seed=seed, s_freq=1, n_trace_slots=n_it, engine=engine)
     assert eng.layout.persistent == 0 and eng.unit_resolution
-    assert eng.kernel_name().startswith({"stream": "lr_stream_kernel<16,", "launch": "lr_scan_unit_kernel<16,", "auto": "lr_packscan_kernel<4, 136>"}[engine])
+    assert eng.kernel_name().startswith({"stream": "lr_stream_kernel<16,", "launch": "lr_scan_unit_kernel<16,", "auto": "lr_packscan_kernel<4, 136, false>"}[engine])
     assert eng.layout.streaming == (1 if engine == "stream" else 0) and eng.layout.packed_scan == (1 if engine == "auto" else 0)
     eng.init(); eng.steps(25); eng.steps(n_it - 25)      # (an odd cut: the pending tables change buffers in the streaming kernel)
     tr = eng.trace_rows()

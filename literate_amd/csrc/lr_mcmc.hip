@@ -1134,7 +1134,9 @@ static bool lr_packscan_planned(const lr_mcmc_config* cfg, const lr_scan_plan& p
     if (!lr_packscan_eligible(cfg, p)) return false;
     const bool general = p.unit == LR_TAB_PAIRGEN;
     const double evals = (double)cfg->n_lineages * (double)cfg->n_chains;
-    return cfg->engine_mode == 7 || cfg->n_chains < (general ? 16 : 32) || evals >= (general ? 1.5e8 : 3.0e8);
+    // (chains that the launches on ts / te would not pipeline either: fewer than two blocks' worth - general times: up to the
+    // sixteen of the wide scan)
+    return cfg->engine_mode == 7 || cfg->n_chains < (general ? 17 : 32) || evals >= (general ? 1.5e8 : 3.0e8);
 }
 
 // Partition layout of the engine.  LR_PARTS (default 2) independent partitions run on their own streams so

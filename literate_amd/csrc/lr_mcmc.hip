@@ -1392,7 +1392,8 @@ static bool lr_persist_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p
     // ... or, at unit resolution, one launch over the packed lineages for all chains + the step kernel (16 chains x 1e7 / 3e7 /
     // 1e8 lineages: 16.3 / 27.0 / 63.9 us per iteration, scan alone 9.6 / 19.7 / 55.8: round 5)
     // (general times: sixteen gathers per group and pair instead of eight)
-    if (lr_packscan_eligible(cfg, p)) t_launch = fmin(t_launch, 11.5 + 5.0 * c / 1024.0 + n * c / (general ? 1.5e13 : 3.1e13) * 1e6);
+    // (only where the launches WOULD scan the packed lineages: lr_packscan_planned)
+    if (lr_packscan_planned(cfg, p)) t_launch = fmin(t_launch, 11.5 + 5.0 * c / 1024.0 + n * c / (general ? 1.5e13 : 3.1e13) * 1e6);
     return t_persist <= t_launch;
 }
 

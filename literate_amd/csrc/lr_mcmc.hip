@@ -1314,8 +1314,13 @@ static double lr_spec_model(const lr_mcmc_config* cfg, int* k_out, bool general 
             if (k_env > 0 && k != k_env) continue;
             // (groups beyond an XCD's 4 MB of L2 stream from HBM with one group of prefetch per lane: measured 0.32 instead of
             // 0.205 us per trip at 10M lineages; round-2 sweep)
-            const bool streaming = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) > 4.0e6;
-            const double slow = streaming ? 1.55 : 1.0;
+            // (... setting in gradually: 1e6 lineages on general times - 4.6 MB of groups and fractions - ran 8.9 us per
+            // iteration of 16 chains where the full penalty predicted 14.7 and the planner took the launches at 15.1: the
+            // round-5 sweep, profiles/r05_packed_scan.txt)
+            const double over = n8 * 16.0 * (general ? 1.0 + LR_FRAC_ARRAYS : 1.0) / 4.0e6 - 1.0;
+            const double sfrac = over <= 0.0 ? 0.0 : (over >= 1.0 ? 1.0 : over);
+            const bool streaming = sfrac >= 0.5;
+            const double slow = 1.0 + 0.55 * sfrac;
             const double trips = slow * n8 / k / (double)((cpb == 1 ? LR_SPEC_THREADS_SINGLE : LR_SPEC_THREADS) - 256);
             // (a trip that waits for its group to arrive from HBM costs what the memory round trip costs: the one-chain form
             // of the scan, which made the L2-resident trips of a team per chain cheaper in round 4, does not shorten it -

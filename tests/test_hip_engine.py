@@ -710,7 +710,7 @@ def test_four_chain_kernel_does_not_depend_on_how_a_run_is_cut_into_launches(gen
     one.close(); cut.close()
 
 
-@pytest.mark.parametrize("mb,md,engine", [(2, 2, "auto"), (2, 2, "launch"), (2, 2, "persistent4"), (1, 1, "auto"),
+@pytest.mark.parametrize("mb,md,engine", [(2, 2, "auto"), (2, 2, "launch"), (2, 2, "persistent4"), (2, 2, "packed"), (1, 1, "auto"),
                                           (0, 0, "auto"), (2, -1, "auto"), (2, 0, "launch"), (1, 2, "auto"),
                                           (2, -2, "auto")])
 def test_ddrate_sampler_follows_oracle(G, golden_dir, mb, md, engine):
@@ -727,7 +727,7 @@ def test_ddrate_sampler_follows_oracle(G, golden_dir, mb, md, engine):
                        n_trace_slots=n_it // 3, chain_offset=off, engine=engine)
     assert np.array_equal(eng.n_spec, D["N_SPEC"]) and np.array_equal(eng.DT, D["DT"])
     if engine != "auto":
-        assert (eng.layout.persistent > 0) == (engine != "launch")
+        assert (eng.layout.persistent > 0) == (engine not in ("launch", "packed")) and eng.layout.packed_scan == (1 if engine == "packed" else 0)
     eng.init(); eng.steps(250); eng.steps(n_it - 250)
     with np.errstate(all="ignore"):
         emp = (D["N_SPEC"] / D["DT"], D["N_EXTI"] / D["DT"])
@@ -838,7 +838,7 @@ def test_end_to_end_simulate_then_recover_key_innovation():
     eng.close()
 
 
-@pytest.mark.parametrize("cb,cd,engine", [(0, 0, "auto"), (0, 0, "launch"), (0, 0, "persistent4"), (1, 0, "auto"), (0, 1, "auto")])
+@pytest.mark.parametrize("cb,cd,engine", [(0, 0, "auto"), (0, 0, "launch"), (0, 0, "persistent4"), (0, 0, "packed"), (1, 0, "auto"), (0, 1, "auto")])
 def test_trend_rate_sampler_follows_oracle(G, golden_dir, cb, cd, engine):
     """trend_rate.py's sampler (:102-196) on the engine (lr_mcmc_config.sampler = 2), metal_bands + the fixture's
     covariate, 9 chains: every sampled log row against the oracle loop fed the same Philox draws."""
@@ -1071,8 +1071,8 @@ def _off_year_grid(ts, te, rng, exact=True):
     return ts2, te2
 
 
-@pytest.mark.parametrize("kind,engine", [("dd", "auto"), ("dd", "persistent4"), ("dd", "spec"), ("trend", "auto"),
-                                         ("trend", "persistent4"), ("trend", "spec")])
+@pytest.mark.parametrize("kind,engine", [("dd", "auto"), ("dd", "persistent4"), ("dd", "spec"), ("dd", "packed"), ("trend", "auto"),
+                                         ("trend", "persistent4"), ("trend", "spec"), ("trend", "packed")])
 def test_parametric_samplers_on_continuous_times(G, golden_dir, kind, engine):
     """`DDRate.py -d <continuous times>` / trend_rate.py select the PARAM x GENERAL instantiations - lr_persist4_kernel<H,
     true, true, .>, lr_spec_kernel<H, T, false, true, .> - which no unit-resolution test reaches (pair-general table
@@ -1103,7 +1103,10 @@ def test_parametric_samplers_on_continuous_times(G, golden_dir, kind, engine):
         assert eng.layout.persistent == 2 and name.startswith("lr_persist4_kernel<") and ", true, true, " in name, name
     elif engine == "spec":
         assert eng.layout.persistent == 3 and name.startswith("lr_spec_kernel<") and ", false, true, " in name, name
-    if eng.layout.persistent:
+    elif engine == "packed":
+        # (the launch-based engine under a parametric sampler, its scan over the packed lineages in the pair-general form)
+        assert eng.layout.persistent == 0 and eng.layout.packed_scan == 1 and name.startswith("lr_packscan_kernel<") and name.endswith("true>"), name
+    if eng.layout.persistent or engine == "packed":
         assert eng.layout.table_mode == 2
     assert np.array_equal(eng.n_spec, nsp) and np.array_equal(eng.n_exti, nex) and np.allclose(eng.DT, dt, rtol=1e-13)
     eng.init(); eng.steps(200); eng.steps(n_it - 200)

@@ -156,7 +156,7 @@ int lr_launch_stream(lr_engine* e, const lr_step_args& a, int64_t n_iters, bool 
 bool lr_packscan_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p);
 void lr_packscan_plan(const lr_mcmc_config* cfg, lr_scan_plan* p, int cus);
 int lr_packscan_pairs(const lr_scan_plan& p, int n_chains);
-int lr_launch_packscan(const lr_engine* e, hipStream_t stream);
+int lr_launch_packscan(const lr_engine* e, int base, int count, hipStream_t stream);
 
 // lr_mcmc.hip
 lr_step_args lr_make_args(const lr_engine* e);

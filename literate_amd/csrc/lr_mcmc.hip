@@ -1139,18 +1139,28 @@ static bool lr_packscan_planned(const lr_mcmc_config* cfg, const lr_scan_plan& p
     return cfg->engine_mode == 7 || cfg->n_chains < (general ? 17 : 32) || evals >= (general ? 1.5e8 : 3.0e8);
 }
 
+// 0: the launches scan ts / te; 1: the packed lineages in one partition; 2: ... in partitions (long scans)
+static int lr_packed_mode(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
+    if (!lr_packscan_planned(cfg, p)) return 0;
+    const char* env = getenv("LR_PACKED_PARTS");          // 1 / 2 force it (read per call: tests switch it)
+    if (env && (atoi(env) == 1 || atoi(env) == 2)) return atoi(env);
+    const double evals = (double)cfg->n_lineages * (double)cfg->n_chains;
+    return evals >= (p.unit == LR_TAB_PAIRGEN ? 4.0e8 : 8.0e8) ? 2 : 1;
+}
+
 // Partition layout of the engine.  LR_PARTS (default 2) independent partitions run on their own streams so
 // that the ramp-up / drain of one partition's launches overlaps the other's; each partition with at least
 // 2*cb chains is software-pipelined in two halves.  All boundaries are multiples of cb.
-// single: one partition, not pipelined (the packed scan: one launch scores a group against ALL chains)
+// packed (lr_packed_mode): the launches scan the packed lineages - never pipelined (one launch scores a group against all
+// chains of its partition); 2: partitions on their own streams overlap one's step kernel with the other's scan, 1: one
+// partition (short scans: two streams of 5-us kernels do not overlap well - 16 chains x 1e7 lineages 20.9 us per iteration in
+// two partitions against 16.4 in one; x 1e8: 54.1 against 63.9)
 static int lr_partition(int n_chains, int cb, bool fused_ok, int base[LR_MAX_PARTS + 1], int hA[LR_MAX_PARTS],
-                        bool pipelined[LR_MAX_PARTS], bool single = false) {
+                        bool pipelined[LR_MAX_PARTS], int packed = 0) {
     static const int want_parts = lr_env_int("LR_PARTS", 2);
     int parts = want_parts < 1 ? 1 : (want_parts > LR_MAX_PARTS ? LR_MAX_PARTS : want_parts);
-    if (single) {
-        base[0] = 0, base[1] = n_chains, hA[0] = n_chains, pipelined[0] = false;
-        return 1;
-    }
+    if (packed) fused_ok = false;
+    if (packed == 1) parts = 1;
     const int groups = (n_chains + cb - 1) / cb;
     const bool pipe = lr_pipeline_env() && fused_ok;
     while (parts > 1 && groups < parts * (pipe ? 2 : 1)) --parts;
@@ -1237,7 +1247,7 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
     const bool packed = lr_packscan_planned(cfg, *p);
-    const int parts = lr_partition(cfg->n_chains, p->cb, lr_fused_supported(*p), base, hA, pipelined, packed);
+    const int parts = lr_partition(cfg->n_chains, p->cb, lr_fused_supported(*p), base, hA, pipelined, lr_packed_mode(cfg, *p));
     if (!pipelined[0]) {
         // the scan over the packed lineages (unit resolution), or - too few chains for two halves, opt-in - the resident
         // streaming kernel, its tiles sized to the device's block slots
@@ -1491,7 +1501,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
         int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
         bool pipelined[LR_MAX_PARTS];
         const bool packed = lr_packscan_planned(cfg, p);
-        const int parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined, packed);
+        const int parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined, lr_packed_mode(cfg, p));
         out->packed_scan = (out->persistent == 0 && packed) ? 1 : 0;
         out->streaming = (out->persistent == 0 && !out->packed_scan && parts == 1 && !pipelined[0] && lr_stream_eligible(cfg, p)) ? 1 : 0;
         out->reserved3 = 0;
@@ -1514,7 +1524,7 @@ extern "C" int lr_mcmc_query_layout(const lr_mcmc_config* cfg, lr_mcmc_layout* o
     {
         int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
         bool pipelined[LR_MAX_PARTS];
-        out->n_parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined, lr_packscan_planned(cfg, p));
+        out->n_parts = lr_partition(cfg->n_chains, p.cb, lr_fused_supported(p), base, hA, pipelined, lr_packed_mode(cfg, p));
         out->pipelined = pipelined[0] ? 1 : 0;
     }
     {
@@ -1543,7 +1553,8 @@ extern "C" int lr_mcmc_create(const lr_mcmc_config* cfg, const double* ts, const
     e->initialised = false;
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
-    e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, lr_fused_supported(e->plan), base, hA, pipelined, lay.packed_scan != 0);
+    e->n_parts = lr_partition(cfg->n_chains, e->plan.cb, lr_fused_supported(e->plan), base, hA, pipelined,
+                              lay.packed_scan ? lr_packed_mode(cfg, e->plan) : 0);
     e->persistent = lay.persistent != 0;
     e->n8 = 0;                                          // groups of packed lineages: known once lr_pack_lineages has run
     e->n8_alloc = lr_groups_alloc(cfg->n_lineages);
@@ -1634,10 +1645,7 @@ static int lr_launch_pairscan(const lr_engine* e, hipStream_t stream) {
 }
 
 static int lr_enqueue_scan_range(const lr_engine* e, int base, int count, hipStream_t stream) {
-    if (e->packed_scan) {
-        if (base != 0 || count != e->cfg.n_chains) return LR_ERR_STATE;      // (never pipelined: all chains in one launch)
-        return lr_launch_packscan(e, stream);
-    }
+    if (e->packed_scan) return lr_launch_packscan(e, base, count, stream);      // (never pipelined: a partition's chains in one launch)
     if (e->plan.unit == LR_TAB_PAIRGEN || (e->persistent && (e->cfg.model == LR_MODEL_KEIDING_DEAD || e->plan.H == LR_H_WIDE))) {
         // pair-general tables / the extant block of model 3: the launch-based twin of the persistent scan, all chains at once
         if (base != 0 || count != e->cfg.n_chains) return LR_ERR_STATE;

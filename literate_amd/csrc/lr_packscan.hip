@@ -27,14 +27,15 @@
 template <int PAIRS, int H, bool GENERAL>
 __global__ __launch_bounds__(LR_PACKSCAN_THREADS) void lr_packscan_kernel(const uint4* __restrict__ idx8, const uint4* __restrict__ frac,
                                                                           long long fstride, long long n8,
-                                                                          const double2* __restrict__ tables, int n_chains, int n_bins,
-                                                                          int tiles, double* __restrict__ partials) {
+                                                                          const double2* __restrict__ tables, int chain_base /* even */,
+                                                                          int n_chains /* chains [chain_base, n_chains) are scored */,
+                                                                          int n_bins, int tiles, double* __restrict__ partials) {
     extern __shared__ double2 tab[];                       // [PAIRS][LR_UNIT_PLANES * H]
     __shared__ double red[LR_PACKSCAN_THREADS / LR_WAVE][2 * PAIRS];
     constexpr int PLANES = LR_UNIT_PLANES * H;             // entries of one pair's table in LDS
     constexpr int ENTS = (GENERAL ? 4 : 2) * H;            // ... and in global memory: S | E (| slopes of S | slopes of E)
     const int tid = threadIdx.x, lane = tid & (LR_WAVE - 1), wave = tid / LR_WAVE;
-    const int tile = blockIdx.x, pair0 = blockIdx.y * PAIRS;
+    const int tile = blockIdx.x, pair0 = chain_base / 2 + blockIdx.y * PAIRS;
     const int n_pairs = (n_chains + 1) / 2;
     const int np = min(PAIRS, n_pairs - pair0);
     // the planes global memory holds, of the block's pairs ([pair][ENTS] double2 = (chain 2 p, chain 2 p + 1)); pair slots
@@ -180,6 +181,9 @@ bool lr_packscan_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
 
 // tiles of the packed scan (every pair group scans every tile)
 void lr_packscan_plan(const lr_mcmc_config* cfg, lr_scan_plan* p, int cus) {
+    // chains per partition boundary: eight at unit resolution (the pair tables lie pair by pair whatever the grouping), so
+    // that sixteen chains already make two partitions - each on its own stream, one's step kernel under the other's scan
+    if (p->unit == LR_TAB_UNIT && p->cb > 8) p->cb = 8, p->groups = (cfg->n_chains + 7) / 8;
     const int pairs = lr_packscan_pairs(*p, cfg->n_chains);
     const int pair_groups = ((cfg->n_chains + 1) / 2 + pairs - 1) / pairs;
     // two blocks per CU and pair group where that leaves a block at least four trips of its 1024 threads, else one
@@ -200,7 +204,7 @@ void lr_packscan_plan(const lr_mcmc_config* cfg, lr_scan_plan* p, int cus) {
 }
 
 template <int PAIRS, int H, bool GENERAL>
-static int lr_packscan_launch(const lr_engine* e, hipStream_t stream) {
+static int lr_packscan_launch(const lr_engine* e, int base, int count, hipStream_t stream) {
     const size_t lds = (size_t)PAIRS * LR_UNIT_PLANES * H * sizeof(double2);
     const void* fn = reinterpret_cast<const void*>(&lr_packscan_kernel<PAIRS, H, GENERAL>);
     if (lds > 64 * 1024) {
@@ -208,40 +212,40 @@ static int lr_packscan_launch(const lr_engine* e, hipStream_t stream) {
         const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (he != hipSuccess) return (int)he;
     }
-    const int n_pairs = (e->cfg.n_chains + 1) / 2;
+    const int n_pairs = (base + count + 1) / 2 - base / 2;
     const dim3 grid(e->plan.tiles, (n_pairs + PAIRS - 1) / PAIRS);
     hipLaunchKernelGGL((lr_packscan_kernel<PAIRS, H, GENERAL>), grid, dim3(LR_PACKSCAN_THREADS), lds, stream,
                        (const uint4*)(e->ws + e->lay.lineage_idx), (const uint4*)(e->ws + e->lay.lineage_frac), (long long)e->n8_alloc, e->n8,
-                       (const double2*)(e->ws + e->lay.tables), e->cfg.n_chains, e->cfg.n_bins, e->plan.tiles,
+                       (const double2*)(e->ws + e->lay.tables), base, base + count, e->cfg.n_bins, e->plan.tiles,
                        (double*)(e->ws + e->lay.partials));
     return (int)hipGetLastError();
 }
 
 template <int H>
-static int lr_packscan_launch_h(const lr_engine* e, hipStream_t stream) {
+static int lr_packscan_launch_h(const lr_engine* e, int base, int count, hipStream_t stream) {
     if (e->plan.unit == LR_TAB_PAIRGEN) {
         switch (lr_packscan_pairs(e->plan, e->cfg.n_chains)) {
-            case 4: return lr_packscan_launch<4, H, true>(e, stream);
-            case 2: return lr_packscan_launch<2, H, true>(e, stream);
-            default: return lr_packscan_launch<1, H, true>(e, stream);
+            case 4: return lr_packscan_launch<4, H, true>(e, base, count, stream);
+            case 2: return lr_packscan_launch<2, H, true>(e, base, count, stream);
+            default: return lr_packscan_launch<1, H, true>(e, base, count, stream);
         }
     }
     switch (lr_packscan_pairs(e->plan, e->cfg.n_chains)) {
-        case 8: return lr_packscan_launch<8, H, false>(e, stream);
-        case 4: return lr_packscan_launch<4, H, false>(e, stream);
-        case 2: return lr_packscan_launch<2, H, false>(e, stream);
-        default: return lr_packscan_launch<1, H, false>(e, stream);
+        case 8: return lr_packscan_launch<8, H, false>(e, base, count, stream);
+        case 4: return lr_packscan_launch<4, H, false>(e, base, count, stream);
+        case 2: return lr_packscan_launch<2, H, false>(e, base, count, stream);
+        default: return lr_packscan_launch<1, H, false>(e, base, count, stream);
     }
 }
 
-// one pass of the packed lineages for ALL chains of the engine
-int lr_launch_packscan(const lr_engine* e, hipStream_t stream) {
-    if (e->n8 <= 0) return LR_ERR_STATE;
+// one pass of the packed lineages for the chains [base, base + count) (base even: a partition of the engine)
+int lr_launch_packscan(const lr_engine* e, int base, int count, hipStream_t stream) {
+    if (e->n8 <= 0 || (base & 1) || count < 1) return LR_ERR_STATE;
     switch (e->plan.H) {
-        case 40: return lr_packscan_launch_h<40>(e, stream);
-        case 72: return lr_packscan_launch_h<72>(e, stream);
-        case 136: return lr_packscan_launch_h<136>(e, stream);
-        case 264: return lr_packscan_launch_h<264>(e, stream);
+        case 40: return lr_packscan_launch_h<40>(e, base, count, stream);
+        case 72: return lr_packscan_launch_h<72>(e, base, count, stream);
+        case 136: return lr_packscan_launch_h<136>(e, base, count, stream);
+        case 264: return lr_packscan_launch_h<264>(e, base, count, stream);
         default: return LR_ERR_SIZE;
     }
 }

@@ -1213,14 +1213,20 @@ _STREAM_RUN = {}
 
 
 @pytest.mark.parametrize("C,model,general", [(2, 0, False), (5, 2, False), (24, 0, False), (70, 1, False),
-                                             (3, 0, True), (12, 2, True), (38, 1, True)])
-def test_packed_scan_engine_against_the_scan_of_ts_te(C, model, general):
+                                             (3, 0, True), (12, 2, True), (38, 1, True),
+                                             # (... in two partitions on their own streams, as long scans run: forced here)
+                                             (24, 2, "parts"), (70, 0, "parts"), (38, 0, "general parts")])
+def test_packed_scan_engine_against_the_scan_of_ts_te(C, model, general, monkeypatch):
     """The launch-based engine scanning the packed lineages (lr_packscan.hip: one launch scores every group against all
     chains, four chain pairs per block - here 1, 3, 12 and 35 pairs: one to nine pair groups, the last one ragged) against
     the same engine scanning ts / te: same proposals, same decisions, likelihoods to rounding (the packed form adds a
     group's lineages in another order), however the run is cut (resume: test_checkpoint_resume_is_bit_identical)."""
     from literate_amd import synth
     from literate_amd.engine import ChainEngine
+    parts = 1
+    if isinstance(general, str):
+        parts, general = 2, general.startswith("general")
+        monkeypatch.setenv("LR_PACKED_PARTS", "2")
     ts, te, _ = synth.make_lineages(200_000, n_bins=100, n_shifts=12, seed=9)
     if general:
         # continuous times on the 2^-32 grid: the packed form's fixed-point fractions are exact there (pair-general tables,
@@ -1231,7 +1237,9 @@ def test_packed_scan_engine_against_the_scan_of_ts_te(C, model, general):
         eng = ChainEngine(ts, te, C, model=model, seed=31, s_freq=1, n_trace_slots=120, engine=engine)
         assert eng.layout.persistent == 0 and eng.layout.packed_scan == (1 if engine == "packed" else 0) and eng.unit_resolution == (not general)
         if engine == "packed":
-            assert eng.layout.n_parts == 1 and eng.layout.pipelined == 0 and eng.kernel_name().startswith("lr_packscan_kernel<")
+            # (never pipelined; one partition: the scans here are short - long ones run in two, on their own streams)
+            assert eng.layout.n_parts == parts and eng.layout.pipelined == 0
+            assert eng.kernel_name().startswith("lr_packscan_kernel<")
             assert eng.kernel_name().endswith("true>" if general else "false>") and eng.layout.table_mode == (2 if general else 1)
         eng.init()
         for n in (1, 50, 69):

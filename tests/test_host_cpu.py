@@ -57,7 +57,12 @@ def test_library_exports_every_declared_symbol():
     # (two rounds of one 1024-thread block per CU) ...
     cfg.engine_mode, cfg.n_chains, cfg.n_lineages = 0, 16, 10_000_000
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0 and lay.streaming == 0 and lay.packed_scan == 1
-    assert lay.tiles <= 512 and lay.n_parts == 1 and lay.pipelined == 0 and lay.chains_per_block == 16 and lay.lineage_idx > 0
+    assert lay.tiles <= 512 and lay.n_parts == 1 and lay.pipelined == 0 and lay.chains_per_block == 8 and lay.lineage_idx > 0
+    # (long scans - 16 chains x 1e8 lineages - run in two partitions of eight chains on their own streams: one's step kernel
+    # under the other's scan)
+    cfg.n_lineages = 100_000_000
+    assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.packed_scan == 1 and lay.n_parts == 2 and lay.pipelined == 0
+    cfg.n_lineages = 10_000_000
     # ... engine_mode 1: the scan of ts / te (one round of four 256-thread blocks per CU)
     cfg.engine_mode = 1
     assert _hip.load().lr_mcmc_query_layout(cfg, lay) == 0 and lay.persistent == 0 and lay.streaming == 0 and lay.packed_scan == 0

@@ -204,7 +204,8 @@ def test_abi_section_prices_the_hbm_streaming_entry_points():
         assert r["packed_scan"] == 1 and "lr_packscan_kernel" in r["kernel"] and r["packed_bytes_per_lineage"] == pytest.approx(16 / 14)
         assert r["evals_per_s"] == pytest.approx(r["lineages"] * r["chains"] / (r["us_per_iter"] * 1e-6)) and r["evals_per_s"] > 5e12
         assert r["lds_frac"] == pytest.approx(r["evals_per_s"] * r["lds_bytes_per_eval"] / 1e9 / (256 * 256 * 2.4), rel=1e-6)
-        assert 0.2 <= r["lds_frac"] <= r["scan_lds_frac"] <= 1.0
+        # (the iteration may beat the ONE launch over all chains that `scan_kernel_us` times: long scans run in two partitions)
+        assert 0.2 <= r["lds_frac"] <= 1.0 and 0.2 <= r["scan_lds_frac"] <= 1.0
         t = r["ts_te"]
         assert t["packed_scan"] == 0 and "lr_scan_unit_kernel" in t["kernel"] and t["passes"] == 1
         assert t["hbm_GBs"] == pytest.approx(16.0 * r["lineages"] * t["passes"] / (t["us_per_iter"] * 1e-6) / 1e9)

@@ -1145,7 +1145,9 @@ static int lr_packed_mode(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
     const char* env = getenv("LR_PACKED_PARTS");          // 1 / 2 force it (read per call: tests switch it)
     if (env && (atoi(env) == 1 || atoi(env) == 2)) return atoi(env);
     const double evals = (double)cfg->n_lineages * (double)cfg->n_chains;
-    return evals >= (p.unit == LR_TAB_PAIRGEN ? 4.0e8 : 8.0e8) ? 2 : 1;
+    // (scratch/exp_packed_parts.py: a tie at n C = 3.2e8, two partitions 3-7 % ahead at 3.8e8 - 6.4e8, 8-16 % beyond; general
+    // times cost twice the gathers per eval)
+    return evals >= (p.unit == LR_TAB_PAIRGEN ? 1.75e8 : 3.5e8) ? 2 : 1;
 }
 
 // Partition layout of the engine.  LR_PARTS (default 2) independent partitions run on their own streams so

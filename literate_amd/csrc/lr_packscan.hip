@@ -1,18 +1,22 @@
-// lr_packscan.hip - the launch-based engine's scan over the PACKED lineages (few chains x very many lineages at unit
-// resolution).
+// lr_packscan.hip - the launch-based engine's scan over the PACKED lineages (few chains, or very many lineages).
 //
-// Until round 5 the launch-based engine re-read ts / te - 16 bytes per lineage - in every iteration: HBM-bound, 36 us per
-// iteration of 16 chains on 1e7 lineages with the scan at 0.97 of what a kernel that only reads the two arrays reaches.
+// Until late in round 5 the launch-based engine re-read ts / te - 16 bytes per lineage - in every iteration: HBM-bound, 36 us
+// per iteration of 16 chains on 1e7 lineages with the scan at 0.97 of what a kernel that only reads the two arrays reaches.
 // The persistent engines never did: they scan the lineages as packed groups (lr_pack.hip: 16 bytes for up to 14 lineages
 // of one birth bin - header = birth entry + count, seven 16-bit byte offsets of death entries or pre-summed pairs of them;
 // csrc/lr_scan.h "unit resolution: pair slots"), 1.14 bytes per lineage, every lineage still scored through its own
-// (birth, death) entries.  This kernel gives the launch-based engine the same stream, ONCE per iteration for ALL its
-// chains: a 1024-thread block per CU stages the pair tables of up to eight chain pairs in LDS (six planes each: S, E and
-// the four pair-sum planes every block derives from E), decodes a group once and scores it against every pair - per group
-// and pair 8 ds_read_b128 + 17 fp64 operations, the operations and their order per (group, pair) those of the
-// persistent scan (lr_persist_scan_pair_slice).  The loop is bound by the LDS gathers (64 per group at eight pairs), not
-// by memory: 11.4 MB per pass at 1e7 lineages.
+// (birth, death) entries.  This kernel gives the launch-based engine the same stream, ONCE per iteration for all the
+// chains of a partition: a 1024-thread block stages the pair tables of up to four chain pairs in LDS (six planes each:
+// S, E and the pair-sum planes every block derives from E - 52 KB at H = 136, two blocks per CU), decodes a group once and
+// scores it against every pair - per group and pair 8 ds_read_b128 + 17 fp64 operations, the operations and their order
+// per (group, pair) those of the persistent scan (lr_persist_scan_pair_slice).  The loop is bound by the LDS gathers, not
+// by memory (11.4 MB per pass at 1e7 lineages): 0.8 of the gather peak at 1e8 lineages, where the four-chain kernel's scan
+// - one pair per decode, twelve of sixteen waves - reaches 0.5 inside its block.
+// 16 chains x 1e7 / 3e7 / 1e8 lineages: 16.5 / 27 / 54-59 us per iteration against 35.5 / 95 / 285 with the scan of ts / te
+// (profiles/r05_packed_scan.txt); general lineage times in the pair-general form (GENERAL below).
 // Tile partials as everywhere: partials[chain * lr_tile_stride(tiles) + tile], summed by lr_chain_step_kernel.
+// The planner (lr_mcmc.hip: lr_packscan_planned, lr_packed_mode) takes it wherever the launches run with few chains or
+// long passes, never pipelined; long scans run in two partitions of the chains on their own streams.
 #include <cstdlib>
 
 #include "lr_engine.h"

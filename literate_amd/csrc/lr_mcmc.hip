@@ -1211,6 +1211,13 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
                 *p = q;
                 return LR_OK;
             }
+            // ... or, on the same tables, under the launch-based engine scanning the packed lineages (their death-side slots
+            // point extant lineages at the extant block)
+            if (lr_packscan_planned(cfg, q)) {
+                *p = q;
+                lr_packscan_plan(cfg, p, lr_device_cus());
+                return LR_OK;
+            }
         }
     }
     if (!p->unit && p->fast && p->n_cls == 1) {
@@ -1702,12 +1709,13 @@ static void lr_prepare_constants(const lr_engine* e, const lr_step_args& a, hipS
 
 // the launch-based engine's packed scan: (re)pack; an input the packing refuses (unsorted beyond LR_MAX_RUNS runs of one
 // birth bin) falls back to the scan of ts / te - same plan, same partials, same results to rounding
-// (general times have no such twin: their tables are the pair-general ones - the error is the caller's)
+// (general times have no such twin: their tables are the pair-general ones - the error is the caller's
 static int lr_pack_for_scan(lr_engine* e, hipStream_t stream) {
     if (!e->lay.packed_scan) return LR_OK;
     const int rc = lr_pack_lineages(e, stream);
     e->packed_scan = rc == LR_OK;
-    return (rc != LR_OK && e->plan.unit == LR_TAB_PAIRGEN) ? rc : LR_OK;
+    // (... nor has model 3 on these tables: the extant block is reached through the packed slots only)
+    return (rc != LR_OK && (e->plan.unit == LR_TAB_PAIRGEN || e->cfg.model == LR_MODEL_KEIDING_DEAD)) ? rc : LR_OK;
 }
 
 extern "C" int lr_mcmc_restore(lr_engine* e, void* stream_) {

@@ -55,6 +55,7 @@ def _oracle_run(G, name, model, seed, chain, n_it, **kw):
                                        # (the launch-based engine scanning the PACKED lineages - the planner's choice for very
                                        # many lineages at unit resolution - forced on this short input: lr_packscan.hip)
                                        (0, dict(engine="packed")), (2, dict(engine="packed", const_rates=1)), (1, dict(engine="packed")),
+                                       (3, dict(engine="packed")), (3, dict(engine="packed", unit_resolution=False)),
                                        (0, dict(engine="stream")), (2, dict(engine="stream", const_rates=1)),
                                        (1, dict(engine="stream", unit_resolution=False)), (2, dict(engine="stream", use_rate_HP=0, Poisson_HP=2.5)),
                                        (1, dict(engine="spec", team=1, cpt=1, planes_by_scanners=0, unit_resolution=False))])
@@ -85,6 +86,7 @@ def test_engine_follows_oracle_trajectory(G, model, kw, monkeypatch):
         assert eng.layout.persistent == 0 and eng.layout.streaming == 1 and eng.kernel_name().startswith("lr_stream_kernel<")
     if ekw["engine"] == "packed":
         assert eng.layout.persistent == 0 and eng.layout.packed_scan == 1 and eng.kernel_name().startswith("lr_packscan_kernel<4,")
+        assert eng.kernel_name().endswith("true>" if ekw["unit_resolution"] is False else "false>")
     if ekw["engine"] == "persistent4" and ekw["unit_resolution"] is not False:
         assert eng.kernel_name().endswith("false, false>" if "LR_P4_HELP" in os.environ else ("true, true>" if p4_spec else "true, false>"))
     # binning done by the engine's own kernel must equal the reference's

@@ -1252,6 +1252,12 @@ static int lr_plan_engine(const lr_mcmc_config* cfg, lr_scan_plan* p) {
             *p = q;
             return LR_OK;
         }
+        // ... or the launch-based engine scanning the packed lineages (two pairs of H = 520 tables per block)
+        if (lr_packscan_planned(cfg, q)) {
+            *p = q;
+            lr_packscan_plan(cfg, p, lr_device_cus());
+            return LR_OK;
+        }
     }
     int base[LR_MAX_PARTS + 1], hA[LR_MAX_PARTS];
     bool pipelined[LR_MAX_PARTS];
@@ -1715,7 +1721,8 @@ static int lr_pack_for_scan(lr_engine* e, hipStream_t stream) {
     const int rc = lr_pack_lineages(e, stream);
     e->packed_scan = rc == LR_OK;
     // (... nor has model 3 on these tables: the extant block is reached through the packed slots only)
-    return (rc != LR_OK && (e->plan.unit == LR_TAB_PAIRGEN || e->cfg.model == LR_MODEL_KEIDING_DEAD)) ? rc : LR_OK;
+    // (... nor the H = 520 class: the scans of ts / te are instantiated up to H = 264)
+    return (rc != LR_OK && (e->plan.unit == LR_TAB_PAIRGEN || e->cfg.model == LR_MODEL_KEIDING_DEAD || e->plan.H == LR_H_WIDE)) ? rc : LR_OK;
 }
 
 extern "C" int lr_mcmc_restore(lr_engine* e, void* stream_) {

@@ -177,7 +177,7 @@ bool lr_packscan_eligible(const lr_mcmc_config* cfg, const lr_scan_plan& p) {
     static const int env = getenv("LR_PACKED_SCAN") ? atoi(getenv("LR_PACKED_SCAN")) : 1;
     if (cfg->engine_mode != 7 && (!env || cfg->engine_mode != 0)) return false;     // (7 = asked for; auto unless switched off)
     if ((p.unit != LR_TAB_UNIT && p.unit != LR_TAB_PAIRGEN) || !p.fast || p.cb < 2) return false;    // pair tables
-    if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264) return false;
+    if (p.H != 40 && p.H != 72 && p.H != 136 && p.H != 264 && p.H != LR_H_WIDE) return false;
     // the packing holds lineage indices as int32 and the groups are addressed by 32-bit offsets (as lr_persist_eligible)
     if (cfg->n_lineages >= (1ll << 31) - 1 || lr_groups_alloc(cfg->n_lineages) * 16 >= (1ll << 32)) return false;
     return true;
@@ -250,6 +250,7 @@ int lr_launch_packscan(const lr_engine* e, int base, int count, hipStream_t stre
         case 72: return lr_packscan_launch_h<72>(e, base, count, stream);
         case 136: return lr_packscan_launch_h<136>(e, base, count, stream);
         case 264: return lr_packscan_launch_h<264>(e, base, count, stream);
+        case LR_H_WIDE: return lr_packscan_launch_h<LR_H_WIDE>(e, base, count, stream);      // (255 .. 512 bins: two pairs per block)
         default: return LR_ERR_SIZE;
     }
 }

@@ -524,7 +524,8 @@ def test_cfg5_ddrate_50k_lineages_256_states():
                                                 (1000, None, "auto"),
                                                 # the launch-based engine's packed scan in every table class, unit and general
                                                 (30, None, "packed"), (64, None, "packed"), (129, None, "packed"), (254, None, "packed"),
-                                                (30, False, "packed"), (120, False, "packed"), (200, False, "packed")])
+                                                (30, False, "packed"), (120, False, "packed"), (200, False, "packed"),
+                                                (300, None, "packed"), (512, None, "packed"), (300, False, "packed")])
 def test_engine_shapes_bins(n_bins, unit, engine):
     """Table half-stride classes (H = 40, 72, 136, 264; a class holds n_bins <= 64 x its bins-per-lane count, so 129..134
     bins move up to H = 264; 255..512 bins: H = 520, persistent kernels only) and the generic kernel beyond them
@@ -554,8 +555,10 @@ def test_engine_shapes_bins(n_bins, unit, engine):
     if engine == "packed":
         # 37 chains = 19 pairs: four pairs per block up to H = 136, at H = 264 (102 KB of planes) as well - five pair groups,
         # the last one ragged; general times in the pair-general form
-        assert eng.layout.persistent == 0 and eng.layout.packed_scan == 1 and eng.kernel_name().startswith("lr_packscan_kernel<4, %d, %s>" % (
-            {30: 40, 64: 72, 120: 136, 129: 264, 200: 264, 254: 264}[n_bins], "true" if unit is False else "false"))
+        # (255 .. 512 bins: the H = 520 class, 100 KB of planes for TWO pairs per block)
+        Hc = {30: 40, 64: 72, 120: 136, 129: 264, 200: 264, 254: 264, 300: 520, 512: 520}[n_bins]
+        assert eng.layout.persistent == 0 and eng.layout.packed_scan == 1 and eng.kernel_name().startswith("lr_packscan_kernel<%d, %d, %s>" % (
+            2 if Hc == 520 else 4, Hc, "true" if unit is False else "false"))
     eng.init(); eng.steps(n_it)
     tr = eng.trace_rows()
     t0, sp, ex, br = lo.bin_events_cli(ts, te)
